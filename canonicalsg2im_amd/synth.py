@@ -1,0 +1,186 @@
+"""Synthetic scene-graph batches that follow the reference's collate contract.
+
+The reference's data loaders need COCO / Visual Genome / CLEVR-Dialog on disk,
+so every test and benchmark here draws seeded synthetic batches instead.  The
+8-tuple this module returns has exactly the layout that
+`sg2im/data/packed_coco.py:467-478` (`coco_collate_fn`) hands to the trainer:
+
+    imgs          f32 (B,3,H,W)
+    objs          i64 (B,O,A)      padded rows are 0 (== `__image__` id)
+    boxes         f32 (B,O,4)      [x0,y0,w,h] in [0,1]; padded rows are -1
+    triplets      i64 (B,T,3)      [s,p,o]; padded rows [0,__padding__,0]
+    conv_counts   f32 (B,P,P+1)    only read with --learned_converse
+    triplet_type  i64 (B,T)        0 original, 1 transitive, 2, 3
+    masks         None             (mask_size == 0 in every BASELINE config)
+    image_ids     i64 (B,)
+
+Vocabularies mirror `sg2im/data/base_dataset.py:14-15,152-161` (8 packed
+predicates) and `sg2im/data/packed_clevr_dialog.py:121-125` (4 attributes).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+PACKED_PREDICATES = ["__padding__", "__in_image__", "__below__", "__above__",
+                     "__left of__", "__right of__", "__inside__", "__surrounding__"]
+
+
+def make_vocab(kind: str = "coco", num_objects: int = None, num_preds: int = None) -> Dict:
+    """Build the vocab dict keys the hot path reads."""
+    if kind == "clevr":
+        sizes = {"shape": 4, "color": 9, "material": 3, "size": 3}
+        attributes = {}
+        for name, n in sizes.items():
+            d = {"__image__": 0}
+            for i in range(1, n):
+                d["%s_%d" % (name, i)] = i
+            attributes[name] = d
+        object_name_to_idx = attributes["shape"]
+        preds = list(PACKED_PREDICATES)
+    else:
+        if num_objects is None:
+            num_objects = {"coco": 184, "vg": 179, "tiny": 7}[kind]
+        object_name_to_idx = {"__image__": 0}
+        for i in range(1, num_objects):
+            object_name_to_idx["obj_%d" % i] = i
+        attributes = {"objects": object_name_to_idx}
+        if num_preds is None:
+            num_preds = {"coco": 8, "vg": 46, "tiny": 8}[kind]
+        preds = list(PACKED_PREDICATES)
+        while len(preds) < num_preds:
+            preds.append("rel_%d" % len(preds))
+        preds = preds[:max(num_preds, 2)]
+    idx_to_name = [None] * (max(object_name_to_idx.values()) + 1)
+    for k, v in object_name_to_idx.items():
+        idx_to_name[v] = k
+    return {
+        "object_name_to_idx": object_name_to_idx,
+        "object_idx_to_name": idx_to_name,
+        "pred_name_to_idx": {p: i for i, p in enumerate(preds)},
+        "pred_idx_to_name": preds,
+        "attributes": attributes,
+    }
+
+
+@dataclass
+class BatchConfig:
+    batch_size: int = 4
+    image_size: int = 64
+    min_objects: int = 3
+    max_objects: int = 8
+    graph: str = "random"          # random | packed | closure
+    pad_objects_to: int = 0        # 0 = pad to the batch max
+    pad_triplets_to: int = 0
+    extra: dict = field(default_factory=dict)
+
+
+# The five BASELINE.json configurations.
+BASELINE_CONFIGS = {
+    "C1": dict(vocab="coco", cfg=BatchConfig(4, 64, 16, 40, "packed")),
+    "C2": dict(vocab="coco", cfg=BatchConfig(16, 128, 3, 8, "random")),
+    "C3": dict(vocab="coco", cfg=BatchConfig(16, 256, 1, 30, "random")),
+    "C4": dict(vocab="vg", cfg=BatchConfig(32, 256, 3, 30, "random")),
+    "C5": dict(vocab="clevr", cfg=BatchConfig(48, 256, 64, 128, "closure")),
+}
+
+
+def _relation(bs, bo, name_to_idx):
+    sx0, sy0, sw, sh = bs
+    ox0, oy0, ow, oh = bo
+    sx1, sy1, ox1, oy1 = sx0 + sw, sy0 + sh, ox0 + ow, oy0 + oh
+    if sx0 < ox0 and sx1 > ox1 and sy0 < oy0 and sy1 > oy1:
+        return name_to_idx["__surrounding__"]
+    if sx0 > ox0 and sx1 < ox1 and sy0 > oy0 and sy1 < oy1:
+        return name_to_idx["__inside__"]
+    dx = (sx0 + sw / 2) - (ox0 + ow / 2)
+    dy = (sy0 + sh / 2) - (oy0 + oh / 2)
+    if abs(dx) >= abs(dy):
+        return name_to_idx["__left of__"] if dx < 0 else name_to_idx["__right of__"]
+    return name_to_idx["__above__"] if dy < 0 else name_to_idx["__below__"]
+
+
+def _sample_graph(rng, boxes, n, mode, vocab):
+    p2i = vocab["pred_name_to_idx"]
+    num_preds = len(vocab["pred_idx_to_name"])
+    trip, ttype = [], []
+    if n <= 1:
+        return trip, ttype
+    if mode == "random":
+        # one random triple per object (sg2im/data/coco.py:372-421)
+        for s in range(n):
+            o = int(rng.integers(0, n - 1))
+            o = o if o < s else o + 1
+            trip.append([s, int(rng.integers(2, num_preds)), o])
+            ttype.append(0)
+    elif mode == "packed":
+        # <=4 nearest neighbours per object, relation from box geometry
+        cen = boxes[:n, :2] + boxes[:n, 2:] / 2
+        for s in range(n):
+            d = np.linalg.norm(cen - cen[s], axis=1)
+            d[s] = np.inf
+            for o in np.argsort(d)[:min(4, n - 1)]:
+                trip.append([s, _relation(boxes[s], boxes[int(o)], p2i), int(o)])
+                ttype.append(0)
+    elif mode == "closure":
+        # every ordered pair; a quarter are "original", the rest transitive
+        for s in range(n):
+            for o in range(n):
+                if s == o:
+                    continue
+                trip.append([s, _relation(boxes[s], boxes[o], p2i), o])
+                ttype.append(0 if (s + o) % 4 == 0 else 1)
+    else:
+        raise ValueError("unknown graph mode %r" % mode)
+    return trip, ttype
+
+
+def make_batch(vocab: Dict, cfg: BatchConfig, seed: int = 0) -> Tuple:
+    """Seeded batch in collate layout; CPU tensors."""
+    rng = np.random.default_rng(seed)
+    B, H = cfg.batch_size, cfg.image_size
+    attr_names = list(vocab["attributes"].keys())
+    A = len(attr_names)
+    sizes = [max(vocab["attributes"][a].values()) + 1 for a in attr_names]
+    num_preds = len(vocab["pred_idx_to_name"])
+    pad_p = vocab["pred_name_to_idx"]["__padding__"]
+
+    per = []
+    for _ in range(B):
+        n = int(rng.integers(cfg.min_objects, cfg.max_objects + 1))
+        o = np.stack([rng.integers(1, max(s, 2), size=n) for s in sizes], axis=1).astype(np.int64)
+        wh = rng.uniform(0.05, 0.45, size=(n, 2))
+        xy = rng.uniform(0.0, 1.0, size=(n, 2)) * (1.0 - wh)
+        bx = np.concatenate([xy, wh], axis=1).astype(np.float32)
+        trip, ttype = _sample_graph(rng, bx, n, cfg.graph, vocab)
+        per.append((o, bx, np.asarray(trip, np.int64).reshape(-1, 3), np.asarray(ttype, np.int64)))
+
+    O = max(cfg.pad_objects_to, max(p[0].shape[0] for p in per))
+    T = max(cfg.pad_triplets_to, max(p[2].shape[0] for p in per), 1)
+    objs = np.zeros((B, O, A), np.int64)
+    boxes = -np.ones((B, O, 4), np.float32)
+    triplets = np.zeros((B, T, 3), np.int64)
+    triplets[:, :, 1] = pad_p
+    ttypes = np.zeros((B, T), np.int64)
+    for b, (o, bx, tr, tt) in enumerate(per):
+        objs[b, :o.shape[0]] = o
+        boxes[b, :bx.shape[0]] = bx
+        triplets[b, :tr.shape[0]] = tr
+        ttypes[b, :tt.shape[0]] = tt
+    imgs = rng.uniform(-1.0, 1.0, size=(B, 3, H, H)).astype(np.float32)
+    conv_counts = np.zeros((B, num_preds, num_preds + 1), np.float32)
+    return (torch.from_numpy(imgs), torch.from_numpy(objs), torch.from_numpy(boxes),
+            torch.from_numpy(triplets), torch.from_numpy(conv_counts), torch.from_numpy(ttypes),
+            None, torch.arange(B, dtype=torch.int64))
+
+
+def shard_batch(batch: Tuple, rank: int, world_size: int) -> Tuple:
+    """Contiguous B/N samples per rank — the partition `nn.DataParallel` scatter
+    makes in the reference (`sync_batchnorm/replicate.py:64-67`, `scripts/args.py:234-236`)."""
+    B = batch[0].shape[0]
+    if B % world_size != 0:
+        raise ValueError("Batch size %d is wrong. It must be a multiple of # GPUs %d." % (B, world_size))
+    n = B // world_size
+    sl = slice(rank * n, (rank + 1) * n)
+    return tuple(None if t is None else t[sl] for t in batch)

@@ -1,0 +1,396 @@
+"""Functional CPU restatement of the reference hot path (see package docstring).
+
+Conventions
+-----------
+* `state` is a flat dict {reference state_dict key: tensor}.  Parameters may
+  require grad; buffers (`running_mean`, `weight_u`, ...) are updated IN PLACE
+  exactly where the reference's modules mutate them.
+* `prefix` selects a sub-module ("gconvs.0.", "up_3.norm_s.", ...).
+* All citations are relative to /root/reference.
+"""
+import math
+import re
+
+import torch
+import torch.nn.functional as F
+
+__all__ = [
+    "attribute_embeddings", "mlp2", "triplet_confidence", "graph_triple_conv", "sg2layout_forward",
+    "remove_dummy_objects", "box_coverage", "boxes_to_layout", "batched_layout",
+    "spectral_weight", "batch_norm_train", "syncbn_multi_replica", "spade", "spade_resblock",
+    "generator_forward", "instance_norm", "nlayer_discriminator", "multiscale_discriminator",
+    "hinge_loss", "gan_loss_multiscale", "generator_losses", "discriminator_losses", "TrainState",
+    "train_step", "make_adam_groups",
+]
+
+ORIGINAL_EDGE, TRANSITIVE_EDGE = 0, 1          # sg2im/data/base_dataset.py:7-8
+
+
+# --------------------------------------------------------------------------- graph encoder
+def attribute_embeddings(state, prefix, objs):
+    """`AttributeEmbeddings.forward` (sg2im/attribute_embed.py:31-48): one table per attribute
+    column, concatenated; the Linear exists iff A > 1 or use_attr_fc_gen (ctor :24-25)."""
+    cols = [F.embedding(objs[..., k], state["%satt_emb_%d.weight" % (prefix, k)])
+            for k in range(objs.shape[-1])]
+    v = torch.cat(cols, dim=-1)
+    wkey = prefix + "attribute_fc_gen.weight"
+    if wkey in state:
+        v = F.linear(v, state[wkey], state[prefix + "attribute_fc_gen.bias"])
+    return v
+
+
+def mlp2(state, prefix, x, final_relu):
+    """`build_mlp([d0,d1,d2])` with mlp_normalization='none' (sg2im/layers.py:6-25):
+    Linear(net.0) ReLU Linear(net.2) [ReLU]."""
+    h = F.relu(F.linear(x, state[prefix + "0.weight"], state[prefix + "0.bias"]))
+    y = F.linear(h, state[prefix + "2.weight"], state[prefix + "2.bias"])
+    return F.relu(y) if final_relu else y
+
+
+def triplet_confidence(w_trans, triplet_type, predicate_ids):
+    """sg2im/graph.py:69-74: 1 for original edges, sigmoid(w[p]) for transitive ones, 0 otherwise."""
+    tt = triplet_type.to(w_trans.dtype)
+    sig = torch.sigmoid(w_trans)
+    return (tt == ORIGINAL_EDGE).to(w_trans.dtype) + (tt == TRANSITIVE_EDGE).to(w_trans.dtype) * sig[predicate_ids]
+
+
+def graph_triple_conv(state, prefix, obj_vecs, pred_vecs, edges, pred_indicators, triplet_type,
+                      predicate_ids, w_trans):
+    """`GraphTripleConv.forward` (sg2im/graph.py:44-113) in batched scatter form.
+
+    The per-sample python loop of :85-107 is replaced by one masked scatter_add per role;
+    SURVEY.md appendix A records that this form is bit-identical on CPU.  Pooling is always an
+    average whose divisor is the SUM OF CONFIDENCES (:101-106); padded triplets
+    (pred_indicators False) still pass through net1 and produce new_p rows (:67, :80)."""
+    B, O, _ = obj_vecs.shape
+    H = state[prefix + "net2.0.weight"].shape[1]                 # hidden_dim
+    Dp = state[prefix + "net1.2.weight"].shape[0] - 2 * H        # predicate_output_dim
+    s_idx, o_idx = edges[..., 0], edges[..., 1]
+    gather = lambda idx: torch.gather(obj_vecs, 1, idx.unsqueeze(-1).expand(-1, -1, obj_vecs.shape[-1]))
+    cur_t = torch.cat([gather(s_idx), pred_vecs, gather(o_idx)], dim=-1)          # :63-66
+    new_t = mlp2(state, prefix + "net1.", cur_t, final_relu=True)                 # :67
+    conf = triplet_confidence(w_trans, triplet_type, predicate_ids)               # :69-74
+    new_t = new_t * conf.unsqueeze(-1)                                            # :76-77
+    new_s, new_p, new_o = new_t[..., :H], new_t[..., H:H + Dp], new_t[..., H + Dp:]
+    valid = pred_indicators.to(new_t.dtype)
+    exp = lambda idx: idx.unsqueeze(-1).expand(-1, -1, H)
+    pooled = torch.zeros(B, O, H, dtype=new_t.dtype)
+    pooled = pooled.scatter_add(1, exp(s_idx), new_s * valid.unsqueeze(-1))       # :98
+    pooled = pooled.scatter_add(1, exp(o_idx), new_o * valid.unsqueeze(-1))       # :99
+    cnt = torch.zeros(B, O, dtype=new_t.dtype)
+    cnt = cnt.scatter_add(1, s_idx, conf * valid).scatter_add(1, o_idx, conf * valid)   # :101-103
+    pooled = torch.where((cnt > 0).unsqueeze(-1), pooled / cnt.clamp_min(1e-38).unsqueeze(-1), pooled)  # :105-106
+    new_obj = mlp2(state, prefix + "net2.", pooled, final_relu=True)              # :110
+    return new_obj, new_p
+
+
+def sg2layout_forward(state, vocab, objs, triplets, triplet_type, prefix=""):
+    """`Sg2LayoutModel.forward` (sg2im/model.py:90-124), mask branch off (mask_size == 0)."""
+    s, p, o = triplets[..., 0], triplets[..., 1], triplets[..., 2]
+    edges = torch.stack([s, o], dim=-1)
+    pred_indicators = p != vocab["pred_name_to_idx"]["__padding__"]                # :107
+    obj_vecs = attribute_embeddings(state, prefix + "attribute_embedding.", objs)  # :108
+    pred_vecs = F.embedding(p, state[prefix + "pred_embeddings.weight"])           # :109
+    w_trans = state[prefix + "trans_candidates_weights"]
+    i = 0
+    while (prefix + "gconvs.%d.net1.0.weight" % i) in state:                       # :111-112
+        obj_vecs, pred_vecs = graph_triple_conv(state, prefix + "gconvs.%d." % i, obj_vecs, pred_vecs,
+                                                edges, pred_indicators, triplet_type, p, w_trans)
+        i += 1
+    boxes_pred = mlp2(state, prefix + "box_net.", obj_vecs, final_relu=False)      # :115
+    return obj_vecs, boxes_pred, None
+
+
+# --------------------------------------------------------------------------- layout
+def remove_dummy_objects(objs_one, vocab):
+    """sg2im/utils.py:56-63 — real objects of ONE sample; only attribute column 0 is tested."""
+    col = objs_one[:, 0]
+    return (col != 0) & (col != vocab["object_name_to_idx"]["__image__"])
+
+
+def box_coverage(lo, size, n):
+    """Separable weight of one box along one axis, (O,n).
+
+    Closed form of `_boxes_to_grid` (sg2im/layout.py:80-112) followed by
+    `F.grid_sample(bilinear, zeros, align_corners=False)` of a CONSTANT 8-pixel line
+    (layout.py:34-35): pixel centres t=linspace(0,1,n); g=2*(t-lo)/size-1;
+    ix=((g+1)*8-1)/2; weight = (1-frac)*[0<=i0<=7] + frac*[0<=i0+1<=7]."""
+    t = torch.linspace(0, 1, steps=n, dtype=lo.dtype).view(1, n)
+    g = ((t - lo.view(-1, 1)) / size.view(-1, 1)).mul(2).sub(1)
+    ix = ((g + 1) * 8 - 1) / 2
+    i0 = torch.floor(ix)
+    fr = ix - i0
+    in0 = ((i0 >= 0) & (i0 <= 7)).to(lo.dtype)
+    in1 = ((i0 + 1 >= 0) & (i0 + 1 <= 7)).to(lo.dtype)
+    return (1 - fr) * in0 + fr * in1
+
+
+def boxes_to_layout(vecs, boxes, H, W=None):
+    """`boxes_to_layout` (sg2im/layout.py:12-45) -> (1,D,H,W); boxes are [x0,y0,w,h] (:95-96).
+    grid_sample of a constant image factorises: sampled[o,d,h,w] = vec[o,d]*cy[o,h]*cx[o,w];
+    `_pool_samples` (:156-188) sums objects (obj_to_img is all zeros)."""
+    W = H if W is None else W
+    cx = box_coverage(boxes[:, 0], boxes[:, 2], W)
+    cy = box_coverage(boxes[:, 1], boxes[:, 3], H)
+    out = torch.zeros(vecs.shape[1], H, W, dtype=vecs.dtype)
+    for o in range(vecs.shape[0]):                  # index order, like scatter_add on CPU
+        out = out + vecs[o].view(-1, 1, 1) * (cy[o].view(1, H, 1) * cx[o].view(1, 1, W))
+    return out.unsqueeze(0)
+
+
+def batched_layout(obj_vecs, objs, boxes, vocab, H):
+    """The per-sample loop of spade/models/networks/generator.py:82-96 and discriminator.py:102-119."""
+    segs = []
+    for b in range(obj_vecs.shape[0]):
+        m = remove_dummy_objects(objs[b], vocab)
+        segs.append(boxes_to_layout(obj_vecs[b][m], boxes[b][m], H, H))
+    return torch.cat(segs, dim=0)
+
+
+# --------------------------------------------------------------------------- generator
+def spectral_weight(state, prefix, training, eps=1e-12):
+    """torch.nn.utils.spectral_norm pre-forward hook (call sites architecture.py:36-39,
+    normalization.py:27): one power iteration per TRAINING-mode call on W.view(out,-1);
+    u,v buffers persist (updated in place); W_eff = W_orig / (u^T W v)."""
+    w = state[prefix + "weight_orig"]
+    u, v = state[prefix + "weight_u"], state[prefix + "weight_v"]
+    wm = w.reshape(w.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps))
+            u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=eps))
+    sigma = torch.dot(u.clone(), torch.mv(wm, v.clone()))
+    return w / sigma
+
+
+def batch_norm_train(x, running_mean, running_var, nbt, training, momentum=0.1, eps=1e-5):
+    """1-device path of `_SynchronizedBatchNorm.forward` (sync_batchnorm/batchnorm.py:65-68) =
+    F.batch_norm(affine=False): biased variance + eps inside the sqrt; running_var unbiased.
+    `num_batches_tracked` is NOT advanced: that forward bypasses `_BatchNorm.forward`."""
+    return F.batch_norm(x, running_mean, running_var, None, None, training, momentum, eps)
+
+
+def syncbn_multi_replica(x_shards, running_mean, running_var, momentum=0.1, eps=1e-5):
+    """N-device path (batchnorm.py:70-93, 128-145): sum and square-sum over all replicas,
+    mean = S/n, var_b = (SS - S*mean)/n, inv_std = clamp(var_b, eps)^-1/2 (CLAMP, not +eps),
+    running_var from the unbiased variance.  Returns the per-shard outputs."""
+    C = x_shards[0].shape[1]
+    n = sum(x.shape[0] * x[0, 0].numel() for x in x_shards)
+    S = sum(x.transpose(0, 1).reshape(C, -1).sum(1) for x in x_shards)
+    SS = sum((x.transpose(0, 1).reshape(C, -1) ** 2).sum(1) for x in x_shards)
+    mean = S / n
+    sumvar = SS - S * mean
+    with torch.no_grad():
+        running_mean.mul_(1 - momentum).add_(momentum * mean.detach())
+        running_var.mul_(1 - momentum).add_(momentum * (sumvar / (n - 1)).detach())
+    inv_std = (sumvar / n).clamp(eps) ** -0.5
+    return [(x - mean.view(1, C, 1, 1)) * inv_std.view(1, C, 1, 1) for x in x_shards]
+
+
+def spade(state, prefix, x, seg, training):
+    """`SPADE.forward` (spade/models/networks/normalization.py:96-110)."""
+    normalized = batch_norm_train(x, state[prefix + "param_free_norm.running_mean"],
+                                  state[prefix + "param_free_norm.running_var"],
+                                  state.get(prefix + "param_free_norm.num_batches_tracked"), training)
+    segr = F.interpolate(seg, size=x.shape[2:], mode="nearest")                               # :102
+    actv = F.relu(F.conv2d(segr, state[prefix + "mlp_shared.0.weight"], state[prefix + "mlp_shared.0.bias"],
+                           padding=1))                                                        # :103
+    gamma = F.conv2d(actv, state[prefix + "mlp_gamma.weight"], state[prefix + "mlp_gamma.bias"], padding=1)
+    beta = F.conv2d(actv, state[prefix + "mlp_beta.weight"], state[prefix + "mlp_beta.bias"], padding=1)
+    return normalized * (1 + gamma) + beta                                                    # :108
+
+
+def spade_resblock(state, prefix, x, seg, training):
+    """`SPADEResnetBlock.forward` (spade/models/networks/architecture.py:50-68)."""
+    if (prefix + "conv_s.weight_orig") in state:                                              # learned shortcut
+        w_s = spectral_weight(state, prefix + "conv_s.", training)
+        x_s = F.conv2d(spade(state, prefix + "norm_s.", x, seg, training), w_s)               # :60-61
+    else:
+        x_s = x
+    w0 = spectral_weight(state, prefix + "conv_0.", training)
+    dx = F.conv2d(F.leaky_relu(spade(state, prefix + "norm_0.", x, seg, training), 0.2), w0,
+                  state[prefix + "conv_0.bias"], padding=1)                                   # :53
+    w1 = spectral_weight(state, prefix + "conv_1.", training)
+    dx = F.conv2d(F.leaky_relu(spade(state, prefix + "norm_1.", dx, seg, training), 0.2), w1,
+                  state[prefix + "conv_1.bias"], padding=1)                                   # :54
+    return x_s + dx
+
+
+def generator_forward(state, vocab, image_size, objs, layout_boxes, training=True, prefix="",
+                      num_upsampling_layers="normal"):
+    """`SPADEGenerator.forward` (spade/models/networks/generator.py:79-127), boxes layout."""
+    H = image_size
+    n_up = {"normal": 5, "more": 6, "most": 7}[num_upsampling_layers]                         # :64-77
+    sw = H // (2 ** n_up)
+    obj_vecs = attribute_embeddings(state, prefix + "attribute_embedding.", objs)             # :80
+    seg = batched_layout(obj_vecs, objs, layout_boxes, vocab, H)                              # :82-96
+    x = F.interpolate(seg, size=(sw, sw))                                                     # :99
+    x = F.conv2d(x, state[prefix + "fc.weight"], state[prefix + "fc.bias"], padding=1)        # :100
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    x = spade_resblock(state, prefix + "head_0.", x, seg, training)
+    x = up(x)
+    x = spade_resblock(state, prefix + "G_middle_0.", x, seg, training)
+    if num_upsampling_layers in ("more", "most"):
+        x = up(x)
+    x = spade_resblock(state, prefix + "G_middle_1.", x, seg, training)
+    for name in ("up_0.", "up_1.", "up_2.", "up_3."):
+        x = up(x)
+        x = spade_resblock(state, prefix + name, x, seg, training)
+    if num_upsampling_layers == "most":
+        x = up(x)
+        x = spade_resblock(state, prefix + "up_4.", x, seg, training)
+    x = F.conv2d(F.leaky_relu(x, 0.2), state[prefix + "conv_img.weight"], state[prefix + "conv_img.bias"],
+                 padding=1)                                                                   # :123
+    return torch.tanh(x)                                                                      # :124
+
+
+# --------------------------------------------------------------------------- discriminator
+def instance_norm(x, eps=1e-5):
+    """nn.InstanceNorm2d(affine=False) (normalization.py:44)."""
+    return F.instance_norm(x, eps=eps)
+
+
+def nlayer_discriminator(state, prefix, x, training):
+    """`NLayerDiscriminator.forward` (spade/models/networks/discriminator.py:164-206): conv4x4 s2
+    p2 + LReLU; (n_layers-1) x [SN-conv4x4 (no bias) + IN + LReLU], last of them stride 1;
+    conv4x4 -> 1.  Returns every block output (feature matching)."""
+    outs = []
+    h = F.leaky_relu(F.conv2d(x, state[prefix + "model0.0.weight"], state[prefix + "model0.0.bias"],
+                              stride=2, padding=2), 0.2)
+    outs.append(h)
+    n = 1
+    while (prefix + "model%d.0.0.weight_orig" % n) in state:
+        last = (prefix + "model%d.0.0.weight_orig" % (n + 1)) not in state
+        w = spectral_weight(state, prefix + "model%d.0.0." % n, training)
+        h = F.leaky_relu(instance_norm(F.conv2d(h, w, None, stride=1 if last else 2, padding=2)), 0.2)
+        outs.append(h)
+        n += 1
+    h = F.conv2d(h, state[prefix + "model%d.0.weight" % n], state[prefix + "model%d.0.bias" % n],
+                 stride=1, padding=2)
+    outs.append(h)
+    return outs
+
+
+def multiscale_discriminator(state, vocab, image_size, img, objs, layout_boxes, training=True, prefix=""):
+    """`MultiscaleDiscriminator.forward` (discriminator.py:97-131): D's own embedding (with fc,
+    :71-72) -> layout -> cat(img, layout) -> num_D scales, avg_pool(3,s2,p1, no pad count) between."""
+    obj_vecs = attribute_embeddings(state, prefix + "attribute_embedding.", objs)
+    seg = batched_layout(obj_vecs, objs, layout_boxes, vocab, image_size)
+    inp = torch.cat([img, seg], dim=1)
+    result, i = [], 0
+    while (prefix + "discriminator_%d.model0.0.weight" % i) in state:
+        result.append(nlayer_discriminator(state, prefix + "discriminator_%d." % i, inp, training))
+        inp = F.avg_pool2d(inp, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)   # :92-93
+        i += 1
+    return result
+
+
+# --------------------------------------------------------------------------- losses
+def hinge_loss(x, target_is_real, for_discriminator):
+    """`GANLoss.loss`, hinge branch (spade/models/networks/loss.py:65-76)."""
+    if for_discriminator:
+        z = torch.zeros_like(x)
+        return -torch.mean(torch.min(x - 1, z)) if target_is_real else -torch.mean(torch.min(-x - 1, z))
+    assert target_is_real
+    return -torch.mean(x)
+
+
+def gan_loss_multiscale(preds, target_is_real, for_discriminator):
+    """`GANLoss.__call__` on the list-of-lists D output (loss.py:78-98): mean over scales of the
+    loss on each scale's LAST map."""
+    return sum(hinge_loss(p[-1], target_is_real, for_discriminator) for p in preds) / len(preds)
+
+
+def generator_losses(opt, d_state, batch, model_out, training=True):
+    """`Pix2PixModel.compute_generator_loss` (sg2im/pix2pix_model.py:65-143) with
+    --no_vgg_loss --use_img_disc 1, mask_size 0."""
+    imgs, objs, boxes = batch[0], batch[1], batch[2]
+    imgs_pred, boxes_pred, _ = model_out
+    H = opt.image_size[0]
+    G = {}
+    if not opt.skip_graph_model:                                                              # :71-85
+        l = F.smooth_l1_loss(boxes_pred.reshape(-1, 4), boxes.reshape(-1, 4), reduction="none") \
+            * opt.bbox_pred_loss_weight
+        flat = objs.reshape(-1, objs.shape[-1])
+        mask = (flat.sum(1, keepdim=True) != 0) if objs.shape[-1] > 1 else (flat != 0)
+        mask = mask.to(torch.float32)
+        l = l * mask
+        G["bbox_pred_all"] = l.view(boxes.shape).sum(dim=[1, 2]) / mask.view(boxes.shape[0], boxes.shape[1]).sum(dim=1)
+        G["bbox_pred"] = G["bbox_pred_all"].mean()
+    if not opt.skip_generation:
+        fake = multiscale_discriminator(d_state, opt.vocab, H, imgs_pred, objs, boxes, training)   # :96
+        G["GAN_Img"] = gan_loss_multiscale(fake, True, False) * opt.discriminator_img_loss_weight
+        if not opt.no_ganFeat_loss:                                                           # :99-109
+            real = multiscale_discriminator(d_state, opt.vocab, H, imgs, objs, boxes, training)
+            feat = torch.zeros(())
+            for i in range(len(fake)):
+                for j in range(len(fake[i]) - 1):
+                    feat = feat + F.l1_loss(fake[i][j], real[i][j].detach()) * opt.lambda_feat / len(fake)
+            G["GAN_Feat"] = feat
+    G["total_loss"] = torch.stack([v for k, v in G.items() if k != "bbox_pred_all"]).sum()    # :141-142
+    return G
+
+
+def discriminator_losses(opt, d_state, batch, model_out, training=True):
+    """`Pix2PixModel.compute_discriminator_loss` (pix2pix_model.py:145-202), use_img_disc 1."""
+    imgs, objs, boxes = batch[0], batch[1], batch[2]
+    imgs_pred = model_out[0].detach()
+    H = opt.image_size[0]
+    fake = multiscale_discriminator(d_state, opt.vocab, H, imgs_pred, objs, boxes, training)   # :159
+    real = multiscale_discriminator(d_state, opt.vocab, H, imgs, objs, boxes, training)        # :161
+    D = {"D_img_fake": gan_loss_multiscale(fake, False, True),
+         "D_img_real": gan_loss_multiscale(real, True, True)}
+    D["total_img_loss"] = D["D_img_fake"] + D["D_img_real"]                                    # :166
+    return D
+
+
+# --------------------------------------------------------------------------- train step
+def make_adam_groups(sg_state, g_state, lr):
+    """Param groups of scripts/train.py:316-322: everything at `lr`, except
+    `trans_candidates_weights` at 1e-2; `converse_candidates_weights` has its own optimizer.
+    Parameters = floating tensors that require grad."""
+    base, trans, seen = [], [], set()
+    trans_id = id(sg_state.get("trans_candidates_weights"))
+    for k, v in list(sg_state.items()) + list(g_state.items()):
+        if not (torch.is_tensor(v) and v.requires_grad) or id(v) in seen:
+            continue
+        if k == "converse_candidates_weights":
+            continue
+        seen.add(id(v))            # the transitive weights are registered under six names (model.py:32,45)
+        (trans if id(v) == trans_id else base).append(v)
+    return [{"params": base, "lr": lr}, {"params": trans, "lr": 1e-2}]
+
+
+class TrainState:
+    """Leaf tensors + optimizers of one replica (what `scripts.train.main` builds at :312-329)."""
+
+    def __init__(self, opt, sg_state, g_state, d_state):
+        self.opt, self.sg, self.g, self.d = opt, sg_state, g_state, d_state
+        self.optimizer = torch.optim.Adam(make_adam_groups(sg_state, g_state, opt.learning_rate))
+        d_params = [v for v in d_state.values() if torch.is_tensor(v) and v.requires_grad]
+        self.optimizer_d_img = torch.optim.Adam(d_params, lr=opt.img_learning_rate,
+                                                betas=(opt.beta1, 0.999))          # meta_models.py:67-69
+
+
+def train_step(ts, batch):
+    """One iteration of scripts/train.py:353-393 (+ :468-485) with use_img_disc=1, no VGG,
+    learned_converse=0.  Returns (G_losses, D_losses, imgs_pred)."""
+    opt = ts.opt
+    imgs, objs, boxes, triplets, _, triplet_type = batch[:6]
+    H = opt.image_size[0]
+    _, boxes_pred, _ = sg2layout_forward(ts.sg, opt.vocab, objs, triplets, triplet_type)      # meta_models.py:43
+    imgs_pred = generator_forward(ts.g, opt.vocab, H, objs, boxes, True,
+                                  num_upsampling_layers=opt.num_upsampling_layers)            # :47-49 (GT boxes)
+    model_out = (imgs_pred, boxes_pred, None)
+    G = generator_losses(opt, ts.d, batch, model_out)                                         # train.py:361
+    ts.optimizer.zero_grad()
+    for v in ts.d.values():
+        if torch.is_tensor(v) and v.grad is not None:
+            v.grad = None
+    G["total_loss"].backward()                                                                # :366-368
+    ts.optimizer.step()
+    D = discriminator_losses(opt, ts.d, batch, model_out)                                     # :390
+    ts.optimizer_d_img.zero_grad()                                                            # :470-472
+    D["total_img_loss"].backward()
+    ts.optimizer_d_img.step()
+    return G, D, imgs_pred.detach()

@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by running the REAL reference on CPU.
+
+Runs only in the build container (needs /root/reference); nothing of the
+reference travels: the outputs are `.npz` files of plain tensors + JSON
+metadata.  Usage:  python tests/golden/make_golden.py
+
+The stub shim below is the one recorded in SURVEY.md appendix A: it satisfies
+imports of packages that are absent here (torchvision, cv2, h5py, ...) and that
+the hot path never executes.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import PIL.Image  # noqa: F401  (sg2im/data/utils.py needs the submodule imported)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Any:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return a[0] if a else None
+
+    def __getattr__(self, n):
+        return _Any
+
+
+_mod("torch.tensor", Tensor=torch.Tensor)
+tv = _mod("torchvision")
+tv.transforms = _mod("torchvision.transforms", Normalize=_Any, Compose=_Any, Resize=_Any, ToTensor=_Any)
+tv.models = _mod("torchvision.models", vgg19=_Any)
+_mod("torchvision.models.inception", inception_v3=_Any)
+_mod("torchvision.utils", save_image=_Any)
+for _n in ("cv2", "h5py", "pycocotools", "pycocotools.mask"):
+    _mod(_n)
+_mod("tensorboardX", SummaryWriter=_Any)
+_mod("imageio", imwrite=_Any)
+
+import warnings  # noqa: E402
+warnings.filterwarnings("ignore")
+
+from scripts.args import parser as ref_parser, init_args as ref_init_args  # noqa: E402  (reference)
+from sg2im.graph import GraphTripleConv, get_predicates_weights  # noqa: E402
+from sg2im.layout import boxes_to_layout  # noqa: E402
+from sg2im.model import Sg2LayoutModel  # noqa: E402
+from sg2im.pix2pix_model import Pix2PixModel  # noqa: E402
+from spade.models.networks.architecture import SPADEResnetBlock  # noqa: E402
+from spade.models.networks.discriminator import MultiscaleDiscriminator  # noqa: E402
+from spade.models.networks.generator import SPADEGenerator  # noqa: E402
+from spade.models.networks.normalization import SPADE  # noqa: E402
+from spade.models.networks.sync_batchnorm import SynchronizedBatchNorm2d  # noqa: E402
+
+from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab  # noqa: E402  (ours: inputs only)
+
+
+def ref_opt(vocab, argv):
+    args = ref_parser.parse_args(argv)
+    args.vocab = vocab
+    args.gpu_ids = "-1"
+    ref_init_args(args)
+    return args
+
+
+def npy(t):
+    return t.detach().cpu().clone().numpy()
+
+
+def sd_np(module, prefix="", skip=()):
+    return {prefix + k: npy(v) for k, v in module.state_dict().items() if not any(s in k for s in skip)}
+
+
+def grads_np(module, prefix="grad:", skip=()):
+    seen, out = {}, {}
+    for k, p in module.named_parameters():
+        if any(s in k for s in skip) or p.grad is None:
+            continue
+        out[prefix + k] = npy(p.grad)
+    return out
+
+
+def save(name, meta, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez(path, __meta__=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
+    print("%-28s %8.1f KB  %d arrays" % (name + ".npz", os.path.getsize(path) / 1024, len(arrays)))
+
+
+# ----------------------------------------------------------------------------- fixtures
+def fx_layout():
+    torch.manual_seed(0)
+    vecs = torch.randn(6, 5, requires_grad=True)
+    boxes = torch.tensor([[0.10, 0.20, 0.50, 0.40],
+                          [0.00, 0.00, 1.00, 1.00],
+                          [0.60, 0.55, 0.35, 0.30],
+                          [0.30, 0.30, 0.07, 0.90],     # thin, runs off the bottom edge
+                          [-0.2, 0.40, 0.60, 0.20],     # starts left of the image
+                          [0.45, 0.05, 0.50, 0.11]], requires_grad=True)
+    arrays = {"vecs": npy(vecs), "boxes": npy(boxes)}
+    for H, W in ((16, 16), (32, 32), (24, 40)):
+        out = boxes_to_layout(vecs, boxes, H, W)
+        w = torch.randn_like(out)
+        gv, gb = torch.autograd.grad((out * w).sum(), [vecs, boxes])
+        tag = "%dx%d" % (H, W)
+        arrays.update({"out_" + tag: npy(out), "w_" + tag: npy(w), "gvecs_" + tag: npy(gv), "gboxes_" + tag: npy(gb)})
+    save("layout", {"sizes": [[16, 16], [32, 32], [24, 40]], "ref": "sg2im/layout.py:12-45"}, **arrays)
+
+
+def _graph_inputs(B, O, T, Din, Dp, P, seed):
+    g = torch.Generator().manual_seed(seed)
+    obj = torch.randn(B, O, Din, generator=g)
+    pred = torch.randn(B, T, Dp, generator=g)
+    edges = torch.randint(0, O, (B, T, 2), generator=g)
+    p = torch.randint(1, P, (B, T), generator=g)
+    tt = torch.randint(0, 4, (B, T), generator=g)
+    p[0, -2:] = 0
+    edges[0, -2:] = 0
+    tt[0, -2:] = 0                                      # padded rows: [0, __padding__, 0], type 0
+    p[1, -1] = 0
+    edges[1, -1] = 0
+    tt[1, -1] = 0
+    edges[:, :, :][edges == O - 1] = 0                  # object O-1 has no incident triplet (count 0)
+    return obj, pred, edges, p, tt
+
+
+def fx_gconv():
+    torch.manual_seed(1)
+    P = 6
+    w_trans = get_predicates_weights(P, "uniform")
+    layer = GraphTripleConv(obj_input_dim=8, object_output_dim=12, predicate_input_dim=6,
+                            predicate_output_dim=10, hidden_dim=16, num_attributes=1,
+                            predicates_transitive_weights=w_trans)
+    obj, pred, edges, p, tt = _graph_inputs(2, 5, 9, 8, 6, P, seed=11)
+    obj.requires_grad_(True)
+    pred.requires_grad_(True)
+    new_obj, new_p = layer(obj, pred, edges, p != 0, tt, p)
+    wo, wp = torch.randn_like(new_obj), torch.randn_like(new_p)
+    ((new_obj * wo).sum() + (new_p * wp).sum()).backward()
+    arrays = sd_np(layer, "sd:")
+    arrays.update(grads_np(layer))
+    arrays.update({"sd:predicates_transitive_weights": npy(w_trans), "grad:predicates_transitive_weights": npy(w_trans.grad),
+                   "obj": npy(obj), "pred": npy(pred), "edges": npy(edges), "p": npy(p), "tt": npy(tt),
+                   "new_obj": npy(new_obj), "new_p": npy(new_p), "wo": npy(wo), "wp": npy(wp),
+                   "gobj": npy(obj.grad), "gpred": npy(pred.grad)})
+    save("gconv", {"ref": "sg2im/graph.py:44-113", "hidden": 16, "dp_out": 10}, **arrays)
+
+
+def fx_sg2layout():
+    for kind, tag in (("tiny", "a1"), ("clevr", "a4")):
+        torch.manual_seed(2)
+        vocab = make_vocab(kind)
+        opt = ref_opt(vocab, ["--embedding_dim", "8", "--gconv_dim", "16", "--gconv_hidden_dim", "24",
+                              "--gconv_num_layers", "3", "--image_size", "32,32"])
+        model = Sg2LayoutModel(opt)
+        batch = make_batch(vocab, BatchConfig(3, 32, 2, 6, "packed"), seed=5)
+        objs, boxes, triplets, tt = batch[1], batch[2], batch[3], batch[5].clone()
+        tt[:, ::3] = 1                                   # some transitive edges
+        tt[triplets[..., 1] == 0] = 0
+        obj_vecs, boxes_pred, _ = model(objs, triplets, tt)
+        wv, wb = torch.randn_like(obj_vecs), torch.randn_like(boxes_pred)
+        ((obj_vecs * wv).sum() + (boxes_pred * wb).sum()).backward()
+        arrays = sd_np(model, "sd:")
+        arrays.update(grads_np(model))
+        arrays.update({"objs": npy(objs), "triplets": npy(triplets), "tt": npy(tt), "obj_vecs": npy(obj_vecs),
+                       "boxes_pred": npy(boxes_pred), "wv": npy(wv), "wb": npy(wb)})
+        save("sg2layout_" + tag, {"ref": "sg2im/model.py:90-124", "vocab": kind,
+                                  "argv": {"embedding_dim": 8, "gconv_dim": 16, "gconv_hidden_dim": 24,
+                                           "gconv_num_layers": 3}}, **arrays)
+
+
+def fx_spade_block():
+    torch.manual_seed(3)
+    vocab = make_vocab("tiny")
+    opt = ref_opt(vocab, ["--embedding_dim", "4", "--image_size", "16,16"])
+    blk = SPADEResnetBlock(12, 6, opt)                   # learned shortcut
+    blk.train()
+    x = torch.randn(2, 12, 8, 8, requires_grad=True)
+    seg = torch.randn(2, 4, 16, 16, requires_grad=True)
+    before = sd_np(blk, "sd:")
+    y = blk(x, seg)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    arrays = dict(before)
+    arrays.update(sd_np(blk, "after:", skip=("weight_orig", "mlp_", "bias")))
+    arrays.update(grads_np(blk))
+    arrays.update({"x": npy(x), "seg": npy(seg), "y": npy(y), "w": npy(w), "gx": npy(x.grad), "gseg": npy(seg.grad)})
+    # second call in eval mode: running stats, no power iteration
+    blk.eval()
+    arrays["y_eval"] = npy(blk(x, seg))
+    save("spade_block", {"ref": "spade/models/networks/architecture.py:50-68", "fin": 12, "fout": 6}, **arrays)
+
+
+def fx_syncbn():
+    torch.manual_seed(4)
+    bn = SynchronizedBatchNorm2d(5, affine=False)
+    xs = [torch.randn(2, 5, 4, 4) * 2 + 1, torch.randn(2, 5, 4, 4) - 3]
+    C = 5
+    n = sum(x.shape[0] * 16 for x in xs)
+    S = sum(x.transpose(0, 1).reshape(C, -1).sum(1) for x in xs)
+    SS = sum((x.transpose(0, 1).reshape(C, -1) ** 2).sum(1) for x in xs)
+    mean, inv_std = bn._compute_mean_std(S, SS, n)       # batchnorm.py:128-145 (the master's reduction)
+    ys = [(x - mean.view(1, C, 1, 1)) * inv_std.view(1, C, 1, 1) for x in xs]
+    # constant channel: variance 0 -> clamp(eps) path
+    save("syncbn", {"ref": "spade/models/networks/sync_batchnorm/batchnorm.py:70-145"},
+         x0=npy(xs[0]), x1=npy(xs[1]), y0=npy(ys[0]), y1=npy(ys[1]), mean=npy(mean), inv_std=npy(inv_std),
+         running_mean=npy(bn.running_mean), running_var=npy(bn.running_var))
+
+
+class _Holder(torch.nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.img_discriminator = d
+
+
+def fx_model_and_step():
+    """Sg2Layout + SPADEGenerator + MultiscaleDiscriminator at 64^2, ngf=2, ndf=4: forward
+    outputs, loss dicts, gradients of the G step, and the state after one full train step
+    (scripts/train.py:353-393 replayed by hand with the reference's own modules)."""
+    torch.manual_seed(7)
+    vocab = make_vocab("tiny")
+    argv = ["--image_size", "64,64", "--embedding_dim", "8", "--gconv_dim", "16", "--gconv_hidden_dim", "24",
+            "--gconv_num_layers", "2", "--ngf", "2", "--ndf", "4", "--no_vgg_loss", "--use_img_disc", "1",
+            "--batch_size", "2"]
+    opt = ref_opt(vocab, argv)
+    sg = Sg2LayoutModel(opt)
+    G = SPADEGenerator(opt)
+    D = MultiscaleDiscriminator(opt)
+    unused = ("repr_net", "image_encoder")               # never used in forward (generator.py:50-62)
+    batch = make_batch(vocab, BatchConfig(2, 64, 2, 5, "packed"), seed=9)
+    imgs, objs, boxes, triplets, _, tt = batch[:6]
+    arrays = {"imgs": npy(imgs), "objs": npy(objs), "boxes": npy(boxes), "triplets": npy(triplets), "tt": npy(tt)}
+    arrays.update(sd_np(sg, "sg:"))
+    arrays.update(sd_np(G, "g:", skip=unused))
+    arrays.update(sd_np(D, "d:", skip=unused))
+
+    gans = Pix2PixModel(opt, discriminator=_Holder(D))
+    sg.train(); G.train(); D.train()
+    trans = [p for n, p in sg.named_parameters() if n == "trans_candidates_weights"]
+    base = [p for n, p in sg.named_parameters() if n not in ("trans_candidates_weights", "converse_candidates_weights")]
+    base += list(G.parameters())
+    optimizer = torch.optim.Adam([{"params": base, "lr": opt.learning_rate}, {"params": trans, "lr": 1e-2}])
+    optimizer_d = torch.optim.Adam(list(D.parameters()), lr=opt.img_learning_rate, betas=(opt.beta1, 0.999))
+
+    # --- forward (meta_models.py:25-51)
+    obj_vecs, boxes_pred, _ = sg(objs, triplets, tt, boxes)
+    imgs_pred = G(objs, boxes, None, test_mode=False)
+    arrays.update({"boxes_pred": npy(boxes_pred), "imgs_pred": npy(imgs_pred)})
+    model_out = (imgs_pred, boxes_pred, None)
+    G_losses = gans(batch, model_out, mode="compute_generator_loss")
+    for k, v in G_losses.items():
+        arrays["G:" + k] = npy(v)
+    G_mean = {k: v.mean() for k, v in G_losses.items()}
+    optimizer.zero_grad()
+    G_mean["total_loss"].backward()
+    for n, p in G.named_parameters():
+        if p.grad is not None and not any(u in n for u in unused):
+            if n.endswith(("conv_img.weight", "fc.weight", "up_3.conv_0.weight_orig", "head_0.norm_0.mlp_gamma.weight",
+                           "up_1.norm_s.mlp_shared.0.weight", "attribute_embedding.att_emb_0.weight")):
+                arrays["ggrad:" + n] = npy(p.grad)
+    for n, p in sg.named_parameters():
+        if p.grad is not None:
+            arrays["sggrad:" + n] = npy(p.grad)
+    optimizer.step()
+    # --- D step (train.py:390-393, :468-472)
+    D_losses = gans(batch, model_out, mode="compute_discriminator_loss")
+    for k, v in D_losses.items():
+        arrays["D:" + k] = npy(v)
+    D_mean = {k: v.mean() for k, v in D_losses.items()}
+    optimizer_d.zero_grad()
+    D_mean["total_img_loss"].backward()
+    for n, p in D.named_parameters():
+        if p.grad is not None and not any(u in n for u in unused):
+            arrays["dgrad:" + n] = npy(p.grad)
+    optimizer_d.step()
+    arrays.update(sd_np(sg, "sg_after:"))
+    arrays.update(sd_np(D, "d_after:", skip=unused))
+    # G after the step: buffers fully, parameters as (sum, abs-sum) checksums + a few tensors
+    for k, v in G.state_dict().items():
+        if any(u in k for u in unused):
+            continue
+        if "running_" in k or "weight_u" in k or "weight_v" in k or "num_batches" in k or \
+                k in ("conv_img.weight", "conv_img.bias", "fc.bias", "up_3.conv_1.weight_orig", "head_0.conv_0.bias"):
+            arrays["g_after:" + k] = npy(v)
+        else:
+            arrays["g_after_sum:" + k] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+    # D features of the real image (layout + concat + both scales) with the post-step weights, eval mode
+    D.eval()
+    with torch.no_grad():
+        feats = D(imgs, objs, boxes)
+    for i, scale in enumerate(feats):
+        for j, f in enumerate(scale):
+            arrays["dfeat_%d_%d" % (i, j)] = npy(f)
+    save("train_step", {"ref": "scripts/train.py:353-393", "argv": argv, "vocab": "tiny",
+                        "note": "use_img_disc=1, no VGG loss, learned_converse=0"}, **arrays)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    fx_layout()
+    fx_gconv()
+    fx_sg2layout()
+    fx_spade_block()
+    fx_syncbn()
+    fx_model_and_step()
