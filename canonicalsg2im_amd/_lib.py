@@ -1,0 +1,129 @@
+"""ctypes binding of libcsg_hip.so (C ABI: include/csg_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc, gfx950).  There is NO fallback:
+if it is missing or a symbol cannot be resolved, importing this module raises, and every op that
+receives a non-HIP tensor raises as well.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsg_hip.so")
+
+MAX_TAPS = 16
+ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
+
+c_i32, c_i64, c_f32, c_f64, c_p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of `csg_conv_desc` (include/csg_hip.h)."""
+    _fields_ = [
+        ("B", c_i32), ("IHp", c_i32), ("IWp", c_i32), ("Cin", c_i32), ("x_cs", c_i32),
+        ("IHv", c_i32), ("IWv", c_i32), ("in_up", c_i32),
+        ("OHg", c_i32), ("OWg", c_i32), ("OHf", c_i32), ("OWf", c_i32), ("os", c_i32), ("ooy", c_i32), ("oox", c_i32),
+        ("Cout", c_i32), ("y_cs", c_i32),
+        ("istride", c_i32), ("ntaps", c_i32), ("wtaps", c_i32),
+        ("tap_dy", c_i32 * MAX_TAPS), ("tap_dx", c_i32 * MAX_TAPS), ("tap_w", c_i32 * MAX_TAPS),
+        ("act", c_i32), ("slope", c_f32), ("accumulate", c_i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/csg_hip.h
+SIGNATURES = {
+    "csg_version": (c_i32, []),
+    "csg_last_error": (ctypes.c_char_p, []),
+    "csg_prof_enable": (c_i32, [c_i32]),
+    "csg_prof_reset": (c_i32, []),
+    "csg_prof_num_kernels": (c_i32, []),
+    "csg_prof_kernel_name": (ctypes.c_char_p, [c_i32]),
+    "csg_prof_read": (c_i32, [c_i32, ctypes.POINTER(c_f64), ctypes.POINTER(c_i64), ctypes.POINTER(c_f64)]),
+    "csg_embed_fwd": (c_i32, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p]),
+    "csg_embed_bwd": (c_i32, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_real_object_mask": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_graph_csr_build": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "csg_gather_concat_fwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_gather_concat_bwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "csg_segment_avg_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p]),
+    "csg_segment_avg_bwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                    c_p, c_p, c_p, c_p]),
+    "csg_layout_fwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p]),
+    "csg_layout_bwd": (c_i32, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
+                               c_i32, c_p]),
+    "csg_conv_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p, c_p, c_p]),
+    "csg_conv_bwd_weight_workspace": (c_i64, [ctypes.POINTER(ConvDesc)]),
+    "csg_conv_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_act_bwd": (c_i32, [c_p, c_p, c_i64, c_i32, c_f32, c_p, c_p]),
+    "csg_colsum": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
+    "csg_norm_stats": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
+    "csg_norm_finalize": (c_i32, [c_p, c_i64, c_i64, c_f64, c_f32, c_i32, c_p, c_p, c_p, c_p, c_f32, c_p]),
+    "csg_norm_apply_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_norm_apply_bwd_reduce": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64,
+                                          c_p]),
+    "csg_norm_apply_bwd_dx": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_f64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_upsample2x_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_upsample2x_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_avgpool3s2_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_avgpool3s2_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libcsg_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "from the repository root; there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.csg_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("libcsg_hip %s failed (%d): %s" % (what, rc, last_error()))
+
+
+def ptr(t):
+    """Device pointer of a HIP tensor (None -> NULL).  CPU tensors are refused: no fallback."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("canonicalsg2im_amd ops need HIP (cuda) tensors; got a %s tensor — there is no CPU path"
+                           % t.device)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---------------------------------------------------------------- per-kernel timing
+def prof_enable(on=True):
+    check(lib.csg_prof_enable(1 if on else 0), "prof_enable")
+
+
+def prof_reset():
+    check(lib.csg_prof_reset(), "prof_reset")
+
+
+def prof_read():
+    """{kernel name: (ms, launches, work)} for kernels that ran."""
+    out = {}
+    for k in range(lib.csg_prof_num_kernels()):
+        ms, n, w = c_f64(), c_i64(), c_f64()
+        check(lib.csg_prof_read(k, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w)), "prof_read")
+        if n.value:
+            out[lib.csg_prof_kernel_name(k).decode()] = (ms.value, n.value, w.value)
+    return out

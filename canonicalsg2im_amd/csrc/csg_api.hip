@@ -1,0 +1,131 @@
+// Version, error text and the per-kernel timing table of libcsg_hip.so.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "csg_common.h"
+
+namespace csg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return CSG_E_LAUNCH;
+  }
+  return CSG_OK;
+}
+
+// ---- timing: a pair of events per launch, resolved lazily in csg_prof_read -------------------
+struct Rec {
+  int kid;
+  double work;
+  hipEvent_t e0, e1;
+};
+static bool g_prof = false;
+static std::mutex g_mu;
+static std::vector<Rec> g_pending;
+static std::vector<hipEvent_t> g_free;
+static double g_ms[K_COUNT];
+static double g_work[K_COUNT];
+static int64_t g_n[K_COUNT];
+static Rec g_cur;
+
+bool prof_on() { return g_prof; }
+
+static hipEvent_t get_event() {
+  if (!g_free.empty()) {
+    hipEvent_t e = g_free.back();
+    g_free.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(int kid, double work, hipStream_t s) {
+  g_mu.lock();
+  g_cur.kid = kid;
+  g_cur.work = work;
+  g_cur.e0 = get_event();
+  g_cur.e1 = get_event();
+  hipEventRecord(g_cur.e0, s);
+}
+
+void prof_end(hipStream_t s) {
+  hipEventRecord(g_cur.e1, s);
+  g_pending.push_back(g_cur);
+  g_mu.unlock();
+}
+
+static void resolve() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& r : g_pending) {
+    hipEventSynchronize(r.e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.e0, r.e1);
+    g_ms[r.kid] += ms;
+    g_work[r.kid] += r.work;
+    g_n[r.kid] += 1;
+    g_free.push_back(r.e0);
+    g_free.push_back(r.e1);
+  }
+  g_pending.clear();
+}
+
+static const char* kNames[K_COUNT] = {
+    "embed_fwd",      "embed_bwd",      "real_object_mask", "graph_csr_build", "gather_concat_fwd", "gather_concat_bwd",
+    "segment_avg_fwd", "segment_avg_bwd", "layout_fwd",       "layout_bwd",      "igemm_fwd",         "igemm_wgrad",
+    "wgrad_reduce",   "act_bwd",        "colsum",           "norm_stats",      "norm_finalize",     "norm_apply_fwd",
+    "norm_bwd_reduce", "norm_bwd_dx",    "upsample2x_fwd",   "upsample2x_bwd",  "avgpool3s2_fwd",    "avgpool3s2_bwd"};
+
+}  // namespace csg
+
+extern "C" {
+
+int csg_version(void) { return 100; }
+const char* csg_last_error(void) { return csg::g_err; }
+
+int csg_prof_enable(int on) {
+  csg::resolve();
+  csg::g_prof = on != 0;
+  return CSG_OK;
+}
+
+int csg_prof_reset(void) {
+  csg::resolve();
+  memset(csg::g_ms, 0, sizeof(csg::g_ms));
+  memset(csg::g_work, 0, sizeof(csg::g_work));
+  memset(csg::g_n, 0, sizeof(csg::g_n));
+  return CSG_OK;
+}
+
+int csg_prof_num_kernels(void) { return csg::K_COUNT; }
+
+const char* csg_prof_kernel_name(int kid) {
+  if (kid < 0 || kid >= csg::K_COUNT) return "";
+  return csg::kNames[kid];
+}
+
+int csg_prof_read(int kid, double* ms, int64_t* launches, double* work) {
+  CSG_REQUIRE(kid >= 0 && kid < csg::K_COUNT, CSG_E_BADSHAPE, "csg_prof_read: bad kernel id %d", kid);
+  csg::resolve();
+  if (ms) *ms = csg::g_ms[kid];
+  if (launches) *launches = csg::g_n[kid];
+  if (work) *work = csg::g_work[kid];
+  return CSG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+// K6 — boxes_to_layout as ONE pass over the output (reference: sg2im/layout.py:12-45,80-112,
+// 156-188; called per sample from spade/models/networks/generator.py:82-96 and
+// discriminator.py:102-119).
+//
+// The reference materialises grid_sample(constant (O,D,8,8) image) = an (O,D,H,W) tensor and
+// scatter_adds it: O times the output in HBM traffic.  grid_sample of a constant image with zero
+// padding factorises into a separable coverage weight, so
+//     layout[b,y,x,d] = sum_o vec[b,o,d] * cy[o,y] * cx[o,x]        (objects in index order)
+// and the kernel writes each output byte exactly once (HBM-bound: S*H*W*4 bytes per image).
+// Output is NHWC; it may be a channel slice of a wider buffer (the discriminator's input), and it
+// may be a nearest-neighbour down-sampled view (the SPADE seg pyramid).
+#include "csg_common.h"
+
+using namespace csg;
+
+// torch.linspace(0,1,n)[i] exactly as ATen evaluates it (symmetric halves)
+__device__ __forceinline__ float lin01(int i, int n) {
+  if (n <= 1) return 0.f;
+  float step = 1.0f / (float)(n - 1);
+  return (i < n / 2) ? (float)i * step : 1.0f - (float)(n - 1 - i) * step;
+}
+
+// coverage of one box along one axis at pixel-centre coordinate t (see oracle/functional.py
+// box_coverage): _boxes_to_grid (layout.py:98-110) then bilinear grid_sample, align_corners=False,
+// zeros padding, on an 8-pixel constant line.
+__device__ __forceinline__ float coverage(float t, float lo, float size) {
+  float g = ((t - lo) / size) * 2.0f - 1.0f;
+  float ix = ((g + 1.0f) * 8.0f - 1.0f) / 2.0f;
+  float i0 = floorf(ix);
+  float fr = ix - i0;
+  float w0 = (i0 >= 0.0f && i0 <= 7.0f) ? (1.0f - fr) : 0.0f;
+  float w1 = (i0 + 1.0f >= 0.0f && i0 + 1.0f <= 7.0f) ? fr : 0.0f;
+  return w0 + w1;
+}
+
+#define LAY_OB 32    // objects per LDS batch
+#define LAY_PXC 256  // max pixels per block chunk
+#define LAY_EPT 8    // float4 elements per thread
+
+__global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ vecs, const float* __restrict__ boxes,
+                                                     const uint8_t* __restrict__ valid, int O, int S, int H, int W,
+                                                     int OH, int OW, int pxc, float* __restrict__ out, int out_cs,
+                                                     int out_off) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_wx = sm;                       // [LAY_OB][pxc]
+  float* s_vec = sm + LAY_OB * pxc;       // [LAY_OB][S]
+  float* s_wy = s_vec + LAY_OB * S;       // [LAY_OB]
+  int* s_act = (int*)(s_wy + LAY_OB);     // [LAY_OB] object index of each active slot
+  int* s_n = s_act + LAY_OB;              // [1]
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * pxc;
+  const int npx = min(pxc, OW - x0);
+  const int qpp = S >> 2;
+  const int nel = npx * qpp;
+  const int ysrc = min((int)(((int64_t)y * H) / OH), H - 1);
+  const float ty = lin01(ysrc, H);
+
+  float4 acc[LAY_EPT];
+  int eq[LAY_EPT], ex[LAY_EPT];
+#pragma unroll
+  for (int i = 0; i < LAY_EPT; ++i) {
+    acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = tid + 256 * i;
+    ex[i] = e / qpp;
+    eq[i] = e - ex[i] * qpp;
+  }
+  const float* bx = boxes + (int64_t)b * O * 4;
+  const uint8_t* vb = valid + (int64_t)b * O;
+  const float* vv = vecs + (int64_t)b * O * S;
+
+  for (int ob = 0; ob < O; ob += LAY_OB) {
+    __syncthreads();
+    if (tid < 64) {  // wave 0: row coverage + ordered compaction of the active objects
+      int o = ob + tid;
+      float wy = 0.f;
+      bool act = false;
+      if (tid < LAY_OB && o < O && vb[o]) {
+        wy = coverage(ty, bx[o * 4 + 1], bx[o * 4 + 3]);
+        act = (wy != 0.0f);
+      }
+      unsigned long long m = __ballot(act);
+      int slot = __popcll(m & ((1ull << tid) - 1ull));
+      if (act) {
+        s_wy[slot] = wy;
+        s_act[slot] = o;
+      }
+      if (tid == 0) *s_n = __popcll(m);
+    }
+    __syncthreads();
+    const int nact = *s_n;
+    if (nact == 0) continue;
+    for (int i = tid; i < nact * npx; i += 256) {
+      int a = i / npx, xl = i - a * npx;
+      int o = s_act[a];
+      int xsrc = min((int)(((int64_t)(x0 + xl) * W) / OW), W - 1);
+      s_wx[a * pxc + xl] = coverage(lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]);
+    }
+    for (int i = tid; i < nact * S; i += 256) {
+      int a = i / S, d = i - a * S;
+      s_vec[a * S + d] = vv[(int64_t)s_act[a] * S + d];
+    }
+    __syncthreads();
+    for (int a = 0; a < nact; ++a) {
+      const float wy = s_wy[a];
+#pragma unroll
+      for (int i = 0; i < LAY_EPT; ++i) {
+        if (tid + 256 * i < nel) {
+          float w = wy * s_wx[a * pxc + ex[i]];
+          float4 v = *(const float4*)&s_vec[a * S + eq[i] * 4];
+          acc[i].x += v.x * w;
+          acc[i].y += v.y * w;
+          acc[i].z += v.z * w;
+          acc[i].w += v.w * w;
+        }
+      }
+    }
+  }
+  float* orow = out + ((int64_t)(b * OH + y) * OW + x0) * out_cs + out_off;
+#pragma unroll
+  for (int i = 0; i < LAY_EPT; ++i) {
+    if (tid + 256 * i < nel) *(float4*)&orow[(int64_t)ex[i] * out_cs + eq[i] * 4] = acc[i];
+  }
+}
+
+// One block per (object, image): reduce dout over the box's support only.
+__global__ __launch_bounds__(256) void k_layout_bwd(const float* __restrict__ dout, int out_cs, int out_off,
+                                                     const float* __restrict__ boxes,
+                                                     const uint8_t* __restrict__ valid, int O, int S, int H, int W,
+                                                     int OH, int OW, float* __restrict__ dvecs, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_wy = sm;            // [OH]
+  float* s_wx = sm + OH;       // [OW]
+  int* s_rng = (int*)(s_wx + OW);  // ylo, yhi, xlo, xhi
+  float* s_red = sm + (((OH + OW + 4) + 3) & ~3);  // [npl][S], 16-byte aligned
+  const int tid = threadIdx.x;
+  const int o = blockIdx.x, b = blockIdx.y;
+  float* dv = dvecs + ((int64_t)b * O + o) * S;
+  if (!valid[(int64_t)b * O + o]) {
+    if (!accumulate)
+      for (int d = tid; d < S; d += 256) dv[d] = 0.f;
+    return;
+  }
+  const float* bx = boxes + ((int64_t)b * O + o) * 4;
+  const float x0 = bx[0], y0 = bx[1], ww = bx[2], hh = bx[3];
+  if (tid < 4) s_rng[tid] = (tid & 1) ? -1 : (1 << 30);
+  __syncthreads();
+  for (int y = tid; y < OH; y += 256) {
+    int ysrc = min((int)(((int64_t)y * H) / OH), H - 1);
+    float w = coverage(lin01(ysrc, H), y0, hh);
+    s_wy[y] = w;
+    if (w != 0.f) {
+      atomicMin(&s_rng[0], y);
+      atomicMax(&s_rng[1], y);
+    }
+  }
+  for (int x = tid; x < OW; x += 256) {
+    int xsrc = min((int)(((int64_t)x * W) / OW), W - 1);
+    float w = coverage(lin01(xsrc, W), x0, ww);
+    s_wx[x] = w;
+    if (w != 0.f) {
+      atomicMin(&s_rng[2], x);
+      atomicMax(&s_rng[3], x);
+    }
+  }
+  __syncthreads();
+  const int ylo = s_rng[0], yhi = s_rng[1], xlo = s_rng[2], xhi = s_rng[3];
+  const int qpp = S >> 2;
+  const int npl = 256 / qpp;
+  const int q = tid % qpp, pl = tid / qpp;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (yhi >= ylo && xhi >= xlo && pl < npl) {
+    const int nx = xhi - xlo + 1, npix = (yhi - ylo + 1) * nx;
+    const float* base = dout + (int64_t)b * OH * OW * out_cs + out_off + q * 4;
+    for (int i = pl; i < npix; i += npl) {
+      int yy = i / nx;
+      int xx = xlo + (i - yy * nx);
+      yy += ylo;
+      float w = s_wy[yy] * s_wx[xx];
+      float4 g = *(const float4*)&base[((int64_t)yy * OW + xx) * out_cs];
+      acc.x += g.x * w;
+      acc.y += g.y * w;
+      acc.z += g.z * w;
+      acc.w += g.w * w;
+    }
+  }
+  if (pl < npl) *(float4*)&s_red[pl * S + q * 4] = acc;
+  __syncthreads();
+  for (int d = tid; d < S; d += 256) {
+    float t = 0.f;
+    for (int p = 0; p < npl; ++p) t += s_red[p * S + d];
+    dv[d] = accumulate ? dv[d] + t : t;
+  }
+}
+
+extern "C" {
+
+int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, int64_t B, int64_t O, int64_t S,
+                   int64_t H, int64_t W, int64_t OH, int64_t OW, float* out, int64_t out_cs, int64_t out_off,
+                   void* stream) {
+  CSG_REQUIRE(B > 0 && O >= 0 && S > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, CSG_E_BADSHAPE,
+              "csg_layout_fwd: bad shape");
+  CSG_REQUIRE(S % 4 == 0 && out_cs % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)out % 16) == 0, CSG_E_UNSUPPORTED,
+              "csg_layout_fwd: S=%ld, out_cs=%ld, out_off=%ld must be multiples of 4 (16-byte rows)", (long)S,
+              (long)out_cs, (long)out_off);
+  CSG_REQUIRE(S <= 1024 && OH <= 65535 && B <= 65535, CSG_E_UNSUPPORTED, "csg_layout_fwd: S/OH/B too large");
+  hipStream_t s = (hipStream_t)stream;
+  const int qpp = (int)(S / 4);
+  int pxc = (LAY_EPT * 256) / qpp;
+  if (pxc > LAY_PXC) pxc = LAY_PXC;
+  if (pxc > OW) pxc = (int)OW;
+  CSG_REQUIRE(pxc >= 1, CSG_E_UNSUPPORTED, "csg_layout_fwd: S too large for one chunk");
+  size_t shm = (size_t)(LAY_OB * pxc + LAY_OB * S + LAY_OB) * 4 + (LAY_OB + 4) * 4;
+  ProfScope p(K_LAYOUT_FWD, (double)B * OH * OW * S * 4, s);  // algorithmic bytes: the output, once
+  dim3 grid((unsigned)cdiv(OW, pxc), (unsigned)OH, (unsigned)B);
+  hipLaunchKernelGGL(k_layout_fwd, grid, dim3(256), shm, s, vecs, boxes, valid, (int)O, (int)S, (int)H, (int)W,
+                     (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off);
+  return check_launch("csg_layout_fwd");
+}
+
+int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,
+                   int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* dvecs,
+                   int accumulate, void* stream) {
+  CSG_REQUIRE(B > 0 && O >= 0 && S > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, CSG_E_BADSHAPE,
+              "csg_layout_bwd: bad shape");
+  CSG_REQUIRE(S % 4 == 0 && out_cs % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)dout % 16) == 0, CSG_E_UNSUPPORTED,
+              "csg_layout_bwd: S, out_cs, out_off must be multiples of 4");
+  CSG_REQUIRE(S <= 1024 && OH <= 4096 && OW <= 4096 && B <= 65535, CSG_E_UNSUPPORTED, "csg_layout_bwd: too large");
+  if (O == 0) return CSG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int qpp = (int)(S / 4);
+  const int npl = 256 / qpp;
+  CSG_REQUIRE(npl >= 1, CSG_E_UNSUPPORTED, "csg_layout_bwd: S too large");
+  size_t shm = (size_t)(((OH + OW + 4) + 3) & ~3) * 4 + (size_t)npl * S * 4;
+  ProfScope p(K_LAYOUT_BWD, (double)B * OH * OW * S * 4, s);
+  hipLaunchKernelGGL(k_layout_bwd, dim3((unsigned)O, (unsigned)B), dim3(256), shm, s, dout, (int)out_cs, (int)out_off,
+                     boxes, valid, (int)O, (int)S, (int)H, (int)W, (int)OH, (int)OW, dvecs, accumulate);
+  return check_launch("csg_layout_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,466 @@
+// K9/K11 — normalisation statistics, SPADE modulation, LeakyReLU, and the small NHWC
+// resampling kernels (K7, avg-pool).  All HBM-bound streaming kernels: 16-byte accesses per lane,
+// channel-fastest NHWC, deterministic two-stage reductions (fp32 partials per pixel chunk,
+// combined in fp64) so that results are bit-reproducible and SyncBN can all-reduce one small
+// message per norm.
+//
+// Reference: sync_batchnorm/batchnorm.py:63-93,128-145 (statistics), normalization.py:96-110
+// (SPADE), architecture.py:53-54,67-68 (LeakyReLU), normalization.py:44 +
+// discriminator.py:181-185 (InstanceNorm + LeakyReLU), generator.py:48 (nearest 2x),
+// discriminator.py:92-93 (avg_pool2d 3/2/1 without pad count).
+#include "csg_common.h"
+
+using namespace csg;
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
+__device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+__device__ __forceinline__ float lrelu_g(float pre, float s) { return pre > 0.f ? 1.f : s; }
+
+// --------------------------------------------------------------------------------- statistics
+// grid (nchunk, G); partial[(g*nchunk + chunk)*2C + {c | C + c}] = {sum x, sum x^2} over the chunk
+__global__ __launch_bounds__(256) void k_norm_stats_partial(const float* __restrict__ x, int64_t P, int C,
+                                                             int64_t x_cs, int nchunk, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [R][Qc][8]
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, g = blockIdx.y;
+  const int64_t per = (P + nchunk - 1) / nchunk;
+  const int64_t p0 = chunk * per, p1 = min(P, p0 + per);
+  const int Q = C >> 2;
+  float* out = partial + ((int64_t)g * nchunk + chunk) * 2 * C;
+  for (int qb = 0; qb < Q; qb += 256) {
+    const int Qc = min(256, Q - qb);
+    const int R = 256 / Qc;
+    const int q = tid % Qc, rr = tid / Qc;
+    float4 s = f4(0.f), ss = f4(0.f);
+    if (rr < R) {
+      const float* xp = x + ((int64_t)g * P) * x_cs + (qb + q) * 4;
+      for (int64_t p = p0 + rr; p < p1; p += R) {
+        float4 v = ld4(xp + p * x_cs);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
+      }
+      st4(&sm[(rr * Qc + q) * 8], s);
+      st4(&sm[(rr * Qc + q) * 8 + 4], ss);
+    }
+    __syncthreads();
+    if (tid < Qc) {
+      float4 a = f4(0.f), b = f4(0.f);
+      for (int r = 0; r < R; ++r) {
+        float4 u = ld4(&sm[(r * Qc + tid) * 8]), v = ld4(&sm[(r * Qc + tid) * 8 + 4]);
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+      }
+      st4(&out[(qb + tid) * 4], a);
+      st4(&out[C + (qb + tid) * 4], b);
+    }
+    __syncthreads();
+  }
+}
+
+// sums[g][j] = sum over chunks (fp64), j in [0, 2C)
+__global__ void k_partial_to_sums(const float* __restrict__ partial, int G, int C2, int nchunk,
+                                  double* __restrict__ sums) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C2) return;
+  int g = i / C2, j = i - g * C2;
+  double a = 0.0;
+  for (int c = 0; c < nchunk; ++c) a += (double)partial[((int64_t)g * nchunk + c) * C2 + j];
+  sums[i] = a;
+}
+
+__global__ void k_partial_to_colsum(const float* __restrict__ partial, int C, int nchunk, float* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0;
+  for (int k = 0; k < nchunk; ++k) a += (double)partial[(int64_t)k * 2 * C + c];
+  out[c] = (float)a;
+}
+
+__global__ void k_norm_finalize(const double* __restrict__ sums, int G, int C, double count, float eps, int mode,
+                                float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
+                                float* __restrict__ rvar, float momentum) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  int g = i / C, c = i - g * C;
+  double S = sums[(int64_t)g * 2 * C + c], SS = sums[(int64_t)g * 2 * C + C + c];
+  double m = S / count;
+  double var = (SS - S * m) / count;
+  if (var < 0.0) var = 0.0;
+  float fv = (float)var;
+  float is = (mode == 1) ? 1.0f / sqrtf(fmaxf(fv, eps)) : 1.0f / sqrtf(fv + eps);
+  mean[i] = (float)m;
+  invstd[i] = is;
+  if (rmean != nullptr && g == 0) {
+    double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)m;
+    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
+// --------------------------------------------------------------------------------- apply fwd
+__global__ __launch_bounds__(256) void k_norm_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd,
+                                                         const float* __restrict__ gb, float slope, int64_t P, int C,
+                                                         int64_t n4, float* __restrict__ y) {
+  const int Q = C >> 2;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = e / Q;
+    const int q = (int)(e - pix * Q);
+    const int64_t g = pix / P;
+    float4 v = ld4(x + e * 4);
+    const float4 m = ld4(mean + g * C + q * 4), r = ld4(invstd + g * C + q * 4);
+    v.x = (v.x - m.x) * r.x; v.y = (v.y - m.y) * r.y; v.z = (v.z - m.z) * r.z; v.w = (v.w - m.w) * r.w;
+    if (gb != nullptr) {
+      const float4 ga = ld4(gb + pix * 2 * C + q * 4), be = ld4(gb + pix * 2 * C + C + q * 4);
+      v.x = v.x * (1.f + ga.x) + be.x; v.y = v.y * (1.f + ga.y) + be.y;
+      v.z = v.z * (1.f + ga.z) + be.z; v.w = v.w * (1.f + ga.w) + be.w;
+    }
+    if (slope != 1.0f) { v.x = lrelu(v.x, slope); v.y = lrelu(v.y, slope); v.z = lrelu(v.z, slope); v.w = lrelu(v.w, slope); }
+    st4(y + e * 4, v);
+  }
+}
+
+// --------------------------------------------------------------------------------- apply bwd
+// pass 1: dgb = [dpre * xhat | dpre], partial sums of dn and dn*xhat (same tiling as the stats kernel)
+__global__ __launch_bounds__(256) void k_norm_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd,
+                                                          const float* __restrict__ gb, float slope, int64_t P, int C,
+                                                          int nchunk, float* __restrict__ dgb,
+                                                          float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, g = blockIdx.y;
+  const int64_t per = (P + nchunk - 1) / nchunk;
+  const int64_t p0 = chunk * per, p1 = min(P, p0 + per);
+  const int Q = C >> 2;
+  float* out = partial + ((int64_t)g * nchunk + chunk) * 2 * C;
+  for (int qb = 0; qb < Q; qb += 256) {
+    const int Qc = min(256, Q - qb);
+    const int R = 256 / Qc;
+    const int q = tid % Qc, rr = tid / Qc;
+    float4 s = f4(0.f), ss = f4(0.f);
+    if (rr < R) {
+      const int co = (qb + q) * 4;
+      const float4 m = ld4(mean + (int64_t)g * C + co), r = ld4(invstd + (int64_t)g * C + co);
+      for (int64_t p = p0 + rr; p < p1; p += R) {
+        const int64_t pix = (int64_t)g * P + p;
+        const float4 xv = ld4(x + pix * C + co);
+        float4 d = ld4(dy + pix * C + co);
+        float4 xh = make_float4((xv.x - m.x) * r.x, (xv.y - m.y) * r.y, (xv.z - m.z) * r.z, (xv.w - m.w) * r.w);
+        float4 dn = d;
+        if (gb != nullptr) {
+          const float4 ga = ld4(gb + pix * 2 * C + co), be = ld4(gb + pix * 2 * C + C + co);
+          if (slope != 1.0f) {
+            d.x *= lrelu_g(xh.x * (1.f + ga.x) + be.x, slope); d.y *= lrelu_g(xh.y * (1.f + ga.y) + be.y, slope);
+            d.z *= lrelu_g(xh.z * (1.f + ga.z) + be.z, slope); d.w *= lrelu_g(xh.w * (1.f + ga.w) + be.w, slope);
+          }
+          st4(dgb + pix * 2 * C + co, make_float4(d.x * xh.x, d.y * xh.y, d.z * xh.z, d.w * xh.w));
+          st4(dgb + pix * 2 * C + C + co, d);
+          dn = make_float4(d.x * (1.f + ga.x), d.y * (1.f + ga.y), d.z * (1.f + ga.z), d.w * (1.f + ga.w));
+        } else if (slope != 1.0f) {
+          dn.x *= lrelu_g(xh.x, slope); dn.y *= lrelu_g(xh.y, slope); dn.z *= lrelu_g(xh.z, slope); dn.w *= lrelu_g(xh.w, slope);
+        }
+        s.x += dn.x; s.y += dn.y; s.z += dn.z; s.w += dn.w;
+        ss.x += dn.x * xh.x; ss.y += dn.y * xh.y; ss.z += dn.z * xh.z; ss.w += dn.w * xh.w;
+      }
+      st4(&sm[(rr * Qc + q) * 8], s);
+      st4(&sm[(rr * Qc + q) * 8 + 4], ss);
+    }
+    __syncthreads();
+    if (tid < Qc) {
+      float4 a = f4(0.f), b = f4(0.f);
+      for (int r = 0; r < R; ++r) {
+        float4 u = ld4(&sm[(r * Qc + tid) * 8]), v = ld4(&sm[(r * Qc + tid) * 8 + 4]);
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+      }
+      st4(&out[(qb + tid) * 4], a);
+      st4(&out[C + (qb + tid) * 4], b);
+    }
+    __syncthreads();
+  }
+}
+
+// pass 2: dx = invstd * (dn - mean(dn) - xhat * mean(dn*xhat))
+__global__ __launch_bounds__(256) void k_norm_bwd_dx(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gb, float slope,
+                                                      const double* __restrict__ dsums, double inv_count, int64_t P,
+                                                      int C, int64_t n4, float* __restrict__ dx) {
+  const int Q = C >> 2;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = e / Q;
+    const int q = (int)(e - pix * Q);
+    const int64_t g = pix / P;
+    const int co = q * 4;
+    const float4 xv = ld4(x + e * 4);
+    float4 d = ld4(dy + e * 4);
+    const float4 m = ld4(mean + g * C + co), r = ld4(invstd + g * C + co);
+    const float4 xh = make_float4((xv.x - m.x) * r.x, (xv.y - m.y) * r.y, (xv.z - m.z) * r.z, (xv.w - m.w) * r.w);
+    float4 dn = d;
+    if (gb != nullptr) {
+      const float4 ga = ld4(gb + pix * 2 * C + co);
+      if (slope != 1.0f) {
+        const float4 be = ld4(gb + pix * 2 * C + C + co);
+        d.x *= lrelu_g(xh.x * (1.f + ga.x) + be.x, slope); d.y *= lrelu_g(xh.y * (1.f + ga.y) + be.y, slope);
+        d.z *= lrelu_g(xh.z * (1.f + ga.z) + be.z, slope); d.w *= lrelu_g(xh.w * (1.f + ga.w) + be.w, slope);
+      }
+      dn = make_float4(d.x * (1.f + ga.x), d.y * (1.f + ga.y), d.z * (1.f + ga.z), d.w * (1.f + ga.w));
+    } else if (slope != 1.0f) {
+      dn.x *= lrelu_g(xh.x, slope); dn.y *= lrelu_g(xh.y, slope); dn.z *= lrelu_g(xh.z, slope); dn.w *= lrelu_g(xh.w, slope);
+    }
+    const double* ds = dsums + g * 2 * C;
+    float4 a = make_float4((float)(ds[co] * inv_count), (float)(ds[co + 1] * inv_count), (float)(ds[co + 2] * inv_count),
+                           (float)(ds[co + 3] * inv_count));
+    float4 b = make_float4((float)(ds[C + co] * inv_count), (float)(ds[C + co + 1] * inv_count),
+                           (float)(ds[C + co + 2] * inv_count), (float)(ds[C + co + 3] * inv_count));
+    float4 o;
+    o.x = r.x * (dn.x - a.x - xh.x * b.x); o.y = r.y * (dn.y - a.y - xh.y * b.y);
+    o.z = r.z * (dn.z - a.z - xh.z * b.z); o.w = r.w * (dn.w - a.w - xh.w * b.w);
+    st4(dx + e * 4, o);
+  }
+}
+
+// --------------------------------------------------------------------------------- elementwise
+__global__ void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int64_t n, int act, float slope,
+                          float* __restrict__ dpre) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float g = dy[i], v = y[i];
+    if (act == CSG_ACT_LEAKY)
+      g *= (v > 0.f ? 1.f : slope);
+    else if (act == CSG_ACT_TANH)
+      g *= (1.f - v * v);
+    dpre[i] = g;
+  }
+}
+
+__global__ void k_upsample2x_fwd(const float* __restrict__ x, int H, int W, int Q, int64_t n4, float* __restrict__ y) {
+  // y is (B, 2H, 2W, C)
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t pix = e / Q;
+    int q = (int)(e - pix * Q);
+    int X = (int)(pix % (2 * W));
+    int64_t t = pix / (2 * W);
+    int Y = (int)(t % (2 * H));
+    int64_t b = t / (2 * H);
+    st4(y + e * 4, ld4(x + (((b * H + (Y >> 1)) * W + (X >> 1)) * (int64_t)Q + q) * 4));
+  }
+}
+
+__global__ void k_upsample2x_bwd(const float* __restrict__ dy, int H, int W, int Q, int64_t n4,
+                                 float* __restrict__ dx) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t pix = e / Q;
+    int q = (int)(e - pix * Q);
+    int xw = (int)(pix % W);
+    int64_t t = pix / W;
+    int yh = (int)(t % H);
+    int64_t b = t / H;
+    const float* base = dy + (((b * 2 * H + 2 * yh) * 2 * W + 2 * xw) * (int64_t)Q + q) * 4;
+    const int64_t rs = (int64_t)2 * W * Q * 4;
+    float4 a = ld4(base), c = ld4(base + Q * 4), d = ld4(base + rs), f = ld4(base + rs + Q * 4);
+    st4(dx + e * 4, make_float4(a.x + c.x + d.x + f.x, a.y + c.y + d.y + f.y, a.z + c.z + d.z + f.z, a.w + c.w + d.w + f.w));
+  }
+}
+
+__global__ void k_avgpool3s2_fwd(const float* __restrict__ x, int H, int W, int OH, int OW, int Q, int64_t n4,
+                                 float* __restrict__ y) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t pix = e / Q;
+    int q = (int)(e - pix * Q);
+    int ox = (int)(pix % OW);
+    int64_t t = pix / OW;
+    int oy = (int)(t % OH);
+    int64_t b = t / OH;
+    float4 a = f4(0.f);
+    int cnt = 0;
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        float4 v = ld4(x + (((b * H + iy) * W + ix) * (int64_t)Q + q) * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        ++cnt;
+      }
+    }
+    float inv = 1.0f / (float)cnt;
+    st4(y + e * 4, make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv));
+  }
+}
+
+__device__ __forceinline__ int win_count(int o, int n) {  // in-bounds taps of a 3-wide window at stride 2, pad 1
+  int lo = o * 2 - 1, hi = o * 2 + 1;
+  if (lo < 0) lo = 0;
+  if (hi > n - 1) hi = n - 1;
+  return hi - lo + 1;
+}
+
+__global__ void k_avgpool3s2_bwd(const float* __restrict__ dy, int H, int W, int OH, int OW, int Q, int64_t n4,
+                                 float* __restrict__ dx) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t pix = e / Q;
+    int q = (int)(e - pix * Q);
+    int ix = (int)(pix % W);
+    int64_t t = pix / W;
+    int iy = (int)(t % H);
+    int64_t b = t / H;
+    float4 a = f4(0.f);
+    // outputs oy with |2*oy - iy| <= 1
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+      if (oy < 0 || oy >= OH) continue;
+      int cy = win_count(oy, H);
+      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox < 0 || ox >= OW) continue;
+        float inv = 1.0f / (float)(cy * win_count(ox, W));
+        float4 v = ld4(dy + (((b * OH + oy) * OW + ox) * (int64_t)Q + q) * 4);
+        a.x += v.x * inv; a.y += v.y * inv; a.z += v.z * inv; a.w += v.w * inv;
+      }
+    }
+    st4(dx + e * 4, a);
+  }
+}
+
+// --------------------------------------------------------------------------------- C ABI
+static inline unsigned ew_grid(int64_t n) {
+  int64_t g = cdiv(n, 256);
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+extern "C" {
+
+int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums, float* partial, int64_t nchunk,
+                   void* stream) {
+  CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_norm_stats: bad shape G=%ld P=%ld C=%ld",
+              (long)G, (long)P, (long)C);
+  CSG_REQUIRE(nchunk >= 1 && nchunk <= 65535 && G <= 65535, CSG_E_BADSHAPE, "csg_norm_stats: bad nchunk");
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope p(K_NORM_STATS, (double)G * P * C * 4, s);
+    hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 4, s, x, P,
+                       (int)C, C, (int)nchunk, partial);
+  }
+  hipLaunchKernelGGL(k_partial_to_sums, dim3((unsigned)cdiv(G * 2 * C, 256)), dim3(256), 0, s, partial, (int)G,
+                     (int)(2 * C), (int)nchunk, sums);
+  return check_launch("csg_norm_stats");
+}
+
+int csg_norm_finalize(const double* sums, int64_t G, int64_t C, double count, float eps, int32_t mode, float* mean,
+                      float* invstd, float* running_mean, float* running_var, float momentum, void* stream) {
+  CSG_REQUIRE(G > 0 && C > 0 && count > 0, CSG_E_BADSHAPE, "csg_norm_finalize: bad shape");
+  CSG_REQUIRE(running_mean == nullptr || G == 1, CSG_E_UNSUPPORTED, "csg_norm_finalize: running stats need G == 1");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_NORM_FINALIZE, (double)G * C * 24, s);
+  hipLaunchKernelGGL(k_norm_finalize, dim3((unsigned)cdiv(G * C, 256)), dim3(256), 0, s, sums, (int)G, (int)C, count,
+                     eps, mode, mean, invstd, running_mean, running_var, momentum);
+  return check_launch("csg_norm_finalize");
+}
+
+int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gb, float slope,
+                       int64_t G, int64_t P, int64_t C, float* y, void* stream) {
+  CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_norm_apply_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n4 = G * P * C / 4;
+  ProfScope p(K_NORM_APPLY_FWD, (double)G * P * C * 4 * (gb ? 4 : 2), s);
+  hipLaunchKernelGGL(k_norm_apply_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, mean, invstd, gb, slope, P, (int)C, n4, y);
+  return check_launch("csg_norm_apply_fwd");
+}
+
+int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
+                              const float* gb, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
+                              double* dsums, float* partial, int64_t nchunk, void* stream) {
+  CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: bad shape");
+  CSG_REQUIRE((gb == nullptr) == (dgb == nullptr), CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: gb/dgb mismatch");
+  CSG_REQUIRE(nchunk >= 1 && nchunk <= 65535 && G <= 65535, CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: bad nchunk");
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope p(K_NORM_BWD_REDUCE, (double)G * P * C * 4 * (gb ? 6 : 2), s);
+    hipLaunchKernelGGL(k_norm_bwd_reduce, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 4, s, dy, x, mean,
+                       invstd, gb, slope, P, (int)C, (int)nchunk, dgb, partial);
+  }
+  hipLaunchKernelGGL(k_partial_to_sums, dim3((unsigned)cdiv(G * 2 * C, 256)), dim3(256), 0, s, partial, (int)G,
+                     (int)(2 * C), (int)nchunk, dsums);
+  return check_launch("csg_norm_apply_bwd_reduce");
+}
+
+int csg_norm_apply_bwd_dx(const float* dy, const float* x, const float* mean, const float* invstd, const float* gb,
+                          float slope, const double* dsums, double count, int64_t G, int64_t P, int64_t C, float* dx,
+                          void* stream) {
+  CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0 && count > 0, CSG_E_BADSHAPE, "csg_norm_apply_bwd_dx: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n4 = G * P * C / 4;
+  ProfScope p(K_NORM_BWD_DX, (double)G * P * C * 4 * (gb ? 5 : 3), s);
+  hipLaunchKernelGGL(k_norm_bwd_dx, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, mean, invstd, gb, slope, dsums,
+                     1.0 / count, P, (int)C, n4, dx);
+  return check_launch("csg_norm_apply_bwd_dx");
+}
+
+int csg_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float slope, float* dpre, void* stream) {
+  CSG_REQUIRE(n >= 0, CSG_E_BADSHAPE, "csg_act_bwd: bad n");
+  if (n == 0) return CSG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_ACT_BWD, (double)n * 12, s);
+  hipLaunchKernelGGL(k_act_bwd, dim3(ew_grid(n)), dim3(256), 0, s, dy, y, n, act, slope, dpre);
+  return check_launch("csg_act_bwd");
+}
+
+int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out, float* partial, int64_t nchunk,
+               void* stream) {
+  CSG_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && x_cs % 4 == 0, CSG_E_BADSHAPE, "csg_colsum: bad shape");
+  CSG_REQUIRE(nchunk >= 1 && nchunk <= 65535, CSG_E_BADSHAPE, "csg_colsum: bad nchunk");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_COLSUM, (double)rows * C * 4, s);
+  hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, 1), dim3(256), 256 * 8 * 4, s, x, rows, (int)C, x_cs,
+                     (int)nchunk, partial);
+  hipLaunchKernelGGL(k_partial_to_colsum, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, partial, (int)C, (int)nchunk,
+                     out);
+  return check_launch("csg_colsum");
+}
+
+int csg_upsample2x_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream) {
+  CSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_upsample2x_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n4 = B * 4 * H * W * C / 4;
+  ProfScope p(K_UPSAMPLE_FWD, (double)n4 * 16 * 1.25, s);
+  hipLaunchKernelGGL(k_upsample2x_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, (int)H, (int)W, (int)(C / 4), n4, y);
+  return check_launch("csg_upsample2x_fwd");
+}
+
+int csg_upsample2x_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream) {
+  CSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_upsample2x_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n4 = B * H * W * C / 4;
+  ProfScope p(K_UPSAMPLE_BWD, (double)n4 * 16 * 5, s);
+  hipLaunchKernelGGL(k_upsample2x_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, (int)H, (int)W, (int)(C / 4), n4, dx);
+  return check_launch("csg_upsample2x_bwd");
+}
+
+int csg_avgpool3s2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream) {
+  CSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_avgpool3s2_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int64_t n4 = B * OH * OW * C / 4;
+  ProfScope p(K_AVGPOOL_FWD, (double)(B * H * W * C + n4 * 4) * 4, s);
+  hipLaunchKernelGGL(k_avgpool3s2_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, (int)H, (int)W, (int)OH, (int)OW,
+                     (int)(C / 4), n4, y);
+  return check_launch("csg_avgpool3s2_fwd");
+}
+
+int csg_avgpool3s2_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream) {
+  CSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_avgpool3s2_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int64_t n4 = B * H * W * C / 4;
+  ProfScope p(K_AVGPOOL_BWD, (double)(B * H * W * C + B * OH * OW * C) * 4, s);
+  hipLaunchKernelGGL(k_avgpool3s2_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, (int)H, (int)W, (int)OH, (int)OW,
+                     (int)(C / 4), n4, dx);
+  return check_launch("csg_avgpool3s2_bwd");
+}
+
+}  // extern "C"

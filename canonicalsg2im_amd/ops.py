@@ -1,0 +1,523 @@
+"""Autograd operators over the C ABI of libcsg_hip.so.
+
+Each `torch.autograd.Function` below calls hand-written gfx950 kernels for forward AND backward;
+PyTorch supplies device memory, the current HIP stream and the autograd graph only.  Image-like
+activations are logical (B,C,H,W) tensors whose MEMORY is NHWC (channel stride 1) — build them
+with `empty_nhwc` / `nhwc`.  Nothing here runs on CPU tensors.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import _lib
+from . import dist as csg_dist
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, check, lib, ptr, stream
+
+__all__ = [
+    "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
+    "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "disc_input", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
+]
+
+
+# ------------------------------------------------------------------------------------ layout helpers
+def nhwc(t):
+    """Return `t` (logical B,C,H,W) with NHWC memory, copying only if needed."""
+    if t.permute(0, 2, 3, 1).is_contiguous():
+        return t
+    return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def empty_nhwc(B, C, H, W, device, zero=False):
+    f = torch.zeros if zero else torch.empty
+    return f((B, H, W, C), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError("canonicalsg2im_amd kernels compute in fp32; got %s" % t.dtype)
+    return t
+
+
+def _chunks(P, G=1):
+    c = max(1, min((P + 511) // 512, max(1, 2048 // max(G, 1))))
+    return int(c)
+
+
+# ------------------------------------------------------------------------------------ convolution
+def _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad, act=ACT_NONE, slope=0.0, x_cs=None, y_cs=None):
+    d = ConvDesc()
+    d.B, d.IHp, d.IWp, d.Cin, d.x_cs = B, IH, IW, Cin, (Cin if x_cs is None else x_cs)
+    d.IHv, d.IWv, d.in_up = IH, IW, 0
+    OH = (IH + 2 * pad - KH) // stride + 1
+    OW = (IW + 2 * pad - KW) // stride + 1
+    d.OHg, d.OWg, d.OHf, d.OWf, d.os, d.ooy, d.oox = OH, OW, OH, OW, 1, 0, 0
+    d.Cout, d.y_cs = Cout, (Cout if y_cs is None else y_cs)
+    d.istride, d.ntaps, d.wtaps = stride, KH * KW, KH * KW
+    for ky in range(KH):
+        for kx in range(KW):
+            s = ky * KW + kx
+            d.tap_dy[s], d.tap_dx[s], d.tap_w[s] = ky - pad, kx - pad, s
+    d.act, d.slope, d.accumulate = act, slope, 0
+    return d, OH, OW
+
+
+def _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
+    """Descriptors that compute dX (B,IH,IW,Cin) from dY (B,OH,OW,Cout) with weights packed
+    [Cin][KH*KW][Cout]: one per parity class of the input grid (a single one for stride 1)."""
+    out = []
+    for py in range(stride):
+        for px in range(stride):
+            gh = (IH - py + stride - 1) // stride
+            gw = (IW - px + stride - 1) // stride
+            if gh <= 0 or gw <= 0:
+                continue
+            d = ConvDesc()
+            d.B, d.IHp, d.IWp, d.Cin, d.x_cs = B, OH, OW, Cout, Cout
+            d.IHv, d.IWv, d.in_up = OH, OW, 0
+            d.OHg, d.OWg, d.OHf, d.OWf, d.os, d.ooy, d.oox = gh, gw, IH, IW, stride, py, px
+            d.Cout, d.y_cs = Cin, Cin
+            d.istride, d.wtaps = 1, KH * KW
+            n = 0
+            for ky in range(KH):
+                if (py + pad - ky) % stride:
+                    continue
+                for kx in range(KW):
+                    if (px + pad - kx) % stride:
+                        continue
+                    d.tap_dy[n], d.tap_dx[n], d.tap_w[n] = (py + pad - ky) // stride, (px + pad - kx) // stride, ky * KW + kx
+                    n += 1
+            d.ntaps = n
+            d.act, d.slope, d.accumulate = ACT_NONE, 0.0, 0
+            out.append(d)
+    return out
+
+
+class _Conv2d(torch.autograd.Function):
+    """y = act(conv2d(x, w) + b) [+ residual] — reference nn.Conv2d call sites listed in
+    include/csg_hip.h (K8/K11)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, stride, pad, act, slope):
+        x = nhwc(_f32(x))
+        B, Cin, IH, IW = x.shape
+        Cout, Cin_w, KH, KW = weight.shape
+        if Cin_w != Cin:
+            raise RuntimeError("conv2d: weight expects %d input channels, x has %d" % (Cin_w, Cin))
+        wp = weight.detach().permute(0, 2, 3, 1).contiguous()          # [Cout][KH][KW][Cin]
+        d, OH, OW = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad, act, slope)
+        y = empty_nhwc(B, Cout, OH, OW, x.device)
+        res = nhwc(residual) if residual is not None else None
+        check(lib.csg_conv_fwd(d, ptr(x), ptr(wp), ptr(bias.detach() if bias is not None else None), ptr(res), ptr(y),
+                               stream()), "conv_fwd")
+        ctx.geom = (B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW, act, slope)
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW, act, slope = ctx.geom
+        dy = nhwc(dy)
+        if act != ACT_NONE:
+            dpre = torch.empty_like(dy)
+            check(lib.csg_act_bwd(ptr(dy), ptr(y), dy.numel(), act, slope, ptr(dpre), stream()), "act_bwd")
+        else:
+            dpre = dy
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().permute(1, 2, 3, 0).contiguous()      # [Cin][KH][KW][Cout]
+            dx = empty_nhwc(B, Cin, IH, IW, dy.device)
+            for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
+                check(lib.csg_conv_fwd(d, ptr(dpre), ptr(wt), None, None, ptr(dx), stream()), "conv_bwd_data")
+        if ctx.needs_input_grad[1]:
+            d, _, _ = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad)
+            nbytes = lib.csg_conv_bwd_weight_workspace(d)
+            if nbytes < 0:
+                raise RuntimeError("conv_bwd_weight_workspace: " + _lib.last_error())
+            ws = torch.empty(max(nbytes // 4, 4), device=dy.device, dtype=torch.float32)
+            dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
+            check(lib.csg_conv_bwd_weight(d, ptr(x), ptr(dpre), ptr(dwp), ptr(ws), nbytes, stream()), "conv_bwd_weight")
+            dw = dwp.permute(0, 3, 1, 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            rows = B * OH * OW
+            nch = _chunks(rows)
+            part = torch.empty(nch * 2 * Cout, device=dy.device, dtype=torch.float32)
+            db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
+            check(lib.csg_colsum(ptr(dpre), rows, Cout, Cout, ptr(db), ptr(part), nch, stream()), "colsum")
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dpre
+        return dx, dw, db, dres, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, residual=None):
+    """Channel counts that are not multiples of 4 (conv_img: 3 outputs, the PatchGAN head: 1) are
+    zero-padded to 16-byte pixel rows; the result is a channel-slice view of the padded output."""
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    pc, po = (-Cin) % 4, (-Cout) % 4
+    if pc:
+        x = F.pad(x, (0, 0, 0, 0, 0, pc))
+        weight = F.pad(weight, (0, 0, 0, 0, 0, pc))
+    if po:
+        weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, po))
+        bias = F.pad(bias, (0, po)) if bias is not None else None
+        residual = F.pad(residual, (0, 0, 0, 0, 0, po)) if residual is not None else None
+    y = _Conv2d.apply(x, weight, bias, residual, int(stride), int(padding), int(act), float(slope))
+    return y[:, :Cout] if po else y
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
+    """F.linear (+ReLU) as a 1x1 implicit GEMM: rows of x are 'pixels'."""
+    lead = x.shape[:-1]
+    K = x.shape[-1]
+    N = weight.shape[0]
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    y = conv2d(x2.view(-1, K, 1, 1), weight.view(N, K, 1, 1), bias, 1, 0, act, slope)
+    return y.reshape(*lead, N)
+
+
+# ------------------------------------------------------------------------------------ normalisation
+def _sync_world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+class _NormAct(torch.autograd.Function):
+    """BatchNorm (G=1) or InstanceNorm (G=B) statistics + optional SPADE modulation + LeakyReLU.
+
+    Batch mode, training: running stats updated as F.batch_norm does; with an initialised process
+    group of N > 1 ranks the (sum, sum^2) message is all-reduced and inv_std uses the reference's
+    N-replica formula clamp(var, eps)^-1/2 (sync_batchnorm/batchnorm.py:128-145)."""
+
+    @staticmethod
+    def forward(ctx, x, gb, running_mean, running_var, instance, training, slope, eps, momentum, sync):
+        x = nhwc(_f32(x))
+        B, C, H, W = x.shape
+        G = B if instance else 1
+        P = (B * H * W) // G
+        dev = x.device
+        world = _sync_world() if (sync and not instance and training) else 1
+        use_batch_stats = training or instance
+        mean = torch.empty(G * C, device=dev, dtype=torch.float32)
+        invstd = torch.empty(G * C, device=dev, dtype=torch.float32)
+        count = float(P * world)
+        if use_batch_stats:
+            nch = _chunks(P, G)
+            part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float32)
+            sums = torch.empty(G * 2 * C, device=dev, dtype=torch.float64)
+            check(lib.csg_norm_stats(ptr(x), G, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
+            if world > 1:
+                csg_dist.all_reduce_stats(sums)
+            rm = running_mean if (training and not instance and running_mean is not None) else None
+            rv = running_var if rm is not None else None
+            check(lib.csg_norm_finalize(ptr(sums), G, C, count, eps, 1 if world > 1 else 0, ptr(mean), ptr(invstd),
+                                        ptr(rm), ptr(rv), momentum, stream()), "norm_finalize")
+        else:
+            mean.copy_(running_mean)
+            invstd.copy_(torch.rsqrt(running_var + eps))
+        gbn = nhwc(gb) if gb is not None else None
+        y = torch.empty_like(x)
+        check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gbn), slope, G, P, C, ptr(y), stream()),
+              "norm_apply_fwd")
+        ctx.save_for_backward(x, gbn, mean, invstd)
+        ctx.cfg = (G, P, C, slope, use_batch_stats, world, count)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gb, mean, invstd = ctx.saved_tensors
+        G, P, C, slope, use_batch_stats, world, count = ctx.cfg
+        dy = nhwc(dy)
+        dev = dy.device
+        dgb = torch.empty_like(gb) if gb is not None else None
+        nch = _chunks(P, G)
+        part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float32)
+        dsums = torch.empty(G * 2 * C, device=dev, dtype=torch.float64)
+        check(lib.csg_norm_apply_bwd_reduce(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, G, P, C, ptr(dgb),
+                                            ptr(dsums), ptr(part), nch, stream()), "norm_bwd_reduce")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if not use_batch_stats:
+                dsums.zero_()                       # eval mode: statistics are constants
+            elif world > 1:
+                csg_dist.all_reduce_stats(dsums)
+            dx = torch.empty_like(x)
+            check(lib.csg_norm_apply_bwd_dx(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, ptr(dsums), count,
+                                            G, P, C, ptr(dx), stream()), "norm_bwd_dx")
+        return dx, dgb, None, None, None, None, None, None, None, None
+
+
+def norm_act(x, gb=None, running_mean=None, running_var=None, instance=False, training=True, slope=1.0, eps=1e-5,
+             momentum=0.1, sync=True):
+    return _NormAct.apply(x, gb, running_mean, running_var, bool(instance), bool(training), float(slope), float(eps),
+                          float(momentum), bool(sync))
+
+
+# ------------------------------------------------------------------------------------ resampling
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(_f32(x))
+        B, C, H, W = x.shape
+        y = empty_nhwc(B, C, 2 * H, 2 * W, x.device)
+        check(lib.csg_upsample2x_fwd(ptr(x), B, H, W, C, ptr(y), stream()), "upsample2x_fwd")
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = nhwc(dy)
+        dx = empty_nhwc(B, C, H, W, dy.device)
+        check(lib.csg_upsample2x_bwd(ptr(dy), B, H, W, C, ptr(dx), stream()), "upsample2x_bwd")
+        return dx
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
+
+
+class _AvgPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(_f32(x))
+        B, C, H, W = x.shape
+        y = empty_nhwc(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, x.device)
+        check(lib.csg_avgpool3s2_fwd(ptr(x), B, H, W, C, ptr(y), stream()), "avgpool_fwd")
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = nhwc(dy)
+        dx = empty_nhwc(B, C, H, W, dy.device)
+        check(lib.csg_avgpool3s2_bwd(ptr(dy), B, H, W, C, ptr(dx), stream()), "avgpool_bwd")
+        return dx
+
+
+def avgpool3s2(x):
+    return _AvgPool3s2.apply(x)
+
+
+# ------------------------------------------------------------------------------------ graph encoder
+class _Embed(torch.autograd.Function):
+    """Concatenated embedding lookups: out[..., k*E:(k+1)*E] = table_k[idx[..., k]]."""
+
+    @staticmethod
+    def forward(ctx, idx, *tables):
+        lead = idx.shape[:-1]
+        A = idx.shape[-1]
+        assert A == len(tables)
+        idx2 = idx.reshape(-1, A).contiguous()
+        rows = idx2.shape[0]
+        dims = [t.shape[1] for t in tables]
+        D = sum(dims)
+        out = torch.empty((rows, D), device=idx.device, dtype=torch.float32)
+        off = 0
+        for k, t in enumerate(tables):
+            tc = _f32(t.detach()).contiguous()
+            check(lib.csg_embed_fwd(ctypes_ptr_off(idx2, k), rows, A, ptr(tc), tc.shape[0], dims[k], ptr(out), D, off,
+                                    stream()), "embed_fwd")
+            off += dims[k]
+        ctx.save_for_backward(idx2)
+        ctx.meta = (A, dims, [t.shape[0] for t in tables], D)
+        return out.reshape(*lead, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx2,) = ctx.saved_tensors
+        A, dims, sizes, D = ctx.meta
+        dout = dout.reshape(-1, D).contiguous()
+        rows = idx2.shape[0]
+        grads, off = [], 0
+        for k in range(A):
+            g = torch.zeros((sizes[k], dims[k]), device=dout.device, dtype=torch.float32)
+            check(lib.csg_embed_bwd(ctypes_ptr_off(idx2, k), rows, A, ptr(dout), D, off, sizes[k], dims[k], ptr(g),
+                                    stream()), "embed_bwd")
+            grads.append(g)
+            off += dims[k]
+        return (None, *grads)
+
+
+def ctypes_ptr_off(t, elem_off):
+    if not t.is_cuda:
+        raise RuntimeError("canonicalsg2im_amd ops need HIP tensors; there is no CPU path")
+    return ctypes.c_void_p(t.data_ptr() + elem_off * t.element_size())
+
+
+def embed(idx, tables):
+    if idx.dtype != torch.int64:
+        raise RuntimeError("embed: indices must be int64 (collate contract)")
+    return _Embed.apply(idx, *tables)
+
+
+def real_object_mask(objs, image_id):
+    """uint8 (B,O): objs[...,0] != 0 and != __image__ (sg2im/utils.py:56-63)."""
+    B, O, A = objs.shape
+    o = objs.contiguous()
+    m = torch.empty((B, O), device=objs.device, dtype=torch.uint8)
+    check(lib.csg_real_object_mask(ptr(o), B, O, A, int(image_id), ptr(m), stream()), "real_object_mask")
+    return m
+
+
+def graph_csr(triplets, O):
+    """(row_ptr (B,O+1) int32, col (B,2T) int32) — incident triplets per object, reference order."""
+    B, T, _ = triplets.shape
+    tr = triplets.contiguous()
+    row_ptr = torch.empty((B, O + 1), device=tr.device, dtype=torch.int32)
+    col = torch.empty((B, max(2 * T, 1)), device=tr.device, dtype=torch.int32)
+    check(lib.csg_graph_csr_build(ptr(tr), B, T, O, ptr(row_ptr), ptr(col), stream()), "graph_csr_build")
+    return row_ptr, col
+
+
+class _GatherConcat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, obj, pred, triplets, row_ptr, col):
+        obj, pred = _f32(obj).contiguous(), _f32(pred).contiguous()
+        B, O, Din = obj.shape
+        T, Dp = pred.shape[1], pred.shape[2]
+        out = torch.empty((B, T, 2 * Din + Dp), device=obj.device, dtype=torch.float32)
+        check(lib.csg_gather_concat_fwd(ptr(obj), ptr(pred), ptr(triplets), B, O, T, Din, Dp, ptr(out), stream()),
+              "gather_concat_fwd")
+        ctx.save_for_backward(row_ptr, col)
+        ctx.dims = (B, O, T, Din, Dp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dcat):
+        row_ptr, col = ctx.saved_tensors
+        B, O, T, Din, Dp = ctx.dims
+        dcat = dcat.contiguous()
+        dobj = torch.empty((B, O, Din), device=dcat.device, dtype=torch.float32)
+        dpred = torch.empty((B, T, Dp), device=dcat.device, dtype=torch.float32)
+        check(lib.csg_gather_concat_bwd(ptr(dcat), ptr(row_ptr), ptr(col), B, O, T, Din, Dp, ptr(dobj), ptr(dpred),
+                                        stream()), "gather_concat_bwd")
+        return dobj, dpred, None, None, None
+
+
+def gather_concat(obj, pred, triplets, row_ptr, col):
+    return _GatherConcat.apply(obj, pred, triplets, row_ptr, col)
+
+
+class _SegmentAvg(torch.autograd.Function):
+    """(pooled (B,O,H), new_p (B,T,Dp)) from net1's output h (B,T,2H+Dp) and confidences (B,T)."""
+
+    @staticmethod
+    def forward(ctx, h, conf, valid, triplets, row_ptr, col, H, Dp):
+        h, conf = _f32(h).contiguous(), _f32(conf).contiguous()
+        B, T, _ = h.shape
+        O = row_ptr.shape[1] - 1
+        pooled = torch.empty((B, O, H), device=h.device, dtype=torch.float32)
+        cnt = torch.empty((B, O), device=h.device, dtype=torch.float32)
+        new_p = torch.empty((B, T, Dp), device=h.device, dtype=torch.float32)
+        check(lib.csg_segment_avg_fwd(ptr(h), ptr(conf), ptr(valid), ptr(row_ptr), ptr(col), B, O, T, H, Dp,
+                                      ptr(pooled), ptr(cnt), ptr(new_p), stream()), "segment_avg_fwd")
+        ctx.save_for_backward(h, conf, valid, triplets, pooled, cnt)
+        ctx.dims = (B, O, T, H, Dp)
+        return pooled, new_p
+
+    @staticmethod
+    def backward(ctx, dpooled, dnew_p):
+        h, conf, valid, triplets, pooled, cnt = ctx.saved_tensors
+        B, O, T, H, Dp = ctx.dims
+        dpooled = dpooled.contiguous()
+        dnew_p = dnew_p.contiguous() if dnew_p is not None else None
+        dh = torch.empty_like(h)
+        dconf = torch.empty_like(conf)
+        scratch = torch.empty((B, O), device=h.device, dtype=torch.float32)
+        check(lib.csg_segment_avg_bwd(ptr(dpooled), ptr(dnew_p), ptr(h), ptr(conf), ptr(valid), ptr(triplets),
+                                      ptr(pooled), ptr(cnt), B, O, T, H, Dp, ptr(dh), ptr(dconf), ptr(scratch),
+                                      stream()), "segment_avg_bwd")
+        return dh, dconf, None, None, None, None, None, None
+
+
+def segment_avg(h, conf, valid, triplets, row_ptr, col, H, Dp):
+    return _SegmentAvg.apply(h, conf, valid, triplets, row_ptr, col, int(H), int(Dp))
+
+
+# ------------------------------------------------------------------------------------ layout
+def _check_boxes(boxes):
+    if boxes.requires_grad:
+        raise NotImplementedError("layout: gradients w.r.t. boxes are not implemented (training feeds GT boxes, "
+                                  "scripts/train.py:358; SURVEY.md §9 item 16)")
+
+
+class _LayoutPyramid(torch.autograd.Function):
+    """boxes_to_layout for a whole batch at several output sizes at once: size h samples the
+    full-resolution layout at rows floor(y*H/h) (= F.interpolate(seg, (h,h), 'nearest'))."""
+
+    @staticmethod
+    def forward(ctx, vecs, boxes, valid, H, sizes):
+        vecs = _f32(vecs).contiguous()
+        boxes = _f32(boxes).contiguous()
+        B, O, S = vecs.shape
+        outs = []
+        for h in sizes:
+            seg = empty_nhwc(B, S, h, h, vecs.device)
+            check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), B, O, S, H, H, h, h, ptr(seg), S, 0, stream()),
+                  "layout_fwd")
+            outs.append(seg)
+        ctx.save_for_backward(boxes, valid)
+        ctx.meta = (B, O, S, H, tuple(sizes))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        boxes, valid = ctx.saved_tensors
+        B, O, S, H, sizes = ctx.meta
+        dvecs = torch.zeros((B, O, S), device=boxes.device, dtype=torch.float32)
+        for h, g in zip(sizes, douts):
+            if g is None:
+                continue
+            g = nhwc(g)
+            check(lib.csg_layout_bwd(ptr(g), S, 0, ptr(boxes), ptr(valid), B, O, S, H, H, h, h, ptr(dvecs), 1, stream()),
+                  "layout_bwd")
+        return dvecs, None, None, None, None
+
+
+def layout_pyramid(vecs, boxes, valid, H, sizes):
+    _check_boxes(boxes)
+    return _LayoutPyramid.apply(vecs, boxes, valid, int(H), tuple(int(s) for s in sizes))
+
+
+class _DiscInput(torch.autograd.Function):
+    """cat([img, layout], dim=1) of discriminator.py:120 built in place: one NHWC buffer with
+    channels [layout(S) | img(3) | zero pad] so that every pixel row is 16-byte aligned; the
+    first conv's weight is permuted to match by the caller."""
+
+    @staticmethod
+    def forward(ctx, img, vecs, boxes, valid, H):
+        vecs = _f32(vecs).contiguous()
+        boxes = _f32(boxes).contiguous()
+        B, O, S = vecs.shape
+        Ct = (S + 3 + 3) // 4 * 4
+        buf = torch.zeros((B, H, H, Ct), device=vecs.device, dtype=torch.float32)
+        buf[..., S:S + 3] = img.permute(0, 2, 3, 1)
+        check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), B, O, S, H, H, H, H, ptr(buf), Ct, 0, stream()),
+              "layout_fwd")
+        ctx.save_for_backward(boxes, valid)
+        ctx.meta = (B, O, S, H, Ct)
+        return buf.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        boxes, valid = ctx.saved_tensors
+        B, O, S, H, Ct = ctx.meta
+        dbuf = nhwc(dbuf)
+        dimg = dvecs = None
+        if ctx.needs_input_grad[0]:
+            dimg = dbuf[:, S:S + 3].contiguous()
+        if ctx.needs_input_grad[1]:
+            dvecs = torch.empty((B, O, S), device=dbuf.device, dtype=torch.float32)
+            check(lib.csg_layout_bwd(ptr(dbuf), Ct, 0, ptr(boxes), ptr(valid), B, O, S, H, H, H, H, ptr(dvecs), 0,
+                                     stream()), "layout_bwd")
+        return dimg, dvecs, None, None, None
+
+
+def disc_input(img, vecs, boxes, valid, H):
+    _check_boxes(boxes)
+    return _DiscInput.apply(_f32(img), vecs, boxes, valid, int(H))

@@ -1,0 +1,48 @@
+"""Trainer-level containers (reference: sg2im/meta_models.py:9-90).  Same attribute names and
+state_dict prefixes (`sg_to_layout.module.*`, `layout_to_image_model.module.*`)."""
+import torch
+import torch.nn as nn
+
+from ..spade.models.networks import MultiscaleDiscriminator, SPADEGenerator
+from ..spade.models.networks.sync_batchnorm import DataParallelWithCallback
+from .model import Sg2LayoutModel
+
+
+class MetaGeneratorModel(nn.Module):
+    def __init__(self, opt, device):
+        super().__init__()
+        self.args = vars(opt)
+        self.vocab = self.args["vocab"]
+        if not self.args['skip_graph_model']:
+            self.sg_to_layout = DataParallelWithCallback(Sg2LayoutModel(opt), device_ids=self.args['gpu_ids']).to(device)
+        if not self.args['skip_generation']:
+            self.layout_to_image_model = DataParallelWithCallback(SPADEGenerator(opt),
+                                                                  device_ids=self.args['gpu_ids']).to(device)
+
+    def forward(self, objs, triplets, triplet_type, boxes_gt=None, masks_gt=None, test_mode=False):
+        boxes_pred = masks_pred = img = None
+        if not self.args['skip_graph_model']:
+            _, boxes_pred, masks_pred = self.sg_to_layout(objs, triplets, triplet_type, boxes_gt)
+        if not self.args["skip_generation"]:
+            layout_boxes = boxes_pred if boxes_gt is None else boxes_gt
+            layout_masks = masks_pred if masks_gt is None else masks_gt
+            img = self.layout_to_image_model(objs, layout_boxes, layout_masks, test_mode=test_mode)
+        return img, boxes_pred, masks_pred
+
+
+class MetaDiscriminatorModel(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.args = vars(opt)
+        self.img_discriminator = MultiscaleDiscriminator(opt)
+        self.img_discriminator.train()
+        if not opt.use_img_disc:
+            raise NotImplementedError("object/mask discriminators are next-row components (SURVEY.md §8f); "
+                                      "use --use_img_disc 1")
+
+    def build_optimizers(self, opt):
+        """Adam(betas=(beta1, 0.999)) per discriminator (reference meta_models.py:67-69); called after
+        the module sits on its device."""
+        self.optimizer_d_img = torch.optim.Adam(list(self.img_discriminator.parameters()),
+                                                lr=opt.img_learning_rate, betas=(opt.beta1, 0.999))
+        return self

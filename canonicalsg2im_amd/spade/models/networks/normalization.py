@@ -1,0 +1,95 @@
+"""SPADE and the discriminator's norm wrapper (reference: spade/models/networks/normalization.py).
+
+One SPADE call = three kernels: mlp_shared conv (+ReLU epilogue), ONE conv producing gamma||beta
+(the two 128->C convs share their input, so their weights are concatenated along Cout), and the
+fused BatchNorm-apply + (1+gamma)*x+beta + LeakyReLU pass (K9)."""
+import re
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.nn.utils.spectral_norm as spectral_norm
+
+from .... import ops
+from ....sg2im.layers import Conv2d, _FusedActivation
+from .sync_batchnorm import LocalBatchNorm2d, SynchronizedBatchNorm2d
+
+
+class SegPyramid:
+    """Layouts of one batch at every resolution the generator needs, produced by one layout
+    kernel per level (nearest sampling folded in) instead of F.interpolate per SPADE call."""
+
+    def __init__(self, levels):
+        self.levels = dict(levels)
+
+    def at(self, h):
+        return self.levels[int(h)]
+
+
+class InstanceNormAct(nn.InstanceNorm2d):
+    """nn.InstanceNorm2d(affine=False) with an optional fused LeakyReLU (`fused_slope`)."""
+
+    def __init__(self, num_features, fused_slope=1.0):
+        super().__init__(num_features, affine=False)
+        self.fused_slope = fused_slope
+
+    def forward(self, x, gb=None, fused_slope=None):
+        slope = self.fused_slope if fused_slope is None else fused_slope
+        return ops.norm_act(x, gb, None, None, instance=True, training=self.training, slope=slope, eps=self.eps)
+
+
+def get_nonspade_norm_layer(opt, norm_type='instance'):
+    def get_out_channel(layer):
+        return getattr(layer, 'out_channels', None) or layer.weight.size(0)
+
+    def add_norm_layer(layer):
+        subnorm_type = norm_type
+        if norm_type.startswith('spectral'):
+            layer = spectral_norm(layer)
+            subnorm_type = norm_type[len('spectral'):]
+        if subnorm_type == 'none' or len(subnorm_type) == 0:
+            return layer
+        if getattr(layer, 'bias', None) is not None:     # bias is meaningless before a normalisation
+            delattr(layer, 'bias')
+            layer.register_parameter('bias', None)
+        if subnorm_type == 'instance':
+            norm_layer = InstanceNormAct(get_out_channel(layer))
+        else:
+            raise NotImplementedError('normalization layer %s is not on the hot path (norm_D default is '
+                                      'spectralinstance)' % subnorm_type)
+        return nn.Sequential(layer, norm_layer)
+
+    return add_norm_layer
+
+
+class SPADE(nn.Module):
+    def __init__(self, config_text, norm_nc, label_nc):
+        super().__init__()
+        assert config_text.startswith('spade')
+        parsed = re.search(r'spade(\D+)(\d)x\d', config_text)
+        kind, ks = str(parsed.group(1)), int(parsed.group(2))
+        if kind == 'instance':
+            self.param_free_norm = InstanceNormAct(norm_nc)
+        elif kind == 'syncbatch':
+            self.param_free_norm = SynchronizedBatchNorm2d(norm_nc, affine=False)
+        elif kind == 'batch':
+            self.param_free_norm = LocalBatchNorm2d(norm_nc, affine=False)
+        else:
+            raise ValueError('%s is not a recognized param-free norm type in SPADE' % kind)
+        nhidden = 128
+        self.pw = ks // 2
+        self.mlp_shared = nn.Sequential(Conv2d(label_nc, nhidden, kernel_size=ks, padding=self.pw,
+                                               act=ops.ACT_LEAKY, slope=0.0), _FusedActivation())
+        self.mlp_gamma = Conv2d(nhidden, norm_nc, kernel_size=ks, padding=self.pw)
+        self.mlp_beta = Conv2d(nhidden, norm_nc, kernel_size=ks, padding=self.pw)
+
+    def forward(self, x, segmap, fused_slope=1.0):
+        if isinstance(segmap, SegPyramid):
+            seg = segmap.at(x.size(2))
+        else:
+            seg = segmap if segmap.shape[2:] == x.shape[2:] else F.interpolate(segmap, size=x.shape[2:], mode='nearest')
+        actv = self.mlp_shared(seg)
+        w = torch.cat([self.mlp_gamma.weight, self.mlp_beta.weight], dim=0)
+        b = torch.cat([self.mlp_gamma.bias, self.mlp_beta.bias], dim=0)
+        gb = ops.conv2d(actv, w, b, 1, self.pw)                     # (B, 2C, h, w): gamma || beta
+        return self.param_free_norm(x, gb=gb, fused_slope=fused_slope)

@@ -184,3 +184,38 @@ def shard_batch(batch: Tuple, rank: int, world_size: int) -> Tuple:
     n = B // world_size
     sl = slice(rank * n, (rank + 1) * n)
     return tuple(None if t is None else t[sl] for t in batch)
+
+
+def deterministic_state(state_dict, seed=0):
+    """Seeded stand-in for a checkpoint: every tensor is a pure function of its name and shape, so
+    the golden-vector script (reference modules) and the tests (oracle / HIP modules) can rebuild
+    identical weights without storing them.  Scales keep activations O(1)."""
+    import zlib
+    out = {}
+    for name in sorted(state_dict.keys()):
+        ref = state_dict[name]
+        # the reference registers ONE transitive-weight Parameter under six names (model.py:32,45)
+        sname = "trans_candidates_weights" if name.endswith("predicates_transitive_weights") else name
+        g = torch.Generator().manual_seed((zlib.crc32(sname.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+        shape = tuple(ref.shape)
+        if not ref.is_floating_point():
+            out[name] = torch.zeros(shape, dtype=ref.dtype)
+        elif name.endswith("weight_u") or name.endswith("weight_v"):
+            v = torch.randn(shape, generator=g)
+            out[name] = v / v.norm().clamp_min(1e-12)
+        elif name.endswith("running_var"):
+            out[name] = 1.0 + 0.2 * torch.rand(shape, generator=g)
+        elif name.endswith("running_mean"):
+            out[name] = 0.1 * torch.randn(shape, generator=g)
+        elif "att_emb" in name or "pred_embeddings" in name:
+            out[name] = torch.randn(shape, generator=g)
+        elif "candidates_weights" in name or "transitive_weights" in name:
+            out[name] = torch.rand(shape, generator=g) * 2 - 1
+        elif len(shape) >= 2:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            out[name] = torch.randn(shape, generator=g) * (1.5 / max(fan_in, 1) ** 0.5)
+        else:
+            out[name] = 0.1 * torch.randn(shape, generator=g)
+    return out

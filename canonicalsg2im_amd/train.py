@@ -1,0 +1,104 @@
+"""One training iteration of the reference trainer (scripts/train.py:346-393, 468-485) on the HIP
+modules, data-parallel over processes.
+
+`Trainer.step(batch)` reproduces the reference's order of operations:
+  model forward (graph encoder; generator on GT boxes) -> generator losses (2 D passes) ->
+  zero_grad / backward / Adam step -> discriminator losses on the detached image (2 D passes) ->
+  per-discriminator zero_grad / backward / Adam step.
+Differences that are unobservable in the results: during the generator
+backward the discriminator's parameters do not require grad, so the weight gradients the reference
+computes and then discards are never computed; errors are raised, not swallowed (§9 item 14)."""
+import torch
+
+from . import dist as csg_dist
+from .scripts.args import make_opt  # noqa: F401  (re-exported)
+from .sg2im.meta_models import MetaDiscriminatorModel, MetaGeneratorModel
+from .sg2im.pix2pix_model import Pix2PixModel
+
+
+class Trainer:
+    def __init__(self, opt, device):
+        self.opt, self.device = opt, device
+        self.model = MetaGeneratorModel(opt, device)
+        self.discriminator = MetaDiscriminatorModel(opt).to(device).build_optimizers(opt)
+        self.gans_model = Pix2PixModel(opt, discriminator=self.discriminator).to(device)
+        self.model.train()
+        csg_dist.broadcast_module(self.model)
+        csg_dist.broadcast_module(self.discriminator)
+        # param groups of scripts/train.py:312-322
+        converse = ['sg_to_layout.module.converse_candidates_weights']
+        trans = ['sg_to_layout.module.trans_candidates_weights']
+        named = list(self.model.named_parameters())
+        base = [p for n, p in named if n not in converse + trans]
+        self.optimizer = torch.optim.Adam([{'params': base, 'lr': opt.learning_rate},
+                                           {'params': [p for n, p in named if n in trans], 'lr': 1e-2}])
+        self.optimizer_converse = torch.optim.Adam([{'params': [p for n, p in named if n in converse], 'lr': 1e-2}])
+        self.g_buckets = csg_dist.GradBuckets(base + [p for n, p in named if n in trans])
+        self.d_params = list(self.discriminator.img_discriminator.parameters())
+        self.d_buckets = csg_dist.GradBuckets(self.d_params)
+
+    def _d_requires_grad(self, flag):
+        for p in self.d_params:
+            p.requires_grad_(flag)
+
+    def step(self, batch):
+        opt = self.opt
+        if opt.learned_converse:
+            raise NotImplementedError("--learned_converse (REINFORCE on the data loader's converse weights) is a "
+                                      "data-loader feature outside the hot path")
+        imgs, objs, boxes, triplets, conv_counts, triplet_type, masks, image_ids = batch
+        model_out = self.model(objs, triplets, triplet_type, boxes_gt=boxes, masks_gt=masks, test_mode=False)
+        # ---- generator update (train.py:361-368)
+        self._d_requires_grad(False)
+        G = self.gans_model(batch, model_out, mode="compute_generator_loss")
+        G = {k: (v if k == "bbox_pred_all" else v.mean()) for k, v in G.items()}
+        self.optimizer.zero_grad(set_to_none=True)
+        G["total_loss"].backward()
+        self.g_buckets.all_reduce_mean()
+        self.optimizer.step()
+        self._d_requires_grad(True)
+        # ---- discriminator update (train.py:388-393, 468-472)
+        D = {}
+        if not opt.skip_generation and opt.freeze_options != "generation":
+            D = self.gans_model(batch, model_out, mode="compute_discriminator_loss")
+            D = {k: v.mean() for k, v in D.items()}
+            self.discriminator.optimizer_d_img.zero_grad(set_to_none=True)
+            D["total_img_loss"].backward()
+            self.d_buckets.all_reduce_mean()
+            self.discriminator.optimizer_d_img.step()
+        return G, D
+
+
+# ------------------------------------------------------------------ test / smoke helpers
+def split_state(trainer):
+    """(sg, g, d) state dicts with the reference's un-prefixed keys."""
+    sg = {k: v for k, v in trainer.model.sg_to_layout.module.state_dict().items()} \
+        if hasattr(trainer.model, "sg_to_layout") else {}
+    g = {k: v for k, v in trainer.model.layout_to_image_model.module.state_dict().items()} \
+        if hasattr(trainer.model, "layout_to_image_model") else {}
+    d = dict(trainer.discriminator.img_discriminator.state_dict())
+    return sg, g, d
+
+
+def oracle_state_from(trainer, oracle_mod):
+    """CPU copy of the trainer's weights as an `oracle.TrainState` (used by tests and smoke() only;
+    the oracle module is passed in so that this package never imports it)."""
+    def leafs(sd, skip=()):
+        out = {}
+        for k, v in sd.items():
+            if any(s in k for s in skip):
+                continue
+            t = v.detach().cpu().clone()
+            is_buf = any(s in k for s in ("running_", "weight_u", "weight_v", "num_batches_tracked"))
+            if t.is_floating_point() and not is_buf:
+                t.requires_grad_(True)
+            out[k] = t
+        return out
+    sg, g, d = split_state(trainer)
+    sg = leafs(sg)
+    if "trans_candidates_weights" in sg:
+        for k in list(sg):
+            if k.endswith("predicates_transitive_weights"):
+                sg[k] = sg["trans_candidates_weights"]
+    unused = ("repr_net", "image_encoder")
+    return oracle_mod.TrainState(trainer.opt, sg, leafs(g, unused), leafs(d, unused))

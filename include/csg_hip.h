@@ -1,0 +1,182 @@
+/*
+ * csg_hip.h — C ABI of libcsg_hip.so: the hand-written gfx950 (MI355X / CDNA4) kernels of the
+ * CanonicalSg2Im training hot path.
+ *
+ * The reference (roeiherz/CanonicalSg2Im) has no FFI of its own: its hot path is PyTorch/ATen
+ * calls issued from Python.  Each entry point below therefore replaces one ATen call site of the
+ * reference (file:line given per function, relative to the reference root); the Python binding
+ * that a maintainer adds on the reference side is the ctypes stub shown in INTEGRATION.md
+ * (the build's own binding is canonicalsg2im_amd/_lib.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked host.
+ *   - the caller allocates every buffer, including workspaces; the library keeps no pointer.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no internal sync,
+ *     safe to capture in a hipGraph (profiling mode excepted).
+ *   - return 0 on success, a negative CSG_E_* code otherwise; csg_last_error() has the text.
+ *     The Python side raises RuntimeError — errors are never swallowed (cf. the reference's
+ *     blanket try/except at scripts/train.py:354,440-441, which is NOT reproduced).
+ *   - activations are NHWC fp32 ("pixels x channels", channel stride 1); a tensor may be a channel
+ *     slice of a wider buffer: `*_cs` is the number of floats per pixel of the underlying buffer.
+ *   - indices are int64 as in the reference's collate output (sg2im/data/packed_coco.py:467-478).
+ */
+#ifndef CSG_HIP_H
+#define CSG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSG_OK 0
+#define CSG_E_BADSHAPE (-1)
+#define CSG_E_UNSUPPORTED (-2)
+#define CSG_E_LAUNCH (-3)
+#define CSG_E_WORKSPACE (-4)
+
+#define CSG_ACT_NONE 0
+#define CSG_ACT_LEAKY 1 /* y = x>0 ? x : slope*x ; ReLU is slope 0 */
+#define CSG_ACT_TANH 2
+
+#define CSG_MAX_TAPS 16
+
+int csg_version(void);
+const char* csg_last_error(void);
+
+/* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline) ------- */
+int csg_prof_enable(int on);
+int csg_prof_reset(void);
+int csg_prof_num_kernels(void);
+const char* csg_prof_kernel_name(int kernel_id);
+/* synchronises the recorded events; ms = summed launch durations, work = summed algorithmic
+ * FLOPs (MFMA-bound kernels) or bytes (HBM-bound kernels) as stated in DESIGN.md */
+int csg_prof_read(int kernel_id, double* ms, int64_t* launches, double* work);
+
+/* ---- K1: attribute / predicate embedding lookup ---------------------------------------------
+ * replaces nn.Embedding x A + torch.cat (sg2im/attribute_embed.py:40-45) and
+ * pred_embeddings (sg2im/model.py:109).
+ * out[r, out_off + 0..dim) = table[idx[r*idx_stride], :]                                       */
+int csg_embed_fwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const float* table, int64_t num_emb,
+                  int64_t dim, float* out, int64_t out_stride, int64_t out_off, void* stream);
+/* dtable[idx[r], :] += dout[r, out_off..]   (dtable must be zero-initialised by the caller)    */
+int csg_embed_bwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const float* dout, int64_t out_stride,
+                  int64_t out_off, int64_t num_emb, int64_t dim, float* dtable, void* stream);
+
+/* ---- real-object mask: sg2im/utils.py:56-63 (remove_dummy_objects), batched, bit-exact ------ */
+int csg_real_object_mask(const int64_t* objs, int64_t B, int64_t O, int64_t A, int64_t image_id, uint8_t* mask,
+                         void* stream);
+
+/* ---- K2/K5 support: per-image CSR of triplets by incident object ------------------------------
+ * row_ptr (B,O+1) int32, col (B,2T) int32 with col = 2*t + role (role 0 subject, 1 object).
+ * Inside a row: all subject entries in t order, then all object entries in t order — the order in
+ * which the reference's two scatter_add calls accumulate (sg2im/graph.py:98-99).               */
+int csg_graph_csr_build(const int64_t* triplets, int64_t B, int64_t T, int64_t O, int32_t* row_ptr, int32_t* col,
+                        void* stream);
+
+/* K2: cur_t = cat(obj[s], pred, obj[o])   (sg2im/graph.py:63-66) */
+int csg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* triplets, int64_t B, int64_t O,
+                          int64_t T, int64_t Din, int64_t Dp, float* out, void* stream);
+int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32_t* col, int64_t B, int64_t O,
+                          int64_t T, int64_t Din, int64_t Dp, float* dobj, float* dpred, void* stream);
+
+/* K4+K5: confidence gate + masked segment average (sg2im/graph.py:69-109).
+ * h = net1 output (B,T,2H+Dp) = [s | p | o]; conf (B,T); valid (B,T) = pred_indicators.
+ * pooled (B,O,H), cnt (B,O), new_p (B,T,Dp) = conf * h[:, H:H+Dp]                               */
+int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid, const int32_t* row_ptr,
+                        const int32_t* col, int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, float* pooled,
+                        float* cnt, float* new_p, void* stream);
+/* dcnt_scratch (B,O) float workspace */
+int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* h, const float* conf,
+                        const uint8_t* valid, const int64_t* triplets, const float* pooled, const float* cnt,
+                        int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, float* dh, float* dconf,
+                        float* dcnt_scratch, void* stream);
+
+/* ---- K6: boxes_to_layout (sg2im/layout.py:12-45), batched over images ------------------------
+ * out[b, y, x, out_off + d] = sum_o valid[b,o] * vecs[b,o,d] * cov(y_src) * cov(x_src)
+ * (OH,OW) may be smaller than (H,W): output pixel y samples full-resolution row
+ * floor(y*H/OH) — the nearest resize of generator.py:99 / normalization.py:102 folded in.       */
+int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, int64_t B, int64_t O, int64_t S,
+                   int64_t H, int64_t W, int64_t OH, int64_t OW, float* out, int64_t out_cs, int64_t out_off,
+                   void* stream);
+/* dvecs (B,O,S) = (accumulate ? dvecs : 0) + sum_{y,x} dout * cov * cov                        */
+int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,
+                   int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* dvecs,
+                   int accumulate, void* stream);
+
+/* ---- K3/K8/K11: implicit-GEMM convolution on fp32 MFMA ---------------------------------------
+ * replaces nn.Conv2d (generator.py:28,46; architecture.py:29-32; normalization.py:89-94;
+ * discriminator.py:175-187) and nn.Linear (sg2im/layers.py:10; a Linear is a 1x1 conv on an
+ * (M,1,1,K) image).  One descriptor covers forward, backward-data (transposed taps, weights packed
+ * [Cin][tap][Cout]) and the parity classes of a stride-2 transposed convolution.
+ *
+ * GEMM view: rows m = (b, gy, gx) over the output grid, cols n = output channel,
+ * k = (tap slot, input channel).  Virtual input coordinate of tap t for grid point (gy,gx):
+ *   iy = gy*istride + tap_dy[t], ix = gx*istride + tap_dx[t]; outside [0,IHv)x[0,IWv) reads 0;
+ *   the physical source pixel is (iy >> in_up, ix >> in_up) (nearest 2x upsample folded in).
+ * Packed weights: w[n][tap_w[t]][c], c fastest, row length wtaps*Cin.
+ * Output pixel of grid point: (gy*os + ooy, gx*os + oox) in an (OHf,OWf) image.                */
+typedef struct csg_conv_desc {
+  int32_t B, IHp, IWp, Cin, x_cs;
+  int32_t IHv, IWv, in_up;
+  int32_t OHg, OWg, OHf, OWf, os, ooy, oox;
+  int32_t Cout, y_cs;
+  int32_t istride, ntaps, wtaps;
+  int32_t tap_dy[CSG_MAX_TAPS], tap_dx[CSG_MAX_TAPS], tap_w[CSG_MAX_TAPS];
+  int32_t act;
+  float slope;
+  int32_t accumulate; /* y += result (after bias/act) instead of y = */
+} csg_conv_desc;
+
+/* y = act(conv(x, w) + bias) [+ residual];  bias and residual may be NULL; residual has y's layout */
+int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
+                 float* y, void* stream);
+/* dw[n][tap][c] = sum_m dy[m][n] * x[src(m,tap)][c]; `d` is the FORWARD descriptor (y_cs = floats per
+ * pixel of dy).  Deterministic split-K: partial slabs in `workspace`, then an ordered reduction. */
+int64_t csg_conv_bwd_weight_workspace(const csg_conv_desc* d);
+int csg_conv_bwd_weight(const csg_conv_desc* d, const float* x, const float* dy, float* dw, float* workspace,
+                        int64_t workspace_bytes, void* stream);
+
+/* dpre = dy * act'(.) evaluated from the OUTPUT y (leaky: y>0 ? 1 : slope; tanh: 1-y^2)          */
+int csg_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float slope, float* dpre, void* stream);
+/* out[c] = sum_rows x[r, c] over (rows, C) with row stride x_cs — bias gradients; partial (nchunk,C) */
+int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out, float* partial, int64_t nchunk,
+               void* stream);
+
+/* ---- K9/K11: BatchNorm / InstanceNorm statistics + SPADE modulation + LeakyReLU ---------------
+ * replaces F.batch_norm (sync_batchnorm/batchnorm.py:65-68), the modulation of
+ * normalization.py:108, F.leaky_relu (architecture.py:53-54,67-68) and nn.InstanceNorm2d +
+ * LeakyReLU (normalization.py:44, discriminator.py:181-185).
+ * x is (G groups, P pixels, C channels): BatchNorm G=1, P=B*h*w; InstanceNorm G=B, P=h*w.
+ * sums (G,2C) double = [sum x | sum x^2]; it is the message SyncBN all-reduces
+ * (batchnorm.py:74-83).                                                                          */
+int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums, float* partial, int64_t nchunk,
+                   void* stream);
+/* mode 0: invstd = 1/sqrt(var+eps) (F.batch_norm); mode 1: invstd = clamp(var,eps)^-1/2
+ * (batchnorm.py:145, N-replica path).  running_* may be NULL; running_var gets the unbiased var. */
+int csg_norm_finalize(const double* sums, int64_t G, int64_t C, double count, float eps, int32_t mode, float* mean,
+                      float* invstd, float* running_mean, float* running_var, float momentum, void* stream);
+/* y = leaky((x-mean)*invstd*(1+gamma)+beta, slope); gb (G*P, 2C) = [gamma | beta] or NULL; slope 1 = no act */
+int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gb, float slope,
+                       int64_t G, int64_t P, int64_t C, float* y, void* stream);
+/* pass 1: dgb (if gb) and dsums (G,2C) double = [sum dn | sum dn*xhat]                          */
+int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
+                              const float* gb, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
+                              double* dsums, float* partial, int64_t nchunk, void* stream);
+/* pass 2: dx = invstd*(dn - dsum0/count - xhat*dsum1/count)                                     */
+int csg_norm_apply_bwd_dx(const float* dy, const float* x, const float* mean, const float* invstd, const float* gb,
+                          float slope, const double* dsums, double count, int64_t G, int64_t P, int64_t C, float* dx,
+                          void* stream);
+
+/* ---- K7 / pooling ------------------------------------------------------------------------------
+ * nearest 2x upsample (generator.py:48,102-121) and its adjoint */
+int csg_upsample2x_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
+int csg_upsample2x_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream);
+/* F.avg_pool2d(3, stride 2, pad 1, count_include_pad=False) (discriminator.py:92-93) */
+int csg_avgpool3s2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
+int csg_avgpool3s2_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSG_HIP_H */

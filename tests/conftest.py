@@ -40,6 +40,14 @@ def sub_state(arrays, prefix, requires_grad=True, device=None):
     return out
 
 
+def state_from_shapes(shapes, seed, requires_grad=True, device=None):
+    """Rebuild the `deterministic_state` a golden file was generated with from its recorded shapes."""
+    from canonicalsg2im_amd.synth import deterministic_state
+    protos = {k: torch.empty(sh, dtype=getattr(torch, dt)) for k, (sh, dt) in shapes.items()}
+    sd = deterministic_state(protos, seed=seed)
+    return sub_state(sd, "", requires_grad=requires_grad, device=device)
+
+
 def assert_close(a, b, rtol=1e-4, atol=1e-5, msg=""):
     a = a.detach().cpu() if torch.is_tensor(a) else torch.as_tensor(a)
     b = b.detach().cpu() if torch.is_tensor(b) else torch.as_tensor(b)

@@ -68,7 +68,7 @@ from spade.models.networks.generator import SPADEGenerator  # noqa: E402
 from spade.models.networks.normalization import SPADE  # noqa: E402
 from spade.models.networks.sync_batchnorm import SynchronizedBatchNorm2d  # noqa: E402
 
-from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab  # noqa: E402  (ours: inputs only)
+from canonicalsg2im_amd.synth import BatchConfig, deterministic_state, make_batch, make_vocab  # noqa: E402  (ours: inputs only)
 
 
 def ref_opt(vocab, argv):
@@ -96,6 +96,11 @@ def grads_np(module, prefix="grad:", skip=()):
     return out
 
 
+def shapes_of(module, skip=()):
+    return {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in module.state_dict().items()
+            if not any(u in k for u in skip)}
+
+
 def save(name, meta, **arrays):
     path = os.path.join(HERE, name + ".npz")
     np.savez(path, __meta__=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
@@ -105,7 +110,7 @@ def save(name, meta, **arrays):
 # ----------------------------------------------------------------------------- fixtures
 def fx_layout():
     torch.manual_seed(0)
-    vecs = torch.randn(6, 5, requires_grad=True)
+    vecs = torch.randn(6, 8, requires_grad=True)
     boxes = torch.tensor([[0.10, 0.20, 0.50, 0.40],
                           [0.00, 0.00, 1.00, 1.00],
                           [0.60, 0.55, 0.35, 0.30],
@@ -143,10 +148,10 @@ def fx_gconv():
     torch.manual_seed(1)
     P = 6
     w_trans = get_predicates_weights(P, "uniform")
-    layer = GraphTripleConv(obj_input_dim=8, object_output_dim=12, predicate_input_dim=6,
-                            predicate_output_dim=10, hidden_dim=16, num_attributes=1,
+    layer = GraphTripleConv(obj_input_dim=8, object_output_dim=20, predicate_input_dim=4,
+                            predicate_output_dim=12, hidden_dim=16, num_attributes=1,
                             predicates_transitive_weights=w_trans)
-    obj, pred, edges, p, tt = _graph_inputs(2, 5, 9, 8, 6, P, seed=11)
+    obj, pred, edges, p, tt = _graph_inputs(2, 5, 9, 8, 4, P, seed=11)
     obj.requires_grad_(True)
     pred.requires_grad_(True)
     new_obj, new_p = layer(obj, pred, edges, p != 0, tt, p)
@@ -158,7 +163,7 @@ def fx_gconv():
                    "obj": npy(obj), "pred": npy(pred), "edges": npy(edges), "p": npy(p), "tt": npy(tt),
                    "new_obj": npy(new_obj), "new_p": npy(new_p), "wo": npy(wo), "wp": npy(wp),
                    "gobj": npy(obj.grad), "gpred": npy(pred.grad)})
-    save("gconv", {"ref": "sg2im/graph.py:44-113", "hidden": 16, "dp_out": 10}, **arrays)
+    save("gconv", {"ref": "sg2im/graph.py:44-113", "hidden": 16, "dp_out": 12}, **arrays)
 
 
 def fx_sg2layout():
@@ -188,22 +193,22 @@ def fx_spade_block():
     torch.manual_seed(3)
     vocab = make_vocab("tiny")
     opt = ref_opt(vocab, ["--embedding_dim", "4", "--image_size", "16,16"])
-    blk = SPADEResnetBlock(12, 6, opt)                   # learned shortcut
+    blk = SPADEResnetBlock(16, 8, opt)                   # learned shortcut
+    blk.load_state_dict(deterministic_state(blk.state_dict(), seed=3))
     blk.train()
-    x = torch.randn(2, 12, 8, 8, requires_grad=True)
+    x = torch.randn(2, 16, 8, 8, requires_grad=True)
     seg = torch.randn(2, 4, 16, 16, requires_grad=True)
-    before = sd_np(blk, "sd:")
     y = blk(x, seg)
     w = torch.randn_like(y)
     (y * w).sum().backward()
-    arrays = dict(before)
-    arrays.update(sd_np(blk, "after:", skip=("weight_orig", "mlp_", "bias")))
+    arrays = sd_np(blk, "after:", skip=("weight_orig", "mlp_", "bias"))
     arrays.update(grads_np(blk))
     arrays.update({"x": npy(x), "seg": npy(seg), "y": npy(y), "w": npy(w), "gx": npy(x.grad), "gseg": npy(seg.grad)})
     # second call in eval mode: running stats, no power iteration
     blk.eval()
     arrays["y_eval"] = npy(blk(x, seg))
-    save("spade_block", {"ref": "spade/models/networks/architecture.py:50-68", "fin": 12, "fout": 6}, **arrays)
+    save("spade_block", {"ref": "spade/models/networks/architecture.py:50-68", "fin": 16, "fout": 8,
+                         "state": "deterministic_state(seed=3)", "embedding_dim": 4, "shapes": shapes_of(blk)}, **arrays)
 
 
 def fx_syncbn():
@@ -235,7 +240,7 @@ def fx_model_and_step():
     torch.manual_seed(7)
     vocab = make_vocab("tiny")
     argv = ["--image_size", "64,64", "--embedding_dim", "8", "--gconv_dim", "16", "--gconv_hidden_dim", "24",
-            "--gconv_num_layers", "2", "--ngf", "2", "--ndf", "4", "--no_vgg_loss", "--use_img_disc", "1",
+            "--gconv_num_layers", "2", "--ngf", "4", "--ndf", "4", "--no_vgg_loss", "--use_img_disc", "1",
             "--batch_size", "2"]
     opt = ref_opt(vocab, argv)
     sg = Sg2LayoutModel(opt)
@@ -245,9 +250,9 @@ def fx_model_and_step():
     batch = make_batch(vocab, BatchConfig(2, 64, 2, 5, "packed"), seed=9)
     imgs, objs, boxes, triplets, _, tt = batch[:6]
     arrays = {"imgs": npy(imgs), "objs": npy(objs), "boxes": npy(boxes), "triplets": npy(triplets), "tt": npy(tt)}
-    arrays.update(sd_np(sg, "sg:"))
-    arrays.update(sd_np(G, "g:", skip=unused))
-    arrays.update(sd_np(D, "d:", skip=unused))
+    sg.load_state_dict(deterministic_state(sg.state_dict(), seed=11))
+    G.load_state_dict(deterministic_state(G.state_dict(), seed=12))
+    D.load_state_dict(deterministic_state(D.state_dict(), seed=13))
 
     gans = Pix2PixModel(opt, discriminator=_Holder(D))
     sg.train(); G.train(); D.train()
@@ -307,7 +312,9 @@ def fx_model_and_step():
         for j, f in enumerate(scale):
             arrays["dfeat_%d_%d" % (i, j)] = npy(f)
     save("train_step", {"ref": "scripts/train.py:353-393", "argv": argv, "vocab": "tiny",
-                        "note": "use_img_disc=1, no VGG loss, learned_converse=0"}, **arrays)
+                        "note": "use_img_disc=1, no VGG loss, learned_converse=0",
+                        "state": "deterministic_state seeds sg=11 g=12 d=13",
+                        "shapes": {"sg": shapes_of(sg), "g": shapes_of(G, unused), "d": shapes_of(D, unused)}}, **arrays)
 
 
 if __name__ == "__main__":

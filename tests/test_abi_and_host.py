@@ -1,0 +1,160 @@
+"""CPU-side checks (no GPU, no compute calls): the C-ABI library loads and exports every symbol
+declared in include/csg_hip.h, the host logic (descriptors, flags, synthetic batches, state_dict
+surface) behaves like the reference, and nothing in the product imports the oracle."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from canonicalsg2im_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "csg_hip.h")).read()
+    declared = set(re.findall(r"\b(csg_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("csg_conv_desc")
+    assert len(declared) >= 30
+    assert declared == set(built.SIGNATURES.keys()), declared ^ set(built.SIGNATURES.keys())
+    for name in declared:
+        assert getattr(built.lib, name) is not None
+    assert built.lib.csg_version() >= 100
+    assert built.lib.csg_prof_num_kernels() > 10
+
+
+def test_conv_descriptor_struct_matches_header(built):
+    import ctypes
+    hdr = open(os.path.join(ROOT, "include", "csg_hip.h")).read()
+    body = hdr[hdr.index("typedef struct csg_conv_desc {"):hdr.index("} csg_conv_desc;")]
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)(?:\[CSG_MAX_TAPS\])?\s*[,;]", body.split("{", 1)[1])
+    assert names == [f[0] for f in built.ConvDesc._fields_]
+    assert ctypes.sizeof(built.ConvDesc) == 4 * (20 + 3 * 16 + 3)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "canonicalsg2im_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import oracle|from oracle)", src, re.M), os.path.join(dirpath, f)
+
+
+def test_ops_refuse_cpu_tensors(built):
+    from canonicalsg2im_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 3, 3), None, 1, 1)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.real_object_mask(torch.zeros(1, 2, 1, dtype=torch.int64), 0)
+
+
+def test_backward_data_descriptors_cover_every_input_pixel_once(built):
+    """Parity classes of the stride-2 transposed convolution: each input pixel belongs to exactly one
+    launch and each (ky,kx) tap is used by exactly one parity class."""
+    from canonicalsg2im_amd.ops import _desc_forward, _descs_backward_data
+    for (IH, K, s, p) in ((9, 4, 2, 2), (8, 4, 2, 2), (7, 3, 1, 1), (6, 4, 1, 2), (5, 1, 1, 0)):
+        d, OH, OW = _desc_forward(2, IH, IH, 8, 12, K, K, s, p)
+        assert OH == (IH + 2 * p - K) // s + 1
+        descs = _descs_backward_data(2, IH, IH, 8, 12, K, K, s, p, OH, OW)
+        seen = torch.zeros(IH, IH, dtype=torch.int32)
+        taps = []
+        for bd in descs:
+            for gy in range(bd.OHg):
+                for gx in range(bd.OWg):
+                    seen[gy * bd.os + bd.ooy, gx * bd.os + bd.oox] += 1
+            for t in range(bd.ntaps):
+                taps.append(bd.tap_w[t])
+                ky = bd.tap_w[t] // K
+                # dY row of grid row j is j + tap_dy: must satisfy iy = s*oy - p + ky
+                assert s * (0 + bd.tap_dy[t]) - p + ky == bd.ooy
+        assert int(seen.min()) == 1 and int(seen.max()) == 1
+        assert sorted(taps) == list(range(K * K))
+
+
+def test_flags_match_reference_defaults():
+    from canonicalsg2im_amd.scripts.args import make_opt
+    from canonicalsg2im_amd.synth import make_vocab
+    opt = make_opt(make_vocab("clevr"), ["--no_vgg_loss"])
+    assert opt.image_size == (256, 256) and opt.embedding_dim == 32 and opt.gconv_dim == 128
+    assert opt.gconv_hidden_dim == 512 and opt.gconv_num_layers == 5 and opt.ngf == 64 and opt.ndf == 64
+    assert opt.norm_G == 'spectralspadesyncbatch3x3' and opt.norm_D == 'spectralinstance'
+    assert opt.num_D == 2 and opt.n_layers_D == 4 and opt.beta1 == 0.5 and opt.learning_rate == 1e-4
+    assert opt.semantic_nc == 4 * 32 and opt.gpu_ids == [0]
+    with pytest.raises(AssertionError):
+        make_opt(make_vocab("coco"), ["--batch_size", "3", "--gpu_ids", "0,1"])
+
+
+def test_synthetic_batch_follows_collate_contract():
+    from canonicalsg2im_amd.synth import BASELINE_CONFIGS, BatchConfig, make_batch, make_vocab, shard_batch
+    vocab = make_vocab("coco")
+    b = make_batch(vocab, BatchConfig(4, 64, 3, 8, "packed"), seed=1)
+    imgs, objs, boxes, triplets, conv, tt, masks, ids = b
+    assert imgs.shape == (4, 3, 64, 64) and imgs.dtype == torch.float32
+    assert objs.dtype == torch.int64 and objs.shape[2] == 1 and boxes.shape[:2] == objs.shape[:2]
+    assert triplets.dtype == torch.int64 and triplets.shape[2] == 3 and tt.shape == triplets.shape[:2]
+    pad = objs[..., 0] == 0
+    assert torch.all(boxes[pad] == -1) and torch.all(boxes[~pad] >= 0)
+    padt = triplets[..., 1] == 0
+    assert torch.all(triplets[padt] == 0)
+    n_obj = (~pad).sum(1)
+    assert torch.all(triplets[..., 0].max(1).values < n_obj) and torch.all(triplets[..., 2].max(1).values < n_obj)
+    b2 = make_batch(vocab, BatchConfig(4, 64, 3, 8, "packed"), seed=1)
+    assert all(torch.equal(x, y) for x, y in zip(b[:6], b2[:6]))
+    s0, s1 = shard_batch(b, 0, 2), shard_batch(b, 1, 2)
+    assert torch.equal(torch.cat([s0[1], s1[1]]), objs)
+    with pytest.raises(ValueError):
+        shard_batch(b, 0, 3)
+    clevr = make_batch(make_vocab("clevr"), BatchConfig(2, 64, 4, 6, "closure"), seed=2)
+    assert clevr[1].shape[2] == 4 and set(clevr[5].unique().tolist()) <= {0, 1}
+    assert set(BASELINE_CONFIGS) == {"C1", "C2", "C3", "C4", "C5"}
+
+
+def test_module_surface_and_state_dict_keys(built):
+    """Constructors, attribute names and checkpoint keys of the drop-in modules."""
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.sg2im.model import get_conv_converse
+    from canonicalsg2im_amd.synth import make_vocab
+    from conftest import load_golden
+    meta, a = load_golden("train_step")
+    opt = T.make_opt(make_vocab(meta["vocab"]), meta["argv"])
+    tr = T.Trainer(opt, torch.device("cpu"))
+    sg, g, d = T.split_state(tr)
+    for mine, want in ((sg, meta["shapes"]["sg"]), (g, meta["shapes"]["g"]), (d, meta["shapes"]["d"])):
+        keys = {k for k in mine if not any(u in k for u in ("repr_net", "image_encoder"))}
+        assert keys == set(want), keys ^ set(want)
+        for k in want:
+            assert list(mine[k].shape) == want[k][0], k
+    full = tr.model.state_dict()
+    assert "sg_to_layout.module.trans_candidates_weights" in full
+    assert "layout_to_image_model.module.up_3.norm_s.param_free_norm.running_var" in full
+    assert any("image_encoder.cnn" in k for k in full) and any("repr_net.0.weight" in k for k in full)
+    m = tr.model.sg_to_layout.module
+    assert all(c.predicates_transitive_weights is m.trans_candidates_weights for c in m.gconvs)   # ONE parameter
+    assert get_conv_converse(tr.model).shape == (8, 8)
+    assert get_conv_converse(full).shape == (8, 8)
+    groups = tr.optimizer.param_groups
+    assert groups[0]["lr"] == opt.learning_rate and groups[1]["lr"] == 1e-2 and len(groups[1]["params"]) == 1
+    assert tr.discriminator.optimizer_d_img.param_groups[0]["betas"] == (0.5, 0.999)
+
+
+def test_out_of_scope_components_fail_loudly(built):
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.sg2im.layout import masks_to_layout
+    from canonicalsg2im_amd.spade.models.networks import AcCropDiscriminator, VGGLoss
+    from canonicalsg2im_amd.synth import make_vocab
+    for ctor in (AcCropDiscriminator, lambda: VGGLoss([0])):
+        with pytest.raises(NotImplementedError):
+            ctor()
+    with pytest.raises(NotImplementedError):
+        masks_to_layout(None, None, None, 8)
+    with pytest.raises(NotImplementedError):
+        T.Trainer(T.make_opt(make_vocab("tiny"), ["--no_vgg_loss", "--image_size", "64,64", "--ngf", "4"]),
+                  torch.device("cpu"))          # default use_img_disc=0 needs the object discriminator

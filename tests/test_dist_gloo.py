@@ -1,0 +1,85 @@
+"""The N>1 path on CPU: two processes over gloo (the GPU box uses the same code over RCCL).
+Covers batch sharding, bucketed gradient averaging (== the reference's DataParallel gradient
+reduction because per-replica losses are means over equal shards, scripts/train.py:363,391),
+parameter broadcast, and the SyncBN (sum, sum^2) exchange with the N-replica formula."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from canonicalsg2im_amd import dist as D
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab, shard_batch
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and D.world_size() == world and D.rank() == rank
+    torch.manual_seed(100 + rank)                       # replicas start DIFFERENT, broadcast fixes it
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    unused = torch.nn.Linear(4, 4)                       # like G's never-used repr_net: no grad, must be skipped
+    D.broadcast_module(net)
+    vocab = make_vocab("tiny")
+    full = make_batch(vocab, BatchConfig(4, 8, 2, 4, "random"), seed=3)
+    mine = shard_batch(full, rank, world)
+    x = mine[2].reshape(mine[2].shape[0], -1)[:, :6]    # boxes as features
+    loss = net(x).pow(2).mean()
+    loss.backward()
+    buckets = D.GradBuckets(list(net.parameters()) + list(unused.parameters()), bucket_bytes=256)
+    nbytes = buckets.all_reduce_mean()
+    # SyncBN message
+    xs = torch.randn(2, 5, 4, 4, generator=torch.Generator().manual_seed(7 + rank)) * (1 + rank) + rank
+    C = 5
+    sums = torch.cat([xs.transpose(0, 1).reshape(C, -1).sum(1), (xs.transpose(0, 1).reshape(C, -1) ** 2).sum(1)]).double()
+    D.all_reduce_stats(sums)
+    out[rank] = {"grads": [p.grad.clone() for p in net.parameters()], "params": [p.detach().clone() for p in net.parameters()],
+                 "sums": sums, "xs": xs, "nbytes": nbytes}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_data_parallel_equals_single_process():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)                          # broadcast made replicas identical
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.allclose(a, b, rtol=0, atol=0)       # averaged gradients identical on both ranks
+    assert r0["nbytes"] > 0
+    # single-process evaluation of the whole batch with rank 0's parameters
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    with torch.no_grad():
+        for p, v in zip(net.parameters(), r0["params"]):
+            p.copy_(v)
+    full = make_batch(make_vocab("tiny"), BatchConfig(4, 8, 2, 4, "random"), seed=3)
+    x = full[2].reshape(4, -1)[:, :6]
+    net(x).pow(2).mean().backward()
+    for p, g in zip(net.parameters(), r0["grads"]):
+        assert torch.allclose(p.grad, g, rtol=1e-5, atol=1e-7)
+    # SyncBN: reduced message + N-replica formula == the oracle's multi-replica evaluation
+    import oracle
+    sums = r0["sums"]
+    assert torch.equal(sums, r1["sums"])
+    C, n = 5, 2 * 2 * 16
+    mean = sums[:C] / n
+    var = (sums[C:] - sums[:C] * mean) / n
+    inv_std = var.clamp(1e-5) ** -0.5
+    ys = oracle.syncbn_multi_replica([r0["xs"], r1["xs"]], torch.zeros(C), torch.ones(C))
+    mine0 = (r0["xs"] - mean.float().view(1, C, 1, 1)) * inv_std.float().view(1, C, 1, 1)
+    assert torch.allclose(mine0, ys[0], rtol=1e-4, atol=1e-5)

@@ -1,0 +1,346 @@
+"""Kernel-level parity on a real MI355X: every C-ABI operator (forward AND backward) against a
+plain fp32 PyTorch CPU evaluation of the same op / the CPU oracle.  Tolerance: rtol 1e-4
+(BASELINE.json north_star); index outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from canonicalsg2im_amd import ops as o
+    return o
+
+
+def dev(t, grad=False):
+    t = t.detach().clone().cuda()
+    return t.requires_grad_(True) if grad else t
+
+
+# ------------------------------------------------------------------------------------ conv / linear
+CONV_CASES = [
+    # B, Cin, Cout, H,  W,  K, s, p, act,            bias, residual
+    (2, 8, 12, 9, 11, 3, 1, 1, "none", True, False),
+    (2, 16, 8, 8, 8, 3, 1, 1, "relu", True, False),
+    (1, 8, 8, 7, 7, 1, 1, 0, "none", False, False),
+    (2, 12, 16, 17, 17, 4, 2, 2, "lrelu", True, False),
+    (2, 16, 8, 9, 9, 4, 1, 2, "none", False, False),
+    (2, 8, 16, 10, 10, 3, 1, 1, "none", True, True),
+    (2, 16, 4, 12, 12, 3, 1, 1, "tanh", True, False),
+    (2, 64, 160, 40, 40, 3, 1, 1, "none", True, False),      # multi-tile M and N, split-K wgrad
+    (3, 36, 64, 33, 33, 4, 2, 2, "lrelu", True, False),      # D's first conv shape (Cin = 32+3+1)
+    (1, 128, 72, 24, 24, 3, 1, 1, "relu", True, False),
+    (2, 32, 8, 6, 6, 4, 2, 2, "none", True, False),          # stride-2 backward-data parity classes
+    (2, 3, 5, 8, 8, 3, 1, 1, "none", True, False),           # channels not multiples of 4 -> padded by the wrapper
+]
+
+
+def _act(y, act):
+    if act == "relu":
+        return F.relu(y)
+    if act == "lrelu":
+        return F.leaky_relu(y, 0.2)
+    if act == "tanh":
+        return torch.tanh(y)
+    return y
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_forward_backward(ops, case):
+    B, Cin, Cout, H, W, K, s, p, act, has_bias, has_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g) if has_bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_bias else None
+    y_ref = _act(F.conv2d(xr, wr, br, stride=s, padding=p), act)
+    res = torch.randn(y_ref.shape, generator=g) if has_res else None
+    rr = res.clone().requires_grad_(True) if has_res else None
+    if has_res:
+        y_ref = y_ref + rr
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+
+    xd, wd = dev(x, True), dev(w, True)
+    bd = dev(b, True) if has_bias else None
+    rd = dev(res, True) if has_res else None
+    code = {"none": (ops.ACT_NONE, 0.0), "relu": (ops.ACT_LEAKY, 0.0), "lrelu": (ops.ACT_LEAKY, 0.2),
+            "tanh": (ops.ACT_TANH, 0.0)}[act]
+    y = ops.conv2d(xd, wd, bd, s, p, code[0], code[1], rd)
+    assert_close(y, y_ref, RTOL, 2e-5, "conv y %s" % (case,))
+    y.backward(gy.cuda())
+    assert_close(xd.grad, xr.grad, RTOL, 2e-5, "conv dx %s" % (case,))
+    # dw sums B*OH*OW products: absolute rounding noise scales with the largest entries
+    assert_close(wd.grad, wr.grad, RTOL, 1e-5 * float(wr.grad.abs().max()) + 1e-5, "conv dw %s" % (case,))
+    if has_bias:
+        assert_close(bd.grad, br.grad, RTOL, 1e-5 * float(br.grad.abs().max()) + 1e-5, "conv db %s" % (case,))
+    if has_res:
+        assert_close(rd.grad, rr.grad, RTOL, 1e-5, "conv dres %s" % (case,))
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(37, 24, 64, True), (300, 128, 512, True), (1000, 512, 1152, True),
+                                        (64, 128, 4, False), (5, 8, 12, False)])
+def test_linear(ops, M, K, N, relu):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x, w, b = torch.randn(3, M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    y_ref = F.linear(xr, wr, br)
+    y_ref = F.relu(y_ref) if relu else y_ref
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd, wd, bd = dev(x, True), dev(w, True), dev(b, True)
+    y = ops.linear(xd, wd, bd, ops.ACT_LEAKY if relu else ops.ACT_NONE, 0.0)
+    assert_close(y, y_ref, RTOL, 2e-5, "linear y")
+    y.backward(gy.cuda())
+    assert_close(xd.grad, xr.grad, RTOL, 2e-5, "linear dx")
+    assert_close(wd.grad, wr.grad, RTOL, 1e-5 * float(wr.grad.abs().max()) + 1e-5, "linear dw")
+    assert_close(bd.grad, br.grad, RTOL, 1e-5 * float(br.grad.abs().max()) + 1e-5, "linear db")
+
+
+# ------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("B,C,H,W,instance,mod,slope", [
+    (3, 8, 5, 7, False, True, 0.2), (2, 16, 9, 9, False, True, 1.0), (2, 64, 12, 12, False, False, 1.0),
+    (3, 12, 6, 5, True, False, 0.2), (2, 1024, 4, 4, False, True, 0.2), (2, 8, 33, 33, True, False, 0.2),
+    (4, 128, 40, 40, False, True, 0.2)])
+def test_norm_act_train(ops, B, C, H, W, instance, mod, slope):
+    g = torch.Generator().manual_seed(C * 3 + H)
+    x = torch.randn(B, C, H, W, generator=g) * 1.7 + 0.3
+    gb = torch.randn(B, 2 * C, H, W, generator=g) * 0.5 if mod else None
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.clone().requires_grad_(True)
+    gbr = gb.clone().requires_grad_(True) if mod else None
+    if instance:
+        n = F.instance_norm(xr, eps=1e-5)
+    else:
+        n = F.batch_norm(xr, rm, rv, None, None, True, 0.1, 1e-5)
+    y_ref = n * (1 + gbr[:, :C]) + gbr[:, C:] if mod else n
+    if slope != 1.0:
+        y_ref = F.leaky_relu(y_ref, slope)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd = dev(x, True)
+    gbd = dev(gb, True) if mod else None
+    rmd, rvd = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    y = ops.norm_act(xd, gbd, None if instance else rmd, None if instance else rvd, instance=instance, training=True,
+                     slope=slope)
+    assert_close(y, y_ref, RTOL, 2e-5, "norm y")
+    y.backward(gy.cuda())
+    assert_close(xd.grad, xr.grad, 2e-4, 3e-5, "norm dx")
+    if mod:
+        assert_close(gbd.grad, gbr.grad, RTOL, 2e-5, "norm dgb")
+    if not instance:
+        assert_close(rmd, rm, RTOL, 1e-6, "running_mean")
+        assert_close(rvd, rv, RTOL, 1e-6, "running_var")
+
+
+def test_norm_act_eval(ops):
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 8, 6, 6
+    x = torch.randn(B, C, H, W, generator=g)
+    gb = torch.randn(B, 2 * C, H, W, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    xr, gbr = x.clone().requires_grad_(True), gb.clone().requires_grad_(True)
+    n = F.batch_norm(xr, rm.clone(), rv.clone(), None, None, False, 0.1, 1e-5)
+    y_ref = F.leaky_relu(n * (1 + gbr[:, :C]) + gbr[:, C:], 0.2)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd, gbd = dev(x, True), dev(gb, True)
+    rmd, rvd = rm.cuda(), rv.cuda()
+    y = ops.norm_act(xd, gbd, rmd, rvd, instance=False, training=False, slope=0.2)
+    assert_close(y, y_ref, RTOL, 2e-5, "eval y")
+    y.backward(gy.cuda())
+    assert_close(xd.grad, xr.grad, RTOL, 2e-5, "eval dx")
+    assert_close(gbd.grad, gbr.grad, RTOL, 2e-5, "eval dgb")
+    assert_close(rmd, rm, 0, 0, "running_mean untouched")
+
+
+# ------------------------------------------------------------------------------------ resampling
+def test_upsample_and_avgpool(ops):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 8, 5, 7, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.interpolate(xr, scale_factor=2, mode="nearest")
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd = dev(x, True)
+    y = ops.upsample2x(xd)
+    assert_close(y, y_ref, 0, 0, "upsample (bit exact)")
+    y.backward(gy.cuda())
+    assert_close(xd.grad, xr.grad, RTOL, 1e-6, "upsample dx")
+    for H, W in ((9, 9), (8, 10), (33, 33)):
+        x = torch.randn(2, 36, H, W, generator=g)
+        xr = x.clone().requires_grad_(True)
+        y_ref = F.avg_pool2d(xr, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)
+        gy = torch.randn(y_ref.shape, generator=g)
+        y_ref.backward(gy)
+        xd = dev(x, True)
+        y = ops.avgpool3s2(xd)
+        assert_close(y, y_ref, RTOL, 1e-6, "avgpool %dx%d" % (H, W))
+        y.backward(gy.cuda())
+        assert_close(xd.grad, xr.grad, RTOL, 1e-6, "avgpool dx %dx%d" % (H, W))
+
+
+# ------------------------------------------------------------------------------------ layout
+def test_layout_golden(ops):
+    """boxes_to_layout against the reference's own output (grid_sample + scatter_add)."""
+    from canonicalsg2im_amd._lib import check, lib, ptr, stream
+    meta, a = load_golden("layout")
+    vecs, boxes = a["vecs"], a["boxes"]
+    O, S = vecs.shape
+    valid = torch.ones(1, O, dtype=torch.uint8).cuda()
+    for H, W in meta["sizes"]:
+        tag = "%dx%d" % (H, W)
+        out = torch.empty(1, H, W, S).cuda()
+        check(lib.csg_layout_fwd(ptr(vecs.cuda()), ptr(boxes.cuda()), ptr(valid), 1, O, S, H, W, H, W, ptr(out), S, 0,
+                                 stream()))
+        assert_close(out.permute(0, 3, 1, 2), a["out_" + tag], RTOL, 2e-6, "layout " + tag)
+        dv = torch.empty(1, O, S).cuda()
+        gw = a["w_" + tag].permute(0, 2, 3, 1).contiguous().cuda()
+        check(lib.csg_layout_bwd(ptr(gw), S, 0, ptr(boxes.cuda()), ptr(valid), 1, O, S, H, W, H, W, ptr(dv), 0, stream()))
+        assert_close(dv[0], a["gvecs_" + tag], RTOL, 1e-5, "layout dvecs " + tag)
+
+
+def test_layout_pyramid_vs_oracle(ops):
+    import oracle
+    g = torch.Generator().manual_seed(21)
+    B, O, S, H = 3, 37, 32, 64
+    vecs = torch.randn(B, O, S, generator=g)
+    wh = torch.rand(B, O, 2, generator=g) * 0.4 + 0.05
+    xy = torch.rand(B, O, 2, generator=g) * (1 - wh)
+    boxes = torch.cat([xy, wh], -1)
+    valid = (torch.rand(B, O, generator=g) > 0.3)
+    sizes = (2, 4, 8, 16, 32, 64)
+    vr = vecs.clone().requires_grad_(True)
+    refs = []
+    for h in sizes:
+        full = torch.cat([oracle.boxes_to_layout(vr[b][valid[b]], boxes[b][valid[b]], H, H) for b in range(B)], 0)
+        refs.append(F.interpolate(full, size=(h, h), mode="nearest"))
+    gys = [torch.randn(r.shape, generator=g) for r in refs]
+    sum((r * gy).sum() for r, gy in zip(refs, gys)).backward()
+    vd = dev(vecs, True)
+    outs = ops.layout_pyramid(vd, boxes.cuda(), valid.to(torch.uint8).cuda(), H, sizes)
+    for h, o, r in zip(sizes, outs, refs):
+        assert_close(o, r, RTOL, 5e-6, "pyramid level %d" % h)
+    sum((o * gy.cuda()).sum() for o, gy in zip(outs, gys)).backward()
+    assert_close(vd.grad, vr.grad, RTOL, 2e-5, "pyramid dvecs")
+
+
+def test_disc_input(ops):
+    import oracle
+    g = torch.Generator().manual_seed(22)
+    B, O, S, H = 2, 9, 8, 32
+    vecs, img = torch.randn(B, O, S, generator=g), torch.randn(B, 3, H, H, generator=g)
+    wh = torch.rand(B, O, 2, generator=g) * 0.4 + 0.05
+    boxes = torch.cat([torch.rand(B, O, 2, generator=g) * (1 - wh), wh], -1)
+    valid = torch.ones(B, O, dtype=torch.bool)
+    valid[0, -3:] = False
+    vr, ir = vecs.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    seg = torch.cat([oracle.boxes_to_layout(vr[b][valid[b]], boxes[b][valid[b]], H, H) for b in range(B)], 0)
+    ref = torch.cat([seg, ir, torch.zeros(B, 1, H, H)], 1)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    vd, idv = dev(vecs, True), dev(img, True)
+    buf = ops.disc_input(idv, vd, boxes.cuda(), valid.to(torch.uint8).cuda(), H)
+    assert_close(buf, ref, RTOL, 5e-6, "disc input buffer")
+    buf.backward(gy.cuda())
+    assert_close(vd.grad, vr.grad, RTOL, 2e-5, "disc input dvecs")
+    assert_close(idv.grad, ir.grad, 0, 0, "disc input dimg")
+
+
+# ------------------------------------------------------------------------------------ graph
+def test_real_object_mask_bit_exact(ops):
+    g = torch.Generator().manual_seed(1)
+    objs = torch.randint(0, 4, (5, 13, 3), generator=g)
+    m = ops.real_object_mask(objs.cuda(), 0).cpu()
+    want = ((objs[..., 0] != 0) & (objs[..., 0] != 0)).to(torch.uint8)
+    assert torch.equal(m, want)
+    m2 = ops.real_object_mask(objs.cuda(), 2).cpu()
+    assert torch.equal(m2, ((objs[..., 0] != 0) & (objs[..., 0] != 2)).to(torch.uint8))
+
+
+def _csr_reference(triplets, O):
+    B, T, _ = triplets.shape
+    rp = np.zeros((B, O + 1), np.int32)
+    col = np.zeros((B, max(2 * T, 1)), np.int32)
+    for b in range(B):
+        rows = [[] for _ in range(O)]
+        for t in range(T):
+            rows[int(triplets[b, t, 0])].append(2 * t)
+        for t in range(T):
+            rows[int(triplets[b, t, 2])].append(2 * t + 1)
+        pos = 0
+        for i in range(O):
+            rp[b, i] = pos
+            col[b, pos:pos + len(rows[i])] = rows[i]
+            pos += len(rows[i])
+        rp[b, O] = pos
+    return rp, col
+
+
+@pytest.mark.parametrize("B,T,O", [(2, 9, 5), (3, 700, 40), (2, 5000, 300), (1, 1, 1)])
+def test_graph_csr_bit_exact(ops, B, T, O):
+    g = torch.Generator().manual_seed(T)
+    tr = torch.stack([torch.randint(0, O, (B, T), generator=g), torch.randint(0, 8, (B, T), generator=g),
+                      torch.randint(0, O, (B, T), generator=g)], -1)
+    rp, col = ops.graph_csr(tr.cuda(), O)
+    rp_ref, col_ref = _csr_reference(tr.numpy(), O)
+    assert np.array_equal(rp.cpu().numpy(), rp_ref)
+    assert np.array_equal(col.cpu().numpy()[:, :2 * T], col_ref[:, :2 * T])
+
+
+def test_embed(ops):
+    g = torch.Generator().manual_seed(3)
+    tabs = [torch.randn(n, 8, generator=g) for n in (4, 9, 3, 3)]
+    idx = torch.stack([torch.randint(0, t.shape[0], (3, 11), generator=g) for t in tabs], -1)
+    tr = [t.clone().requires_grad_(True) for t in tabs]
+    ref = torch.cat([F.embedding(idx[..., k], tr[k]) for k in range(4)], -1)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    td = [dev(t, True) for t in tabs]
+    out = ops.embed(idx.cuda(), td)
+    assert_close(out, ref, 0, 0, "embedding (bit exact)")
+    out.backward(gy.cuda())
+    for k in range(4):
+        assert_close(td[k].grad, tr[k].grad, RTOL, 1e-5, "dtable %d" % k)
+
+
+def test_gather_concat_and_segment_avg_vs_golden(ops):
+    """The (s,p,o) gather and the confidence-weighted average of GraphTripleConv against the
+    reference's own layer output: net1/net2 evaluated with plain CPU torch around the two kernels."""
+    meta, a = load_golden("gconv")
+    H, Dp = meta["hidden"], meta["dp_out"]
+    obj, pred = dev(a["obj"], True), dev(a["pred"], True)
+    edges, p, tt = a["edges"].cuda(), a["p"].cuda(), a["tt"].cuda()
+    tr = torch.stack([edges[..., 0], p, edges[..., 1]], -1).contiguous()
+    rp, col = ops.graph_csr(tr, obj.shape[1])
+    cat = ops.gather_concat(obj, pred, tr, rp, col)
+    sd = {k[3:]: dev(v, True) for k, v in a.items() if k.startswith("sd:")}
+    w_trans = sd["predicates_transitive_weights"]
+    h = F.relu(F.linear(F.relu(F.linear(cat, sd["net1.0.weight"], sd["net1.0.bias"])), sd["net1.2.weight"],
+                        sd["net1.2.bias"]))
+    conf = (tt == 0).float() + (tt == 1).float() * torch.sigmoid(w_trans)[p]
+    pooled, new_p = ops.segment_avg(h, conf, (p != 0).to(torch.uint8), tr, rp, col, H, Dp)
+    new_obj = F.relu(F.linear(F.relu(F.linear(pooled, sd["net2.0.weight"], sd["net2.0.bias"])), sd["net2.2.weight"],
+                              sd["net2.2.bias"]))
+    assert_close(new_obj, a["new_obj"], RTOL, 2e-6, "new_obj")
+    assert_close(new_p, a["new_p"], RTOL, 2e-6, "new_p")
+    ((new_obj * a["wo"].cuda()).sum() + (new_p * a["wp"].cuda()).sum()).backward()
+    assert_close(obj.grad, a["gobj"], RTOL, 1e-5, "dobj")
+    assert_close(pred.grad, a["gpred"], RTOL, 1e-5, "dpred")
+    assert_close(w_trans.grad, a["grad:predicates_transitive_weights"], RTOL, 1e-5, "dw_trans")
+    for k in ("net1.0.weight", "net1.2.bias", "net2.0.weight", "net2.2.weight"):
+        assert_close(sd[k].grad, a["grad:" + k], RTOL, 1e-5, "d" + k)
+
+
+def test_cpu_tensor_is_refused(ops):
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 3, 3), None, 1, 1)

@@ -1,0 +1,235 @@
+"""Module-level parity on a real MI355X: the drop-in modules (same constructor arguments and
+state_dict keys as the reference) against the golden vectors produced by the reference and
+against the CPU oracle, plus size-independent properties at BASELINE.json's full sizes."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close, load_golden, state_from_shapes
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _load(module, state, strict=True):
+    sd = {k: v.detach().clone() for k, v in state.items()}
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if not any(u in k for u in ("repr_net", "image_encoder"))]
+    assert not unexpected, unexpected
+    if strict:
+        assert not missing, missing
+    return module
+
+
+@pytest.mark.parametrize("tag", ["a1", "a4"])
+def test_sg2layout_vs_reference(cuda, tag):
+    from canonicalsg2im_amd.scripts.args import make_opt
+    from canonicalsg2im_amd.sg2im.model import Sg2LayoutModel
+    from canonicalsg2im_amd.synth import make_vocab
+    meta, a = load_golden("sg2layout_" + tag)
+    vocab = make_vocab(meta["vocab"])
+    kw = {k: v for k, v in meta["argv"].items()}
+    opt = make_opt(vocab, ["--image_size", "32,32"], **kw)
+    model = Sg2LayoutModel(opt)
+    _load(model, {k[3:]: v for k, v in a.items() if k.startswith("sd:")})
+    model = model.to(cuda)
+    obj_vecs, boxes_pred, _ = model(a["objs"].cuda(), a["triplets"].cuda(), a["tt"].cuda())
+    assert_close(obj_vecs, a["obj_vecs"], RTOL, 2e-6, "obj_vecs")
+    assert_close(boxes_pred, a["boxes_pred"], RTOL, 2e-6, "boxes_pred")
+    ((obj_vecs * a["wv"].cuda()).sum() + (boxes_pred * a["wb"].cuda()).sum()).backward()
+    n = 0
+    for k, p in model.named_parameters():
+        if ("grad:" + k) in a and p.grad is not None:
+            assert_close(p.grad, a["grad:" + k], RTOL, 1e-5, "d" + k)
+            n += 1
+    assert n > 10
+
+
+def test_spade_resblock_vs_reference(cuda):
+    from canonicalsg2im_amd.scripts.args import make_opt
+    from canonicalsg2im_amd.spade.models.networks.architecture import SPADEResnetBlock
+    from canonicalsg2im_amd.synth import make_vocab
+    meta, a = load_golden("spade_block")
+    opt = make_opt(make_vocab("tiny"), ["--image_size", "16,16"], embedding_dim=meta["embedding_dim"])
+    blk = SPADEResnetBlock(meta["fin"], meta["fout"], opt)
+    _load(blk, state_from_shapes(meta["shapes"], seed=3, requires_grad=False))
+    blk = blk.to(cuda).train()
+    x = a["x"].cuda().requires_grad_(True)
+    seg = a["seg"].cuda().requires_grad_(True)
+    y = blk(x, seg)
+    assert_close(y, a["y"], RTOL, 1e-5, "block out")
+    (y * a["w"].cuda()).sum().backward()
+    assert_close(x.grad, a["gx"], RTOL, 1e-5, "dx")
+    assert_close(seg.grad, a["gseg"], RTOL, 1e-5, "dseg")
+    sd = blk.state_dict()
+    for k, p in blk.named_parameters():
+        if ("grad:" + k) in a:
+            assert_close(p.grad, a["grad:" + k], 2e-4, 1e-5, "d" + k)
+    for k, v in a.items():
+        if k.startswith("after:"):
+            assert_close(sd[k[6:]], v, RTOL, 1e-6, "state " + k[6:])
+    blk.eval()
+    with torch.no_grad():
+        assert_close(blk(a["x"].cuda(), a["seg"].cuda()), a["y_eval"], RTOL, 1e-5, "eval out")
+
+
+def _trainer_from_golden(cuda):
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import make_vocab
+    meta, a = load_golden("train_step")
+    opt = T.make_opt(make_vocab(meta["vocab"]), meta["argv"])
+    tr = T.Trainer(opt, cuda)
+    sh = meta["shapes"]
+    _load(tr.model.sg_to_layout.module, state_from_shapes(sh["sg"], 11, requires_grad=False))
+    _load(tr.model.layout_to_image_model.module, state_from_shapes(sh["g"], 12, requires_grad=False), strict=False)
+    _load(tr.discriminator.img_discriminator, state_from_shapes(sh["d"], 13, requires_grad=False), strict=False)
+    batch = [a["imgs"], a["objs"], a["boxes"], a["triplets"], None, a["tt"], None, None]
+    batch = [None if t is None else t.cuda() for t in batch]
+    return meta, a, opt, tr, batch
+
+
+def test_full_train_step_vs_reference(cuda):
+    """scripts/train.py:353-393 on the HIP modules against the step replayed with the reference's
+    own modules: image, loss dicts, gradients, spectral-norm / BatchNorm state, post-step weights."""
+    from canonicalsg2im_amd import train as T
+    meta, a, opt, tr, batch = _trainer_from_golden(cuda)
+    G, D = tr.step(batch)
+    for k in ("bbox_pred_all", "bbox_pred", "GAN_Img", "GAN_Feat", "total_loss"):
+        assert_close(G[k].reshape(a["G:" + k].shape), a["G:" + k], RTOL, 1e-5, "G " + k)
+    for k in ("D_img_fake", "D_img_real", "total_img_loss"):
+        assert_close(D[k].reshape(a["D:" + k].shape), a["D:" + k], RTOL, 1e-5, "D " + k)
+    sg, g, d = T.split_state(tr)
+    gnamed = dict(tr.model.layout_to_image_model.module.named_parameters())
+    sgnamed = dict(tr.model.sg_to_layout.module.named_parameters())
+    dnamed = dict(tr.discriminator.img_discriminator.named_parameters())
+    n = 0
+    for k, v in a.items():
+        if k.startswith("ggrad:"):
+            assert_close(gnamed[k[6:]].grad, v, 1e-3, 1e-6, k)
+            n += 1
+        elif k.startswith("sggrad:") and sgnamed[k[7:]].grad is not None:
+            assert_close(sgnamed[k[7:]].grad, v, 1e-3, 1e-6, k)
+            n += 1
+        elif k.startswith("dgrad:"):
+            assert_close(dnamed[k[6:]].grad, v, 1e-3, 1e-6, k)
+            n += 1
+    assert n > 30
+    lr = opt.learning_rate
+
+    def check_param(name, mine, want, gkey):          # see tests/test_oracle_golden.py for the rationale
+        if gkey in a:
+            gr = a[gkey]
+            sig = gr.abs() > 1e-5 * gr.abs().max().clamp_min(1e-30)
+            assert_close(mine.detach().cpu()[sig], want[sig], 1e-3, 2e-6, name)
+        assert_close(mine, want, 0, 2.2 * (1e-2 if "trans" in name else lr), name)
+
+    for k, v in a.items():
+        if k.startswith("sg_after:"):
+            check_param(k, sg[k[9:]], v, "sggrad:" + k[9:])
+        elif k.startswith("d_after:"):
+            name = k[8:]
+            if "weight_u" in name or "weight_v" in name:
+                assert_close(d[name], v, 1e-3, 2e-6, k)
+            else:
+                check_param(k, d[name], v, "dgrad:" + name)
+        elif k.startswith("g_after:"):
+            name = k[8:]
+            if any(b in name for b in ("running_", "weight_u", "weight_v", "num_batches")):
+                assert_close(g[name], v, 1e-3, 2e-6, k)
+            else:
+                check_param(k, g[name], v, "ggrad:" + name)
+
+
+def test_generated_image_vs_reference(cuda):
+    meta, a, opt, tr, batch = _trainer_from_golden(cuda)
+    with torch.no_grad():
+        img, boxes_pred, _ = tr.model(batch[1], batch[3], batch[5], boxes_gt=batch[2])
+    # tanh output of a 7-block generator: 1e-4 of the output scale (|img| <= 1)
+    assert_close(img, a["imgs_pred"], RTOL, 1e-4, "imgs_pred")
+    assert_close(boxes_pred, a["boxes_pred"], RTOL, 1e-5, "boxes_pred")
+
+
+def test_discriminator_features_eval_vs_reference(cuda):
+    from canonicalsg2im_amd import train as T
+    meta, a, opt, tr, batch = _trainer_from_golden(cuda)
+    D = tr.discriminator.img_discriminator
+    _load(D, {k[8:]: v for k, v in a.items() if k.startswith("d_after:")}, strict=False)
+    D.eval()
+    with torch.no_grad():
+        feats = D(batch[0], batch[1], batch[2])
+    for i, scale in enumerate(feats):
+        for j, f in enumerate(scale):
+            assert_close(f, a["dfeat_%d_%d" % (i, j)], RTOL, 1e-5, "dfeat %d %d" % (i, j))
+
+
+def test_two_steps_vs_oracle_128(cuda):
+    """A COCO-like batch at 128x128 (BASELINE config C2 shape, narrower nets so the CPU oracle stays
+    fast): two consecutive optimisation steps, HIP trainer vs oracle, same initial weights."""
+    import oracle
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
+    vocab = make_vocab("coco")
+    opt = T.make_opt(vocab, ["--image_size", "128,128", "--ngf", "8", "--ndf", "8", "--no_vgg_loss",
+                             "--use_img_disc", "1", "--batch_size", "3", "--gconv_hidden_dim", "128",
+                             "--gconv_dim", "64"])
+    torch.manual_seed(5)
+    tr = T.Trainer(opt, cuda)
+    ts = T.oracle_state_from(tr, oracle)
+    for step in range(2):
+        batch = make_batch(vocab, BatchConfig(3, 128, 3, 8, "random"), seed=40 + step)
+        G, D = tr.step([None if t is None else t.cuda() for t in batch])
+        Go, Do, _ = oracle.train_step(ts, batch)
+        for k in ("bbox_pred", "GAN_Img", "GAN_Feat", "total_loss"):
+            assert_close(G[k].reshape(()), Go[k].reshape(()), 2e-3 if step else 2e-4, 1e-5, "step %d G %s" % (step, k))
+        for k in ("D_img_fake", "D_img_real"):
+            assert_close(D[k].reshape(()), Do[k].reshape(()), 2e-3 if step else 2e-4, 1e-5, "step %d D %s" % (step, k))
+
+
+# ----------------------------------------------------------------------------- full-size properties
+def test_layout_full_size_checksum_and_linearity(cuda):
+    """256x256, S=32, 30 objects/img, B=16 (config C3): (1) sum over pixels of the layout equals
+    sum_o vec[o] * (sum_y cy[o,y]) * (sum_x cx[o,x]) evaluated on the CPU; (2) linearity in vecs."""
+    import oracle
+    from canonicalsg2im_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, O, S, H = 16, 30, 32, 256
+    vecs, vecs2 = torch.randn(B, O, S, generator=g), torch.randn(B, O, S, generator=g)
+    wh = torch.rand(B, O, 2, generator=g) * 0.4 + 0.05
+    boxes = torch.cat([torch.rand(B, O, 2, generator=g) * (1 - wh), wh], -1)
+    valid = torch.ones(B, O, dtype=torch.uint8)
+    (seg,) = ops.layout_pyramid(vecs.cuda(), boxes.cuda(), valid.cuda(), H, (H,))
+    (seg2,) = ops.layout_pyramid(vecs2.cuda(), boxes.cuda(), valid.cuda(), H, (H,))
+    (seg12,) = ops.layout_pyramid((vecs + 2 * vecs2).cuda(), boxes.cuda(), valid.cuda(), H, (H,))
+    assert_close(seg12, seg + 2 * seg2, 1e-4, 1e-4, "layout linearity")
+    want = torch.zeros(B, S, dtype=torch.float64)
+    for b in range(B):
+        cx = oracle.box_coverage(boxes[b, :, 0], boxes[b, :, 2], H).double().sum(1)
+        cy = oracle.box_coverage(boxes[b, :, 1], boxes[b, :, 3], H).double().sum(1)
+        want[b] = (vecs[b].double() * (cx * cy).unsqueeze(1)).sum(0)
+    got = seg.double().sum(dim=(2, 3)).cpu()
+    assert_close(got, want, 1e-4, 1e-2, "layout checksum")
+
+
+def test_conv_full_size_locality(cuda):
+    """The dominant generator conv (gamma||beta, 128 -> 256 channels at 256x256, B=4): a 12x12
+    output window must equal F.conv2d of the matching 14x14 input window on the CPU."""
+    from canonicalsg2im_amd import ops
+    g = torch.Generator().manual_seed(78)
+    B, Cin, Cout, H = 4, 128, 256, 256
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 34.0
+    b = torch.randn(Cout, generator=g)
+    y = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, 1)
+    for (bi, y0, x0) in ((0, 0, 0), (1, 100, 37), (3, 244, 244), (2, 127, 200)):
+        ya, xa = max(y0 - 1, 0), max(x0 - 1, 0)
+        yb, xb = min(y0 + 13, H), min(x0 + 13, H)
+        patch = F.pad(x[bi:bi + 1, :, ya:yb, xa:xb], (1 if x0 == 0 else 0, 1 if x0 + 13 > H else 0,
+                                                      1 if y0 == 0 else 0, 1 if y0 + 13 > H else 0))
+        ref = F.conv2d(patch, w, b)
+        assert_close(y[bi:bi + 1, :, y0:y0 + 12, x0:x0 + 12], ref, 1e-4, 2e-5, "window (%d,%d,%d)" % (bi, y0, x0))
