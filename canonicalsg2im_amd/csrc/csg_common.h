@@ -20,7 +20,9 @@ enum KernelId {
   K_SEGAVG_BWD,
   K_LAYOUT_FWD,
   K_LAYOUT_BWD,
-  K_IGEMM_FWD,
+  K_IGEMM_FWD,    // k_igemm_fwd<128>
+  K_IGEMM_FWD64,  // k_igemm_fwd<64>
+  K_SPLITK_EPI,
   K_IGEMM_WGRAD,
   K_WGRAD_REDUCE,
   K_ACT_BWD,

@@ -6,32 +6,79 @@
 // k-ordered fp32 FMA chain, so this path keeps the reference's precision (no TF32/bf16).
 //
 // GEMM view (forward and backward-data): rows m = output pixels, cols n = output channels,
-// k = (tap, input channel).  Block tile 128 x BN x 32, 4 waves (2x2), each wave 64 x BN/2 as
-// 2 x NI tiles of 32x32.  Both operands are staged global -> registers -> LDS as [row][32 k]
-// with rows padded to 36 floats: every fragment read is one conflict-free ds_read_b128 that
-// feeds FOUR MFMAs (the k index inside a group of 8 is permuted identically for A and B).
-// LDS is double-buffered: one barrier per K-tile, next tile's global loads in flight during
-// the 64 MFMAs of the current one; 2 blocks/CU so a second wave covers each SIMD's gaps.
+// k = (tap, input channel).  Block tile 128 x BN x 32 (BN = 128 / 64 / 32), 4 waves.  Both
+// operands are staged global -> registers -> LDS as [row][32 k] with rows padded to 36 floats:
+// every fragment read is one conflict-free ds_read_b128 that feeds FOUR MFMAs (the k index inside
+// a group of 8 is permuted identically for A and B).  LDS is double-buffered: one barrier per
+// K-tile, the next tile's global loads are in flight during the 64 MFMAs of the current one.
 //
-// Weight gradient: rows = output channels (A = dY), cols = (tap, input channel) (B = gathered
-// X), reduction over pixels, split across blocks into slabs that an ordered pass sums
-// (bit-reproducible, no atomics).
+// Loads go through buffer descriptors (SRDs): a lane whose tap falls outside the image, whose
+// row is past M/N or whose k is past K simply gets an out-of-range offset and the hardware returns
+// zeros — the loader is branch-free, so hipcc interleaves its ~50 VALU ops with the MFMAs
+// (the first version's exec-masked loads left 30 % of the matrix pipe idle: profiles/r01b).
+//
+// Small grids (few output tiles, long K — the low-resolution layers and their backward-data) are
+// split along K into slabs that a second ordered pass sums and finishes (bias/activation/residual);
+// no atomics, results are reproducible.
+//
+// Weight gradient: rows = output channels (A = dY), cols = (tap, input channel) (B = gathered X),
+// reduction over pixels, split across blocks into slabs + ordered reduction as well.
 #include "csg_common.h"
 
 using namespace csg;
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// 128-bit raw buffer load.  hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b128 to a ONE-dword
+// load (llvm.amdgcn.raw.ptr.buffer.load.i32; verified on hardware with tools/probe), so the LLVM
+// intrinsic is declared directly, with the descriptor as four plain dwords.
+__device__ f32x4 csg_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.v4f32");
+
+__device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r.x = (int)(a & 0xffffffffu);
+  r.y = (int)((a >> 32) & 0xffffu);   // stride 0: raw buffer, offsets in bytes
+  r.z = (int)bytes;                   // num_records: loads at or past it return 0
+  r.w = 0x00020000;                   // DATA_FORMAT_32
+  return r;
+}
+
+#define IG_BM 128
+#define IG_BK 32
+#define IG_LD 36
+#define OOB_OFF 0x80000000u           // >= any num_records we ever set: the load returns 0
+#define MAX_RECORDS 0x7FFFFFF0ll
+
+struct FastDiv {                      // exact n / d for 32-bit unsigned n (Granlund-Montgomery round-up)
+  unsigned m, s1, s2;
+};
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
 
 struct IgemmParams {
   csg_conv_desc d;
   int M, Ktot, wrow;
   int mtiles, ntiles;
   int simple_out;  // output pixel index == m
+  int ksplit, kt_per_split;
+  FastDiv div_ow, div_oh;
+  unsigned img_bytes;   // bytes of one input image (IHp*IWp*x_cs*4)
 };
-
-#define IG_BM 128
-#define IG_BK 32
-#define IG_LD 36
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles
@@ -51,11 +98,23 @@ __device__ __forceinline__ void load_taps(const csg_conv_desc& d, int* s_tap, in
   }
 }
 
+__device__ __forceinline__ void decompose(const IgemmParams& p, unsigned m, int& b, int& gy, int& gx) {
+  unsigned t = fdiv(m, p.div_ow);
+  gx = (int)(m - t * (unsigned)p.d.OWg);
+  unsigned bb = fdiv(t, p.div_oh);
+  gy = (int)(t - bb * (unsigned)p.d.OHg);
+  b = (int)bb;
+}
+
+
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                       const float* __restrict__ res, float* __restrict__ y) {
-  constexpr int NI = BN / 64;
+                                                       const float* __restrict__ res, float* __restrict__ y,
+                                                       float* __restrict__ ws) {
+  constexpr int MI = BN == 32 ? 1 : 2;       // 32x32 tiles per wave along m
+  constexpr int NI = BN == 128 ? 2 : 1;      // ... along n
+  constexpr int WM = BN == 32 ? 4 : 2;       // waves along m
   constexpr int BROWS = BN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -63,92 +122,122 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
   int* s_tap = (int*)(Bs + 2 * BN * IG_LD);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
-  const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
   const csg_conv_desc& d = p.d;
+  int bid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles * p.ksplit);
+  int ks = 0;
+  if (p.ksplit > 1) {
+    ks = bid % p.ksplit;
+    bid /= p.ksplit;
+  }
+  const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
 
   load_taps(d, s_tap, tid);
 
+  // ---- buffer descriptors (wave-uniform): A based at the image of this tile's first row
+  const int m_first = min(mt * IG_BM, p.M - 1);
+  const int b0 = (int)fdiv(fdiv((unsigned)m_first, p.div_ow), p.div_oh);
+  const long long a_rem = (long long)(d.B - b0) * p.img_bytes;
+  const i32x4 rsA = make_srd(x + (long long)b0 * (p.img_bytes >> 2), (unsigned)(a_rem < MAX_RECORDS ? a_rem : MAX_RECORDS));
+  const long long w_bytes = (long long)d.Cout * p.wrow * 4;
+  const i32x4 rsB = make_srd(w, (unsigned)(w_bytes < MAX_RECORDS ? w_bytes : MAX_RECORDS));
+
   const int r0 = tid >> 3, kc = tid & 7;
-  int a_rb[4], a_iy0[4], a_ix0[4];
+  unsigned a_base[4];
+  int a_iy0[4], a_ix0[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int m = mt * IG_BM + r0 + 32 * i;
-    bool ok = m < p.M;
-    int mm = ok ? m : 0;
-    int t = mm / d.OWg;
-    int gx = mm - t * d.OWg;
-    int b = t / d.OHg;
-    int gy = t - b * d.OHg;
-    a_rb[i] = b * d.IHp;
+    const int m = mt * IG_BM + r0 + 32 * i;
+    const bool ok = m < p.M;
+    int b, gy, gx;
+    decompose(p, (unsigned)(ok ? m : 0), b, gy, gx);
+    a_base[i] = (unsigned)(b - b0) * p.img_bytes;
     a_iy0[i] = ok ? gy * d.istride : -(1 << 28);
     a_ix0[i] = gx * d.istride;
   }
-  int b_n[BROWS];
+  unsigned b_base[BROWS];
 #pragma unroll
-  for (int i = 0; i < BROWS; ++i) b_n[i] = nt * BN + r0 + 32 * i;
+  for (int i = 0; i < BROWS; ++i) {
+    const int n = nt * BN + r0 + 32 * i;
+    b_base[i] = n < d.Cout ? (unsigned)n * (unsigned)p.wrow * 4u : OOB_OFF;
+  }
 
-  float4 ra[4], rb[BROWS];
-  const int nkt = (p.Ktot + IG_BK - 1) / IG_BK;
+  const int nkt_all = (p.Ktot + IG_BK - 1) / IG_BK;
+  const int kt0 = ks * p.kt_per_split;
+  const int kt1 = min(nkt_all, kt0 + p.kt_per_split);
+  // this thread's k position (tap slot, channel) of the tile being loaded, advanced incrementally
+  int k_cur = kt0 * IG_BK + kc * 4;
+  int slot = k_cur / d.Cin;
+  int cch = k_cur - slot * d.Cin;
+
+  f32x4 ra[4], rb[BROWS];
   __syncthreads();  // s_tap visible
 
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * IG_BK + kc * 4;
-    const bool kv = k0 < p.Ktot;
-    const int slot = kv ? k0 / d.Cin : 0;
-    const int c = k0 - slot * d.Cin;
-    const int dy = s_tap[slot], dx = s_tap[16 + slot], tw = s_tap[32 + slot];
+  auto load_tile = [&]() {
+    const bool kv = k_cur < p.Ktot;
+    const int sl = kv ? slot : 0;
+    const int dy = s_tap[sl], dx = s_tap[16 + sl], tw = s_tap[32 + sl];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
       const bool inb = kv && (unsigned)iy < (unsigned)d.IHv && (unsigned)ix < (unsigned)d.IWv;
-      const int64_t off = ((int64_t)(a_rb[i] + (iy >> d.in_up)) * d.IWp + (ix >> d.in_up)) * d.x_cs + c;
-      ra[i] = inb ? *(const float4*)(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned off =
+          a_base[i] + (unsigned)(((iy >> d.in_up) * d.IWp + (ix >> d.in_up)) * d.x_cs + cch) * 4u;
+      ra[i] = csg_buffer_load_f32x4(rsA, (int)(inb ? off : OOB_OFF), 0, 0);
     }
-    const int64_t wcol = (int64_t)tw * d.Cin + c;
+    const unsigned wcol = (unsigned)(tw * d.Cin + cch) * 4u;
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) {
-      const bool nb = kv && b_n[i] < d.Cout;
-      rb[i] = nb ? *(const float4*)(w + (int64_t)b_n[i] * p.wrow + wcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < BROWS; ++i)
+      rb[i] = csg_buffer_load_f32x4(rsB, (int)((kv && b_base[i] != OOB_OFF) ? b_base[i] + wcol : OOB_OFF), 0, 0);
+    // advance to the next K tile
+    k_cur += IG_BK;
+    cch += IG_BK;
+    while (cch >= d.Cin) {
+      cch -= d.Cin;
+      ++slot;
     }
   };
   auto store_tile = [&](int buf) {
     float* a = As + buf * IG_BM * IG_LD + r0 * IG_LD + kc * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(float4*)(a + 32 * i * IG_LD) = ra[i];
+    for (int i = 0; i < 4; ++i) *(f32x4*)(a + 32 * i * IG_LD) = ra[i];
     float* b = Bs + buf * BN * IG_LD + r0 * IG_LD + kc * 4;
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) *(float4*)(b + 32 * i * IG_LD) = rb[i];
+    for (int i = 0; i < BROWS; ++i) *(f32x4*)(b + 32 * i * IG_LD) = rb[i];
   };
 
-  f32x16 acc[2][NI];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, hh = lane >> 5;
+  const int wm = BN == 32 ? wave : (wave >> 1), wn = BN == 32 ? 0 : (wave & 1);
+  const int r = lane & 31, hh = lane >> 5;
+  constexpr int WROWS = IG_BM / WM;      // A rows per wave
+  constexpr int WCOLS = BN / (4 / WM);   // B rows (output channels) per wave
 
-  load_tile(0);
-  store_tile(0);
+  if (kt0 < kt1) {
+    load_tile();
+    store_tile(0);
+  }
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
-    const float* Ab = As + buf * IG_BM * IG_LD + (wm * 64 + r) * IG_LD + 4 * hh;
-    const float* Bb = Bs + buf * BN * IG_LD + (wn * (BN / 2) + r) * IG_LD + 4 * hh;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) load_tile();
+    const float* Ab = As + buf * IG_BM * IG_LD + (wm * WROWS + r) * IG_LD + 4 * hh;
+    const float* Bb = Bs + buf * BN * IG_LD + (wn * WCOLS + r) * IG_LD + 4 * hh;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float4 a[2], b[NI];
-      a[0] = *(const float4*)(Ab + g * 8);
-      a[1] = *(const float4*)(Ab + 32 * IG_LD + g * 8);
+      float4 a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const float4*)(Ab + mi * 32 * IG_LD + g * 8);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) b[ni] = *(const float4*)(Bb + ni * 32 * IG_LD + g * 8);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
@@ -157,31 +246,44 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
         }
     }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    if (kt + 1 < kt1) store_tile(buf ^ 1);
     __syncthreads();
   }
 
   // epilogue: D[i][j], j = lane&31 (output channel), i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
+  if (p.ksplit > 1) {
+    float* slab = ws + (long long)ks * p.M * d.Cout;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = nt * BN + wn * WCOLS + ni * 32 + r;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mt * IG_BM + wm * WROWS + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (n < d.Cout && m < p.M) slab[(long long)m * d.Cout + n] = acc[mi][ni][e];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int n = nt * BN + wn * (BN / 2) + ni * 32 + r;
+    const int n = nt * BN + wn * WCOLS + ni * 32 + r;
     const bool nok = n < d.Cout;
     const float bv = (bias != nullptr && nok) ? bias[n] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = mt * IG_BM + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int m = mt * IG_BM + wm * WROWS + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
         if (nok && m < p.M) {
-          int64_t pix = m;
+          long long pix = m;
           if (!p.simple_out) {
-            int t = m / d.OWg;
-            int gx = m - t * d.OWg;
-            int b = t / d.OHg;
-            int gy = t - b * d.OHg;
-            pix = ((int64_t)b * d.OHf + gy * d.os + d.ooy) * d.OWf + gx * d.os + d.oox;
+            int b, gy, gx;
+            decompose(p, (unsigned)m, b, gy, gx);
+            pix = ((long long)b * d.OHf + gy * d.os + d.ooy) * d.OWf + gx * d.os + d.oox;
           }
-          const int64_t off = pix * d.y_cs + n;
+          const long long off = pix * d.y_cs + n;
           float v = acc[mi][ni][e] + bv;
           if (d.act == CSG_ACT_LEAKY)
             v = v > 0.f ? v : v * d.slope;
@@ -196,16 +298,62 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
   }
 }
 
+// second pass of a split-K launch: ordered slab sum + the forward epilogue, 4 channels per thread
+__global__ __launch_bounds__(256) void k_splitk_epilogue(IgemmParams p, const float* __restrict__ ws,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ res, float* __restrict__ y) {
+  const csg_conv_desc& d = p.d;
+  const int q = d.Cout >> 2;
+  const long long n4 = (long long)p.M * q;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+    const unsigned m = (unsigned)(e / q);
+    const int n = (int)(e - (long long)m * q) * 4;
+    const float* src = ws + (long long)m * d.Cout + n;
+    float4 a = *(const float4*)src;
+    for (int s = 1; s < p.ksplit; ++s) {
+      const float4 t = *(const float4*)(src + (long long)s * p.M * d.Cout);
+      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    long long pix = m;
+    if (!p.simple_out) {
+      int b, gy, gx;
+      decompose(p, m, b, gy, gx);
+      pix = ((long long)b * d.OHf + gy * d.os + d.ooy) * d.OWf + gx * d.os + d.oox;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    float* dst = y + pix * d.y_cs + n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = v[j] + (bias != nullptr ? bias[n + j] : 0.f);
+      if (d.act == CSG_ACT_LEAKY)
+        t = t > 0.f ? t : t * d.slope;
+      else if (d.act == CSG_ACT_TANH)
+        t = tanhf(t);
+      if (res != nullptr) t += res[pix * d.y_cs + n + j];
+      if (d.accumulate) t += dst[j];
+      dst[j] = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------- weight grad
-// tile: 128 output channels (i) x 128 (tap,cin) columns (j), 32 pixels per reduction step
-#define WG_LD 128
+// tile: BI output channels (i) x 128 (tap,cin) columns (j), 32 pixels per reduction step
+#define WG_LDB 128
+template <int BI>
 __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const float* __restrict__ x,
                                                          const float* __restrict__ dy, float* __restrict__ out,
                                                          int itiles, int jtiles, int nsplit, int cps) {
+  constexpr int WI = BI == 32 ? 1 : 2;          // waves along i
+  constexpr int WJ = 4 / WI;                    // waves along j
+  constexpr int MI = BI / (WI * 32);            // 32x32 tiles per wave along i
+  constexpr int NJ = 128 / (WJ * 32);           // ... along j
+  constexpr int CQ = BI / 4;                    // float4 columns of the dY tile
+  constexpr int RP = 256 / CQ;                  // dY rows loaded per pass
+  constexpr int AIT = 32 / RP;                  // passes
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                      // [2][32][128]  dY tile, [pixel][n]
-  float* Bs = smem + 2 * 32 * WG_LD;     // [2][32][128]  X tile,  [pixel][kk]
-  int* s_tap = (int*)(Bs + 2 * 32 * WG_LD);
+  float* As = smem;                      // [2][32][BI]   dY tile, [pixel][n]
+  float* Bs = smem + 2 * 32 * BI;        // [2][32][128]  X tile,  [pixel][kk]
+  int* s_tap = (int*)(Bs + 2 * 32 * WG_LDB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const csg_conv_desc& d = p.d;
@@ -217,55 +365,68 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
   load_taps(d, s_tap, tid);
   __syncthreads();
 
+  // X tile: this thread's column is a fixed (tap, channel)
   const int pr = tid >> 5, c4 = tid & 31;
-  // this thread's column of the X tile: fixed (tap, channel)
   const int kk0 = jt * 128 + c4 * 4;
   const bool kv = kk0 < p.Ktot;
   const int slot = kv ? kk0 / d.Cin : 0;
   const int cch = kk0 - slot * d.Cin;
   const int tdy = s_tap[slot], tdx = s_tap[16 + slot];
-  // this thread's column of the dY tile
-  const int n0 = it * 128 + c4 * 4;
-  const bool nv = n0 < d.Cout;  // Cout % 4 == 0
+  // dY tile: this thread's column
+  const int apr = tid / CQ, ac4 = tid % CQ;
+  const int n0 = it * BI + ac4 * 4;
+  const unsigned a_col = n0 < d.Cout ? (unsigned)n0 * 4u : OOB_OFF;   // Cout % 4 == 0
 
   const int nch = (p.M + 31) / 32;
   const int ch0 = sp * cps, ch1 = min(nch, ch0 + cps);
 
-  float4 ra[4], rb[4];
+  // X descriptor: based at the image of the split's first pixel (a split may span many images only
+  // when images are small, so offsets stay far below 2 GB; checked on the host)
+  const int m_first = min(ch0 * 32, p.M - 1);
+  const int b0 = (int)fdiv(fdiv((unsigned)m_first, p.div_ow), p.div_oh);
+  const long long x_rem = (long long)(d.B - b0) * p.img_bytes;
+  const i32x4 rsX = make_srd(x + (long long)b0 * (p.img_bytes >> 2), (unsigned)(x_rem < MAX_RECORDS ? x_rem : MAX_RECORDS));
+
+  f32x4 ra[AIT], rb[4];
   auto load_tile = [&](int ch) {
+    // dY rows of this chunk: descriptor re-based per chunk, rows past M fall out of range
+    const int rows = min(32, p.M - ch * 32);
+    const i32x4 rsY = make_srd(dy + (long long)ch * 32 * d.y_cs, (unsigned)(rows * d.y_cs * 4));
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const unsigned off = (unsigned)((apr + RP * i) * d.y_cs) * 4u;
+      ra[i] = csg_buffer_load_f32x4(rsY, (int)(a_col != OOB_OFF ? off + a_col : OOB_OFF), 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = ch * 32 + pr + 8 * i;
       const bool ok = m < p.M;
-      ra[i] = (ok && nv) ? *(const float4*)(dy + (int64_t)m * d.y_cs + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const int mm = ok ? m : 0;
-      const int t = mm / d.OWg;
-      const int gx = mm - t * d.OWg;
-      const int b = t / d.OHg;
-      const int gy = t - b * d.OHg;
+      int b, gy, gx;
+      decompose(p, (unsigned)(ok ? m : 0), b, gy, gx);
       const int iy = gy * d.istride + tdy, ix = gx * d.istride + tdx;
       const bool inb = ok && kv && (unsigned)iy < (unsigned)d.IHv && (unsigned)ix < (unsigned)d.IWv;
-      const int64_t off = ((int64_t)(b * d.IHp + (iy >> d.in_up)) * d.IWp + (ix >> d.in_up)) * d.x_cs + cch;
-      rb[i] = inb ? *(const float4*)(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned off = (unsigned)(b - b0) * p.img_bytes +
+                           (unsigned)(((iy >> d.in_up) * d.IWp + (ix >> d.in_up)) * d.x_cs + cch) * 4u;
+      rb[i] = csg_buffer_load_f32x4(rsX, (int)(inb ? off : OOB_OFF), 0, 0);
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(float4*)(As + buf * 32 * WG_LD + (pr + 8 * i) * WG_LD + c4 * 4) = ra[i];
-      *(float4*)(Bs + buf * 32 * WG_LD + (pr + 8 * i) * WG_LD + c4 * 4) = rb[i];
-    }
+    for (int i = 0; i < AIT; ++i) *(f32x4*)(As + buf * 32 * BI + (apr + RP * i) * BI + ac4 * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + buf * 32 * WG_LDB + (pr + 8 * i) * WG_LDB + c4 * 4) = rb[i];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
 
-  const int wi = wave >> 1, wj = wave & 1, r = lane & 31, hh = lane >> 5;
+  const int wi = BI == 32 ? 0 : (wave >> 1), wj = BI == 32 ? wave : (wave & 1);
+  const int r = lane & 31, hh = lane >> 5;
 
   if (ch0 < ch1) {
     load_tile(ch0);
@@ -275,35 +436,39 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
   for (int ch = ch0; ch < ch1; ++ch) {
     const int buf = (ch - ch0) & 1;
     if (ch + 1 < ch1) load_tile(ch + 1);
-    const float* Ab = As + buf * 32 * WG_LD + hh * WG_LD + wi * 64 + r;
-    const float* Bb = Bs + buf * 32 * WG_LD + hh * WG_LD + wj * 64 + r;
+    const float* Ab = As + buf * 32 * BI + hh * BI + wi * (MI * 32) + r;
+    const float* Bb = Bs + buf * 32 * WG_LDB + hh * WG_LDB + wj * (NJ * 32) + r;
 #pragma unroll
     for (int kp = 0; kp < 16; ++kp) {
-      const float a0 = Ab[kp * 2 * WG_LD], a1 = Ab[kp * 2 * WG_LD + 32];
-      const float b0 = Bb[kp * 2 * WG_LD], b1 = Bb[kp * 2 * WG_LD + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float a[MI], b[NJ];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = Ab[kp * 2 * BI + mi * 32];
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) b[nj] = Bb[kp * 2 * WG_LDB + nj * 32];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
     }
     if (ch + 1 < ch1) store_tile(buf ^ 1);
     __syncthreads();
   }
 
   // D[i = n][j = kk]; slab layout [split][Cout][wrow] with the weight-tap index applied
-  float* slab = out + (int64_t)sp * d.Cout * p.wrow;
+  float* slab = out + (long long)sp * d.Cout * p.wrow;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int kk = jt * 128 + wj * 64 + ni * 32 + r;
+  for (int nj = 0; nj < NJ; ++nj) {
+    const int kk = jt * 128 + wj * (NJ * 32) + nj * 32 + r;
     if (kk < p.Ktot) {
       const int sl = kk / d.Cin;
       const int col = s_tap[32 + sl] * d.Cin + (kk - sl * d.Cin);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int n = it * 128 + wi * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (n < d.Cout) slab[(int64_t)n * p.wrow + col] = acc[mi][ni][e];
+          const int n = it * BI + wi * (MI * 32) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (n < d.Cout) slab[(long long)n * p.wrow + col] = acc[mi][nj][e];
         }
       }
     }
@@ -340,6 +505,12 @@ static int validate(const csg_conv_desc* d, const char* who) {
   int64_t M = (int64_t)d->B * d->OHg * d->OWg;
   CSG_REQUIRE(M < (1ll << 31) - 256, CSG_E_UNSUPPORTED, "%s: too many output pixels", who);
   CSG_REQUIRE((int64_t)d->B * d->OHf * d->OWf < (1ll << 31), CSG_E_UNSUPPORTED, "%s: output too large", who);
+  // 32-bit buffer offsets: a 128-row tile may straddle images; keep that span below 2 GB
+  const int64_t img_bytes = (int64_t)d->IHp * d->IWp * d->x_cs * 4;
+  const int64_t npix = (int64_t)d->OHg * d->OWg;
+  const int64_t span = (127 / npix + 2) * img_bytes;
+  CSG_REQUIRE(span < MAX_RECORDS, CSG_E_UNSUPPORTED, "%s: one input image is too large for 32-bit offsets", who);
+  CSG_REQUIRE((int64_t)d->Cout * d->wtaps * d->Cin * 4 < MAX_RECORDS, CSG_E_UNSUPPORTED, "%s: weights too large", who);
   return CSG_OK;
 }
 
@@ -349,25 +520,50 @@ static void fill(IgemmParams& p, const csg_conv_desc* d) {
   p.Ktot = d->ntaps * d->Cin;
   p.wrow = d->wtaps * d->Cin;
   p.simple_out = (d->os == 1 && d->ooy == 0 && d->oox == 0 && d->OHg == d->OHf && d->OWg == d->OWf) ? 1 : 0;
+  p.ksplit = 1;
+  p.kt_per_split = (p.Ktot + IG_BK - 1) / IG_BK;
+  p.div_ow = make_fastdiv((unsigned)d->OWg);
+  p.div_oh = make_fastdiv((unsigned)d->OHg);
+  p.img_bytes = (unsigned)((int64_t)d->IHp * d->IWp * d->x_cs * 4);
+  p.mtiles = p.ntiles = 0;
+}
+
+static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
+
+// split-K plan for the forward kernel: only when the tile grid cannot fill the chip
+static void fwd_plan(IgemmParams& p) {
+  const int bn = pick_bn(p.d.Cout);
+  p.mtiles = (p.M + IG_BM - 1) / IG_BM;
+  p.ntiles = (p.d.Cout + bn - 1) / bn;
+  const int nkt = (p.Ktot + IG_BK - 1) / IG_BK;
+  const int blocks = p.mtiles * p.ntiles;
+  int ks = 1;
+  if (blocks < 320 && nkt >= 16 && p.d.Cout % 4 == 0) {
+    ks = (640 + blocks - 1) / blocks;
+    if (ks > nkt / 8) ks = nkt / 8;
+    if (ks > 64) ks = 64;
+    if (ks < 1) ks = 1;
+  }
+  p.kt_per_split = (nkt + ks - 1) / ks;
+  p.ksplit = (nkt + p.kt_per_split - 1) / p.kt_per_split;
 }
 
 template <int BN>
 static int launch_fwd(IgemmParams& p, const float* x, const float* w, const float* bias, const float* res, float* y,
-                      hipStream_t s) {
-  p.mtiles = (p.M + IG_BM - 1) / IG_BM;
-  p.ntiles = (p.d.Cout + BN - 1) / BN;
+                      float* ws, hipStream_t s) {
   static bool attr_set = false;
   size_t shm = (size_t)(2 * IG_BM * IG_LD + 2 * BN * IG_LD) * 4 + 48 * 4;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)k_igemm_fwd<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)k_igemm_fwd<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_igemm_fwd<BN>, dim3((unsigned)(p.mtiles * p.ntiles)), dim3(256), shm, s, p, x, w, bias, res, y);
+  hipLaunchKernelGGL(k_igemm_fwd<BN>, dim3((unsigned)(p.mtiles * p.ntiles * p.ksplit)), dim3(256), shm, s, p, x, w, bias,
+                     res, y, ws);
   return check_launch("csg_conv_fwd");
 }
 
-static void wgrad_plan(const IgemmParams& p, int& itiles, int& jtiles, int& nsplit, int& cps) {
-  itiles = (p.d.Cout + 127) / 128;
+static void wgrad_plan(const IgemmParams& p, int bi, int& itiles, int& jtiles, int& nsplit, int& cps) {
+  itiles = (p.d.Cout + bi - 1) / bi;
   jtiles = (p.Ktot + 127) / 128;
   const int nch = (p.M + 31) / 32;
   int base = itiles * jtiles;
@@ -381,21 +577,68 @@ static void wgrad_plan(const IgemmParams& p, int& itiles, int& jtiles, int& nspl
   nsplit = (nch + cps - 1) / cps;  // no empty splits
 }
 
+template <int BI>
+static int launch_wgrad(IgemmParams& p, const float* x, const float* dy, float* out, int itiles, int jtiles,
+                        int nsplit, int cps, hipStream_t s) {
+  static bool attr_set = false;
+  size_t shm = (size_t)(2 * 32 * BI + 2 * 32 * WG_LDB) * 4 + 48 * 4;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_igemm_wgrad<BI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_igemm_wgrad<BI>, dim3((unsigned)(itiles * jtiles * nsplit)), dim3(256), shm, s, p, x, dy, out,
+                     itiles, jtiles, nsplit, cps);
+  return check_launch("csg_conv_bwd_weight");
+}
+
+static int pick_bi(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
+
 extern "C" {
 
+int64_t csg_conv_fwd_workspace(const csg_conv_desc* d) {
+  if (validate(d, "csg_conv_fwd_workspace")) return -1;
+  IgemmParams p;
+  fill(p, d);
+  fwd_plan(p);
+  return p.ksplit > 1 ? (int64_t)p.ksplit * p.M * d->Cout * 4 : 0;
+}
+
 int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
-                 float* y, void* stream) {
+                 float* y, float* workspace, int64_t workspace_bytes, void* stream) {
   int rc = validate(d, "csg_conv_fwd");
   if (rc) return rc;
   CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, CSG_E_UNSUPPORTED,
               "csg_conv_fwd: x and w must be 16-byte aligned");
   IgemmParams p;
   fill(p, d);
+  fwd_plan(p);
+  const int64_t need = p.ksplit > 1 ? (int64_t)p.ksplit * p.M * d->Cout * 4 : 0;
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {  // caller gave no slabs: run unsplit
+    p.ksplit = 1;
+    p.kt_per_split = (p.Ktot + IG_BK - 1) / IG_BK;
+  }
   hipStream_t s = (hipStream_t)stream;
-  // algorithmic FLOPs: 2 * M * Ktot * Cout (zero-padding taps included, as FlopCounterMode counts them)
-  ProfScope ps(K_IGEMM_FWD, 2.0 * p.M * (double)p.Ktot * d->Cout, s);
-  if (d->Cout <= 64) return launch_fwd<64>(p, x, w, bias, residual, y, s);
-  return launch_fwd<128>(p, x, w, bias, residual, y, s);
+  const int bn = pick_bn(d->Cout);
+  {
+    // algorithmic FLOPs: 2 * M * Ktot * Cout (zero-padding taps included, as FlopCounterMode counts them)
+    ProfScope ps(bn == 128 ? K_IGEMM_FWD : K_IGEMM_FWD64, 2.0 * p.M * (double)p.Ktot * d->Cout, s);
+    if (bn == 32)
+      rc = launch_fwd<32>(p, x, w, bias, residual, y, workspace, s);
+    else if (bn == 64)
+      rc = launch_fwd<64>(p, x, w, bias, residual, y, workspace, s);
+    else
+      rc = launch_fwd<128>(p, x, w, bias, residual, y, workspace, s);
+    if (rc) return rc;
+  }
+  if (p.ksplit > 1) {
+    ProfScope ps(K_SPLITK_EPI, (double)(p.ksplit + 1) * p.M * d->Cout * 4, s);
+    const int64_t n4 = (int64_t)p.M * d->Cout / 4;
+    int64_t g = cdiv(n4, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)g), dim3(256), 0, s, p, workspace, bias, residual, y);
+    rc = check_launch("csg_conv_fwd(split-K epilogue)");
+  }
+  return rc;
 }
 
 int64_t csg_conv_bwd_weight_workspace(const csg_conv_desc* d) {
@@ -403,7 +646,7 @@ int64_t csg_conv_bwd_weight_workspace(const csg_conv_desc* d) {
   IgemmParams p;
   fill(p, d);
   int it, jt, ns, cps;
-  wgrad_plan(p, it, jt, ns, cps);
+  wgrad_plan(p, pick_bi(d->Cout), it, jt, ns, cps);
   return ns > 1 ? (int64_t)ns * d->Cout * p.wrow * 4 : 0;
 }
 
@@ -418,27 +661,31 @@ int csg_conv_bwd_weight(const csg_conv_desc* d, const float* x, const float* dy,
   CSG_REQUIRE(d->ntaps == d->wtaps, CSG_E_UNSUPPORTED, "csg_conv_bwd_weight: every weight tap must be listed");
   CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 16) == 0, CSG_E_UNSUPPORTED,
               "csg_conv_bwd_weight: pointers must be 16-byte aligned");
+  CSG_REQUIRE((int64_t)32 * d->y_cs * 4 < MAX_RECORDS, CSG_E_UNSUPPORTED, "csg_conv_bwd_weight: y_cs too large");
   IgemmParams p;
   fill(p, d);
-  p.mtiles = p.ntiles = 0;
+  const int bi = pick_bi(d->Cout);
   int itiles, jtiles, nsplit, cps;
-  wgrad_plan(p, itiles, jtiles, nsplit, cps);
+  wgrad_plan(p, bi, itiles, jtiles, nsplit, cps);
+  // a split's pixel range must stay within 32-bit offsets of its first image
+  {
+    const int64_t npix = (int64_t)d->OHg * d->OWg;
+    const int64_t span = (((int64_t)cps * 32 + npix - 1) / npix + 1) * (int64_t)p.img_bytes;
+    CSG_REQUIRE(span < MAX_RECORDS, CSG_E_UNSUPPORTED, "csg_conv_bwd_weight: split spans more than 2 GB of input");
+  }
   const int64_t need = nsplit > 1 ? (int64_t)nsplit * d->Cout * p.wrow * 4 : 0;
   CSG_REQUIRE(workspace_bytes >= need && (need == 0 || workspace != nullptr), CSG_E_WORKSPACE,
               "csg_conv_bwd_weight: workspace %ld < %ld bytes", (long)workspace_bytes, (long)need);
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  size_t shm = (size_t)(4 * 32 * WG_LD) * 4 + 48 * 4;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)k_igemm_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
   {
     ProfScope ps(K_IGEMM_WGRAD, 2.0 * p.M * (double)p.Ktot * d->Cout, s);
     float* out = nsplit > 1 ? workspace : dw;
-    hipLaunchKernelGGL(k_igemm_wgrad, dim3((unsigned)(itiles * jtiles * nsplit)), dim3(256), shm, s, p, x, dy, out,
-                       itiles, jtiles, nsplit, cps);
-    rc = check_launch("csg_conv_bwd_weight");
+    if (bi == 32)
+      rc = launch_wgrad<32>(p, x, dy, out, itiles, jtiles, nsplit, cps, s);
+    else if (bi == 64)
+      rc = launch_wgrad<64>(p, x, dy, out, itiles, jtiles, nsplit, cps, s);
+    else
+      rc = launch_wgrad<128>(p, x, dy, out, itiles, jtiles, nsplit, cps, s);
     if (rc) return rc;
   }
   if (nsplit > 1) {

@@ -59,23 +59,22 @@ __global__ __launch_bounds__(256) void k_norm_stats_partial(const float* __restr
   }
 }
 
-// sums[g][j] = sum over chunks (fp64), j in [0, 2C)
-__global__ void k_partial_to_sums(const float* __restrict__ partial, int G, int C2, int nchunk,
-                                  double* __restrict__ sums) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= G * C2) return;
-  int g = i / C2, j = i - g * C2;
+// Second stage of every two-stage reduction: out[g][j] = sum over chunks of partial[g][chunk][j],
+// accumulated in fp64 in a fixed order.  Block = 64 columns x 4 chunk lanes.
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_partial_reduce(const float* __restrict__ partial, int ncols, int nchunk,
+                                                         int out_cols, OutT* __restrict__ out) {
+  __shared__ double sm[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cl, g = blockIdx.y;
   double a = 0.0;
-  for (int c = 0; c < nchunk; ++c) a += (double)partial[((int64_t)g * nchunk + c) * C2 + j];
-  sums[i] = a;
-}
-
-__global__ void k_partial_to_colsum(const float* __restrict__ partial, int C, int nchunk, float* __restrict__ out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0;
-  for (int k = 0; k < nchunk; ++k) a += (double)partial[(int64_t)k * 2 * C + c];
-  out[c] = (float)a;
+  if (j < out_cols) {
+    const float* p = partial + (int64_t)g * nchunk * ncols + j;
+    for (int c = rl; c < nchunk; c += 4) a += (double)p[(int64_t)c * ncols];
+  }
+  sm[rl][cl] = a;
+  __syncthreads();
+  if (rl == 0 && j < out_cols) out[(int64_t)g * out_cols + j] = (OutT)(sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl]);
 }
 
 __global__ void k_norm_finalize(const double* __restrict__ sums, int G, int C, double count, float eps, int mode,
@@ -346,8 +345,8 @@ int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums
     hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 4, s, x, P,
                        (int)C, C, (int)nchunk, partial);
   }
-  hipLaunchKernelGGL(k_partial_to_sums, dim3((unsigned)cdiv(G * 2 * C, 256)), dim3(256), 0, s, partial, (int)G,
-                     (int)(2 * C), (int)nchunk, sums);
+  hipLaunchKernelGGL(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 64), (unsigned)G), dim3(256), 0, s, partial,
+                     (int)(2 * C), (int)nchunk, (int)(2 * C), sums);
   return check_launch("csg_norm_stats");
 }
 
@@ -384,8 +383,8 @@ int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean
     hipLaunchKernelGGL(k_norm_bwd_reduce, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 4, s, dy, x, mean,
                        invstd, gb, slope, P, (int)C, (int)nchunk, dgb, partial);
   }
-  hipLaunchKernelGGL(k_partial_to_sums, dim3((unsigned)cdiv(G * 2 * C, 256)), dim3(256), 0, s, partial, (int)G,
-                     (int)(2 * C), (int)nchunk, dsums);
+  hipLaunchKernelGGL(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 64), (unsigned)G), dim3(256), 0, s, partial,
+                     (int)(2 * C), (int)nchunk, (int)(2 * C), dsums);
   return check_launch("csg_norm_apply_bwd_reduce");
 }
 
@@ -418,8 +417,8 @@ int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out
   ProfScope p(K_COLSUM, (double)rows * C * 4, s);
   hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, 1), dim3(256), 256 * 8 * 4, s, x, rows, (int)C, x_cs,
                      (int)nchunk, partial);
-  hipLaunchKernelGGL(k_partial_to_colsum, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, partial, (int)C, (int)nchunk,
-                     out);
+  hipLaunchKernelGGL(k_partial_reduce<float>, dim3((unsigned)cdiv(C, 64), 1), dim3(256), 0, s, partial, (int)(2 * C),
+                     (int)nchunk, (int)C, out);
   return check_launch("csg_colsum");
 }
 

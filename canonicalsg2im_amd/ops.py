@@ -41,7 +41,8 @@ def _f32(t):
 
 
 def _chunks(P, G=1):
-    c = max(1, min((P + 511) // 512, max(1, 2048 // max(G, 1))))
+    """Pixel chunks of a two-stage reduction: >= 512 pixels each, <= ~1024 blocks in flight."""
+    c = max(1, min((P + 511) // 512, max(1, 1024 // max(G, 1))))
     return int(c)
 
 
@@ -94,6 +95,15 @@ def _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
     return out
 
 
+def _conv_launch(d, x, w, bias, res, y, what):
+    """csg_conv_fwd with the split-K slabs it asks for."""
+    nbytes = lib.csg_conv_fwd_workspace(d)
+    if nbytes < 0:
+        raise RuntimeError("conv_fwd_workspace: " + _lib.last_error())
+    ws = torch.empty(nbytes // 4, device=y.device, dtype=torch.float32) if nbytes > 0 else None
+    check(lib.csg_conv_fwd(d, ptr(x), ptr(w), ptr(bias), ptr(res), ptr(y), ptr(ws), nbytes, stream()), what)
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv2d(x, w) + b) [+ residual] — reference nn.Conv2d call sites listed in
     include/csg_hip.h (K8/K11)."""
@@ -109,8 +119,7 @@ class _Conv2d(torch.autograd.Function):
         d, OH, OW = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad, act, slope)
         y = empty_nhwc(B, Cout, OH, OW, x.device)
         res = nhwc(residual) if residual is not None else None
-        check(lib.csg_conv_fwd(d, ptr(x), ptr(wp), ptr(bias.detach() if bias is not None else None), ptr(res), ptr(y),
-                               stream()), "conv_fwd")
+        _conv_launch(d, x, wp, bias.detach() if bias is not None else None, res, y, "conv_fwd")
         ctx.geom = (B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW, act, slope)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
@@ -131,7 +140,7 @@ class _Conv2d(torch.autograd.Function):
             wt = weight.detach().permute(1, 2, 3, 0).contiguous()      # [Cin][KH][KW][Cout]
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
             for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
-                check(lib.csg_conv_fwd(d, ptr(dpre), ptr(wt), None, None, ptr(dx), stream()), "conv_bwd_data")
+                _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
         if ctx.needs_input_grad[1]:
             d, _, _ = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad)
             nbytes = lib.csg_conv_bwd_weight_workspace(d)

@@ -128,9 +128,13 @@ typedef struct csg_conv_desc {
   int32_t accumulate; /* y += result (after bias/act) instead of y = */
 } csg_conv_desc;
 
-/* y = act(conv(x, w) + bias) [+ residual];  bias and residual may be NULL; residual has y's layout */
+/* y = act(conv(x, w) + bias) [+ residual];  bias and residual may be NULL; residual has y's layout.
+ * Layers whose output grid is too small to fill 256 CUs are split along K into `workspace` slabs
+ * that an ordered second pass sums (csg_conv_fwd_workspace bytes; with a NULL/short workspace the
+ * launch simply runs unsplit). */
+int64_t csg_conv_fwd_workspace(const csg_conv_desc* d);
 int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
-                 float* y, void* stream);
+                 float* y, float* workspace, int64_t workspace_bytes, void* stream);
 /* dw[n][tap][c] = sum_m dy[m][n] * x[src(m,tap)][c]; `d` is the FORWARD descriptor (y_cs = floats per
  * pixel of dy).  Deterministic split-K: partial slabs in `workspace`, then an ordered reduction. */
 int64_t csg_conv_bwd_weight_workspace(const csg_conv_desc* d);

@@ -196,16 +196,16 @@ def test_layout_golden(ops):
     meta, a = load_golden("layout")
     vecs, boxes = a["vecs"], a["boxes"]
     O, S = vecs.shape
+    vd, bd = vecs.cuda(), boxes.cuda()                   # keep the device tensors alive across the launches
     valid = torch.ones(1, O, dtype=torch.uint8).cuda()
     for H, W in meta["sizes"]:
         tag = "%dx%d" % (H, W)
         out = torch.empty(1, H, W, S).cuda()
-        check(lib.csg_layout_fwd(ptr(vecs.cuda()), ptr(boxes.cuda()), ptr(valid), 1, O, S, H, W, H, W, ptr(out), S, 0,
-                                 stream()))
+        check(lib.csg_layout_fwd(ptr(vd), ptr(bd), ptr(valid), 1, O, S, H, W, H, W, ptr(out), S, 0, stream()))
         assert_close(out.permute(0, 3, 1, 2), a["out_" + tag], RTOL, 2e-6, "layout " + tag)
         dv = torch.empty(1, O, S).cuda()
         gw = a["w_" + tag].permute(0, 2, 3, 1).contiguous().cuda()
-        check(lib.csg_layout_bwd(ptr(gw), S, 0, ptr(boxes.cuda()), ptr(valid), 1, O, S, H, W, H, W, ptr(dv), 0, stream()))
+        check(lib.csg_layout_bwd(ptr(gw), S, 0, ptr(bd), ptr(valid), 1, O, S, H, W, H, W, ptr(dv), 0, stream()))
         assert_close(dv[0], a["gvecs_" + tag], RTOL, 1e-5, "layout dvecs " + tag)
 
 
