@@ -172,14 +172,24 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
   f32x4 ra[4], rb[BROWS];
   __syncthreads();  // s_tap visible
 
+  // tap of the tile to be loaded next, fetched from LDS one tile ahead so that its latency hides
+  // behind the MFMAs instead of heading the loader
+  int t_dy, t_dx, t_tw;
+  auto fetch_tap = [&]() {
+    const int sl = (k_cur < p.Ktot) ? slot : 0;
+    t_dy = s_tap[sl];
+    t_dx = s_tap[16 + sl];
+    t_tw = s_tap[32 + sl];
+  };
+  fetch_tap();
+
   auto load_tile = [&]() {
     const bool kv = k_cur < p.Ktot;
-    const int sl = kv ? slot : 0;
-    const int dy = s_tap[sl], dx = s_tap[16 + sl], tw = s_tap[32 + sl];
+    const int dy = t_dy, dx = t_dx, tw = t_tw;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-      const bool inb = kv && (unsigned)iy < (unsigned)d.IHv && (unsigned)ix < (unsigned)d.IWv;
+      const bool inb = kv & ((unsigned)iy < (unsigned)d.IHv) & ((unsigned)ix < (unsigned)d.IWv);
       const unsigned off =
           a_base[i] + (unsigned)(((iy >> d.in_up) * d.IWp + (ix >> d.in_up)) * d.x_cs + cch) * 4u;
       ra[i] = csg_buffer_load_f32x4(rsA, (int)(inb ? off : OOB_OFF), 0, 0);
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
     const unsigned wcol = (unsigned)(tw * d.Cin + cch) * 4u;
 #pragma unroll
     for (int i = 0; i < BROWS; ++i)
-      rb[i] = csg_buffer_load_f32x4(rsB, (int)((kv && b_base[i] != OOB_OFF) ? b_base[i] + wcol : OOB_OFF), 0, 0);
+      rb[i] = csg_buffer_load_f32x4(rsB, (int)((kv & (b_base[i] != OOB_OFF)) ? b_base[i] + wcol : OOB_OFF), 0, 0);
     // advance to the next K tile
     k_cur += IG_BK;
     cch += IG_BK;
@@ -195,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
       cch -= d.Cin;
       ++slot;
     }
+    fetch_tap();
   };
   auto store_tile = [&](int buf) {
     float* a = As + buf * IG_BM * IG_LD + r0 * IG_LD + kc * 4;

@@ -60,21 +60,35 @@ __global__ __launch_bounds__(256) void k_norm_stats_partial(const float* __restr
 }
 
 // Second stage of every two-stage reduction: out[g][j] = sum over chunks of partial[g][chunk][j],
-// accumulated in fp64 in a fixed order.  Block = 64 columns x 4 chunk lanes.
+// accumulated in fp64 in a fixed order.  Block = 32 columns x 8 chunk lanes, 4 loads in flight.
 template <typename OutT>
 __global__ __launch_bounds__(256) void k_partial_reduce(const float* __restrict__ partial, int ncols, int nchunk,
                                                          int out_cols, OutT* __restrict__ out) {
-  __shared__ double sm[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + cl, g = blockIdx.y;
+  __shared__ double sm[8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cl, g = blockIdx.y;
   double a = 0.0;
   if (j < out_cols) {
     const float* p = partial + (int64_t)g * nchunk * ncols + j;
-    for (int c = rl; c < nchunk; c += 4) a += (double)p[(int64_t)c * ncols];
+    int c = rl;
+    for (; c + 24 < nchunk; c += 32) {
+      const float v0 = p[(int64_t)c * ncols], v1 = p[(int64_t)(c + 8) * ncols];
+      const float v2 = p[(int64_t)(c + 16) * ncols], v3 = p[(int64_t)(c + 24) * ncols];
+      a += (double)v0;
+      a += (double)v1;
+      a += (double)v2;
+      a += (double)v3;
+    }
+    for (; c < nchunk; c += 8) a += (double)p[(int64_t)c * ncols];
   }
   sm[rl][cl] = a;
   __syncthreads();
-  if (rl == 0 && j < out_cols) out[(int64_t)g * out_cols + j] = (OutT)(sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl]);
+  if (rl == 0 && j < out_cols) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += sm[r][cl];
+    out[(int64_t)g * out_cols + j] = (OutT)t;
+  }
 }
 
 __global__ void k_norm_finalize(const double* __restrict__ sums, int G, int C, double count, float eps, int mode,
@@ -345,7 +359,7 @@ int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums
     hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 4, s, x, P,
                        (int)C, C, (int)nchunk, partial);
   }
-  hipLaunchKernelGGL(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 64), (unsigned)G), dim3(256), 0, s, partial,
+  hipLaunchKernelGGL(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
                      (int)(2 * C), (int)nchunk, (int)(2 * C), sums);
   return check_launch("csg_norm_stats");
 }
@@ -383,7 +397,7 @@ int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean
     hipLaunchKernelGGL(k_norm_bwd_reduce, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 4, s, dy, x, mean,
                        invstd, gb, slope, P, (int)C, (int)nchunk, dgb, partial);
   }
-  hipLaunchKernelGGL(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 64), (unsigned)G), dim3(256), 0, s, partial,
+  hipLaunchKernelGGL(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
                      (int)(2 * C), (int)nchunk, (int)(2 * C), dsums);
   return check_launch("csg_norm_apply_bwd_reduce");
 }
@@ -417,7 +431,7 @@ int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out
   ProfScope p(K_COLSUM, (double)rows * C * 4, s);
   hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, 1), dim3(256), 256 * 8 * 4, s, x, rows, (int)C, x_cs,
                      (int)nchunk, partial);
-  hipLaunchKernelGGL(k_partial_reduce<float>, dim3((unsigned)cdiv(C, 64), 1), dim3(256), 0, s, partial, (int)(2 * C),
+  hipLaunchKernelGGL(k_partial_reduce<float>, dim3((unsigned)cdiv(C, 32), 1), dim3(256), 0, s, partial, (int)(2 * C),
                      (int)nchunk, (int)C, out);
   return check_launch("csg_colsum");
 }

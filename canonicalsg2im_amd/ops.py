@@ -41,8 +41,9 @@ def _f32(t):
 
 
 def _chunks(P, G=1):
-    """Pixel chunks of a two-stage reduction: >= 512 pixels each, <= ~1024 blocks in flight."""
-    c = max(1, min((P + 511) // 512, max(1, 1024 // max(G, 1))))
+    """Pixel chunks of a two-stage reduction: >= 32 pixels each, up to ~1024 blocks in flight
+    (low-resolution layers have few pixels but up to 1024 channels: they need many small chunks)."""
+    c = max(1, min(P // 32, max(1, 1024 // max(G, 1))))
     return int(c)
 
 
