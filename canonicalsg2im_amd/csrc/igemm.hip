@@ -251,61 +251,90 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+          // weights as the first operand: D[i = channel][j = pixel], so each lane holds one pixel
+          // and runs of 4 consecutive channels -> 16-byte epilogue stores
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].x, a[mi].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].y, a[mi].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].z, a[mi].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].w, a[mi].w, acc[mi][ni], 0, 0, 0);
         }
     }
     if (kt + 1 < kt1) store_tile(buf ^ 1);
     __syncthreads();
   }
 
-  // epilogue: D[i][j], j = lane&31 (output channel), i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
-  if (p.ksplit > 1) {
-    float* slab = ws + (long long)ks * p.M * d.Cout;
+  // epilogue: D[i][j], j = lane&31 = pixel, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel:
+  // registers 4g..4g+3 of a tile are channels 8g + 4*(lane>>5) + 0..3 of this lane's pixel.
+  const bool vec = ((d.Cout | d.y_cs) & 3) == 0;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int n = nt * BN + wn * WCOLS + ni * 32 + r;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = mt * IG_BM + wm * WROWS + mi * 32 + r;
+    if (m >= p.M) continue;
+    if (p.ksplit > 1) {  // raw partial sums into this split's slab (Cout % 4 == 0 on this path)
+      float* srow = ws + ((long long)ks * p.M + m) * d.Cout;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mt * IG_BM + wm * WROWS + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (n < d.Cout && m < p.M) slab[(long long)m * d.Cout + n] = acc[mi][ni][e];
+        for (int g = 0; g < 4; ++g) {
+          const int n = nt * BN + wn * WCOLS + ni * 32 + 8 * g + 4 * hh;
+          if (n < d.Cout)
+            *(float4*)(srow + n) = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2],
+                                               acc[mi][ni][4 * g + 3]);
         }
+      continue;
     }
-    return;
-  }
+    long long pix = m;
+    if (!p.simple_out) {
+      int b, gy, gx;
+      decompose(p, (unsigned)m, b, gy, gx);
+      pix = ((long long)b * d.OHf + gy * d.os + d.ooy) * d.OWf + gx * d.os + d.oox;
+    }
+    float* yrow = y + pix * d.y_cs;
+    const float* rrow = res != nullptr ? res + pix * d.y_cs : nullptr;
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = nt * BN + wn * WCOLS + ni * 32 + r;
-    const bool nok = n < d.Cout;
-    const float bv = (bias != nullptr && nok) ? bias[n] : 0.f;
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = mt * IG_BM + wm * WROWS + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (nok && m < p.M) {
-          long long pix = m;
-          if (!p.simple_out) {
-            int b, gy, gx;
-            decompose(p, (unsigned)m, b, gy, gx);
-            pix = ((long long)b * d.OHf + gy * d.os + d.ooy) * d.OWf + gx * d.os + d.oox;
+      for (int g = 0; g < 4; ++g) {
+        const int n = nt * BN + wn * WCOLS + ni * 32 + 8 * g + 4 * hh;
+        if (n >= d.Cout) continue;
+        float v[4] = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+        if (vec) {
+          if (bias != nullptr) {
+            const float4 bv = *(const float4*)(bias + n);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
           }
-          const long long off = pix * d.y_cs + n;
-          float v = acc[mi][ni][e] + bv;
-          if (d.act == CSG_ACT_LEAKY)
-            v = v > 0.f ? v : v * d.slope;
-          else if (d.act == CSG_ACT_TANH)
-            v = tanhf(v);
-          if (res != nullptr) v += res[off];
-          if (d.accumulate) v += y[off];
-          y[off] = v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (d.act == CSG_ACT_LEAKY)
+              v[j] = v[j] > 0.f ? v[j] : v[j] * d.slope;
+            else if (d.act == CSG_ACT_TANH)
+              v[j] = tanhf(v[j]);
+          }
+          if (rrow != nullptr) {
+            const float4 rv = *(const float4*)(rrow + n);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          }
+          if (d.accumulate) {
+            const float4 ov = *(const float4*)(yrow + n);
+            v[0] += ov.x; v[1] += ov.y; v[2] += ov.z; v[3] += ov.w;
+          }
+          *(float4*)(yrow + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (n + j < d.Cout) {
+              float t = v[j] + (bias != nullptr ? bias[n + j] : 0.f);
+              if (d.act == CSG_ACT_LEAKY)
+                t = t > 0.f ? t : t * d.slope;
+              else if (d.act == CSG_ACT_TANH)
+                t = tanhf(t);
+              if (rrow != nullptr) t += rrow[n + j];
+              if (d.accumulate) t += yrow[n + j];
+              yrow[n + j] = t;
+            }
+          }
         }
       }
-    }
   }
 }
 
@@ -460,29 +489,32 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj)
-          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[nj], a[mi], acc[mi][nj], 0, 0, 0);
     }
     if (ch + 1 < ch1) store_tile(buf ^ 1);
     __syncthreads();
   }
 
-  // D[i = n][j = kk]; slab layout [split][Cout][wrow] with the weight-tap index applied
+  // D[i = kk][j = n]: a lane owns output channel n and runs of 4 consecutive (tap,c) columns, which
+  // are contiguous in the slab row [split][Cout][wrow] (Cin % 4 == 0, so a run never straddles taps)
   float* slab = out + (long long)sp * d.Cout * p.wrow;
 #pragma unroll
-  for (int nj = 0; nj < NJ; ++nj) {
-    const int kk = jt * 128 + wj * (NJ * 32) + nj * 32 + r;
-    if (kk < p.Ktot) {
-      const int sl = kk / d.Cin;
-      const int col = s_tap[32 + sl] * d.Cin + (kk - sl * d.Cin);
+  for (int mi = 0; mi < MI; ++mi) {
+    const int n = it * BI + wi * (MI * 32) + mi * 32 + r;
+    if (n >= d.Cout) continue;
+    float* srow = slab + (long long)n * p.wrow;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
+    for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int n = it * BI + wi * (MI * 32) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (n < d.Cout) slab[(long long)n * p.wrow + col] = acc[mi][nj][e];
+      for (int g = 0; g < 4; ++g) {
+        const int kk = jt * 128 + wj * (NJ * 32) + nj * 32 + 8 * g + 4 * hh;
+        if (kk < p.Ktot) {
+          const int sl = kk / d.Cin;
+          const int col = s_tap[32 + sl] * d.Cin + (kk - sl * d.Cin);
+          *(float4*)(srow + col) = make_float4(acc[mi][nj][4 * g], acc[mi][nj][4 * g + 1], acc[mi][nj][4 * g + 2],
+                                               acc[mi][nj][4 * g + 3]);
         }
       }
-    }
   }
 }
 
@@ -541,6 +573,23 @@ static void fill(IgemmParams& p, const csg_conv_desc* d) {
 
 static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
 
+// Number of K (or pixel) splits for a grid of `blocks` tiles with `steps` reduction steps each.
+// 512 blocks are resident at once (2 per CU); the launch takes ceil(blocks*s/512) rounds of
+// steps/s each.  Pick the smallest s whose cost is within 3 % of the best (slabs cost traffic).
+static int pick_split(int blocks, int steps, int min_steps, int max_split) {
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= max_split && steps / s >= min_steps; ++s) {
+    const double rounds = (double)((blocks * (long long)s + 511) / 512);
+    const double cost = rounds * ((steps + s - 1) / s) + 0.25 * s;   // + slab write/reduce per split
+    if (cost < best_cost * 0.97) {
+      best_cost = cost;
+      best = s;
+    }
+  }
+  return best;
+}
+
 // split-K plan for the forward kernel: only when the tile grid cannot fill the chip
 static void fwd_plan(IgemmParams& p) {
   const int bn = pick_bn(p.d.Cout);
@@ -549,12 +598,7 @@ static void fwd_plan(IgemmParams& p) {
   const int nkt = (p.Ktot + IG_BK - 1) / IG_BK;
   const int blocks = p.mtiles * p.ntiles;
   int ks = 1;
-  if (blocks < 320 && nkt >= 16 && p.d.Cout % 4 == 0) {
-    ks = (640 + blocks - 1) / blocks;
-    if (ks > nkt / 8) ks = nkt / 8;
-    if (ks > 64) ks = 64;
-    if (ks < 1) ks = 1;
-  }
+  if (blocks < 1024 && nkt >= 16 && p.d.Cout % 4 == 0) ks = pick_split(blocks, nkt, 8, 64);
   p.kt_per_split = (nkt + ks - 1) / ks;
   p.ksplit = (nkt + p.kt_per_split - 1) / p.kt_per_split;
 }
@@ -577,13 +621,7 @@ static void wgrad_plan(const IgemmParams& p, int bi, int& itiles, int& jtiles, i
   itiles = (p.d.Cout + bi - 1) / bi;
   jtiles = (p.Ktot + 127) / 128;
   const int nch = (p.M + 31) / 32;
-  int base = itiles * jtiles;
-  nsplit = 1024 / base;
-  if (nsplit < 1) nsplit = 1;
-  int maxsplit = nch / 8;
-  if (maxsplit < 1) maxsplit = 1;
-  if (nsplit > maxsplit) nsplit = maxsplit;
-  if (nsplit > 256) nsplit = 256;
+  nsplit = pick_split(itiles * jtiles, nch, 8, 256);
   cps = (nch + nsplit - 1) / nsplit;
   nsplit = (nch + cps - 1) / cps;  // no empty splits
 }
