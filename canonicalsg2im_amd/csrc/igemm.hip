@@ -23,6 +23,8 @@
 //
 // Weight gradient: rows = output channels (A = dY), cols = (tap, input channel) (B = gathered X),
 // reduction over pixels, split across blocks into slabs + ordered reduction as well.
+#include <stddef.h>
+
 #include "csg_common.h"
 
 using namespace csg;
@@ -87,15 +89,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-__device__ __forceinline__ void load_taps(const csg_conv_desc& d, int* s_tap, int tid) {
-#pragma unroll
-  for (int i = 0; i < CSG_MAX_TAPS; ++i) {
-    if (tid == i) {
-      s_tap[i] = d.tap_dy[i];
-      s_tap[16 + i] = d.tap_dx[i];
-      s_tap[32 + i] = d.tap_w[i];
-    }
-  }
+// The three tap tables are 48 consecutive ints of the by-value kernel argument.  Lanes 0..47 copy
+// them from the kernarg segment with ONE vector load each (indexing them per lane through scalar
+// registers would cost 48 SGPRs and spill the hot loop's scalars).
+__device__ __forceinline__ void load_taps(int* s_tap, int tid) {
+  const int* ka = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
+  if (tid < 3 * CSG_MAX_TAPS) s_tap[tid] = ka[offsetof(csg_conv_desc, tap_dy) / 4 + tid];
 }
 
 __device__ __forceinline__ void decompose(const IgemmParams& p, unsigned m, int& b, int& gy, int& gx) {
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
   }
   const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
 
-  load_taps(d, s_tap, tid);
+  load_taps(s_tap, tid);
 
   // ---- buffer descriptors (wave-uniform): A based at the image of this tile's first row
   const int m_first = min(mt * IG_BM, p.M - 1);
@@ -168,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
   int k_cur = kt0 * IG_BK + kc * 4;
   int slot = k_cur / d.Cin;
   int cch = k_cur - slot * d.Cin;
+  const int step_slots = IG_BK / d.Cin, step_rem = IG_BK - step_slots * d.Cin;
 
   f32x4 ra[4], rb[BROWS];
   __syncthreads();  // s_tap visible
@@ -198,13 +198,13 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
 #pragma unroll
     for (int i = 0; i < BROWS; ++i)
       rb[i] = csg_buffer_load_f32x4(rsB, (int)((kv & (b_base[i] != OOB_OFF)) ? b_base[i] + wcol : OOB_OFF), 0, 0);
-    // advance to the next K tile
+    // advance to the next K tile (branch-free: 32 = step_slots * Cin + step_rem)
     k_cur += IG_BK;
-    cch += IG_BK;
-    while (cch >= d.Cin) {
-      cch -= d.Cin;
-      ++slot;
-    }
+    cch += step_rem;
+    slot += step_slots;
+    const bool wrap = cch >= d.Cin;
+    cch = wrap ? cch - d.Cin : cch;
+    slot = wrap ? slot + 1 : slot;
     fetch_tap();
   };
   auto store_tile = [&](int buf) {
@@ -235,9 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
   }
   __syncthreads();
 
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tile();
+  auto compute_tile = [&](int buf) {
     const float* Ab = As + buf * IG_BM * IG_LD + (wm * WROWS + r) * IG_LD + 4 * hh;
     const float* Bb = Bs + buf * BN * IG_LD + (wn * WCOLS + r) * IG_LD + 4 * hh;
 #pragma unroll
@@ -259,9 +257,27 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].w, a[mi].w, acc[mi][ni], 0, 0, 0);
         }
     }
-    if (kt + 1 < kt1) store_tile(buf ^ 1);
+  };
+  // steady state: ONE basic block per K tile (next tile's loads, this tile's MFMAs, LDS refill),
+  // so the scheduler is free to slot the loader's VALU/VMEM work between the 64-cycle MFMAs;
+  // the last tile is peeled
+  int buf = 0;
+  for (int kt = kt0; kt + 1 < kt1; ++kt) {
+    load_tile();
+    compute_tile(buf);
+    store_tile(buf ^ 1);
+    // issue order inside the block: the 8 global loads go out EARLY (their data is needed only at
+    // the LDS refill after the last MFMA), each with its address arithmetic, two MFMAs apart
+#pragma unroll
+    for (int i = 0; i < 4 + BROWS; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);   // VALU
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
+    }
     __syncthreads();
+    buf ^= 1;
   }
+  if (kt0 < kt1) compute_tile(buf);
 
   // epilogue: D[i][j], j = lane&31 = pixel, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel:
   // registers 4g..4g+3 of a tile are channels 8g + 4*(lane>>5) + 0..3 of this lane's pixel.
@@ -402,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
   bid /= nsplit;
   const int jt = bid % jtiles, it = bid / jtiles;
 
-  load_taps(d, s_tap, tid);
+  load_taps(s_tap, tid);
   __syncthreads();
 
   // X tile: this thread's column is a fixed (tap, channel)
@@ -473,27 +489,46 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
     store_tile(0);
   }
   __syncthreads();
-  for (int ch = ch0; ch < ch1; ++ch) {
-    const int buf = (ch - ch0) & 1;
-    if (ch + 1 < ch1) load_tile(ch + 1);
+  auto compute_tile = [&](int buf) {
     const float* Ab = As + buf * 32 * BI + hh * BI + wi * (MI * 32) + r;
     const float* Bb = Bs + buf * 32 * WG_LDB + hh * WG_LDB + wj * (NJ * 32) + r;
+    // fragments of pixel pair kp+1 are fetched from LDS before the MFMAs of pair kp are issued
+    float a[2][MI], b[2][NJ];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[0][mi] = Ab[mi * 32];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) b[0][nj] = Bb[nj * 32];
 #pragma unroll
     for (int kp = 0; kp < 16; ++kp) {
-      float a[MI], b[NJ];
+      if (kp + 1 < 16) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = Ab[kp * 2 * BI + mi * 32];
+        for (int mi = 0; mi < MI; ++mi) a[(kp + 1) & 1][mi] = Ab[(kp + 1) * 2 * BI + mi * 32];
 #pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) b[nj] = Bb[kp * 2 * WG_LDB + nj * 32];
+        for (int nj = 0; nj < NJ; ++nj) b[(kp + 1) & 1][nj] = Bb[(kp + 1) * 2 * WG_LDB + nj * 32];
+      }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj)
-          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[nj], a[mi], acc[mi][nj], 0, 0, 0);
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[kp & 1][nj], a[kp & 1][mi], acc[mi][nj], 0, 0, 0);
     }
-    if (ch + 1 < ch1) store_tile(buf ^ 1);
+  };
+  // steady state = one basic block per 32-pixel chunk (see k_igemm_fwd); last chunk peeled
+  int buf = 0;
+  for (int ch = ch0; ch + 1 < ch1; ++ch) {
+    load_tile(ch + 1);
+    compute_tile(buf);
+    store_tile(buf ^ 1);
+#pragma unroll
+    for (int i = 0; i < 4 + AIT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);   // VALU
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
+    }
     __syncthreads();
+    buf ^= 1;
   }
+  if (ch0 < ch1) compute_tile(buf);
 
   // D[i = kk][j = n]: a lane owns output channel n and runs of 4 consecutive (tap,c) columns, which
   // are contiguous in the slab row [split][Cout][wrow] (Cin % 4 == 0, so a run never straddles taps)
