@@ -33,20 +33,70 @@ __device__ __forceinline__ float coverage(float t, float lo, float size) {
   return w0 + w1;
 }
 
+// support test for an n-pixel source line (coverage() is the n = 8 case of boxes_to_layout)
+__device__ __forceinline__ float coverage_n(float t, float lo, float size, int n) {
+  float g = ((t - lo) / size) * 2.0f - 1.0f;
+  float ix = ((g + 1.0f) * (float)n - 1.0f) / 2.0f;
+  float i0 = floorf(ix);
+  float fr = ix - i0;
+  float w0 = (i0 >= 0.0f && i0 <= (float)(n - 1)) ? (1.0f - fr) : 0.0f;
+  float w1 = (i0 + 1.0f >= 0.0f && i0 + 1.0f <= (float)(n - 1)) ? fr : 0.0f;
+  return w0 + w1;
+}
+
+// Bilinear tap of grid_sample(align_corners=False, zeros padding) along one axis of an n-pixel
+// image: returns the lower tap index i0 (may be -1 .. n-1), its weight w0 and the upper tap's w1,
+// each already zeroed when the tap is outside the image.
+__device__ __forceinline__ void axis_taps(float t, float lo, float size, int n, int& i0, float& w0, float& w1) {
+  float g = ((t - lo) / size) * 2.0f - 1.0f;
+  float ix = ((g + 1.0f) * (float)n - 1.0f) / 2.0f;
+  float f0 = floorf(ix);
+  float fr = ix - f0;
+  // clamp before the int conversion: far-away boxes give huge |ix|
+  f0 = fminf(fmaxf(f0, -2.0f), (float)n);
+  i0 = (int)f0;
+  w0 = (i0 >= 0 && i0 <= n - 1) ? (1.0f - fr) : 0.0f;
+  w1 = (i0 + 1 >= 0 && i0 + 1 <= n - 1) ? fr : 0.0f;
+}
+
+// weight of one object at one output pixel when a (M,M) mask modulates it (masks_to_layout,
+// sg2im/layout.py:48-77): bilinear sample of the mask; the row taps (iy0, wy0, wy1) are precomputed
+__device__ __forceinline__ float mask_weight(const float* __restrict__ mk, int M, int iy0, float wy0, float wy1,
+                                             float tx, float x0, float ww) {
+  int ix0;
+  float wx0, wx1;
+  axis_taps(tx, x0, ww, M, ix0, wx0, wx1);
+  float acc = 0.f;
+  if (wy0 != 0.f) {
+    const float* row = mk + iy0 * M;
+    if (wx0 != 0.f) acc += row[ix0] * wy0 * wx0;
+    if (wx1 != 0.f) acc += row[ix0 + 1] * wy0 * wx1;
+  }
+  if (wy1 != 0.f) {
+    const float* row = mk + (iy0 + 1) * M;
+    if (wx0 != 0.f) acc += row[ix0] * wy1 * wx0;
+    if (wx1 != 0.f) acc += row[ix0 + 1] * wy1 * wx1;
+  }
+  return acc;
+}
+
 #define LAY_OB 32    // objects per LDS batch
 #define LAY_PXC 256  // max pixels per block chunk
 #define LAY_EPT 8    // float4 elements per thread
 
 __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ vecs, const float* __restrict__ boxes,
-                                                     const uint8_t* __restrict__ valid, int O, int S, int H, int W,
-                                                     int OH, int OW, int pxc, float* __restrict__ out, int out_cs,
-                                                     int out_off) {
+                                                     const uint8_t* __restrict__ valid,
+                                                     const float* __restrict__ masks, int M, int O, int S, int H,
+                                                     int W, int OH, int OW, int pxc, float* __restrict__ out,
+                                                     int out_cs, int out_off) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_wx = sm;                       // [LAY_OB][pxc]
   float* s_vec = sm + LAY_OB * pxc;       // [LAY_OB][S]
   float* s_wy = s_vec + LAY_OB * S;       // [LAY_OB]
   int* s_act = (int*)(s_wy + LAY_OB);     // [LAY_OB] object index of each active slot
   int* s_n = s_act + LAY_OB;              // [1]
+  float* s_wy1 = (float*)(s_n + 4);       // [LAY_OB] mask path: weight of the upper row tap
+  int* s_iy0 = (int*)(s_wy1 + LAY_OB);    // [LAY_OB] mask path: lower row tap index
 
   const int tid = threadIdx.x;
   const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * pxc;
@@ -75,14 +125,23 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
       int o = ob + tid;
       float wy = 0.f;
       bool act = false;
+      float wy1 = 0.f;
+      int iy0 = 0;
       if (tid < LAY_OB && o < O && vb[o]) {
-        wy = coverage(ty, bx[o * 4 + 1], bx[o * 4 + 3]);
-        act = (wy != 0.0f);
+        if (masks == nullptr) {
+          wy = coverage(ty, bx[o * 4 + 1], bx[o * 4 + 3]);
+          act = (wy != 0.0f);
+        } else {
+          axis_taps(ty, bx[o * 4 + 1], bx[o * 4 + 3], M, iy0, wy, wy1);
+          act = (wy != 0.0f) || (wy1 != 0.0f);
+        }
       }
       unsigned long long m = __ballot(act);
       int slot = __popcll(m & ((1ull << tid) - 1ull));
       if (act) {
         s_wy[slot] = wy;
+        s_wy1[slot] = wy1;
+        s_iy0[slot] = iy0;
         s_act[slot] = o;
       }
       if (tid == 0) *s_n = __popcll(m);
@@ -94,7 +153,11 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
       int a = i / npx, xl = i - a * npx;
       int o = s_act[a];
       int xsrc = min((int)(((int64_t)(x0 + xl) * W) / OW), W - 1);
-      s_wx[a * pxc + xl] = coverage(lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]);
+      if (masks == nullptr)
+        s_wx[a * pxc + xl] = coverage(lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]);
+      else  // full 2-D weight of this pixel; the row factor below is 1
+        s_wx[a * pxc + xl] = mask_weight(masks + ((int64_t)b * O + o) * M * M, M, s_iy0[a], s_wy[a], s_wy1[a],
+                                         lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]);
     }
     for (int i = tid; i < nact * S; i += 256) {
       int a = i / S, d = i - a * S;
@@ -102,7 +165,7 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
     }
     __syncthreads();
     for (int a = 0; a < nact; ++a) {
-      const float wy = s_wy[a];
+      const float wy = masks == nullptr ? s_wy[a] : 1.0f;
 #pragma unroll
       for (int i = 0; i < LAY_EPT; ++i) {
         if (tid + 256 * i < nel) {
@@ -126,8 +189,10 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
 // One block per (object, image): reduce dout over the box's support only.
 __global__ __launch_bounds__(256) void k_layout_bwd(const float* __restrict__ dout, int out_cs, int out_off,
                                                      const float* __restrict__ boxes,
-                                                     const uint8_t* __restrict__ valid, int O, int S, int H, int W,
-                                                     int OH, int OW, float* __restrict__ dvecs, int accumulate) {
+                                                     const uint8_t* __restrict__ valid,
+                                                     const float* __restrict__ masks, int M, int O, int S, int H,
+                                                     int W, int OH, int OW, float* __restrict__ dvecs,
+                                                     int accumulate) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_wy = sm;            // [OH]
   float* s_wx = sm + OH;       // [OW]
@@ -147,7 +212,7 @@ __global__ __launch_bounds__(256) void k_layout_bwd(const float* __restrict__ do
   __syncthreads();
   for (int y = tid; y < OH; y += 256) {
     int ysrc = min((int)(((int64_t)y * H) / OH), H - 1);
-    float w = coverage(lin01(ysrc, H), y0, hh);
+    float w = masks == nullptr ? coverage(lin01(ysrc, H), y0, hh) : coverage_n(lin01(ysrc, H), y0, hh, M);
     s_wy[y] = w;
     if (w != 0.f) {
       atomicMin(&s_rng[0], y);
@@ -156,7 +221,7 @@ __global__ __launch_bounds__(256) void k_layout_bwd(const float* __restrict__ do
   }
   for (int x = tid; x < OW; x += 256) {
     int xsrc = min((int)(((int64_t)x * W) / OW), W - 1);
-    float w = coverage(lin01(xsrc, W), x0, ww);
+    float w = masks == nullptr ? coverage(lin01(xsrc, W), x0, ww) : coverage_n(lin01(xsrc, W), x0, ww, M);
     s_wx[x] = w;
     if (w != 0.f) {
       atomicMin(&s_rng[2], x);
@@ -176,7 +241,16 @@ __global__ __launch_bounds__(256) void k_layout_bwd(const float* __restrict__ do
       int yy = i / nx;
       int xx = xlo + (i - yy * nx);
       yy += ylo;
-      float w = s_wy[yy] * s_wx[xx];
+      float w;
+      if (masks == nullptr) {
+        w = s_wy[yy] * s_wx[xx];
+      } else {
+        int iy0;
+        float wy0, wy1;
+        axis_taps(lin01(min((int)(((int64_t)yy * H) / OH), H - 1), H), y0, hh, M, iy0, wy0, wy1);
+        w = mask_weight(masks + ((int64_t)b * O + o) * M * M, M, iy0, wy0, wy1,
+                        lin01(min((int)(((int64_t)xx * W) / OW), W - 1), W), x0, ww);
+      }
       float4 g = *(const float4*)&base[((int64_t)yy * OW + xx) * out_cs];
       acc.x += g.x * w;
       acc.y += g.y * w;
@@ -195,9 +269,10 @@ __global__ __launch_bounds__(256) void k_layout_bwd(const float* __restrict__ do
 
 extern "C" {
 
-int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, int64_t B, int64_t O, int64_t S,
-                   int64_t H, int64_t W, int64_t OH, int64_t OW, float* out, int64_t out_cs, int64_t out_off,
-                   void* stream) {
+int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M,
+                   int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* out,
+                   int64_t out_cs, int64_t out_off, void* stream) {
+  CSG_REQUIRE(masks == nullptr || (M >= 1 && M <= 1024), CSG_E_BADSHAPE, "csg_layout_fwd: bad mask size %ld", (long)M);
   CSG_REQUIRE(B > 0 && O >= 0 && S > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, CSG_E_BADSHAPE,
               "csg_layout_fwd: bad shape");
   CSG_REQUIRE(S % 4 == 0 && out_cs % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)out % 16) == 0, CSG_E_UNSUPPORTED,
@@ -210,17 +285,18 @@ int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, 
   if (pxc > LAY_PXC) pxc = LAY_PXC;
   if (pxc > OW) pxc = (int)OW;
   CSG_REQUIRE(pxc >= 1, CSG_E_UNSUPPORTED, "csg_layout_fwd: S too large for one chunk");
-  size_t shm = (size_t)(LAY_OB * pxc + LAY_OB * S + LAY_OB) * 4 + (LAY_OB + 4) * 4;
+  size_t shm = (size_t)(LAY_OB * pxc + LAY_OB * S + LAY_OB) * 4 + (LAY_OB + 4) * 4 + 2 * LAY_OB * 4;
   ProfScope p(K_LAYOUT_FWD, (double)B * OH * OW * S * 4, s);  // algorithmic bytes: the output, once
   dim3 grid((unsigned)cdiv(OW, pxc), (unsigned)OH, (unsigned)B);
-  hipLaunchKernelGGL(k_layout_fwd, grid, dim3(256), shm, s, vecs, boxes, valid, (int)O, (int)S, (int)H, (int)W,
-                     (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off);
+  hipLaunchKernelGGL(k_layout_fwd, grid, dim3(256), shm, s, vecs, boxes, valid, masks, (int)M, (int)O, (int)S, (int)H,
+                     (int)W, (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off);
   return check_launch("csg_layout_fwd");
 }
 
 int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,
-                   int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* dvecs,
-                   int accumulate, void* stream) {
+                   const float* masks, int64_t M, int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH,
+                   int64_t OW, float* dvecs, int accumulate, void* stream) {
+  CSG_REQUIRE(masks == nullptr || (M >= 1 && M <= 1024), CSG_E_BADSHAPE, "csg_layout_bwd: bad mask size %ld", (long)M);
   CSG_REQUIRE(B > 0 && O >= 0 && S > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, CSG_E_BADSHAPE,
               "csg_layout_bwd: bad shape");
   CSG_REQUIRE(S % 4 == 0 && out_cs % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)dout % 16) == 0, CSG_E_UNSUPPORTED,
@@ -234,7 +310,7 @@ int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const flo
   size_t shm = (size_t)(((OH + OW + 4) + 3) & ~3) * 4 + (size_t)npl * S * 4;
   ProfScope p(K_LAYOUT_BWD, (double)B * OH * OW * S * 4, s);
   hipLaunchKernelGGL(k_layout_bwd, dim3((unsigned)O, (unsigned)B), dim3(256), shm, s, dout, (int)out_cs, (int)out_off,
-                     boxes, valid, (int)O, (int)S, (int)H, (int)W, (int)OH, (int)OW, dvecs, accumulate);
+                     boxes, valid, masks, (int)M, (int)O, (int)S, (int)H, (int)W, (int)OH, (int)OW, dvecs, accumulate);
   return check_launch("csg_layout_bwd");
 }
 

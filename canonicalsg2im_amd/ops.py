@@ -456,42 +456,53 @@ def _check_boxes(boxes):
                                   "scripts/train.py:358; SURVEY.md §9 item 16)")
 
 
+def _prep_masks(masks):
+    """(B,O,M,M) int64/float masks -> contiguous fp32 (what the reference's `.float()` does), or None."""
+    if masks is None:
+        return None, 0
+    m = masks.to(torch.float32).contiguous()
+    if m.requires_grad:
+        raise NotImplementedError("layout: gradients w.r.t. masks are not implemented (training feeds GT masks)")
+    return m, int(m.shape[-1])
+
+
 class _LayoutPyramid(torch.autograd.Function):
-    """boxes_to_layout for a whole batch at several output sizes at once: size h samples the
-    full-resolution layout at rows floor(y*H/h) (= F.interpolate(seg, (h,h), 'nearest'))."""
+    """boxes_to_layout / masks_to_layout for a whole batch at several output sizes at once: size h
+    samples the full-resolution layout at rows floor(y*H/h) (= F.interpolate(seg, (h,h), 'nearest'))."""
 
     @staticmethod
-    def forward(ctx, vecs, boxes, valid, H, sizes):
+    def forward(ctx, vecs, boxes, valid, masks, H, sizes):
         vecs = _f32(vecs).contiguous()
         boxes = _f32(boxes).contiguous()
+        masks, M = _prep_masks(masks)
         B, O, S = vecs.shape
         outs = []
         for h in sizes:
             seg = empty_nhwc(B, S, h, h, vecs.device)
-            check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), B, O, S, H, H, h, h, ptr(seg), S, 0, stream()),
-                  "layout_fwd")
+            check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, h, h, ptr(seg), S,
+                                     0, stream()), "layout_fwd")
             outs.append(seg)
-        ctx.save_for_backward(boxes, valid)
-        ctx.meta = (B, O, S, H, tuple(sizes))
+        ctx.save_for_backward(boxes, valid, masks)
+        ctx.meta = (B, O, S, H, M, tuple(sizes))
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        boxes, valid = ctx.saved_tensors
-        B, O, S, H, sizes = ctx.meta
+        boxes, valid, masks = ctx.saved_tensors
+        B, O, S, H, M, sizes = ctx.meta
         dvecs = torch.zeros((B, O, S), device=boxes.device, dtype=torch.float32)
         for h, g in zip(sizes, douts):
             if g is None:
                 continue
             g = nhwc(g)
-            check(lib.csg_layout_bwd(ptr(g), S, 0, ptr(boxes), ptr(valid), B, O, S, H, H, h, h, ptr(dvecs), 1, stream()),
-                  "layout_bwd")
-        return dvecs, None, None, None, None
+            check(lib.csg_layout_bwd(ptr(g), S, 0, ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, h, h,
+                                     ptr(dvecs), 1, stream()), "layout_bwd")
+        return dvecs, None, None, None, None, None
 
 
-def layout_pyramid(vecs, boxes, valid, H, sizes):
+def layout_pyramid(vecs, boxes, valid, H, sizes, masks=None):
     _check_boxes(boxes)
-    return _LayoutPyramid.apply(vecs, boxes, valid, int(H), tuple(int(s) for s in sizes))
+    return _LayoutPyramid.apply(vecs, boxes, valid, masks, int(H), tuple(int(s) for s in sizes))
 
 
 class _DiscInput(torch.autograd.Function):
@@ -500,34 +511,35 @@ class _DiscInput(torch.autograd.Function):
     first conv's weight is permuted to match by the caller."""
 
     @staticmethod
-    def forward(ctx, img, vecs, boxes, valid, H):
+    def forward(ctx, img, vecs, boxes, valid, masks, H):
         vecs = _f32(vecs).contiguous()
         boxes = _f32(boxes).contiguous()
+        masks, M = _prep_masks(masks)
         B, O, S = vecs.shape
         Ct = (S + 3 + 3) // 4 * 4
         buf = torch.zeros((B, H, H, Ct), device=vecs.device, dtype=torch.float32)
         buf[..., S:S + 3] = img.permute(0, 2, 3, 1)
-        check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), B, O, S, H, H, H, H, ptr(buf), Ct, 0, stream()),
-              "layout_fwd")
-        ctx.save_for_backward(boxes, valid)
-        ctx.meta = (B, O, S, H, Ct)
+        check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, H, H, ptr(buf), Ct, 0,
+                                 stream()), "layout_fwd")
+        ctx.save_for_backward(boxes, valid, masks)
+        ctx.meta = (B, O, S, H, Ct, M)
         return buf.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dbuf):
-        boxes, valid = ctx.saved_tensors
-        B, O, S, H, Ct = ctx.meta
+        boxes, valid, masks = ctx.saved_tensors
+        B, O, S, H, Ct, M = ctx.meta
         dbuf = nhwc(dbuf)
         dimg = dvecs = None
         if ctx.needs_input_grad[0]:
             dimg = dbuf[:, S:S + 3].contiguous()
         if ctx.needs_input_grad[1]:
             dvecs = torch.empty((B, O, S), device=dbuf.device, dtype=torch.float32)
-            check(lib.csg_layout_bwd(ptr(dbuf), Ct, 0, ptr(boxes), ptr(valid), B, O, S, H, H, H, H, ptr(dvecs), 0,
-                                     stream()), "layout_bwd")
-        return dimg, dvecs, None, None, None
+            check(lib.csg_layout_bwd(ptr(dbuf), Ct, 0, ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, H, H,
+                                     ptr(dvecs), 0, stream()), "layout_bwd")
+        return dimg, dvecs, None, None, None, None
 
 
-def disc_input(img, vecs, boxes, valid, H):
+def disc_input(img, vecs, boxes, valid, H, masks=None):
     _check_boxes(boxes)
-    return _DiscInput.apply(_f32(img), vecs, boxes, valid, int(H))
+    return _DiscInput.apply(_f32(img), vecs, boxes, valid, masks, int(H))

@@ -20,4 +20,16 @@ def boxes_to_layout(vecs, boxes, H, W=None, pooling='sum'):
 
 
 def masks_to_layout(vecs, boxes, masks, H, W=None, pooling='sum', test_mode=False):
-    raise NotImplementedError("masks_to_layout (--mask_size > 0) is outside the hot path (SURVEY.md §8f row 4)")
+    """vecs (O,D), boxes (O,4) xywh, masks (O,M,M) -> (1,D,H,W) (reference sg2im/layout.py:48-77):
+    each object's vector is modulated by the bilinear sample of its mask over its box."""
+    if pooling != 'sum':
+        raise ValueError('Invalid pooling "%s"' % pooling)
+    if test_mode:
+        raise NotImplementedError("masks_to_layout(test_mode=True) is the inference-time painter's compositing "
+                                  "(layout.py:139-151), outside the training hot path")
+    W = H if W is None else W
+    if W != H:
+        raise NotImplementedError("masks_to_layout: non-square layouts are not on the hot path")
+    valid = torch.ones((1, vecs.size(0)), dtype=torch.uint8, device=vecs.device)
+    (out,) = ops.layout_pyramid(vecs.unsqueeze(0), boxes.unsqueeze(0), valid, H, (H,), masks=masks.unsqueeze(0))
+    return out

@@ -81,12 +81,10 @@ class MultiscaleDiscriminator(BaseNetwork):
 
     def forward(self, img, objs, layout_boxes, layout_masks=None, gt_train=True, fool=False):
         """`fool` is accepted and ignored, as in the reference."""
-        if layout_masks is not None:
-            raise NotImplementedError("mask layouts (--mask_size > 0) are outside the hot path")
         obj_vecs = self.attribute_embedding(objs)
         valid = real_object_mask(objs, self.opt.vocab)
         S = obj_vecs.size(-1)
-        x = ops.disc_input(img, obj_vecs, layout_boxes, valid, self.opt.image_size[0])
+        x = ops.disc_input(img, obj_vecs, layout_boxes, valid, self.opt.image_size[0], masks=layout_masks)
         result = []
         for name, D in self.named_children():
             if name.startswith('discriminator'):

@@ -67,8 +67,8 @@ class SPADEGenerator(BaseNetwork):
         return sw, round(sw / opt.aspect_ratio)
 
     def forward(self, objs, layout_boxes, layout_masks, test_mode=False):
-        if layout_masks is not None:
-            raise NotImplementedError("mask layouts (--mask_size > 0) are outside the hot path")
+        if layout_masks is not None and test_mode:
+            raise NotImplementedError("masks_to_layout(test_mode=True) compositing is an inference-only path")
         if self.sw != self.sh:
             raise NotImplementedError("aspect_ratio != 1 is not on the hot path")
         H = self.opt.image_size[0]
@@ -78,7 +78,7 @@ class SPADEGenerator(BaseNetwork):
         while h <= H:
             sizes.append(h)
             h *= 2
-        seg = SegPyramid(zip(sizes, ops.layout_pyramid(obj_vecs, layout_boxes, valid, H, sizes)))
+        seg = SegPyramid(zip(sizes, ops.layout_pyramid(obj_vecs, layout_boxes, valid, H, sizes, masks=layout_masks)))
         x = self.fc(seg.at(self.sw))          # F.interpolate(seg, (sh,sw)) == pyramid level sw
         x = self.head_0(x, seg)
         x = ops.upsample2x(x)

@@ -92,17 +92,19 @@ int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* 
                         int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, float* dh, float* dconf,
                         float* dcnt_scratch, void* stream);
 
-/* ---- K6: boxes_to_layout (sg2im/layout.py:12-45), batched over images ------------------------
+/* ---- K6: boxes_to_layout (sg2im/layout.py:12-45) and masks_to_layout (:48-77, train mode), batched
  * out[b, y, x, out_off + d] = sum_o valid[b,o] * vecs[b,o,d] * cov(y_src) * cov(x_src)
+ * With `masks` (B,O,M,M) fp32 non-NULL the weight of object o at a pixel is the bilinear sample of
+ * its mask over the box (grid_sample, align_corners=False, zeros padding) instead of cov*cov.
  * (OH,OW) may be smaller than (H,W): output pixel y samples full-resolution row
  * floor(y*H/OH) — the nearest resize of generator.py:99 / normalization.py:102 folded in.       */
-int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, int64_t B, int64_t O, int64_t S,
-                   int64_t H, int64_t W, int64_t OH, int64_t OW, float* out, int64_t out_cs, int64_t out_off,
-                   void* stream);
+int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M,
+                   int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* out,
+                   int64_t out_cs, int64_t out_off, void* stream);
 /* dvecs (B,O,S) = (accumulate ? dvecs : 0) + sum_{y,x} dout * cov * cov                        */
 int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,
-                   int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* dvecs,
-                   int accumulate, void* stream);
+                   const float* masks, int64_t M, int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH,
+                   int64_t OW, float* dvecs, int accumulate, void* stream);
 
 /* ---- K3/K8/K11: implicit-GEMM convolution on fp32 MFMA ---------------------------------------
  * replaces nn.Conv2d (generator.py:28,46; architecture.py:29-32; normalization.py:89-94;

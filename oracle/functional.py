@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 __all__ = [
     "attribute_embeddings", "mlp2", "triplet_confidence", "graph_triple_conv", "sg2layout_forward",
-    "remove_dummy_objects", "box_coverage", "boxes_to_layout", "batched_layout",
+    "remove_dummy_objects", "box_coverage", "boxes_to_layout", "masks_to_layout", "batched_layout",
     "spectral_weight", "batch_norm_train", "syncbn_multi_replica", "spade", "spade_resblock",
     "generator_forward", "instance_norm", "nlayer_discriminator", "multiscale_discriminator",
     "hinge_loss", "gan_loss_multiscale", "generator_losses", "discriminator_losses", "TrainState",
@@ -135,6 +135,37 @@ def boxes_to_layout(vecs, boxes, H, W=None):
     out = torch.zeros(vecs.shape[1], H, W, dtype=vecs.dtype)
     for o in range(vecs.shape[0]):                  # index order, like scatter_add on CPU
         out = out + vecs[o].view(-1, 1, 1) * (cy[o].view(1, H, 1) * cx[o].view(1, 1, W))
+    return out.unsqueeze(0)
+
+
+def _axis_taps(lo, size, n_out, n_src):
+    """(i0, w0, w1): lower tap index and the two tap weights (zeroed outside the source) of the
+    bilinear grid_sample(align_corners=False, zeros) along one axis — box_coverage generalised."""
+    t = torch.linspace(0, 1, steps=n_out, dtype=lo.dtype).view(1, n_out)
+    g = ((t - lo.view(-1, 1)) / size.view(-1, 1)).mul(2).sub(1)
+    ix = ((g + 1) * n_src - 1) / 2
+    i0 = torch.floor(ix)
+    fr = ix - i0
+    w0 = (1 - fr) * ((i0 >= 0) & (i0 <= n_src - 1)).to(lo.dtype)
+    w1 = fr * ((i0 + 1 >= 0) & (i0 + 1 <= n_src - 1)).to(lo.dtype)
+    return i0.clamp(-1, n_src - 1).long(), w0, w1
+
+
+def masks_to_layout(vecs, boxes, masks, H, W=None):
+    """`masks_to_layout`, train mode (sg2im/layout.py:48-77): vec[o] x bilinear sample of mask[o]
+    over box o, summed over objects.  masks (O,M,M) int or float."""
+    W = H if W is None else W
+    O, M = masks.shape[0], masks.shape[1]
+    mk = F.pad(masks.to(vecs.dtype), (1, 1, 1, 1))                  # index -1 and M read zeros
+    ix0, wx0, wx1 = _axis_taps(boxes[:, 0], boxes[:, 2], W, M)
+    iy0, wy0, wy1 = _axis_taps(boxes[:, 1], boxes[:, 3], H, M)
+    out = torch.zeros(vecs.shape[1], H, W, dtype=vecs.dtype)
+    for o in range(O):
+        r0, r1 = mk[o][iy0[o] + 1], mk[o][iy0[o] + 2]               # (H, M+2) source rows of each output row
+        c0, c1 = ix0[o] + 1, ix0[o] + 2
+        w = wy0[o].view(H, 1) * (r0[:, c0] * wx0[o].view(1, W) + r0[:, c1] * wx1[o].view(1, W)) + \
+            wy1[o].view(H, 1) * (r1[:, c0] * wx0[o].view(1, W) + r1[:, c1] * wx1[o].view(1, W))
+        out = out + vecs[o].view(-1, 1, 1) * w.unsqueeze(0)
     return out.unsqueeze(0)
 
 

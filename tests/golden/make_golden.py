@@ -59,7 +59,7 @@ warnings.filterwarnings("ignore")
 
 from scripts.args import parser as ref_parser, init_args as ref_init_args  # noqa: E402  (reference)
 from sg2im.graph import GraphTripleConv, get_predicates_weights  # noqa: E402
-from sg2im.layout import boxes_to_layout  # noqa: E402
+from sg2im.layout import boxes_to_layout, masks_to_layout  # noqa: E402
 from sg2im.model import Sg2LayoutModel  # noqa: E402
 from sg2im.pix2pix_model import Pix2PixModel  # noqa: E402
 from spade.models.networks.architecture import SPADEResnetBlock  # noqa: E402
@@ -125,6 +125,23 @@ def fx_layout():
         tag = "%dx%d" % (H, W)
         arrays.update({"out_" + tag: npy(out), "w_" + tag: npy(w), "gvecs_" + tag: npy(gv), "gboxes_" + tag: npy(gb)})
     save("layout", {"sizes": [[16, 16], [32, 32], [24, 40]], "ref": "sg2im/layout.py:12-45"}, **arrays)
+
+
+def fx_masks_layout():
+    torch.manual_seed(6)
+    vecs = torch.randn(5, 8, requires_grad=True)
+    boxes = torch.tensor([[0.10, 0.20, 0.50, 0.40], [0.00, 0.00, 1.00, 1.00], [0.60, 0.55, 0.35, 0.30],
+                          [0.30, 0.30, 0.07, 0.90], [-0.2, 0.40, 0.60, 0.20]])
+    masks = (torch.rand(5, 16, 16) > 0.4).long()                    # collate gives int64 masks
+    soft = torch.rand(5, 16, 16)                                    # mask-net style float masks
+    arrays = {"vecs": npy(vecs), "boxes": npy(boxes), "masks": npy(masks), "soft": npy(soft)}
+    for H in (32, 64):
+        for tag, m in (("int", masks), ("soft", soft)):
+            out = masks_to_layout(vecs, boxes, m, H, H)
+            w = torch.randn_like(out)
+            (gv,) = torch.autograd.grad((out * w).sum(), [vecs])
+            arrays.update({"out_%s_%d" % (tag, H): npy(out), "w_%s_%d" % (tag, H): npy(w), "gvecs_%s_%d" % (tag, H): npy(gv)})
+    save("masks_layout", {"sizes": [32, 64], "ref": "sg2im/layout.py:48-77"}, **arrays)
 
 
 def _graph_inputs(B, O, T, Din, Dp, P, seed):
@@ -320,6 +337,7 @@ def fx_model_and_step():
 if __name__ == "__main__":
     torch.set_num_threads(4)
     fx_layout()
+    fx_masks_layout()
     fx_gconv()
     fx_sg2layout()
     fx_spade_block()

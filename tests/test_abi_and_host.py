@@ -153,8 +153,8 @@ def test_out_of_scope_components_fail_loudly(built):
     for ctor in (AcCropDiscriminator, lambda: VGGLoss([0])):
         with pytest.raises(NotImplementedError):
             ctor()
-    with pytest.raises(NotImplementedError):
-        masks_to_layout(None, None, None, 8)
+    with pytest.raises(NotImplementedError):          # inference-time compositing only
+        masks_to_layout(torch.zeros(1, 4), torch.zeros(1, 4), torch.zeros(1, 2, 2), 8, test_mode=True)
     with pytest.raises(NotImplementedError):
         T.Trainer(T.make_opt(make_vocab("tiny"), ["--no_vgg_loss", "--image_size", "64,64", "--ngf", "4"]),
                   torch.device("cpu"))          # default use_img_disc=0 needs the object discriminator

@@ -201,12 +201,54 @@ def test_layout_golden(ops):
     for H, W in meta["sizes"]:
         tag = "%dx%d" % (H, W)
         out = torch.empty(1, H, W, S).cuda()
-        check(lib.csg_layout_fwd(ptr(vd), ptr(bd), ptr(valid), 1, O, S, H, W, H, W, ptr(out), S, 0, stream()))
+        check(lib.csg_layout_fwd(ptr(vd), ptr(bd), ptr(valid), None, 0, 1, O, S, H, W, H, W, ptr(out), S, 0, stream()))
         assert_close(out.permute(0, 3, 1, 2), a["out_" + tag], RTOL, 2e-6, "layout " + tag)
         dv = torch.empty(1, O, S).cuda()
         gw = a["w_" + tag].permute(0, 2, 3, 1).contiguous().cuda()
-        check(lib.csg_layout_bwd(ptr(gw), S, 0, ptr(bd), ptr(valid), 1, O, S, H, W, H, W, ptr(dv), 0, stream()))
+        check(lib.csg_layout_bwd(ptr(gw), S, 0, ptr(bd), ptr(valid), None, 0, 1, O, S, H, W, H, W, ptr(dv), 0, stream()))
         assert_close(dv[0], a["gvecs_" + tag], RTOL, 1e-5, "layout dvecs " + tag)
+
+
+def test_masks_to_layout_golden(ops):
+    """masks_to_layout (train mode) through the drop-in function against the reference's output."""
+    from canonicalsg2im_amd.sg2im.layout import masks_to_layout
+    meta, a = load_golden("masks_layout")
+    for H in meta["sizes"]:
+        for tag, key in (("int", "masks"), ("soft", "soft")):
+            vd = dev(a["vecs"], True)
+            out = masks_to_layout(vd, a["boxes"].cuda(), a[key].cuda(), H, H)
+            assert_close(out, a["out_%s_%d" % (tag, H)], RTOL, 2e-6, "masks layout %s %d" % (tag, H))
+            (out * a["w_%s_%d" % (tag, H)].cuda()).sum().backward()
+            assert_close(vd.grad, a["gvecs_%s_%d" % (tag, H)], RTOL, 1e-5, "masks layout dvecs %s %d" % (tag, H))
+    with pytest.raises(NotImplementedError):
+        masks_to_layout(vd, a["boxes"].cuda(), a["masks"].cuda(), 32, 32, test_mode=True)
+
+
+def test_masked_pyramid_and_disc_input_vs_oracle(ops):
+    import oracle
+    g = torch.Generator().manual_seed(31)
+    B, O, S, H, M = 2, 11, 8, 64, 16
+    vecs, img = torch.randn(B, O, S, generator=g), torch.randn(B, 3, H, H, generator=g)
+    wh = torch.rand(B, O, 2, generator=g) * 0.4 + 0.05
+    boxes = torch.cat([torch.rand(B, O, 2, generator=g) * (1 - wh), wh], -1)
+    masks = (torch.rand(B, O, M, M, generator=g) > 0.5).long()
+    valid = torch.ones(B, O, dtype=torch.bool)
+    valid[1, -2:] = False
+    vr = vecs.clone().requires_grad_(True)
+    full = torch.cat([oracle.masks_to_layout(vr[b][valid[b]], boxes[b][valid[b]], masks[b][valid[b]], H, H)
+                      for b in range(B)], 0)
+    sizes = (8, 32, 64)
+    refs = [F.interpolate(full, size=(h, h), mode="nearest") for h in sizes]
+    gys = [torch.randn(r.shape, generator=g) for r in refs]
+    sum((r * gy).sum() for r, gy in zip(refs, gys)).backward()
+    vd = dev(vecs, True)
+    outs = ops.layout_pyramid(vd, boxes.cuda(), valid.to(torch.uint8).cuda(), H, sizes, masks=masks.cuda())
+    for h, o, r in zip(sizes, outs, refs):
+        assert_close(o, r, RTOL, 5e-6, "masked pyramid level %d" % h)
+    sum((o * gy.cuda()).sum() for o, gy in zip(outs, gys)).backward()
+    assert_close(vd.grad, vr.grad, RTOL, 2e-5, "masked pyramid dvecs")
+    buf = ops.disc_input(img.cuda(), vecs.cuda(), boxes.cuda(), valid.to(torch.uint8).cuda(), H, masks=masks.cuda())
+    assert_close(buf[:, :S], full, RTOL, 5e-6, "masked disc input")
 
 
 def test_layout_pyramid_vs_oracle(ops):

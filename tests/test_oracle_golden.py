@@ -173,3 +173,14 @@ def test_discriminator_features_eval():
     for i, scale in enumerate(feats):
         for j, f in enumerate(scale):
             assert_close(f, a["dfeat_%d_%d" % (i, j)], RTOL, 1e-5, "dfeat %d %d" % (i, j))
+
+
+def test_masks_to_layout():
+    meta, a = load_golden("masks_layout")
+    for H in meta["sizes"]:
+        for tag, key in (("int", "masks"), ("soft", "soft")):
+            vecs = a["vecs"].clone().requires_grad_(True)
+            out = oracle.masks_to_layout(vecs, a["boxes"], a[key], H, H)
+            assert_close(out, a["out_%s_%d" % (tag, H)], RTOL, ATOL, "masks layout %s %d" % (tag, H))
+            (gv,) = torch.autograd.grad((out * a["w_%s_%d" % (tag, H)]).sum(), [vecs])
+            assert_close(gv, a["gvecs_%s_%d" % (tag, H)], RTOL, 1e-5, "masks layout dvecs %s %d" % (tag, H))
