@@ -6,7 +6,9 @@
 A "step" is one iteration of scripts/train.py:353-393 (graph encoder + AttSPADE generator forward,
 generator losses through two PatchGAN passes, backward + Adam; discriminator losses through two more
 passes, backward + Adam) on one synthetic COCO-shaped batch (config C3 of BASELINE.json: 256x256,
-batch 16 per GPU, 1..30 objects per image, default widths ngf=ndf=64, --no_vgg_loss --use_img_disc 1).
+batch 16 per GPU, 1..30 objects per image, default widths ngf=ndf=64, the reference's default
+discriminator set = image + object-crop discriminators, --no_vgg_loss because the pretrained VGG19 is
+not available offline).
 For N > 1 the driver launches this file under torch.distributed.run: one rank per GPU, RCCL
 gradient all-reduce + SyncBN statistics, per-GPU batch fixed (weak scaling).  Rank 0 prints ONE
 JSON line.  Inputs are resident in HBM before the timed region.
@@ -34,6 +36,8 @@ def parse():
     p.add_argument("--config", default="C3", help="BASELINE config whose graph statistics to draw (C2..C5)")
     p.add_argument("--ngf", type=int, default=64)
     p.add_argument("--ndf", type=int, default=64)
+    p.add_argument("--use_img_disc", type=int, default=0,
+                   help="0 = the reference's default COCO/VG recipe (image + object discriminators); 1 = image only")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_image_size", type=int, default=None)
     p.add_argument("--no_prof", action="store_true", help="skip the per-kernel HIP-event timing")
@@ -91,7 +95,7 @@ def main():
     cfg = base["cfg"]
     H = args.image_size
     opt_argv = ["--image_size", "%d,%d" % (H, H), "--ngf", str(args.ngf), "--ndf", str(args.ndf), "--no_vgg_loss",
-                "--use_img_disc", "1"]
+                "--use_img_disc", str(args.use_img_disc)]
     opt = T.make_opt(vocab, opt_argv + ["--batch_size", str(args.batch * world), "--gpu_ids",
                                         ",".join(str(i) for i in range(world))])
     torch.manual_seed(0)
@@ -137,9 +141,10 @@ def main():
         "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config %s: COCO-shaped AttSPADE %dx%d, batch %d/GPU, %d-%d objects/img, "
-                               "ngf=%d ndf=%d, --no_vgg_loss --use_img_disc 1; Sg2Layout GCN + SPADE G + 2-scale "
-                               "PatchGAN D, fwd+bwd+Adam" % (args.config, H, H, args.batch, cfg.min_objects,
-                                                               cfg.max_objects, args.ngf, args.ndf),
+                               "ngf=%d ndf=%d, --no_vgg_loss --use_img_disc %d; Sg2Layout GCN + SPADE G + 2-scale "
+                               "PatchGAN D%s, fwd+bwd+Adam" % (args.config, H, H, args.batch, cfg.min_objects,
+                                                                 cfg.max_objects, args.ngf, args.ndf, args.use_img_disc,
+                                                                 "" if args.use_img_disc else " + object-crop D"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         "losses_finite": loss_ok,
     }

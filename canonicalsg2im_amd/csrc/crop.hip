@@ -1,0 +1,132 @@
+// Differentiable bilinear object crops for the object discriminator
+// (reference: sg2im/bilinear.py:44-94 — crop_bbox_batch_cudnn + crop_bbox).
+//
+// The reference expands the image once per object ((sum O, C, H, W) tensor) and calls
+// F.grid_sample; here each output pixel of each crop gathers its 4 source pixels directly from the
+// object's own image (NHWC), so the traffic is the crops themselves.  Backward scatters with float
+// atomics (crops of different objects overlap in the image): ~3 M atomics per step, far below the
+// chip's atomic rate; the summation order, hence the last bits of d(image), can vary run to run.
+#include "csg_common.h"
+
+using namespace csg;
+
+// torch.linspace(0,1,n)[i] and torch.linspace(1,0,n)[i] as ATen evaluates them
+__device__ __forceinline__ float lin_up(int i, int n) {
+  if (n <= 1) return 0.f;
+  float step = 1.0f / (float)(n - 1);
+  return (i < n / 2) ? (float)i * step : 1.0f - (float)(n - 1 - i) * step;
+}
+__device__ __forceinline__ float lin_down(int i, int n) {
+  if (n <= 1) return 1.f;
+  float step = -1.0f / (float)(n - 1);
+  return (i < n / 2) ? 1.0f + (float)i * step : 0.0f - (float)(n - 1 - i) * step;
+}
+
+struct CropTaps {
+  int ix0, iy0;
+  float w00, w01, w10, w11;  // [y][x]
+};
+
+// boxes are [x0,y0,w,h] in [0,1]; crop_bbox maps them to [-1,1] corners and interpolates the
+// sampling grid with tensor_linspace (start_w*start + end_w*end), then grid_sample(bilinear, zeros,
+// align_corners=False)
+__device__ __forceinline__ CropTaps crop_taps(const float* __restrict__ box, int x, int y, int WW, int HH, int W,
+                                              int H) {
+  const float bx0 = 2.0f * box[0] - 1.0f, by0 = 2.0f * box[1] - 1.0f;
+  const float bx1 = 2.0f * (box[0] + box[2]) - 1.0f, by1 = 2.0f * (box[1] + box[3]) - 1.0f;
+  const float gx = lin_down(x, WW) * bx0 + lin_up(x, WW) * bx1;
+  const float gy = lin_down(y, HH) * by0 + lin_up(y, HH) * by1;
+  const float fx = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+  const float fy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+  float x0f = fminf(fmaxf(floorf(fx), -2.0f), (float)W), y0f = fminf(fmaxf(floorf(fy), -2.0f), (float)H);
+  const float tx = fx - floorf(fx), ty = fy - floorf(fy);
+  CropTaps t;
+  t.ix0 = (int)x0f;
+  t.iy0 = (int)y0f;
+  const bool x0ok = t.ix0 >= 0 && t.ix0 < W, x1ok = t.ix0 + 1 >= 0 && t.ix0 + 1 < W;
+  const bool y0ok = t.iy0 >= 0 && t.iy0 < H, y1ok = t.iy0 + 1 >= 0 && t.iy0 + 1 < H;
+  t.w00 = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f;
+  t.w01 = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
+  t.w10 = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f;
+  t.w11 = (x1ok && y1ok) ? tx * ty : 0.f;
+  return t;
+}
+
+__global__ void k_crop_fwd(const float* __restrict__ img, int H, int W, int cs, int C, const float* __restrict__ boxes,
+                           const int64_t* __restrict__ img_idx, int64_t total, int HH, int WW, int out_cs,
+                           float* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(e % WW);
+    const int64_t t1 = e / WW;
+    const int y = (int)(t1 % HH);
+    const int64_t n = t1 / HH;
+    const CropTaps t = crop_taps(boxes + n * 4, x, y, WW, HH, W, H);
+    const float* base = img + (int64_t)img_idx[n] * H * W * cs;
+    float* o = out + e * out_cs;
+    for (int c = 0; c < out_cs; ++c) {
+      float v = 0.f;
+      if (c < C) {
+        if (t.w00 != 0.f) v += t.w00 * base[((int64_t)t.iy0 * W + t.ix0) * cs + c];
+        if (t.w01 != 0.f) v += t.w01 * base[((int64_t)t.iy0 * W + t.ix0 + 1) * cs + c];
+        if (t.w10 != 0.f) v += t.w10 * base[((int64_t)(t.iy0 + 1) * W + t.ix0) * cs + c];
+        if (t.w11 != 0.f) v += t.w11 * base[((int64_t)(t.iy0 + 1) * W + t.ix0 + 1) * cs + c];
+      }
+      o[c] = v;
+    }
+  }
+}
+
+__global__ void k_crop_bwd(const float* __restrict__ dout, int H, int W, int cs, int C, const float* __restrict__ boxes,
+                           const int64_t* __restrict__ img_idx, int64_t total, int HH, int WW, int out_cs,
+                           float* __restrict__ dimg) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(e % WW);
+    const int64_t t1 = e / WW;
+    const int y = (int)(t1 % HH);
+    const int64_t n = t1 / HH;
+    const CropTaps t = crop_taps(boxes + n * 4, x, y, WW, HH, W, H);
+    float* base = dimg + (int64_t)img_idx[n] * H * W * cs;
+    const float* g = dout + e * out_cs;
+    for (int c = 0; c < C; ++c) {
+      const float v = g[c];
+      if (t.w00 != 0.f) atomicAdd(&base[((int64_t)t.iy0 * W + t.ix0) * cs + c], t.w00 * v);
+      if (t.w01 != 0.f) atomicAdd(&base[((int64_t)t.iy0 * W + t.ix0 + 1) * cs + c], t.w01 * v);
+      if (t.w10 != 0.f) atomicAdd(&base[((int64_t)(t.iy0 + 1) * W + t.ix0) * cs + c], t.w10 * v);
+      if (t.w11 != 0.f) atomicAdd(&base[((int64_t)(t.iy0 + 1) * W + t.ix0 + 1) * cs + c], t.w11 * v);
+    }
+  }
+}
+
+extern "C" {
+
+int csg_crop_fwd(const float* img, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C, const float* boxes,
+                 const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, float* out, int64_t out_cs, void* stream) {
+  CSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && img_cs >= C && out_cs >= C && HH > 0 && WW > 0 && N >= 0,
+              CSG_E_BADSHAPE, "csg_crop_fwd: bad shape");
+  if (N == 0) return CSG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = N * HH * WW;
+  ProfScope p(K_CROP_FWD, (double)total * (C * 4 + out_cs) * 4, s);
+  int64_t g = cdiv(total, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_crop_fwd, dim3((unsigned)g), dim3(256), 0, s, img, (int)H, (int)W, (int)img_cs, (int)C, boxes,
+                     img_idx, total, (int)HH, (int)WW, (int)out_cs, out);
+  return check_launch("csg_crop_fwd");
+}
+
+int csg_crop_bwd(const float* dout, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C, const float* boxes,
+                 const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, int64_t out_cs, float* dimg, void* stream) {
+  CSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && img_cs >= C && out_cs >= C && HH > 0 && WW > 0 && N >= 0,
+              CSG_E_BADSHAPE, "csg_crop_bwd: bad shape");
+  if (N == 0) return CSG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = N * HH * WW;
+  ProfScope p(K_CROP_BWD, (double)total * (C * 4 + out_cs) * 4, s);
+  int64_t g = cdiv(total, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_crop_bwd, dim3((unsigned)g), dim3(256), 0, s, dout, (int)H, (int)W, (int)img_cs, (int)C, boxes,
+                     img_idx, total, (int)HH, (int)WW, (int)out_cs, dimg);
+  return check_launch("csg_crop_bwd");
+}
+
+}  // extern "C"

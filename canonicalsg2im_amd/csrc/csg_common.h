@@ -36,6 +36,8 @@ enum KernelId {
   K_UPSAMPLE_BWD,
   K_AVGPOOL_FWD,
   K_AVGPOOL_BWD,
+  K_CROP_FWD,
+  K_CROP_BWD,
   K_COUNT
 };
 

@@ -17,7 +17,8 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, check, lib, ptr, stre
 
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
-    "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "disc_input", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
+    "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "disc_input", "crop_objects", "ACT_NONE", "ACT_LEAKY",
+    "ACT_TANH",
 ]
 
 
@@ -168,7 +169,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, r
     Cout, Cin = weight.shape[0], weight.shape[1]
     pc, po = (-Cin) % 4, (-Cout) % 4
     if pc:
-        x = F.pad(x, (0, 0, 0, 0, 0, pc))
+        if x.shape[1] == Cin:                  # an already padded input (e.g. the 4-channel object crops) is used as is
+            x = F.pad(x, (0, 0, 0, 0, 0, pc))
         weight = F.pad(weight, (0, 0, 0, 0, 0, pc))
     if po:
         weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, po))
@@ -543,3 +545,41 @@ class _DiscInput(torch.autograd.Function):
 def disc_input(img, vecs, boxes, valid, H, masks=None):
     _check_boxes(boxes)
     return _DiscInput.apply(_f32(img), vecs, boxes, valid, masks, int(H))
+
+
+# ------------------------------------------------------------------------------------ object crops
+class _CropObjects(torch.autograd.Function):
+    """Bilinear crops of every real object's box from its own image (sg2im/bilinear.py:44-94).
+    Output (N, Cp, HH, HH) NHWC with Cp = channels padded to a multiple of 4 (extra channels 0)."""
+
+    @staticmethod
+    def forward(ctx, img, boxes, img_idx, HH):
+        img = nhwc(_f32(img))
+        B, C, H, W = img.shape
+        boxes = _f32(boxes).contiguous()
+        N = boxes.shape[0]
+        Cp = (C + 3) // 4 * 4
+        out = empty_nhwc(N, Cp, HH, HH, img.device)
+        check(lib.csg_crop_fwd(ptr(img), B, H, W, C, C, ptr(boxes), ptr(img_idx), N, HH, HH, ptr(out), Cp, stream()),
+              "crop_fwd")
+        ctx.save_for_backward(boxes, img_idx)
+        ctx.meta = (B, C, H, W, N, HH, Cp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        boxes, img_idx = ctx.saved_tensors
+        B, C, H, W, N, HH, Cp = ctx.meta
+        dimg = None
+        if ctx.needs_input_grad[0]:
+            dout = nhwc(dout)
+            dimg = empty_nhwc(B, C, H, W, dout.device, zero=True)
+            check(lib.csg_crop_bwd(ptr(dout), B, H, W, C, C, ptr(boxes), ptr(img_idx), N, HH, HH, Cp, ptr(dimg),
+                                   stream()), "crop_bwd")
+        return dimg, None, None, None
+
+
+def crop_objects(img, boxes, img_idx, HH):
+    """img (B,C,H,W); boxes (N,4) xywh of the real objects in (image, object) order; img_idx (N,) int64."""
+    _check_boxes(boxes)
+    return _CropObjects.apply(img, boxes, img_idx.contiguous(), int(HH))

@@ -82,6 +82,53 @@ class Interpolate(nn.Module):
                                          align_corners=self.align_corners)
 
 
+class BatchNormAct(nn.BatchNorm2d):
+    """nn.BatchNorm2d (affine, running stats) whose forward is the fused HIP statistics + apply pass;
+    a following LeakyReLU can be folded in with `fused_slope`.  The per-channel affine is fed to the
+    kernel as a broadcast gamma||beta map (these layers only see the small object crops)."""
+
+    def __init__(self, num_features, fused_slope=1.0):
+        super().__init__(num_features)
+        self.fused_slope = fused_slope
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("canonicalsg2im_amd ops need HIP (cuda) tensors; there is no CPU path")
+        if self.training and self.track_running_stats:
+            self.num_batches_tracked.add_(1)
+        B, C, H, W = x.shape
+        gb = torch.cat([self.weight - 1.0, self.bias]).view(1, 2 * C, 1, 1).expand(B, 2 * C, H, W)
+        return ops.norm_act(x, gb, self.running_mean, self.running_var, instance=False, training=self.training,
+                            slope=self.fused_slope, eps=self.eps, momentum=self.momentum, sync=False)
+
+
+def build_hot_cnn(arch, normalization='batch', activation='leakyrelu-0.2', padding='valid'):
+    """build_cnn for the object discriminator (arch 'C4-64-2,C4-128-2,C4-256-2'): same nn.Sequential
+    indices and state_dict keys as the reference builder, executed on the HIP kernels — Conv2d on the
+    implicit GEMM, BatchNorm + LeakyReLU fused in one pass."""
+    if isinstance(arch, str):
+        arch = arch.split(',')
+    if normalization != 'batch' or not activation.lower().startswith('leakyrelu'):
+        raise NotImplementedError("object discriminator: only d_normalization=batch, d_activation=leakyrelu-* "
+                                  "(the trainer defaults) are on the hot path")
+    slope = float(activation.split('-')[1]) if '-' in activation else 0.01
+    cur, first, layers = 3, True, []
+    for s in arch:
+        if s[0] != 'C':
+            raise NotImplementedError('build_hot_cnn: layer "%s" is not on the hot path' % s)
+        if not first:
+            layers.append(BatchNormAct(cur, fused_slope=slope))
+            layers.append(_FusedActivation())
+        first = False
+        vals = [int(v) for v in s[1:].split('-')]
+        K, nxt = vals[0], vals[1]
+        stride = vals[2] if len(vals) == 3 else 1
+        pad = (K - 1) // 2 if padding == 'same' else 0
+        layers.append(Conv2d(cur, nxt, kernel_size=K, padding=pad, stride=stride))
+        cur = nxt
+    return nn.Sequential(*layers), cur
+
+
 def build_cnn(arch, normalization='batch', activation='relu', padding='same', pooling='max', init='default'):
     """Arch-string CNN ('C4-64-2,C4-128-2,...', reference sg2im/layers.py:28-112).  On the hot path it
     only creates the never-executed `image_encoder` parameters of G and D (generator.py:50-62), so

@@ -3,7 +3,8 @@ state_dict prefixes (`sg_to_layout.module.*`, `layout_to_image_model.module.*`).
 import torch
 import torch.nn as nn
 
-from ..spade.models.networks import MultiscaleDiscriminator, SPADEGenerator
+from ..spade.models.networks import (AcCropDiscriminator, MultiscaleDiscriminator, MultiscaleMaskDiscriminator2,
+                                     SPADEGenerator)
 from ..spade.models.networks.sync_batchnorm import DataParallelWithCallback
 from .model import Sg2LayoutModel
 
@@ -37,12 +38,22 @@ class MetaDiscriminatorModel(nn.Module):
         self.img_discriminator = MultiscaleDiscriminator(opt)
         self.img_discriminator.train()
         if not opt.use_img_disc:
-            raise NotImplementedError("object/mask discriminators are next-row components (SURVEY.md §8f); "
-                                      "use --use_img_disc 1")
+            self.obj_discriminator = AcCropDiscriminator(vocab=opt.vocab, arch=opt.d_obj_arch,
+                                                         normalization=opt.d_normalization,
+                                                         activation=opt.d_activation, padding=opt.d_padding,
+                                                         object_size=opt.crop_size)
+            self.obj_discriminator.train()
+            self.mask_discriminator = MultiscaleMaskDiscriminator2(opt)
+            self.mask_discriminator.train()
 
     def build_optimizers(self, opt):
-        """Adam(betas=(beta1, 0.999)) per discriminator (reference meta_models.py:67-69); called after
-        the module sits on its device."""
+        """Adam(betas=(beta1, 0.999)) per discriminator (reference meta_models.py:67-69,79-81,88-90);
+        called after the module sits on its device."""
         self.optimizer_d_img = torch.optim.Adam(list(self.img_discriminator.parameters()),
                                                 lr=opt.img_learning_rate, betas=(opt.beta1, 0.999))
+        if not opt.use_img_disc:
+            self.optimizer_d_obj = torch.optim.Adam(list(self.obj_discriminator.parameters()),
+                                                    lr=opt.learning_rate, betas=(opt.beta1, 0.999))
+            self.optimizer_d_mask = torch.optim.Adam(list(self.mask_discriminator.parameters()),
+                                                     lr=opt.mask_learning_rate, betas=(opt.beta1, 0.999))
         return self

@@ -64,8 +64,13 @@ class Pix2PixModel(torch.nn.Module):
                 G['GAN_Feat'] = feat.squeeze(0)
             if not self.opt.no_vgg_loss:
                 G['VGG'] = self.criterionVGG(imgs_pred, imgs) * self.opt.lambda_vgg
-            if not self.opt.use_img_disc:
-                raise NotImplementedError("object discriminator losses: next-row component; use --use_img_disc 1")
+            if not self.opt.use_img_disc:                      # object discriminator (:115-121)
+                scores_fake, ac_loss, _ = self.netD_obj(imgs_pred, objs, boxes)
+                G['GAN_Obj'] = self.criterionGAN(scores_fake, True, for_discriminator=False).squeeze(0) \
+                    * self.opt.discriminator_obj_loss_weight
+                G['GAN_Ac'] = ac_loss * self.opt.ac_loss_weight
+                if getattr(self, 'netD_mask', None) is not None and self.opt.mask_size > 0 and masks_pred is not None:
+                    raise NotImplementedError("mask discriminator losses (--mask_size > 0) are outside the hot path")
         scalars = [k for k in G if k != "bbox_pred_all"]
         G['total_loss'] = torch.stack([G[k] for k in scalars], dim=0).sum()
         return G
@@ -81,7 +86,19 @@ class Pix2PixModel(torch.nn.Module):
         D["D_img_real"] = self.criterionGAN(gt_real, True, for_discriminator=True)
         D["total_img_loss"] = torch.stack(list(D.values()), dim=0).sum()
         if not self.opt.use_img_disc:
-            raise NotImplementedError("object discriminator losses: next-row component; use --use_img_disc 1")
+            # "wrong layout" pass: `fool` is ignored by the discriminator, the value is logged but never
+            # back-propagated; it still advances the spectral-norm state, so it is replayed (:168-172)
+            with torch.no_grad():
+                pred_wrong = self.netD_img(imgs, objs, boxes, layout_masks=masks, gt_train=True, fool=True)
+                D["D_img_wrong"] = self.criterionGAN(pred_wrong, False, for_discriminator=True) * (1 / 2) * (.5)
+            scores_real, ac_loss_real, self.d_real_crops = self.netD_obj(imgs, objs, boxes)       # :178-185
+            scores_fake, ac_loss_fake, self.d_fake_crops = self.netD_obj(imgs_pred, objs, boxes)
+            D["D_obj"] = self.gan_d_loss(scores_real, scores_fake) * 0.5
+            D["D_ac_real"] = ac_loss_real
+            D["D_ac_fake"] = ac_loss_fake
+            D["total_obj_loss"] = torch.stack([D["D_obj"], D["D_ac_real"], D["D_ac_fake"]], dim=0).sum()
+            if self.opt.mask_size > 0 and model_out[2] is not None:
+                raise NotImplementedError("mask discriminator losses (--mask_size > 0) are outside the hot path")
         return D
 
     def forward(self, batch, model_out, mode):

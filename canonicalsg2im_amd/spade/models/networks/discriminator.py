@@ -2,10 +2,11 @@
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .... import ops
 from ....sg2im.attribute_embed import AttributeEmbeddings
-from ....sg2im.layers import Conv2d, _FusedActivation, build_mlp
+from ....sg2im.layers import Conv2d, GlobalAvgPool, Linear, _FusedActivation, build_hot_cnn, build_mlp
 from ....sg2im.utils import real_object_mask
 from .base_network import BaseNetwork
 from .generator import AppearanceEncoder
@@ -94,18 +95,83 @@ class MultiscaleDiscriminator(BaseNetwork):
         return result
 
 
+class AcDiscriminator(nn.Module):
+    """Auxiliary-classifier object discriminator (reference discriminator.py:209-237): crops ->
+    CNN -> global average pool -> Linear(1024) -> {real/fake score, object class logits}."""
+
+    def __init__(self, vocab, arch, normalization='none', activation='relu', padding='same', pooling='avg'):
+        super().__init__()
+        self.vocab = vocab
+        cnn, D = build_hot_cnn(arch, normalization=normalization, activation=activation, padding=padding)
+        self.cnn = nn.Sequential(cnn, GlobalAvgPool(), Linear(D, 1024))
+        num_objects = max(vocab['object_name_to_idx'].values()) + 1
+        self.real_classifier = Linear(1024, 1)
+        self.obj_classifier = Linear(1024, num_objects)
+
+    def forward(self, x, y):
+        if x.dim() == 3:
+            x = x[:, None]
+        feats = self.cnn[0](x)
+        vecs = self.cnn[2](self.cnn[1](feats))
+        real_scores = self.real_classifier(vecs)
+        obj_scores = self.obj_classifier(vecs)
+        ac_loss = F.cross_entropy(obj_scores, y)          # (N, classes) logits: a tiny tensor op
+        return real_scores, ac_loss
+
+
 class AcCropDiscriminator(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """reference discriminator.py:240-261: bilinear crops of every real object, then AcDiscriminator."""
+
+    def __init__(self, vocab, arch, normalization='none', activation='relu', object_size=64, padding='same',
+                 pooling='avg'):
         super().__init__()
-        raise NotImplementedError("the object-crop discriminator is the next-row component (SURVEY.md §8f rank 1); "
-                                  "train with --use_img_disc 1")
+        self.vocab = vocab
+        self.discriminator = AcDiscriminator(vocab, arch, normalization, activation, padding, pooling)
+        self.object_size = object_size
+
+    def forward(self, imgs, objs, boxes):
+        valid = real_object_mask(objs, self.vocab)
+        nz = valid.nonzero()                                # (N,2) [image, object], image-major like the reference
+        img_idx = nz[:, 0].contiguous()
+        flat_boxes = boxes[nz[:, 0], nz[:, 1]]
+        labels = objs[nz[:, 0], nz[:, 1], 0]
+        crops = ops.crop_objects(imgs, flat_boxes, img_idx, self.object_size)
+        real_scores, ac_loss = self.discriminator(crops, labels)
+        return real_scores, ac_loss, crops[:, :imgs.size(1)]
 
 
-class AcDiscriminator(AcCropDiscriminator):
-    pass
+class NLayerMaskDiscriminator2(NLayerDiscriminator):
+    def compute_D_input_nc(self):
+        return max(self.opt.vocab['object_name_to_idx'].values()) + 2
 
 
-class MultiscaleMaskDiscriminator2(nn.Module):
-    def __init__(self, *args, **kwargs):
+class MultiscaleMaskDiscriminator2(BaseNetwork):
+    """Mask discriminator (reference discriminator.py:264-308): one-hot(object) x mask -> PatchGAN.
+    Only exercised with --mask_size > 0; always constructed when use_img_disc=0 (meta_models.py:83-90)."""
+
+    def __init__(self, opt):
         super().__init__()
-        raise NotImplementedError("the mask discriminator needs --mask_size > 0 (SURVEY.md §8f rank 4)")
+        self.opt = opt
+        for i in range(opt.num_D):
+            self.add_module('discriminator_%d' % i, NLayerMaskDiscriminator2(opt))
+
+    def downsample(self, input):
+        return ops.avgpool3s2(input) if input.size(1) % 4 == 0 else \
+            F.avg_pool2d(input, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def forward(self, objs, layout_masks, gt_train=True):
+        valid = real_object_mask(objs, self.opt.vocab).bool()
+        nz = valid.nonzero()
+        labels = objs[nz[:, 0], nz[:, 1], 0]
+        masks = layout_masks[nz[:, 0], nz[:, 1]].float()
+        M = masks.size(-1)
+        ncls = max(self.opt.vocab['object_name_to_idx'].values()) + 1
+        one_hot = F.one_hot(labels, ncls).to(masks.dtype).view(-1, ncls, 1, 1).expand(-1, -1, M, M)
+        x = torch.cat([one_hot, masks.unsqueeze(1)], dim=1)
+        result = []
+        for name, D in self.named_children():
+            if name.startswith('discriminator'):
+                out = D(x)
+                result.append(out if not self.opt.no_ganFeat_loss else [out])
+                x = self.downsample(x)
+        return result

@@ -36,9 +36,14 @@ class Trainer:
         self.g_buckets = csg_dist.GradBuckets(base + [p for n, p in named if n in trans])
         self.d_params = list(self.discriminator.img_discriminator.parameters())
         self.d_buckets = csg_dist.GradBuckets(self.d_params)
+        self.dobj_params, self.dobj_buckets = [], None
+        if not opt.use_img_disc:
+            csg_dist.broadcast_module(self.discriminator.obj_discriminator)
+            self.dobj_params = list(self.discriminator.obj_discriminator.parameters())
+            self.dobj_buckets = csg_dist.GradBuckets(self.dobj_params)
 
     def _d_requires_grad(self, flag):
-        for p in self.d_params:
+        for p in self.d_params + self.dobj_params:
             p.requires_grad_(flag)
 
     def step(self, batch):
@@ -66,6 +71,11 @@ class Trainer:
             D["total_img_loss"].backward()
             self.d_buckets.all_reduce_mean()
             self.discriminator.optimizer_d_img.step()
+            if not opt.use_img_disc:                                    # train.py:478-480
+                self.discriminator.optimizer_d_obj.zero_grad(set_to_none=True)
+                D["total_obj_loss"].backward()
+                self.dobj_buckets.all_reduce_mean()
+                self.discriminator.optimizer_d_obj.step()
         return G, D
 
 
@@ -78,6 +88,10 @@ def split_state(trainer):
         if hasattr(trainer.model, "layout_to_image_model") else {}
     d = dict(trainer.discriminator.img_discriminator.state_dict())
     return sg, g, d
+
+
+def obj_disc_state(trainer):
+    return dict(trainer.discriminator.obj_discriminator.state_dict())
 
 
 def oracle_state_from(trainer, oracle_mod):
@@ -101,4 +115,5 @@ def oracle_state_from(trainer, oracle_mod):
             if k.endswith("predicates_transitive_weights"):
                 sg[k] = sg["trans_candidates_weights"]
     unused = ("repr_net", "image_encoder")
-    return oracle_mod.TrainState(trainer.opt, sg, leafs(g, unused), leafs(d, unused))
+    dobj = leafs(obj_disc_state(trainer)) if not trainer.opt.use_img_disc else None
+    return oracle_mod.TrainState(trainer.opt, sg, leafs(g, unused), leafs(d, unused), dobj)

@@ -182,6 +182,16 @@ int csg_upsample2x_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t
 int csg_avgpool3s2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
 int csg_avgpool3s2_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream);
 
+/* ---- object crops for the object discriminator (sg2im/bilinear.py:44-94) ---------------------------
+ * out[n, y, x, c] = bilinear sample (grid_sample, align_corners=False, zeros padding) of image
+ * img_idx[n] over box n ([x0,y0,w,h] in [0,1]); img is NHWC with img_cs floats per pixel, C used;
+ * out is (N,HH,WW,out_cs) with channels >= C written as 0.  Backward adds into dimg (zeroed by the
+ * caller) with float atomics. */
+int csg_crop_fwd(const float* img, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C, const float* boxes,
+                 const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, float* out, int64_t out_cs, void* stream);
+int csg_crop_bwd(const float* dout, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C, const float* boxes,
+                 const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, int64_t out_cs, float* dimg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ __all__ = [
     "spectral_weight", "batch_norm_train", "syncbn_multi_replica", "spade", "spade_resblock",
     "generator_forward", "instance_norm", "nlayer_discriminator", "multiscale_discriminator",
     "hinge_loss", "gan_loss_multiscale", "generator_losses", "discriminator_losses", "TrainState",
-    "train_step", "make_adam_groups",
+    "train_step", "make_adam_groups", "crop_objects", "ac_crop_discriminator", "bce_loss",
 ]
 
 ORIGINAL_EDGE, TRANSITIVE_EDGE = 0, 1          # sg2im/data/base_dataset.py:7-8
@@ -316,6 +316,64 @@ def multiscale_discriminator(state, vocab, image_size, img, objs, layout_boxes, 
     return result
 
 
+# --------------------------------------------------------------------------- object discriminator
+def crop_objects(imgs, objs, boxes, vocab, HH):
+    """`crop_bbox_batch_cudnn` + `crop_bbox` (sg2im/bilinear.py:44-94): for every real object, in
+    (image, object) order, a bilinear HHxHH crop of its box from its own image; also returns the
+    object labels (discriminator.py:253-260)."""
+    crops, labels = [], []
+    for b in range(imgs.shape[0]):
+        m = remove_dummy_objects(objs[b], vocab)
+        bx = boxes[b][m]
+        n = bx.shape[0]
+        if n == 0:
+            continue
+        pts = torch.stack([bx[:, 0], bx[:, 1], bx[:, 0] + bx[:, 2], bx[:, 1] + bx[:, 3]], dim=1)   # metrics.py:4-8
+        pts = 2 * pts - 1                                                                           # bilinear.py:86
+        up = torch.linspace(0, 1, steps=HH).view(1, HH)
+        down = torch.linspace(1, 0, steps=HH).view(1, HH)
+        X = down * pts[:, 0:1] + up * pts[:, 2:3]                                                   # tensor_linspace
+        Y = down * pts[:, 1:2] + up * pts[:, 3:4]
+        grid = torch.stack([X.view(n, 1, HH).expand(n, HH, HH), Y.view(n, HH, 1).expand(n, HH, HH)], dim=3)
+        feats = imgs[b:b + 1].expand(n, -1, -1, -1)
+        crops.append(F.grid_sample(feats, grid, mode="bilinear", padding_mode="zeros", align_corners=False))
+        labels.append(objs[b][m][:, 0])
+    return torch.cat(crops, dim=0), torch.cat(labels, dim=0)
+
+
+def _batch_norm_affine(state, prefix, x, training):
+    """nn.BatchNorm2d (affine, running stats, num_batches_tracked) as build_cnn creates it
+    (sg2im/layers.py:132-136)."""
+    if training:
+        state[prefix + "num_batches_tracked"].add_(1)
+    return F.batch_norm(x, state[prefix + "running_mean"], state[prefix + "running_var"], state[prefix + "weight"],
+                        state[prefix + "bias"], training, 0.1, 1e-5)
+
+
+def ac_crop_discriminator(state, vocab, imgs, objs, boxes, crop_size, training=True, prefix=""):
+    """`AcCropDiscriminator.forward` -> `AcDiscriminator.forward` (discriminator.py:209-261) with the
+    trainer's defaults: arch C4-64-2,C4-128-2,C4-256-2, batch norm, leakyrelu-0.2, 'valid' padding."""
+    crops, labels = crop_objects(imgs, objs, boxes, vocab, crop_size)
+    p = prefix + "discriminator.cnn.0."
+    h = F.conv2d(crops, state[p + "0.weight"], state[p + "0.bias"], stride=2)
+    h = F.leaky_relu(_batch_norm_affine(state, p + "1.", h, training), 0.2)
+    h = F.conv2d(h, state[p + "3.weight"], state[p + "3.bias"], stride=2)
+    h = F.leaky_relu(_batch_norm_affine(state, p + "4.", h, training), 0.2)
+    h = F.conv2d(h, state[p + "6.weight"], state[p + "6.bias"], stride=2)
+    v = h.reshape(h.shape[0], h.shape[1], -1).mean(dim=2)                                           # GlobalAvgPool
+    v = F.linear(v, state[prefix + "discriminator.cnn.2.weight"], state[prefix + "discriminator.cnn.2.bias"])
+    real = F.linear(v, state[prefix + "discriminator.real_classifier.weight"],
+                    state[prefix + "discriminator.real_classifier.bias"])
+    cls = F.linear(v, state[prefix + "discriminator.obj_classifier.weight"],
+                   state[prefix + "discriminator.obj_classifier.bias"])
+    return real, F.cross_entropy(cls, labels), crops
+
+
+def bce_loss(x, target):
+    """sg2im/losses.py:23-41."""
+    return (x.clamp(min=0) - x * target + (1 + (-x.abs()).exp()).log()).mean()
+
+
 # --------------------------------------------------------------------------- losses
 def hinge_loss(x, target_is_real, for_discriminator):
     """`GANLoss.loss`, hinge branch (spade/models/networks/loss.py:65-76)."""
@@ -332,9 +390,9 @@ def gan_loss_multiscale(preds, target_is_real, for_discriminator):
     return sum(hinge_loss(p[-1], target_is_real, for_discriminator) for p in preds) / len(preds)
 
 
-def generator_losses(opt, d_state, batch, model_out, training=True):
-    """`Pix2PixModel.compute_generator_loss` (sg2im/pix2pix_model.py:65-143) with
-    --no_vgg_loss --use_img_disc 1, mask_size 0."""
+def generator_losses(opt, d_state, batch, model_out, training=True, dobj_state=None):
+    """`Pix2PixModel.compute_generator_loss` (sg2im/pix2pix_model.py:65-143) with --no_vgg_loss and
+    mask_size 0; the object-discriminator terms (:115-121) when use_img_disc == 0."""
     imgs, objs, boxes = batch[0], batch[1], batch[2]
     imgs_pred, boxes_pred, _ = model_out
     H = opt.image_size[0]
@@ -358,12 +416,17 @@ def generator_losses(opt, d_state, batch, model_out, training=True):
                 for j in range(len(fake[i]) - 1):
                     feat = feat + F.l1_loss(fake[i][j], real[i][j].detach()) * opt.lambda_feat / len(fake)
             G["GAN_Feat"] = feat
+        if not opt.use_img_disc:                                                              # :115-121
+            scores_fake, ac_loss, _ = ac_crop_discriminator(dobj_state, opt.vocab, imgs_pred, objs, boxes,
+                                                            opt.crop_size, training)
+            G["GAN_Obj"] = hinge_loss(scores_fake, True, False) * opt.discriminator_obj_loss_weight
+            G["GAN_Ac"] = ac_loss * opt.ac_loss_weight
     G["total_loss"] = torch.stack([v for k, v in G.items() if k != "bbox_pred_all"]).sum()    # :141-142
     return G
 
 
-def discriminator_losses(opt, d_state, batch, model_out, training=True):
-    """`Pix2PixModel.compute_discriminator_loss` (pix2pix_model.py:145-202), use_img_disc 1."""
+def discriminator_losses(opt, d_state, batch, model_out, training=True, dobj_state=None):
+    """`Pix2PixModel.compute_discriminator_loss` (pix2pix_model.py:145-202)."""
     imgs, objs, boxes = batch[0], batch[1], batch[2]
     imgs_pred = model_out[0].detach()
     H = opt.image_size[0]
@@ -372,6 +435,17 @@ def discriminator_losses(opt, d_state, batch, model_out, training=True):
     D = {"D_img_fake": gan_loss_multiscale(fake, False, True),
          "D_img_real": gan_loss_multiscale(real, True, True)}
     D["total_img_loss"] = D["D_img_fake"] + D["D_img_real"]                                    # :166
+    if not opt.use_img_disc:
+        with torch.no_grad():                                                                  # :168-172: logged only
+            wrong = multiscale_discriminator(d_state, opt.vocab, H, imgs, objs, boxes, training)
+            D["D_img_wrong"] = gan_loss_multiscale(wrong, False, True) * (1 / 2) * (.5)
+        s_real, ac_real, _ = ac_crop_discriminator(dobj_state, opt.vocab, imgs, objs, boxes, opt.crop_size, training)
+        s_fake, ac_fake, _ = ac_crop_discriminator(dobj_state, opt.vocab, imgs_pred, objs, boxes, opt.crop_size,
+                                                   training)
+        r, f = s_real.reshape(-1), s_fake.reshape(-1)                                          # losses.py:70-87
+        D["D_obj"] = (bce_loss(r, torch.ones_like(r)) + bce_loss(f, torch.zeros_like(f))) * 0.5
+        D["D_ac_real"], D["D_ac_fake"] = ac_real, ac_fake
+        D["total_obj_loss"] = D["D_obj"] + D["D_ac_real"] + D["D_ac_fake"]                     # :185
     return D
 
 
@@ -395,8 +469,11 @@ def make_adam_groups(sg_state, g_state, lr):
 class TrainState:
     """Leaf tensors + optimizers of one replica (what `scripts.train.main` builds at :312-329)."""
 
-    def __init__(self, opt, sg_state, g_state, d_state):
-        self.opt, self.sg, self.g, self.d = opt, sg_state, g_state, d_state
+    def __init__(self, opt, sg_state, g_state, d_state, dobj_state=None):
+        self.opt, self.sg, self.g, self.d, self.dobj = opt, sg_state, g_state, d_state, dobj_state
+        if dobj_state is not None:
+            po = [v for v in dobj_state.values() if torch.is_tensor(v) and v.requires_grad]
+            self.optimizer_d_obj = torch.optim.Adam(po, lr=opt.learning_rate, betas=(opt.beta1, 0.999))  # :79-81
         self.optimizer = torch.optim.Adam(make_adam_groups(sg_state, g_state, opt.learning_rate))
         d_params = [v for v in d_state.values() if torch.is_tensor(v) and v.requires_grad]
         self.optimizer_d_img = torch.optim.Adam(d_params, lr=opt.img_learning_rate,
@@ -413,15 +490,19 @@ def train_step(ts, batch):
     imgs_pred = generator_forward(ts.g, opt.vocab, H, objs, boxes, True,
                                   num_upsampling_layers=opt.num_upsampling_layers)            # :47-49 (GT boxes)
     model_out = (imgs_pred, boxes_pred, None)
-    G = generator_losses(opt, ts.d, batch, model_out)                                         # train.py:361
+    G = generator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj)                     # train.py:361
     ts.optimizer.zero_grad()
-    for v in ts.d.values():
+    for v in list(ts.d.values()) + list((ts.dobj or {}).values()):
         if torch.is_tensor(v) and v.grad is not None:
             v.grad = None
     G["total_loss"].backward()                                                                # :366-368
     ts.optimizer.step()
-    D = discriminator_losses(opt, ts.d, batch, model_out)                                     # :390
+    D = discriminator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj)                 # :390
     ts.optimizer_d_img.zero_grad()                                                            # :470-472
     D["total_img_loss"].backward()
     ts.optimizer_d_img.step()
+    if not opt.use_img_disc:                                                                  # :478-480
+        ts.optimizer_d_obj.zero_grad()
+        D["total_obj_loss"].backward()
+        ts.optimizer_d_obj.step()
     return G, D, imgs_pred.detach()

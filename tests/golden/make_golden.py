@@ -63,7 +63,7 @@ from sg2im.layout import boxes_to_layout, masks_to_layout  # noqa: E402
 from sg2im.model import Sg2LayoutModel  # noqa: E402
 from sg2im.pix2pix_model import Pix2PixModel  # noqa: E402
 from spade.models.networks.architecture import SPADEResnetBlock  # noqa: E402
-from spade.models.networks.discriminator import MultiscaleDiscriminator  # noqa: E402
+from spade.models.networks.discriminator import AcCropDiscriminator, MultiscaleDiscriminator  # noqa: E402
 from spade.models.networks.generator import SPADEGenerator  # noqa: E402
 from spade.models.networks.normalization import SPADE  # noqa: E402
 from spade.models.networks.sync_batchnorm import SynchronizedBatchNorm2d  # noqa: E402
@@ -245,9 +245,86 @@ def fx_syncbn():
 
 
 class _Holder(torch.nn.Module):
-    def __init__(self, d):
+    def __init__(self, d, dobj=None):
         super().__init__()
         self.img_discriminator = d
+        if dobj is not None:
+            self.obj_discriminator = dobj
+            self.mask_discriminator = None
+
+
+def fx_crops():
+    from sg2im.bilinear import crop_bbox_batch
+    torch.manual_seed(8)
+    vocab = make_vocab("tiny")
+    batch = make_batch(vocab, BatchConfig(3, 32, 1, 4, "random"), seed=4)
+    imgs, objs, boxes = batch[0].clone().requires_grad_(True), batch[1], batch[2].clone()
+    boxes[0, 0] = torch.tensor([0.7, 0.6, 0.5, 0.6])           # runs off the image: zero padding
+    crops = crop_bbox_batch(imgs, objs, boxes, 16, vocab=vocab)
+    w = torch.randn_like(crops)
+    (gi,) = torch.autograd.grad((crops * w).sum(), [imgs])
+    save("crops", {"ref": "sg2im/bilinear.py:12-94", "vocab": "tiny", "size": 16}, imgs=npy(imgs), objs=npy(objs),
+         boxes=npy(boxes), crops=npy(crops), w=npy(w), gimgs=npy(gi))
+
+
+def fx_step_objdisc():
+    """The DEFAULT trainer configuration (use_img_disc=0): image + object discriminators, both D steps."""
+    torch.manual_seed(17)
+    vocab = make_vocab("tiny")
+    argv = ["--image_size", "64,64", "--embedding_dim", "8", "--gconv_dim", "16", "--gconv_hidden_dim", "24",
+            "--gconv_num_layers", "2", "--ngf", "4", "--ndf", "4", "--no_vgg_loss", "--batch_size", "2",
+            "--crop_size", "32", "--d_obj_arch", "C4-8-2,C4-16-2,C4-32-2"]
+    opt = ref_opt(vocab, argv)
+    assert not opt.use_img_disc
+    sg, G, D = Sg2LayoutModel(opt), SPADEGenerator(opt), MultiscaleDiscriminator(opt)
+    Dobj = AcCropDiscriminator(vocab=vocab, arch=opt.d_obj_arch, normalization=opt.d_normalization,
+                               activation=opt.d_activation, padding=opt.d_padding, object_size=opt.crop_size)
+    unused = ("repr_net", "image_encoder")
+    sg.load_state_dict(deterministic_state(sg.state_dict(), seed=21))
+    G.load_state_dict(deterministic_state(G.state_dict(), seed=22))
+    D.load_state_dict(deterministic_state(D.state_dict(), seed=23))
+    Dobj.load_state_dict(deterministic_state(Dobj.state_dict(), seed=24))
+    batch = make_batch(vocab, BatchConfig(2, 64, 2, 5, "packed"), seed=19)
+    imgs, objs, boxes, triplets, _, tt = batch[:6]
+    arrays = {"imgs": npy(imgs), "objs": npy(objs), "boxes": npy(boxes), "triplets": npy(triplets), "tt": npy(tt)}
+    gans = Pix2PixModel(opt, discriminator=_Holder(D, Dobj))
+    for m in (sg, G, D, Dobj):
+        m.train()
+    trans = [p for n, p in sg.named_parameters() if n == "trans_candidates_weights"]
+    base = [p for n, p in sg.named_parameters() if n not in ("trans_candidates_weights", "converse_candidates_weights")]
+    base += list(G.parameters())
+    optimizer = torch.optim.Adam([{"params": base, "lr": opt.learning_rate}, {"params": trans, "lr": 1e-2}])
+    opt_d = torch.optim.Adam(list(D.parameters()), lr=opt.img_learning_rate, betas=(opt.beta1, 0.999))
+    opt_o = torch.optim.Adam(list(Dobj.parameters()), lr=opt.learning_rate, betas=(opt.beta1, 0.999))
+    _, boxes_pred, _ = sg(objs, triplets, tt, boxes)
+    imgs_pred = G(objs, boxes, None, test_mode=False)
+    model_out = (imgs_pred, boxes_pred, None)
+    G_losses = gans(batch, model_out, mode="compute_generator_loss")
+    for k, v in G_losses.items():
+        arrays["G:" + k] = npy(v)
+    optimizer.zero_grad()
+    {k: v.mean() for k, v in G_losses.items()}["total_loss"].backward()
+    for n, p in G.named_parameters():
+        if p.grad is not None and n.endswith(("conv_img.weight", "up_3.conv_0.weight_orig", "head_0.norm_0.mlp_gamma.weight")):
+            arrays["ggrad:" + n] = npy(p.grad)
+    optimizer.step()
+    D_losses = gans(batch, model_out, mode="compute_discriminator_loss")
+    for k, v in D_losses.items():
+        arrays["D:" + k] = npy(v)
+    Dm = {k: v.mean() for k, v in D_losses.items()}
+    opt_d.zero_grad(); Dm["total_img_loss"].backward(); opt_d.step()
+    opt_o.zero_grad(); Dm["total_obj_loss"].backward()
+    for n, p in Dobj.named_parameters():
+        arrays["ograd:" + n] = npy(p.grad)
+    opt_o.step()
+    arrays.update(sd_np(Dobj, "o_after:"))
+    for k, v in D.state_dict().items():
+        if "weight_u" in k:
+            arrays["d_after:" + k] = npy(v)              # 5 D_img calls advanced the power iteration 5x
+    save("train_step_objdisc", {"ref": "scripts/train.py:353-393,468-485", "argv": argv, "vocab": "tiny",
+                                "state": "deterministic_state seeds sg=21 g=22 d=23 dobj=24",
+                                "shapes": {"sg": shapes_of(sg), "g": shapes_of(G, unused), "d": shapes_of(D, unused),
+                                           "dobj": shapes_of(Dobj)}}, **arrays)
 
 
 def fx_model_and_step():
@@ -343,3 +420,5 @@ if __name__ == "__main__":
     fx_spade_block()
     fx_syncbn()
     fx_model_and_step()
+    fx_crops()
+    fx_step_objdisc()

@@ -383,6 +383,22 @@ def test_gather_concat_and_segment_avg_vs_golden(ops):
         assert_close(sd[k].grad, a["grad:" + k], RTOL, 1e-5, "d" + k)
 
 
+def test_object_crops_golden(ops):
+    """crop_bbox_batch of the reference (expand + grid_sample) vs the gather kernel, fwd + d(image)."""
+    from canonicalsg2im_amd.synth import make_vocab
+    meta, a = load_golden("crops")
+    vocab = make_vocab(meta["vocab"])
+    objs, boxes = a["objs"].cuda(), a["boxes"].cuda()
+    valid = ops.real_object_mask(objs, vocab["object_name_to_idx"]["__image__"])
+    nz = valid.nonzero()
+    imgs = dev(a["imgs"], True)
+    crops = ops.crop_objects(imgs, boxes[nz[:, 0], nz[:, 1]], nz[:, 0].contiguous(), meta["size"])
+    assert crops.shape[1] == 4 and float(crops.detach()[:, 3].abs().max()) == 0.0          # padded channel is zero
+    assert_close(crops[:, :3], a["crops"], RTOL, 2e-6, "crops")
+    (crops[:, :3] * a["w"].cuda()).sum().backward()
+    assert_close(imgs.grad, a["gimgs"], RTOL, 1e-5, "d imgs")
+
+
 def test_cpu_tensor_is_refused(ops):
     with pytest.raises(RuntimeError):
         ops.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 3, 3), None, 1, 1)

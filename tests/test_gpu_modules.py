@@ -146,6 +146,45 @@ def test_full_train_step_vs_reference(cuda):
                 check_param(k, g[name], v, "ggrad:" + name)
 
 
+def test_default_step_with_object_discriminator_vs_reference(cuda):
+    """The reference's DEFAULT configuration (use_img_disc=0): image + object discriminators, three
+    optimisers.  Loss dicts, object-discriminator gradients / BatchNorm state, and D_img's spectral
+    norm vector after its five calls per step."""
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import make_vocab
+    meta, a = load_golden("train_step_objdisc")
+    opt = T.make_opt(make_vocab(meta["vocab"]), meta["argv"])
+    tr = T.Trainer(opt, cuda)
+    sh = meta["shapes"]
+    _load(tr.model.sg_to_layout.module, state_from_shapes(sh["sg"], 21, requires_grad=False))
+    _load(tr.model.layout_to_image_model.module, state_from_shapes(sh["g"], 22, requires_grad=False), strict=False)
+    _load(tr.discriminator.img_discriminator, state_from_shapes(sh["d"], 23, requires_grad=False), strict=False)
+    _load(tr.discriminator.obj_discriminator, state_from_shapes(sh["dobj"], 24, requires_grad=False))
+    batch = [a["imgs"], a["objs"], a["boxes"], a["triplets"], None, a["tt"], None, None]
+    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    for k in ("bbox_pred", "GAN_Img", "GAN_Feat", "GAN_Obj", "GAN_Ac", "total_loss"):
+        assert_close(G[k].reshape(a["G:" + k].shape), a["G:" + k], RTOL, 1e-5, "G " + k)
+    for k in ("D_img_fake", "D_img_real", "total_img_loss", "D_img_wrong", "D_obj", "D_ac_real", "D_ac_fake",
+              "total_obj_loss"):
+        assert_close(D[k].reshape(a["D:" + k].shape), a["D:" + k], RTOL, 1e-5, "D " + k)
+    onamed = dict(tr.discriminator.obj_discriminator.named_parameters())
+    osd = tr.discriminator.obj_discriminator.state_dict()
+    dsd = tr.discriminator.img_discriminator.state_dict()
+    gnamed = dict(tr.model.layout_to_image_model.module.named_parameters())
+    n = 0
+    for k, v in a.items():
+        if k.startswith("ograd:"):
+            assert_close(onamed[k[6:]].grad, v, 1e-3, 2e-6, k)
+            n += 1
+        elif k.startswith("ggrad:"):
+            assert_close(gnamed[k[6:]].grad, v, 1e-3, 1e-6, k)
+        elif k.startswith("d_after:"):
+            assert_close(dsd[k[8:]], v, 1e-3, 2e-6, k)
+        elif k.startswith("o_after:") and ("running_" in k or "num_batches" in k):
+            assert_close(osd[k[8:]], v, 1e-3, 2e-6, k)
+    assert n >= 12
+
+
 def test_generated_image_vs_reference(cuda):
     meta, a, opt, tr, batch = _trainer_from_golden(cuda)
     with torch.no_grad():

@@ -184,3 +184,52 @@ def test_masks_to_layout():
             assert_close(out, a["out_%s_%d" % (tag, H)], RTOL, ATOL, "masks layout %s %d" % (tag, H))
             (gv,) = torch.autograd.grad((out * a["w_%s_%d" % (tag, H)]).sum(), [vecs])
             assert_close(gv, a["gvecs_%s_%d" % (tag, H)], RTOL, 1e-5, "masks layout dvecs %s %d" % (tag, H))
+
+
+def test_object_crops():
+    meta, a = load_golden("crops")
+    vocab = make_vocab(meta["vocab"])
+    imgs = a["imgs"].clone().requires_grad_(True)
+    crops, labels = oracle.crop_objects(imgs, a["objs"], a["boxes"], vocab, meta["size"])
+    assert_close(crops, a["crops"], RTOL, ATOL, "crops")
+    (gi,) = torch.autograd.grad((crops * a["w"]).sum(), [imgs])
+    assert_close(gi, a["gimgs"], RTOL, 1e-5, "d imgs")
+    want = torch.cat([a["objs"][b][oracle.remove_dummy_objects(a["objs"][b], vocab)][:, 0] for b in range(3)])
+    assert torch.equal(labels, want)
+
+
+def _objdisc_fixture():
+    meta, a = load_golden("train_step_objdisc")
+    vocab = make_vocab(meta["vocab"])
+    opt = make_opt(vocab, meta["argv"])
+    sh = meta["shapes"]
+    sg = state_from_shapes(sh["sg"], seed=21)
+    w = sg["trans_candidates_weights"]
+    for k in list(sg):
+        if k.endswith("predicates_transitive_weights"):
+            sg[k] = w
+    g, d = state_from_shapes(sh["g"], seed=22), state_from_shapes(sh["d"], seed=23)
+    dobj = state_from_shapes(sh["dobj"], seed=24)
+    batch = (a["imgs"], a["objs"], a["boxes"], a["triplets"], None, a["tt"], None, None)
+    return meta, a, opt, sg, g, d, dobj, batch
+
+
+def test_default_train_step_with_object_discriminator():
+    """use_img_disc=0 (the reference's default recipe): image + object discriminators."""
+    meta, a, opt, sg, g, d, dobj, batch = _objdisc_fixture()
+    ts = oracle.TrainState(opt, sg, g, d, dobj)
+    G, D, _ = oracle.train_step(ts, batch)
+    for k in ("bbox_pred", "GAN_Img", "GAN_Feat", "GAN_Obj", "GAN_Ac", "total_loss"):
+        assert_close(G[k].reshape(a["G:" + k].shape), a["G:" + k], RTOL, 1e-5, "G " + k)
+    for k in ("D_img_fake", "D_img_real", "total_img_loss", "D_img_wrong", "D_obj", "D_ac_real", "D_ac_fake",
+              "total_obj_loss"):
+        assert_close(D[k].reshape(a["D:" + k].shape), a["D:" + k], RTOL, 1e-5, "D " + k)
+    for k, v in a.items():
+        if k.startswith("ograd:"):
+            assert_close(dobj[k[6:]].grad, v, 1e-3, 1e-6, k)
+        elif k.startswith("ggrad:"):
+            assert_close(g[k[6:]].grad, v, 1e-3, 1e-6, k)
+        elif k.startswith("d_after:"):
+            assert_close(d[k[8:]], v, 1e-3, 2e-6, k)             # u after FIVE power iterations
+        elif k.startswith("o_after:") and ("running_" in k or "num_batches" in k):
+            assert_close(dobj[k[8:]], v, 1e-3, 2e-6, k)
