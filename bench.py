@@ -55,7 +55,7 @@ def cpu_baseline(opt_argv, vocab, cfg, image_size):
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     argv = [a for a in opt_argv]
-    nimg = 4                                              # bounded sample: ~10-20 s of CPU work
+    nimg = 8                                              # bounded sample: ~10-20 s of CPU work
     opt = T.make_opt(vocab, argv + ["--batch_size", str(nimg)])
     torch.manual_seed(0)
     tr = T.Trainer(opt, torch.device("cpu"))            # parameter container only; nothing is run on it
