@@ -132,6 +132,23 @@ def main():
         _lib.prof_enable(False)
     loss_ok = bool(torch.isfinite(G["total_loss"]).item() and torch.isfinite(Dl["total_img_loss"]).item())
 
+    # BASELINE.json's second metric: the SPADE generator alone, forward + backward (no optimiser step)
+    gen_ms = None
+    if H in (64, 128, 256) and args.ngf == 64:
+        gen = trainer.model.layout_to_image_model
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        for it in range(reps + 1):
+            if it == 1:
+                e0.record()
+            b = batches[it % nb]
+            img = gen(b[1], b[2], None, test_mode=False)
+            img.mean().backward()
+            trainer.optimizer.zero_grad(set_to_none=True)
+        e1.record()
+        torch.cuda.synchronize()
+        gen_ms = e0.elapsed_time(e1) / reps
+
     if rank != 0:
         return
     imgs = args.batch * world * args.steps
@@ -167,6 +184,17 @@ def main():
                                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(wwork / (wms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
         out["kernels"] = kern
+    if gen_ms is not None:
+        # algorithmic work of SPADEGenerator fwd+bwd per image (FlopCounterMode; S = 32 or 128)
+        S = len(vocab["attributes"]) * 32
+        gflop = {(256, 32): 870.75, (128, 32): 217.69, (64, 32): 54.42, (256, 128): 3 * 348.37}.get((H, S))
+        if gflop:
+            tf = gflop * args.batch / gen_ms            # GFLOP/ms == TFLOP/s
+            out["generator_fwd_bwd"] = {"ms": round(gen_ms, 2), "algorithmic_gflop_per_img": gflop,
+                                        "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                                        "note": "SPADEGenerator forward+backward on one %d-image batch, all kernels "
+                                                "(convs, norms, layout, resampling) included" % args.batch}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(opt_argv, vocab, cfg, args.cpu_image_size or H)
     print(json.dumps(out), flush=True)

@@ -413,9 +413,11 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const csg_conv_desc& d = p.d;
-  int bid = blockIdx.x;
-  const int sp = bid % nsplit;
-  bid /= nsplit;
+  // block order: all (channel tile, tap tile) pairs of one pixel split are adjacent and land on the
+  // same XCD, so the split's dY rows and X pixels are fetched from HBM once and re-read from that L2
+  int bid = xcd_remap(blockIdx.x, itiles * jtiles * nsplit);
+  const int sp = bid / (itiles * jtiles);
+  bid -= sp * (itiles * jtiles);
   const int jt = bid % jtiles, it = bid / jtiles;
 
   load_taps(s_tap, tid);
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
       int b, gy, gx;
       decompose(p, (unsigned)(ok ? m : 0), b, gy, gx);
       const int iy = gy * d.istride + tdy, ix = gx * d.istride + tdx;
-      const bool inb = ok && kv && (unsigned)iy < (unsigned)d.IHv && (unsigned)ix < (unsigned)d.IWv;
+      const bool inb = ok & kv & ((unsigned)iy < (unsigned)d.IHv) & ((unsigned)ix < (unsigned)d.IWv);
       const unsigned off = (unsigned)(b - b0) * p.img_bytes +
                            (unsigned)(((iy >> d.in_up) * d.IWp + (ix >> d.in_up)) * d.x_cs + cch) * 4u;
       rb[i] = csg_buffer_load_f32x4(rsX, (int)(inb ? off : OOB_OFF), 0, 0);
