@@ -49,11 +49,13 @@ class MetaDiscriminatorModel(nn.Module):
     def build_optimizers(self, opt):
         """Adam(betas=(beta1, 0.999)) per discriminator (reference meta_models.py:67-69,79-81,88-90);
         called after the module sits on its device."""
+        on_gpu = next(self.img_discriminator.parameters()).is_cuda
+        fused = {'fused': True} if on_gpu else {}
         self.optimizer_d_img = torch.optim.Adam(list(self.img_discriminator.parameters()),
-                                                lr=opt.img_learning_rate, betas=(opt.beta1, 0.999))
+                                                lr=opt.img_learning_rate, betas=(opt.beta1, 0.999), **fused)
         if not opt.use_img_disc:
             self.optimizer_d_obj = torch.optim.Adam(list(self.obj_discriminator.parameters()),
-                                                    lr=opt.learning_rate, betas=(opt.beta1, 0.999))
+                                                    lr=opt.learning_rate, betas=(opt.beta1, 0.999), **fused)
             self.optimizer_d_mask = torch.optim.Adam(list(self.mask_discriminator.parameters()),
-                                                     lr=opt.mask_learning_rate, betas=(opt.beta1, 0.999))
+                                                     lr=opt.mask_learning_rate, betas=(opt.beta1, 0.999), **fused)
         return self

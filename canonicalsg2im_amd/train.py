@@ -30,8 +30,9 @@ class Trainer:
         trans = ['sg_to_layout.module.trans_candidates_weights']
         named = list(self.model.named_parameters())
         base = [p for n, p in named if n not in converse + trans]
+        fused = {'fused': True} if torch.device(device).type == 'cuda' else {}   # one multi-tensor kernel per step
         self.optimizer = torch.optim.Adam([{'params': base, 'lr': opt.learning_rate},
-                                           {'params': [p for n, p in named if n in trans], 'lr': 1e-2}])
+                                           {'params': [p for n, p in named if n in trans], 'lr': 1e-2}], **fused)
         self.optimizer_converse = torch.optim.Adam([{'params': [p for n, p in named if n in converse], 'lr': 1e-2}])
         self.g_buckets = csg_dist.GradBuckets(base + [p for n, p in named if n in trans])
         self.d_params = list(self.discriminator.img_discriminator.parameters())
