@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
   int cch = k_cur - slot * d.Cin;
   const int step_slots = IG_BK / d.Cin, step_rem = IG_BK - step_slots * d.Cin;
 
-  f32x4 ra[4], rb[BROWS];
+  f32x4 ra0[4], rb0[BROWS], ra1[4], rb1[BROWS];   // two sets: loads run two K tiles ahead of the MFMAs
   __syncthreads();  // s_tap visible
 
   // tap of the tile to be loaded next, fetched from LDS one tile ahead so that its latency hides
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
   };
   fetch_tap();
 
-  auto load_tile = [&]() {
+  auto load_tile = [&](f32x4* ra, f32x4* rb) {
     const bool kv = k_cur < p.Ktot;
     const int dy = t_dy, dx = t_dx, tw = t_tw;
 #pragma unroll
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
     slot = wrap ? slot + 1 : slot;
     fetch_tap();
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const f32x4* ra, const f32x4* rb) {
     float* a = As + buf * IG_BM * IG_LD + r0 * IG_LD + kc * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) *(f32x4*)(a + 32 * i * IG_LD) = ra[i];
@@ -230,9 +230,10 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
   constexpr int WCOLS = BN / (4 / WM);   // B rows (output channels) per wave
 
   if (kt0 < kt1) {
-    load_tile();
-    store_tile(0);
+    load_tile(ra0, rb0);
+    store_tile(0, ra0, rb0);
   }
+  if (kt0 + 1 < kt1) load_tile(ra1, rb1);
   __syncthreads();
 
   auto compute_tile = [&](int buf) {
@@ -258,26 +259,38 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
         }
     }
   };
-  // steady state: ONE basic block per K tile (next tile's loads, this tile's MFMAs, LDS refill),
-  // so the scheduler is free to slot the loader's VALU/VMEM work between the 64-cycle MFMAs;
-  // the last tile is peeled
-  int buf = 0;
-  for (int kt = kt0; kt + 1 < kt1; ++kt) {
-    load_tile();
+  // steady state: branch-free body, two K tiles per trip.  Invariant at the top: tile kt is in
+  // LDS[buf] and tile kt+1 is in flight in register set 1; the loads issued in a half-trip are only
+  // consumed (LDS refill) one half-trip later, so their latency hides behind 64 MFMAs.
+  int kt = kt0, buf = 0;
+  for (; kt + 3 < kt1; kt += 2) {
+    load_tile(ra0, rb0);
     compute_tile(buf);
-    store_tile(buf ^ 1);
-    // issue order inside the block: the 8 global loads go out EARLY (their data is needed only at
-    // the LDS refill after the last MFMA), each with its address arithmetic, two MFMAs apart
-#pragma unroll
-    for (int i = 0; i < 4 + BROWS; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);   // VALU
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
-    }
+    store_tile(buf ^ 1, ra1, rb1);
     __syncthreads();
-    buf ^= 1;
+    load_tile(ra1, rb1);
+    compute_tile(buf ^ 1);
+    store_tile(buf, ra0, rb0);
+    __syncthreads();
   }
-  if (kt0 < kt1) compute_tile(buf);
+  const int left = kt1 - kt;            // 0..3 tiles remain
+  if (left == 3) {
+    load_tile(ra0, rb0);
+    compute_tile(buf);
+    store_tile(buf ^ 1, ra1, rb1);
+    __syncthreads();
+    compute_tile(buf ^ 1);
+    store_tile(buf, ra0, rb0);
+    __syncthreads();
+    compute_tile(buf);
+  } else if (left == 2) {
+    compute_tile(buf);
+    store_tile(buf ^ 1, ra1, rb1);
+    __syncthreads();
+    compute_tile(buf ^ 1);
+  } else if (left == 1) {
+    compute_tile(buf);
+  }
 
   // epilogue: D[i][j], j = lane&31 = pixel, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel:
   // registers 4g..4g+3 of a tile are channels 8g + 4*(lane>>5) + 0..3 of this lane's pixel.
@@ -445,8 +458,10 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
   const long long x_rem = (long long)(d.B - b0) * p.img_bytes;
   const i32x4 rsX = make_srd(x + (long long)b0 * (p.img_bytes >> 2), (unsigned)(x_rem < MAX_RECORDS ? x_rem : MAX_RECORDS));
 
-  f32x4 ra[AIT], rb[4];
-  auto load_tile = [&](int ch) {
+  // two register sets: the loads of chunk t+2 are issued during the MFMAs of chunk t and consumed
+  // (LDS refill) at the end of chunk t+1, so their latency has a whole chunk to hide behind
+  f32x4 ra0[AIT], rb0[4], ra1[AIT], rb1[4];
+  auto load_tile = [&](int ch, f32x4* ra, f32x4* rb) {
     // dY rows of this chunk: descriptor re-based per chunk, rows past M fall out of range
     const int rows = min(32, p.M - ch * 32);
     const i32x4 rsY = make_srd(dy + (long long)ch * 32 * d.y_cs, (unsigned)(rows * d.y_cs * 4));
@@ -468,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
       rb[i] = csg_buffer_load_f32x4(rsX, (int)(inb ? off : OOB_OFF), 0, 0);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const f32x4* ra, const f32x4* rb) {
 #pragma unroll
     for (int i = 0; i < AIT; ++i) *(f32x4*)(As + buf * 32 * BI + (apr + RP * i) * BI + ac4 * 4) = ra[i];
 #pragma unroll
@@ -486,11 +501,6 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
   const int wi = BI == 32 ? 0 : (wave >> 1), wj = BI == 32 ? wave : (wave & 1);
   const int r = lane & 31, hh = lane >> 5;
 
-  if (ch0 < ch1) {
-    load_tile(ch0);
-    store_tile(0);
-  }
-  __syncthreads();
   auto compute_tile = [&](int buf) {
     const float* Ab = As + buf * 32 * BI + hh * BI + wi * (MI * 32) + r;
     const float* Bb = Bs + buf * 32 * WG_LDB + hh * WG_LDB + wj * (NJ * 32) + r;
@@ -515,22 +525,43 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
           acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[kp & 1][nj], a[kp & 1][mi], acc[mi][nj], 0, 0, 0);
     }
   };
-  // steady state = one basic block per 32-pixel chunk (see k_igemm_fwd); last chunk peeled
-  int buf = 0;
-  for (int ch = ch0; ch + 1 < ch1; ++ch) {
-    load_tile(ch + 1);
-    compute_tile(buf);
-    store_tile(buf ^ 1);
-#pragma unroll
-    for (int i = 0; i < 4 + AIT; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);   // VALU
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
-    }
-    __syncthreads();
-    buf ^= 1;
+
+  // invariant at the top of the steady loop: chunk `ch` is in LDS[buf], chunk ch+1 is in flight in set 1
+  int ch = ch0, buf = 0;
+  if (ch0 < ch1) {
+    load_tile(ch0, ra0, rb0);
+    store_tile(0, ra0, rb0);
   }
-  if (ch0 < ch1) compute_tile(buf);
+  if (ch0 + 1 < ch1) load_tile(ch0 + 1, ra1, rb1);
+  __syncthreads();
+  for (; ch + 3 < ch1; ch += 2) {      // branch-free body: two chunks per trip
+    load_tile(ch + 2, ra0, rb0);
+    compute_tile(buf);
+    store_tile(buf ^ 1, ra1, rb1);
+    __syncthreads();
+    load_tile(ch + 3, ra1, rb1);
+    compute_tile(buf ^ 1);
+    store_tile(buf, ra0, rb0);
+    __syncthreads();
+  }
+  const int left = ch1 - ch;            // 0..3 chunks remain
+  if (left == 3) {
+    load_tile(ch + 2, ra0, rb0);
+    compute_tile(buf);
+    store_tile(buf ^ 1, ra1, rb1);
+    __syncthreads();
+    compute_tile(buf ^ 1);
+    store_tile(buf, ra0, rb0);
+    __syncthreads();
+    compute_tile(buf);
+  } else if (left == 2) {
+    compute_tile(buf);
+    store_tile(buf ^ 1, ra1, rb1);
+    __syncthreads();
+    compute_tile(buf ^ 1);
+  } else if (left == 1) {
+    compute_tile(buf);
+  }
 
   // D[i = kk][j = n]: a lane owns output channel n and runs of 4 consecutive (tap,c) columns, which
   // are contiguous in the slab row [split][Cout][wrow] (Cin % 4 == 0, so a run never straddles taps)
