@@ -129,12 +129,36 @@ class AcCropDiscriminator(nn.Module):
         self.discriminator = AcDiscriminator(vocab, arch, normalization, activation, padding, pooling)
         self.object_size = object_size
 
-    def forward(self, imgs, objs, boxes):
+    def prefetch_index(self, objs):
+        """Start fetching the real-object list of this batch WITHOUT draining the GPU queue: the mask
+        kernel and a 1-byte-per-object copy to pinned memory are enqueued now; `forward` (called much
+        later in the step) only waits on their event.  Calling `nonzero()` in forward instead would
+        synchronise the whole stream three times per step."""
         valid = real_object_mask(objs, self.vocab)
-        nz = valid.nonzero()                                # (N,2) [image, object], image-major like the reference
-        img_idx = nz[:, 0].contiguous()
-        flat_boxes = boxes[nz[:, 0], nz[:, 1]]
-        labels = objs[nz[:, 0], nz[:, 1], 0]
+        host = torch.empty(valid.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(valid, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._index_cache = (objs.data_ptr(), objs._version, tuple(objs.shape), host, ev, None)
+
+    def _object_index(self, objs):
+        c = getattr(self, "_index_cache", None)
+        if c is not None and c[:3] == (objs.data_ptr(), objs._version, tuple(objs.shape)):
+            if c[5] is None:
+                c[4].synchronize()
+                nz = c[3].nonzero()                          # on the host copy: image-major, like the reference
+                dev = (nz[:, 0].contiguous().to(objs.device, non_blocking=True),
+                       nz[:, 1].contiguous().to(objs.device, non_blocking=True))
+                self._index_cache = c[:5] + (dev,)
+                return dev
+            return c[5]
+        nz = real_object_mask(objs, self.vocab).nonzero()   # (N,2) [image, object]; synchronises
+        return nz[:, 0].contiguous(), nz[:, 1].contiguous()
+
+    def forward(self, imgs, objs, boxes):
+        img_idx, obj_idx = self._object_index(objs)
+        flat_boxes = boxes[img_idx, obj_idx]
+        labels = objs[img_idx, obj_idx, 0]
         crops = ops.crop_objects(imgs, flat_boxes, img_idx, self.object_size)
         real_scores, ac_loss = self.discriminator(crops, labels)
         return real_scores, ac_loss, crops[:, :imgs.size(1)]

@@ -53,6 +53,8 @@ class Trainer:
             raise NotImplementedError("--learned_converse (REINFORCE on the data loader's converse weights) is a "
                                       "data-loader feature outside the hot path")
         imgs, objs, boxes, triplets, conv_counts, triplet_type, masks, image_ids = batch
+        if not opt.use_img_disc and objs.is_cuda:
+            self.discriminator.obj_discriminator.prefetch_index(objs)
         model_out = self.model(objs, triplets, triplet_type, boxes_gt=boxes, masks_gt=masks, test_mode=False)
         # ---- generator update (train.py:361-368)
         self._d_requires_grad(False)
