@@ -41,6 +41,9 @@ def parse():
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_image_size", type=int, default=None)
     p.add_argument("--no_prof", action="store_true", help="skip the per-kernel HIP-event timing")
+    p.add_argument("--no_gen_metric", action="store_true",
+                   help="skip the generator-only fwd+bwd passes (use under rocprofv3 so that its per-kernel "
+                        "averages cover the same launch mix as the timed region)")
     return p.parse_args()
 
 
@@ -134,7 +137,7 @@ def main():
 
     # BASELINE.json's second metric: the SPADE generator alone, forward + backward (no optimiser step)
     gen_ms = None
-    if H in (64, 128, 256) and args.ngf == 64:
+    if H in (64, 128, 256) and args.ngf == 64 and not args.no_gen_metric:
         gen = trainer.model.layout_to_image_model
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 3

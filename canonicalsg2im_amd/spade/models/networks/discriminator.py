@@ -135,7 +135,10 @@ class AcCropDiscriminator(nn.Module):
         later in the step) only waits on their event.  Calling `nonzero()` in forward instead would
         synchronise the whole stream three times per step."""
         valid = real_object_mask(objs, self.vocab)
-        host = torch.empty(valid.shape, dtype=torch.uint8, pin_memory=True)
+        host = getattr(self, "_pinned", None)
+        if host is None or host.shape != valid.shape:       # pinned allocations are slow: keep one per shape
+            host = torch.empty(valid.shape, dtype=torch.uint8, pin_memory=True)
+            self._pinned = host
         host.copy_(valid, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
