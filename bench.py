@@ -40,6 +40,10 @@ def parse():
                    help="0 = the reference's default COCO/VG recipe (image + object discriminators); 1 = image only")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_image_size", type=int, default=None)
+    p.add_argument("--vgg_loss", type=int, default=0,
+                   help="1 = keep the VGG perceptual term (reference default; random-feature VGG19 here, the "
+                        "pretrained weights cannot be downloaded); 0 = --no_vgg_loss, the configuration "
+                        "SURVEY.md 8(d) quotes the metric on")
     p.add_argument("--no_prof", action="store_true", help="skip the per-kernel HIP-event timing")
     p.add_argument("--no_gen_metric", action="store_true",
                    help="skip the generator-only fwd+bwd passes (use under rocprofv3 so that its per-kernel "
@@ -97,8 +101,12 @@ def main():
     vocab = make_vocab(base["vocab"])
     cfg = base["cfg"]
     H = args.image_size
-    opt_argv = ["--image_size", "%d,%d" % (H, H), "--ngf", str(args.ngf), "--ndf", str(args.ndf), "--no_vgg_loss",
+    opt_argv = ["--image_size", "%d,%d" % (H, H), "--ngf", str(args.ngf), "--ndf", str(args.ndf),
                 "--use_img_disc", str(args.use_img_disc)]
+    if args.vgg_loss:
+        os.environ.setdefault("CSG_VGG19_RANDOM", "1")
+    else:
+        opt_argv.append("--no_vgg_loss")
     opt = T.make_opt(vocab, opt_argv + ["--batch_size", str(args.batch * world), "--gpu_ids",
                                         ",".join(str(i) for i in range(world))])
     torch.manual_seed(0)
@@ -161,9 +169,11 @@ def main():
         "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config %s: COCO-shaped AttSPADE %dx%d, batch %d/GPU, %d-%d objects/img, "
-                               "ngf=%d ndf=%d, --no_vgg_loss --use_img_disc %d; Sg2Layout GCN + SPADE G + 2-scale "
+                               "ngf=%d ndf=%d, %s --use_img_disc %d; Sg2Layout GCN + SPADE G + 2-scale "
                                "PatchGAN D%s, fwd+bwd+Adam" % (args.config, H, H, args.batch, cfg.min_objects,
-                                                                 cfg.max_objects, args.ngf, args.ndf, args.use_img_disc,
+                                                                 cfg.max_objects, args.ngf, args.ndf,
+                                                                 "VGG loss (random features)" if args.vgg_loss
+                                                                 else "--no_vgg_loss", args.use_img_disc,
                                                                  "" if args.use_img_disc else " + object-crop D"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         "losses_finite": loss_ok,

@@ -89,7 +89,8 @@ static const char* kNames[K_COUNT] = {
     "embed_fwd",      "embed_bwd",      "real_object_mask", "graph_csr_build", "gather_concat_fwd", "gather_concat_bwd",
     "segment_avg_fwd", "segment_avg_bwd", "layout_fwd",       "layout_bwd",      "igemm_fwd",         "igemm_fwd64",   "splitk_epilogue", "igemm_wgrad",
     "wgrad_reduce",   "act_bwd",        "colsum",           "norm_stats",      "norm_finalize",     "norm_apply_fwd",
-    "norm_bwd_reduce", "norm_bwd_dx",    "upsample2x_fwd",   "upsample2x_bwd",  "avgpool3s2_fwd",    "avgpool3s2_bwd", "crop_fwd", "crop_bwd"};
+    "norm_bwd_reduce", "norm_bwd_dx",    "upsample2x_fwd",   "upsample2x_bwd",  "avgpool3s2_fwd",    "avgpool3s2_bwd", "crop_fwd", "crop_bwd",
+    "maxpool2_fwd",   "maxpool2_bwd",   "l1_mean_fwd",      "l1_mean_bwd"};
 
 }  // namespace csg
 

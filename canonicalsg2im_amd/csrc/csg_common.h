@@ -38,6 +38,10 @@ enum KernelId {
   K_AVGPOOL_BWD,
   K_CROP_FWD,
   K_CROP_BWD,
+  K_MAXPOOL_FWD,
+  K_MAXPOOL_BWD,
+  K_L1_FWD,
+  K_L1_BWD,
   K_COUNT
 };
 

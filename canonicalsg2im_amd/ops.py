@@ -17,8 +17,8 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, check, lib, ptr, stre
 
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
-    "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "disc_input", "crop_objects", "ACT_NONE", "ACT_LEAKY",
-    "ACT_TANH",
+    "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "disc_input", "crop_objects", "maxpool2", "l1_mean",
+    "pack_conv_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
 
 
@@ -111,13 +111,16 @@ class _Conv2d(torch.autograd.Function):
     include/csg_hip.h (K8/K11)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, pad, act, slope):
+    def forward(ctx, x, weight, bias, residual, stride, pad, act, slope, packs=None):
         x = nhwc(_f32(x))
         B, Cin, IH, IW = x.shape
         Cout, Cin_w, KH, KW = weight.shape
+        if packs is not None:
+            Cin_w = packs[0].shape[3]              # packed weights carry their own channel padding
         if Cin_w != Cin:
             raise RuntimeError("conv2d: weight expects %d input channels, x has %d" % (Cin_w, Cin))
-        wp = weight.detach().permute(0, 2, 3, 1).contiguous()          # [Cout][KH][KW][Cin]
+        ctx.packs = packs
+        wp = packs[0] if packs is not None else weight.detach().permute(0, 2, 3, 1).contiguous()   # [Cout][KH][KW][Cin]
         d, OH, OW = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad, act, slope)
         y = empty_nhwc(B, Cout, OH, OW, x.device)
         res = nhwc(residual) if residual is not None else None
@@ -139,7 +142,8 @@ class _Conv2d(torch.autograd.Function):
             dpre = dy
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().permute(1, 2, 3, 0).contiguous()      # [Cin][KH][KW][Cout]
+            wt = ctx.packs[1] if ctx.packs is not None else \
+                weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
             for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
                 _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
@@ -160,23 +164,35 @@ class _Conv2d(torch.autograd.Function):
             check(lib.csg_colsum(ptr(dpre), rows, Cout, Cout, ptr(db), ptr(part), nch, stream()), "colsum")
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dpre
-        return dx, dw, db, dres, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, residual=None):
+def pack_conv_weight(weight):
+    """The two kernel-side layouts of a FROZEN (Cout,Cin,KH,KW) weight, for `conv2d(..., packs=)`:
+    [Cout][KH][KW][Cin] for the forward and [Cin][KH][KW][Cout] for backward-data, input channels
+    zero-padded to a multiple of 4.  Trainable weights are repacked per call instead."""
+    pc = (-weight.shape[1]) % 4
+    w = F.pad(weight.detach(), (0, 0, 0, 0, 0, pc)) if pc else weight.detach()
+    return w.permute(0, 2, 3, 1).contiguous(), w.permute(1, 2, 3, 0).contiguous()
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, residual=None, packs=None):
     """Channel counts that are not multiples of 4 (conv_img: 3 outputs, the PatchGAN head: 1) are
     zero-padded to 16-byte pixel rows; the result is a channel-slice view of the padded output."""
     Cout, Cin = weight.shape[0], weight.shape[1]
     pc, po = (-Cin) % 4, (-Cout) % 4
+    if packs is not None and po:
+        raise RuntimeError("conv2d: packed weights need an output-channel count that is a multiple of 4")
     if pc:
         if x.shape[1] == Cin:                  # an already padded input (e.g. the 4-channel object crops) is used as is
             x = F.pad(x, (0, 0, 0, 0, 0, pc))
-        weight = F.pad(weight, (0, 0, 0, 0, 0, pc))
+        if packs is None:
+            weight = F.pad(weight, (0, 0, 0, 0, 0, pc))
     if po:
         weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, po))
         bias = F.pad(bias, (0, po)) if bias is not None else None
         residual = F.pad(residual, (0, 0, 0, 0, 0, po)) if residual is not None else None
-    y = _Conv2d.apply(x, weight, bias, residual, int(stride), int(padding), int(act), float(slope))
+    y = _Conv2d.apply(x, weight, bias, residual, int(stride), int(padding), int(act), float(slope), packs)
     return y[:, :Cout] if po else y
 
 
@@ -313,6 +329,65 @@ class _AvgPool3s2(torch.autograd.Function):
 
 def avgpool3s2(x):
     return _AvgPool3s2.apply(x)
+
+
+class _MaxPool2(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) (torchvision vgg19().features, reference architecture.py:96-110)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(_f32(x))
+        B, C, H, W = x.shape
+        y = empty_nhwc(B, C, H // 2, W // 2, x.device)
+        check(lib.csg_maxpool2_fwd(ptr(x), B, H, W, C, ptr(y), stream()), "maxpool2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = nhwc(dy)
+        dx = torch.empty_like(x)
+        check(lib.csg_maxpool2_bwd(ptr(dy), ptr(x), B, H, W, C, ptr(dx), stream()), "maxpool2_bwd")
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _L1Mean(torch.autograd.Function):
+    """nn.L1Loss()(a, b) with b a constant (reference loss.py:115: the target is detached)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32(a), _f32(b)
+        if a.shape != b.shape or a.stride() != b.stride():
+            raise RuntimeError("l1_mean: operands must share shape and memory layout")
+        if not a.permute(0, 2, 3, 1).is_contiguous() and not a.is_contiguous():
+            raise RuntimeError("l1_mean: operands must be dense")
+        n = a.numel()
+        nbytes = lib.csg_l1_mean_workspace(n)
+        if nbytes < 0:
+            raise RuntimeError("l1_mean: element count %d is not a multiple of 4" % n)
+        ws = torch.empty(nbytes // 8, device=a.device, dtype=torch.float64)
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        check(lib.csg_l1_mean_fwd(ptr(a), ptr(b), n, ptr(out), ptr(ws), nbytes, stream()), "l1_mean_fwd")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a)
+        g = g.contiguous()
+        check(lib.csg_l1_mean_bwd(ptr(a), ptr(b), ptr(g), a.numel(), ptr(da), stream()), "l1_mean_bwd")
+        return da, None
+
+
+def l1_mean(a, b):
+    return _L1Mean.apply(a, b.detach())
 
 
 # ------------------------------------------------------------------------------------ graph encoder

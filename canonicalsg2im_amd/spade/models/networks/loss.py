@@ -40,10 +40,24 @@ class GANLoss(nn.Module):
 
 
 class VGGLoss(nn.Module):
-    def __init__(self, gpu_ids):
+    """Reference: spade/models/networks/loss.py:102-117 — sum_i w_i * L1(vgg(x)[i], vgg(y)[i].detach()),
+    w = 1/32, 1/16, 1/8, 1/4, 1.  The target pass runs without autograd (its features are constants)."""
+
+    def __init__(self, gpu_ids, weights=None):
         super().__init__()
-        raise NotImplementedError("VGGLoss needs pretrained torchvision weights; next-row component "
-                                  "(SURVEY.md §8f rank 2) — train with --no_vgg_loss")
+        from .architecture import VGG19
+        self.vgg = VGG19(weights=weights)
+        self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+
+    def forward(self, x, y):
+        from .... import ops
+        x_vgg = self.vgg(x)
+        with torch.no_grad():
+            y_vgg = self.vgg(y)
+        loss = 0
+        for w, fx, fy in zip(self.weights, x_vgg, y_vgg):
+            loss = loss + w * ops.l1_mean(fx, fy)
+        return loss
 
 
 class KLDLoss(nn.Module):

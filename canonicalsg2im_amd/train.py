@@ -119,4 +119,7 @@ def oracle_state_from(trainer, oracle_mod):
                 sg[k] = sg["trans_candidates_weights"]
     unused = ("repr_net", "image_encoder")
     dobj = leafs(obj_disc_state(trainer)) if not trainer.opt.use_img_disc else None
-    return oracle_mod.TrainState(trainer.opt, sg, leafs(g, unused), leafs(d, unused), dobj)
+    vgg = None
+    if hasattr(trainer.gans_model, "criterionVGG"):
+        vgg = {k: v.detach().cpu().clone() for k, v in trainer.gans_model.criterionVGG.vgg.state_dict().items()}
+    return oracle_mod.TrainState(trainer.opt, sg, leafs(g, unused), leafs(d, unused), dobj, vgg)

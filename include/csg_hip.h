@@ -192,6 +192,19 @@ int csg_crop_fwd(const float* img, int64_t B, int64_t H, int64_t W, int64_t img_
 int csg_crop_bwd(const float* dout, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C, const float* boxes,
                  const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, int64_t out_cs, float* dimg, void* stream);
 
+/* ---- perceptual loss helpers (spade/models/networks/architecture.py:93-123, loss.py:102-117) --------
+ * nn.MaxPool2d(kernel 2, stride 2) of torchvision's vgg19().features (floor mode; the backward
+ * routes each gradient to the first maximum of its window, as ATen does, and needs the pool's
+ * input x); nn.L1Loss() between two feature maps of n floats: out[0] = mean |a - b|, and
+ * da = sign(a - b) * gout[0] / n.  The workspace holds per-block fp64 partial sums. */
+int csg_maxpool2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
+int csg_maxpool2_bwd(const float* dy, const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* dx,
+                     void* stream);
+int64_t csg_l1_mean_workspace(int64_t n);
+int csg_l1_mean_fwd(const float* a, const float* b, int64_t n, float* out, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+int csg_l1_mean_bwd(const float* a, const float* b, const float* gout, int64_t n, float* da, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

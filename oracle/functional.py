@@ -20,7 +20,7 @@ __all__ = [
     "spectral_weight", "batch_norm_train", "syncbn_multi_replica", "spade", "spade_resblock",
     "generator_forward", "instance_norm", "nlayer_discriminator", "multiscale_discriminator",
     "hinge_loss", "gan_loss_multiscale", "generator_losses", "discriminator_losses", "TrainState",
-    "train_step", "make_adam_groups", "crop_objects", "ac_crop_discriminator", "bce_loss",
+    "train_step", "make_adam_groups", "crop_objects", "ac_crop_discriminator", "bce_loss", "vgg19_features", "vgg_loss",
 ]
 
 ORIGINAL_EDGE, TRANSITIVE_EDGE = 0, 1          # sg2im/data/base_dataset.py:7-8
@@ -390,9 +390,45 @@ def gan_loss_multiscale(preds, target_is_real, for_discriminator):
     return sum(hinge_loss(p[-1], target_is_real, for_discriminator) for p in preds) / len(preds)
 
 
-def generator_losses(opt, d_state, batch, model_out, training=True, dobj_state=None):
-    """`Pix2PixModel.compute_generator_loss` (sg2im/pix2pix_model.py:65-143) with --no_vgg_loss and
-    mask_size 0; the object-discriminator terms (:115-121) when use_img_disc == 0."""
+VGG19_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512)
+VGG19_TAPS = (1, 6, 11, 20, 29)     # features[] index of relu1_1 .. relu5_1: the last layer of each slice
+
+
+def vgg19_features(state, x):
+    """`VGG19.forward` (spade/models/networks/architecture.py:93-123): the outputs of the five slices
+    features[0:2], [2:7], [7:12], [12:21], [21:30] of torchvision's vgg19 (configuration 'E':
+    conv3x3 pad 1 + ReLU, MaxPool2d(2, 2)).  `state` uses the reference module's keys
+    (`slice{k}.{features index}.weight|bias`)."""
+    bounds = (2, 7, 12, 21, 30)
+    outs, idx = [], 0
+    for v in VGG19_CFG:
+        k = next(i for i, b in enumerate(bounds) if idx < b) + 1
+        if v == "M":
+            x = F.max_pool2d(x, kernel_size=2, stride=2)
+            idx += 1
+        else:
+            x = F.relu(F.conv2d(x, state["slice%d.%d.weight" % (k, idx)], state["slice%d.%d.bias" % (k, idx)],
+                                padding=1))
+            idx += 2
+            if idx - 1 in VGG19_TAPS:
+                outs.append(x)
+    return outs
+
+
+def vgg_loss(state, x, y):
+    """`VGGLoss.forward` (spade/models/networks/loss.py:102-117)."""
+    weights = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)
+    fx, fy = vgg19_features(state, x), vgg19_features(state, y)
+    loss = 0
+    for w, a, b in zip(weights, fx, fy):
+        loss = loss + w * F.l1_loss(a, b.detach())
+    return loss
+
+
+def generator_losses(opt, d_state, batch, model_out, training=True, dobj_state=None, vgg_state=None):
+    """`Pix2PixModel.compute_generator_loss` (sg2im/pix2pix_model.py:65-143) with mask_size 0; the VGG
+    term (:111-113) unless --no_vgg_loss; the object-discriminator terms (:115-121) when
+    use_img_disc == 0."""
     imgs, objs, boxes = batch[0], batch[1], batch[2]
     imgs_pred, boxes_pred, _ = model_out
     H = opt.image_size[0]
@@ -416,6 +452,8 @@ def generator_losses(opt, d_state, batch, model_out, training=True, dobj_state=N
                 for j in range(len(fake[i]) - 1):
                     feat = feat + F.l1_loss(fake[i][j], real[i][j].detach()) * opt.lambda_feat / len(fake)
             G["GAN_Feat"] = feat
+        if not opt.no_vgg_loss:                                                               # :111-113
+            G["VGG"] = vgg_loss(vgg_state, imgs_pred, imgs) * opt.lambda_vgg
         if not opt.use_img_disc:                                                              # :115-121
             scores_fake, ac_loss, _ = ac_crop_discriminator(dobj_state, opt.vocab, imgs_pred, objs, boxes,
                                                             opt.crop_size, training)
@@ -469,8 +507,9 @@ def make_adam_groups(sg_state, g_state, lr):
 class TrainState:
     """Leaf tensors + optimizers of one replica (what `scripts.train.main` builds at :312-329)."""
 
-    def __init__(self, opt, sg_state, g_state, d_state, dobj_state=None):
+    def __init__(self, opt, sg_state, g_state, d_state, dobj_state=None, vgg_state=None):
         self.opt, self.sg, self.g, self.d, self.dobj = opt, sg_state, g_state, d_state, dobj_state
+        self.vgg = vgg_state                                   # frozen VGG19 weights (None with --no_vgg_loss)
         if dobj_state is not None:
             po = [v for v in dobj_state.values() if torch.is_tensor(v) and v.requires_grad]
             self.optimizer_d_obj = torch.optim.Adam(po, lr=opt.learning_rate, betas=(opt.beta1, 0.999))  # :79-81
@@ -481,8 +520,8 @@ class TrainState:
 
 
 def train_step(ts, batch):
-    """One iteration of scripts/train.py:353-393 (+ :468-485) with use_img_disc=1, no VGG,
-    learned_converse=0.  Returns (G_losses, D_losses, imgs_pred)."""
+    """One iteration of scripts/train.py:353-393 (+ :468-485) with learned_converse=0 (VGG term when
+    `ts.vgg` is given and --no_vgg_loss is absent; object discriminator when use_img_disc=0).  Returns (G_losses, D_losses, imgs_pred)."""
     opt = ts.opt
     imgs, objs, boxes, triplets, _, triplet_type = batch[:6]
     H = opt.image_size[0]
@@ -490,7 +529,7 @@ def train_step(ts, batch):
     imgs_pred = generator_forward(ts.g, opt.vocab, H, objs, boxes, True,
                                   num_upsampling_layers=opt.num_upsampling_layers)            # :47-49 (GT boxes)
     model_out = (imgs_pred, boxes_pred, None)
-    G = generator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj)                     # train.py:361
+    G = generator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj, vgg_state=ts.vgg)   # train.py:361
     ts.optimizer.zero_grad()
     for v in list(ts.d.values()) + list((ts.dobj or {}).values()):
         if torch.is_tensor(v) and v.grad is not None:

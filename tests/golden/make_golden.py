@@ -411,8 +411,58 @@ def fx_model_and_step():
                         "shapes": {"sg": shapes_of(sg), "g": shapes_of(G, unused), "d": shapes_of(D, unused)}}, **arrays)
 
 
+def _tv_vgg19(pretrained=False):
+    """Stand-in for torchvision.models.vgg19 (absent here): the public configuration 'E' feature stack
+    with default-initialised weights — the fixture overwrites them by name afterwards."""
+    import torch.nn as nn
+    layers, cin = [], 3
+    for v in (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M'):
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    m = nn.Module()
+    m.features = nn.Sequential(*layers)
+    return m
+
+
+def fx_vgg():
+    """VGGLoss / VGG19 of the reference (loss.py:102-117, architecture.py:93-123) on seeded weights."""
+    import torch.nn as nn
+    import spade.models.networks.architecture as ref_arch
+    from spade.models.networks.loss import VGGLoss
+    ref_arch.torchvision.models.vgg19 = _tv_vgg19
+    cuda, nn.Module.cuda = nn.Module.cuda, (lambda self, *a, **k: self)      # VGGLoss calls .cuda() (loss.py:105)
+    try:
+        crit = VGGLoss([])
+    finally:
+        nn.Module.cuda = cuda
+    crit.vgg.load_state_dict(deterministic_state(crit.vgg.state_dict(), seed=31))
+    g = torch.Generator().manual_seed(77)
+    x = (torch.rand(2, 3, 36, 44, generator=g) * 2 - 1).requires_grad_(True)
+    y = torch.rand(2, 3, 36, 44, generator=g) * 2 - 1
+    feats = crit.vgg(x)
+    loss = crit(x, y)
+    loss.backward()
+    arrays = {"x": npy(x), "y": npy(y), "loss": npy(loss), "grad_x": npy(x.grad)}
+    for i, f in enumerate(feats):
+        arrays["feat_abs_mean_%d" % i] = npy(f.abs().mean())
+        if i >= 2:
+            arrays["feat_%d" % i] = npy(f)
+    save("vgg_loss", {"ref": "spade/models/networks/loss.py:102-117, architecture.py:93-123",
+                      "state": "deterministic_state seed 31 over the reference VGG19's state_dict",
+                      "note": "torchvision is absent: vgg19() is the public configuration-E stack built in "
+                              "make_golden.py; the slicing, loss weights and detach are the reference's",
+                      "shapes": shapes_of(crit.vgg)}, **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if len(sys.argv) > 1:                      # regenerate selected fixtures: make_golden.py fx_vgg ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     fx_layout()
     fx_masks_layout()
     fx_gconv()

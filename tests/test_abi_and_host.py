@@ -145,16 +145,22 @@ def test_module_surface_and_state_dict_keys(built):
     assert tr.discriminator.optimizer_d_img.param_groups[0]["betas"] == (0.5, 0.999)
 
 
-def test_out_of_scope_components_fail_loudly(built):
+def test_out_of_scope_components_fail_loudly(built, monkeypatch):
     from canonicalsg2im_amd import train as T
     from canonicalsg2im_amd.sg2im.layout import masks_to_layout
     from canonicalsg2im_amd.spade.models.networks import VGGLoss
     from canonicalsg2im_amd.synth import make_vocab
-    with pytest.raises(NotImplementedError):
+    monkeypatch.delenv("CSG_VGG19_WEIGHTS", raising=False)
+    monkeypatch.delenv("CSG_VGG19_RANDOM", raising=False)
+    with pytest.raises(RuntimeError, match="CSG_VGG19_WEIGHTS"):     # no pretrained weights, no silent random features
         VGGLoss([0])
+    vgg = VGGLoss([0], weights="random").vgg                          # reference VGG19 keys (architecture.py:101-110)
+    assert list(vgg.state_dict())[:6] == ["slice1.0.weight", "slice1.0.bias", "slice2.2.weight", "slice2.2.bias",
+                                          "slice2.5.weight", "slice2.5.bias"]
+    assert len(vgg.state_dict()) == 26 and "slice5.28.weight" in vgg.state_dict()
     with pytest.raises(NotImplementedError):          # inference-time compositing only
         masks_to_layout(torch.zeros(1, 4), torch.zeros(1, 4), torch.zeros(1, 2, 2), 8, test_mode=True)
-    with pytest.raises(NotImplementedError):          # default flags keep the VGG loss on: pretrained weights needed
+    with pytest.raises(RuntimeError, match="CSG_VGG19_WEIGHTS"):     # default flags keep the VGG loss on
         T.Trainer(T.make_opt(make_vocab("tiny"), ["--image_size", "64,64", "--ngf", "4"]), torch.device("cpu"))
     tr = T.Trainer(T.make_opt(make_vocab("tiny"), ["--no_vgg_loss", "--image_size", "64,64", "--ngf", "4"]),
                    torch.device("cpu"))         # default use_img_disc=0: object + mask discriminators exist

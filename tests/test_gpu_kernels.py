@@ -189,6 +189,35 @@ def test_upsample_and_avgpool(ops):
         assert_close(xd.grad, xr.grad, RTOL, 1e-6, "avgpool dx %dx%d" % (H, W))
 
 
+def test_maxpool2_and_l1_mean(ops):
+    """MaxPool2d(2,2) incl. odd sizes and tied maxima (gradient goes to the first maximum, as ATen);
+    mean |a-b| and its gradient (sign(0) = 0)."""
+    g = torch.Generator().manual_seed(10)
+    for H, W in ((6, 8), (7, 9), (36, 44)):
+        x = torch.round(torch.randn(2, 12, H, W, generator=g) * 2).clamp_min(0) / 2      # many ties, many zeros
+        xr = x.clone().requires_grad_(True)
+        y_ref = F.max_pool2d(xr, kernel_size=2, stride=2)
+        gy = torch.randn(y_ref.shape, generator=g)
+        y_ref.backward(gy)
+        xd = dev(x, True)
+        y = ops.maxpool2(xd)
+        assert_close(y, y_ref, 0, 0, "maxpool %dx%d (bit exact)" % (H, W))
+        y.backward(gy.cuda())
+        assert_close(xd.grad, xr.grad, 0, 0, "maxpool dx %dx%d (bit exact)" % (H, W))
+    for shape in ((2, 8, 5, 7), (3, 64, 33, 31), (1, 4, 1, 1)):
+        a = torch.randn(shape, generator=g)
+        b = torch.randn(shape, generator=g)
+        b[0, :2] = a[0, :2]                                                              # exact zeros of a-b
+        ar = a.clone().requires_grad_(True)
+        l_ref = F.l1_loss(ar, b) * 3.0
+        l_ref.backward()
+        ad = dev(a, True)
+        l = ops.l1_mean(ops.nhwc(ad), ops.nhwc(b.cuda())) * 3.0
+        assert_close(l, l_ref, 1e-5, 1e-7, "l1 mean %s" % (shape,))
+        l.backward()
+        assert_close(ad.grad, ar.grad, 1e-6, 1e-9, "l1 grad %s" % (shape,))
+
+
 # ------------------------------------------------------------------------------------ layout
 def test_layout_golden(ops):
     """boxes_to_layout against the reference's own output (grid_sample + scatter_add)."""

@@ -230,6 +230,73 @@ def test_two_steps_vs_oracle_128(cuda):
             assert_close(D[k].reshape(()), Do[k].reshape(()), 2e-3 if step else 2e-4, 1e-5, "step %d D %s" % (step, k))
 
 
+def test_vgg_loss_vs_reference(cuda):
+    """VGG19 + VGGLoss (reference loss.py:102-117) with the fixture's seeded weights: features, loss and
+    the gradient w.r.t. the generated image; state_dict keys equal the reference's VGG19."""
+    from canonicalsg2im_amd.spade.models.networks.loss import VGGLoss
+    meta, a = load_golden("vgg_loss")
+    st = state_from_shapes(meta["shapes"], seed=31, requires_grad=False)
+    crit = VGGLoss([], weights="random")
+    assert set(crit.vgg.state_dict().keys()) == set(meta["shapes"].keys())
+    crit.vgg.load_state_dict(st)
+    crit = crit.to(cuda)
+    assert not any(p.requires_grad for p in crit.parameters())
+    x = a["x"].cuda().requires_grad_(True)
+    feats = crit.vgg(x)
+    for i, f in enumerate(feats):
+        assert_close(f.abs().mean(), a["feat_abs_mean_%d" % i], RTOL, 1e-6, "vgg feat mean %d" % i)
+        if i >= 2:
+            assert_close(f, a["feat_%d" % i], RTOL, 1e-5, "vgg feat %d" % i)
+    loss = crit(x, a["y"].cuda())
+    assert_close(loss, a["loss"], RTOL, 1e-6, "vgg loss")
+    loss.backward()
+    # sign(a-b) and ReLU gates flip on ulp-level feature differences: tolerance relative to the gradient's scale
+    assert_close(x.grad, a["grad_x"], RTOL, 2e-3 * float(a["grad_x"].abs().max()), "vgg dx")
+
+
+def test_vgg19_needs_weights(cuda, monkeypatch):
+    """Without pretrained weights the constructor refuses (no silent random features)."""
+    from canonicalsg2im_amd.spade.models.networks.architecture import VGG19
+    monkeypatch.delenv("CSG_VGG19_WEIGHTS", raising=False)
+    monkeypatch.delenv("CSG_VGG19_RANDOM", raising=False)
+    try:
+        import torchvision  # noqa: F401
+        pytest.skip("torchvision present")
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError, match="CSG_VGG19_WEIGHTS"):
+        VGG19()
+
+
+def test_step_with_vgg_loss_vs_oracle(cuda, monkeypatch):
+    """The default objective (VGG term on, object discriminator on) for one step at 64x64: every
+    loss term of the HIP trainer against the oracle with the same (random-feature) VGG weights."""
+    import oracle
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
+    monkeypatch.setenv("CSG_VGG19_RANDOM", "1")
+    vocab = make_vocab("coco")
+    opt = T.make_opt(vocab, ["--image_size", "64,64", "--ngf", "8", "--ndf", "8", "--batch_size", "3",
+                             "--gconv_hidden_dim", "128", "--gconv_dim", "64"])
+    assert not opt.no_vgg_loss and not opt.use_img_disc
+    torch.manual_seed(6)
+    tr = T.Trainer(opt, cuda)
+    ts = T.oracle_state_from(tr, oracle)
+    assert ts.vgg is not None
+    batch = make_batch(vocab, BatchConfig(3, 64, 3, 8, "random"), seed=50)
+    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    Go, Do, _ = oracle.train_step(ts, batch)
+    assert set(G.keys()) == set(Go.keys()) and "VGG" in G
+    for k in ("bbox_pred", "GAN_Img", "GAN_Feat", "VGG", "GAN_Obj", "GAN_Ac", "total_loss"):
+        assert_close(G[k].reshape(()), Go[k].reshape(()), 2e-4, 1e-5, "G %s" % k)
+    for k in ("D_img_fake", "D_img_real", "D_obj", "D_ac_real", "D_ac_fake"):
+        assert_close(D[k].reshape(()), Do[k].reshape(()), 2e-4, 1e-5, "D %s" % k)
+    # the generator moved the same way: compare a large weight after the Adam step where gradients are significant
+    sg, g, d = T.split_state(tr)
+    w, wo = g["conv_img.weight"], ts.g["conv_img.weight"]
+    assert_close(w, wo, 0, 2.2 * opt.learning_rate, "conv_img.weight after step")
+
+
 # ----------------------------------------------------------------------------- full-size properties
 def test_layout_full_size_checksum_and_linearity(cuda):
     """256x256, S=32, 30 objects/img, B=16 (config C3): (1) sum over pixels of the layout equals

@@ -233,3 +233,20 @@ def test_default_train_step_with_object_discriminator():
             assert_close(d[k[8:]], v, 1e-3, 2e-6, k)             # u after FIVE power iterations
         elif k.startswith("o_after:") and ("running_" in k or "num_batches" in k):
             assert_close(dobj[k[8:]], v, 1e-3, 2e-6, k)
+
+
+def test_vgg_loss():
+    """VGG19 slices + VGGLoss (loss.py:102-117) on the seeded weights the fixture was made with."""
+    meta, a = load_golden("vgg_loss")
+    st = state_from_shapes(meta["shapes"], seed=31, requires_grad=False)
+    x = a["x"].clone().requires_grad_(True)
+    feats = oracle.vgg19_features(st, x)
+    assert len(feats) == 5
+    for i, f in enumerate(feats):
+        assert_close(f.abs().mean(), a["feat_abs_mean_%d" % i], RTOL, ATOL, "vgg feat mean %d" % i)
+        if i >= 2:
+            assert_close(f, a["feat_%d" % i], RTOL, 1e-5, "vgg feat %d" % i)
+    loss = oracle.vgg_loss(st, x, a["y"])
+    assert_close(loss, a["loss"], RTOL, ATOL, "vgg loss")
+    loss.backward()
+    assert_close(x.grad, a["grad_x"], RTOL, 1e-6, "vgg dx")
