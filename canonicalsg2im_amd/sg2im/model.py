@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from .attribute_embed import AttributeEmbeddings
 from .graph import GraphTopology, GraphTripleConv, get_predicates_weights
-from .layers import build_mlp
+from .layers import BatchNormAct, Conv2d, Interpolate, _FusedActivation, build_mlp
 
 
 def get_conv_converse(model):
@@ -44,8 +44,33 @@ class Sg2LayoutModel(nn.Module):
         self.box_net = build_mlp([args["gconv_dim"], args["gconv_hidden_dim"], 4],
                                  batch_norm=args["mlp_normalization"], final_nonlinearity=None)
         self.mask_net = None
+        self.mask_noise = None       # tests pin the (1, mask_noise_dim) noise row here; None = draw per forward
         if args["mask_size"] is not None and args["mask_size"] > 0:
-            raise NotImplementedError("mask_size > 0 (mask net) is outside the hot path (SURVEY.md §8f row 4)")
+            self.mask_net = self._build_mask_net(args['g_mask_dim'], args["mask_size"])
+
+    def _build_mask_net(self, dim, mask_size):
+        """[Upsample x2, Conv3x3, BatchNorm2d, ReLU] * log2(M) + Conv1x1 -> 1 (reference model.py:67-79);
+        same nn.Sequential indices / state_dict keys, BatchNorm + ReLU fused into one pass."""
+        layers, cur_size = [], 1
+        while cur_size < mask_size:
+            layers.append(Interpolate(scale_factor=2, mode='nearest'))
+            layers.append(Conv2d(dim, dim, kernel_size=3, padding=1))
+            layers.append(BatchNormAct(dim, fused_slope=0.0))
+            layers.append(_FusedActivation())
+            cur_size *= 2
+        if cur_size != mask_size:
+            raise ValueError('Mask size must be a power of 2')
+        layers.append(Conv2d(dim, 1, kernel_size=1))
+        return nn.Sequential(*layers)
+
+    def create_mask_vecs(self, objs, obj_vecs):
+        """obj_vecs || one noise row shared by every object of the batch (reference model.py:81-88)."""
+        B, O = objs.size(0), objs.size(1)
+        noise = self.mask_noise
+        if noise is None:
+            noise = torch.randn((1, self.mask_noise_dim), dtype=obj_vecs.dtype, device=obj_vecs.device)
+        noise = noise.to(obj_vecs.device).repeat((B, O, 1)).view(B, O, self.mask_noise_dim)
+        return torch.cat([obj_vecs, noise], dim=-1)
 
     def forward(self, objs, triplets, triplet_type, boxes_gt=None, masks_gt=None):
         s, p, o = triplets[..., 0], triplets[..., 1], triplets[..., 2]
@@ -57,7 +82,13 @@ class Sg2LayoutModel(nn.Module):
         for conv in self.gconvs:
             obj_vecs, pred_vecs = conv(obj_vecs, pred_vecs, edges, pred_indicators, triplet_type, p, topology=topo)
         boxes_pred = self.box_net(obj_vecs)
-        return obj_vecs, boxes_pred, None
+        masks_pred = None
+        if self.args["mask_size"] > 0:                                   # model.py:118-123
+            B, O = objs.size(0), objs.size(1)
+            mask_vecs = self.create_mask_vecs(objs, obj_vecs)
+            scores = self.mask_net(mask_vecs.view(B * O, -1, 1, 1))
+            masks_pred = scores.reshape(B, O, scores.size(2), scores.size(3)).sigmoid()
+        return obj_vecs, boxes_pred, masks_pred
 
     def attribute_embedding_pred(self, p):
         from .. import ops

@@ -55,8 +55,12 @@ class Pix2PixModel(torch.nn.Module):
             l = l * mask
             G["bbox_pred_all"] = l.view(boxes.shape).sum(dim=[1, 2]) / mask.view(boxes.shape[0], boxes.shape[1]).sum(dim=1)
             G["bbox_pred"] = G["bbox_pred_all"].mean()
-            if masks is not None:
-                raise NotImplementedError("mask losses (--mask_size > 0) are outside the hot path")
+            if masks is not None:                                   # :88-92 — BCE over the real objects' masks
+                M = masks.size(-1)
+                bce = F.binary_cross_entropy(masks_pred.reshape(-1, M, M), masks.reshape(-1, M, M).float(),
+                                             reduction='none').mean(dim=(1, 2))
+                # mean over real objects, as masks_loss[object_mask.nonzero()[:, 0]].mean() without the host sync
+                G["masks_pred"] = (bce * mask.view(-1)).sum() / mask.sum() * self.opt.mask_pred_loss_weight
         if not self.opt.skip_generation:
             pred_fake = self.netD_img(imgs_pred, objs, boxes, layout_masks=masks, gt_train=True, fool=False)
             G['GAN_Img'] = self.criterionGAN(pred_fake, True, for_discriminator=False).squeeze(0) \
@@ -78,7 +82,18 @@ class Pix2PixModel(torch.nn.Module):
                     * self.opt.discriminator_obj_loss_weight
                 G['GAN_Ac'] = ac_loss * self.opt.ac_loss_weight
                 if getattr(self, 'netD_mask', None) is not None and self.opt.mask_size > 0 and masks_pred is not None:
-                    raise NotImplementedError("mask discriminator losses (--mask_size > 0) are outside the hot path")
+                    scores_fake = self.netD_mask(objs, masks_pred)                                # :124-138
+                    G['GAN_Mask'] = self.criterionGAN(scores_fake, True, for_discriminator=False).squeeze(0) \
+                        * self.opt.discriminator_img_loss_weight
+                    if not self.opt.no_ganFeat_loss:
+                        scores_real = self.netD_mask(objs, masks)
+                        num_D = len(scores_fake)
+                        feat = imgs.new_zeros(1)
+                        for i in range(num_D):
+                            for j in range(len(scores_fake[i]) - 1):
+                                feat = feat + self.criterionFeat(scores_fake[i][j], scores_real[i][j].detach()) \
+                                    * self.opt.lambda_feat / num_D
+                        G['GAN_Mask_Feat'] = feat.squeeze(0)
         scalars = [k for k in G if k != "bbox_pred_all"]
         G['total_loss'] = torch.stack([G[k] for k in scalars], dim=0).sum()
         return G
@@ -105,8 +120,12 @@ class Pix2PixModel(torch.nn.Module):
             D["D_ac_real"] = ac_loss_real
             D["D_ac_fake"] = ac_loss_fake
             D["total_obj_loss"] = torch.stack([D["D_obj"], D["D_ac_real"], D["D_ac_fake"]], dim=0).sum()
-            if self.opt.mask_size > 0 and model_out[2] is not None:
-                raise NotImplementedError("mask discriminator losses (--mask_size > 0) are outside the hot path")
+            if self.opt.mask_size > 0 and model_out[2] is not None:                               # :188-196
+                scores_fake = self.netD_mask(objs, model_out[2].detach())
+                scores_real = self.netD_mask(objs, masks)
+                D["D_mask_fake"] = self.criterionGAN(scores_fake, False, for_discriminator=True) * 0.5
+                D["D_mask_real"] = self.criterionGAN(scores_real, True, for_discriminator=True) * 0.5
+                D["total_mask_loss"] = torch.stack([D["D_mask_fake"], D["D_mask_real"]], dim=0).sum()
         return D
 
     def forward(self, batch, model_out, mode):

@@ -183,18 +183,22 @@ class MultiscaleMaskDiscriminator2(BaseNetwork):
             self.add_module('discriminator_%d' % i, NLayerMaskDiscriminator2(opt))
 
     def downsample(self, input):
-        return ops.avgpool3s2(input) if input.size(1) % 4 == 0 else \
-            F.avg_pool2d(input, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)
+        return ops.avgpool3s2(input)
 
     def forward(self, objs, layout_masks, gt_train=True):
+        """Input per REAL object (image-major order, as the reference's per-sample loop): one-hot(class)
+        broadcast over the M x M grid, then the mask as the last channel; built directly with the channel
+        count padded to a multiple of 4 (zeros) so that conv and avg-pool kernels take it as is."""
         valid = real_object_mask(objs, self.opt.vocab).bool()
         nz = valid.nonzero()
         labels = objs[nz[:, 0], nz[:, 1], 0]
         masks = layout_masks[nz[:, 0], nz[:, 1]].float()
-        M = masks.size(-1)
+        N, M = masks.size(0), masks.size(-1)
         ncls = max(self.opt.vocab['object_name_to_idx'].values()) + 1
-        one_hot = F.one_hot(labels, ncls).to(masks.dtype).view(-1, ncls, 1, 1).expand(-1, -1, M, M)
-        x = torch.cat([one_hot, masks.unsqueeze(1)], dim=1)
+        Cp = ncls + 1 + (-(ncls + 1)) % 4
+        one_hot = F.one_hot(labels, Cp).to(masks.dtype).view(N, Cp, 1, 1)
+        x = one_hot + F.pad(masks.unsqueeze(1), (0, 0, 0, 0, ncls, Cp - ncls - 1))      # (N, Cp, M, M)
+        x = ops.nhwc(x)
         result = []
         for name, D in self.named_children():
             if name.startswith('discriminator'):

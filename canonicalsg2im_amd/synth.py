@@ -74,6 +74,7 @@ class BatchConfig:
     pad_objects_to: int = 0        # 0 = pad to the batch max
     pad_triplets_to: int = 0
     extra: dict = field(default_factory=dict)
+    mask_size: int = 0             # M > 0: per-object (M,M) int64 segmentation masks (sg2im/data/coco.py:301-346)
 
 
 # The five BASELINE.json configurations.
@@ -170,9 +171,22 @@ def make_batch(vocab: Dict, cfg: BatchConfig, seed: int = 0) -> Tuple:
         ttypes[b, :tt.shape[0]] = tt
     imgs = rng.uniform(-1.0, 1.0, size=(B, 3, H, H)).astype(np.float32)
     conv_counts = np.zeros((B, num_preds, num_preds + 1), np.float32)
+    masks = None
+    if cfg.mask_size > 0:
+        # an axis-aligned ellipse per real object; padded rows stay 0 (coco.py:512-515)
+        M = cfg.mask_size
+        masks_np = np.zeros((B, O, M, M), np.int64)
+        yy, xx = np.meshgrid((np.arange(M) + 0.5) / M, (np.arange(M) + 0.5) / M, indexing="ij")
+        for b, (o, _, _, _) in enumerate(per):
+            n = o.shape[0]
+            c = rng.uniform(0.35, 0.65, size=(n, 2))
+            r = rng.uniform(0.2, 0.5, size=(n, 2))
+            for i in range(n):
+                masks_np[b, i] = (((xx - c[i, 0]) / r[i, 0]) ** 2 + ((yy - c[i, 1]) / r[i, 1]) ** 2 <= 1.0)
+        masks = torch.from_numpy(masks_np)
     return (torch.from_numpy(imgs), torch.from_numpy(objs), torch.from_numpy(boxes),
             torch.from_numpy(triplets), torch.from_numpy(conv_counts), torch.from_numpy(ttypes),
-            None, torch.arange(B, dtype=torch.int64))
+            masks, torch.arange(B, dtype=torch.int64))
 
 
 def shard_batch(batch: Tuple, rank: int, world_size: int) -> Tuple:

@@ -42,9 +42,14 @@ class Trainer:
             csg_dist.broadcast_module(self.discriminator.obj_discriminator)
             self.dobj_params = list(self.discriminator.obj_discriminator.parameters())
             self.dobj_buckets = csg_dist.GradBuckets(self.dobj_params)
+        self.dmask_params, self.dmask_buckets = [], None
+        if not opt.use_img_disc and opt.mask_size > 0:
+            csg_dist.broadcast_module(self.discriminator.mask_discriminator)
+            self.dmask_params = list(self.discriminator.mask_discriminator.parameters())
+            self.dmask_buckets = csg_dist.GradBuckets(self.dmask_params)
 
     def _d_requires_grad(self, flag):
-        for p in self.d_params + self.dobj_params:
+        for p in self.d_params + self.dobj_params + self.dmask_params:
             p.requires_grad_(flag)
 
     def step(self, batch):
@@ -79,6 +84,11 @@ class Trainer:
                 D["total_obj_loss"].backward()
                 self.dobj_buckets.all_reduce_mean()
                 self.discriminator.optimizer_d_obj.step()
+            if opt.mask_size > 0 and "total_mask_loss" in D:             # train.py:482-485
+                self.discriminator.optimizer_d_mask.zero_grad(set_to_none=True)
+                D["total_mask_loss"].backward()
+                self.dmask_buckets.all_reduce_mean()
+                self.discriminator.optimizer_d_mask.step()
         return G, D
 
 
@@ -122,4 +132,9 @@ def oracle_state_from(trainer, oracle_mod):
     vgg = None
     if hasattr(trainer.gans_model, "criterionVGG"):
         vgg = {k: v.detach().cpu().clone() for k, v in trainer.gans_model.criterionVGG.vgg.state_dict().items()}
-    return oracle_mod.TrainState(trainer.opt, sg, leafs(g, unused), leafs(d, unused), dobj, vgg)
+    dmask = noise = None
+    if not trainer.opt.use_img_disc and trainer.opt.mask_size > 0:
+        dmask = leafs(dict(trainer.discriminator.mask_discriminator.state_dict()))
+        noise = trainer.model.sg_to_layout.module.mask_noise
+        noise = None if noise is None else noise.detach().cpu().clone()
+    return oracle_mod.TrainState(trainer.opt, sg, leafs(g, unused), leafs(d, unused), dobj, vgg, dmask, noise)

@@ -20,7 +20,7 @@ __all__ = [
     "spectral_weight", "batch_norm_train", "syncbn_multi_replica", "spade", "spade_resblock",
     "generator_forward", "instance_norm", "nlayer_discriminator", "multiscale_discriminator",
     "hinge_loss", "gan_loss_multiscale", "generator_losses", "discriminator_losses", "TrainState",
-    "train_step", "make_adam_groups", "crop_objects", "ac_crop_discriminator", "bce_loss", "vgg19_features", "vgg_loss",
+    "train_step", "make_adam_groups", "crop_objects", "ac_crop_discriminator", "bce_loss", "vgg19_features", "vgg_loss", "mask_net", "mask_discriminator",
 ]
 
 ORIGINAL_EDGE, TRANSITIVE_EDGE = 0, 1          # sg2im/data/base_dataset.py:7-8
@@ -84,8 +84,23 @@ def graph_triple_conv(state, prefix, obj_vecs, pred_vecs, edges, pred_indicators
     return new_obj, new_p
 
 
-def sg2layout_forward(state, vocab, objs, triplets, triplet_type, prefix=""):
-    """`Sg2LayoutModel.forward` (sg2im/model.py:90-124), mask branch off (mask_size == 0)."""
+def mask_net(state, prefix, mask_vecs, training=True):
+    """`Sg2LayoutModel.mask_net` (sg2im/model.py:67-79): [nearest x2, Conv3x3, BatchNorm2d, ReLU]* then
+    Conv1x1 -> 1, over EVERY (sample, slot) pair incl. padded slots (model.py:121)."""
+    x = mask_vecs.reshape(-1, mask_vecs.shape[-1], 1, 1)
+    i = 0
+    while (prefix + "%d.running_mean" % (i + 2)) in state:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        x = F.conv2d(x, state[prefix + "%d.weight" % (i + 1)], state[prefix + "%d.bias" % (i + 1)], padding=1)
+        x = F.relu(_batch_norm_affine(state, prefix + "%d." % (i + 2), x, training))
+        i += 4
+    return F.conv2d(x, state[prefix + "%d.weight" % i], state[prefix + "%d.bias" % i])
+
+
+def sg2layout_forward(state, vocab, objs, triplets, triplet_type, prefix="", mask_noise=None):
+    """`Sg2LayoutModel.forward` (sg2im/model.py:90-124).  The mask branch (:118-123) runs when the
+    state holds a mask net; `mask_noise` is the (1, mask_noise_dim) row `create_mask_vecs` draws
+    with torch.randn (:85) — passed in so that both sides of a comparison use the same draw."""
     s, p, o = triplets[..., 0], triplets[..., 1], triplets[..., 2]
     edges = torch.stack([s, o], dim=-1)
     pred_indicators = p != vocab["pred_name_to_idx"]["__padding__"]                # :107
@@ -98,7 +113,13 @@ def sg2layout_forward(state, vocab, objs, triplets, triplet_type, prefix=""):
                                                 edges, pred_indicators, triplet_type, p, w_trans)
         i += 1
     boxes_pred = mlp2(state, prefix + "box_net.", obj_vecs, final_relu=False)      # :115
-    return obj_vecs, boxes_pred, None
+    masks_pred = None
+    if (prefix + "mask_net.1.weight") in state:                                    # :118-123
+        B, O = objs.shape[0], objs.shape[1]
+        noise = mask_noise.repeat((B, O, 1)).view(B, O, -1)                        # :85-86
+        scores = mask_net(state, prefix + "mask_net.", torch.cat([obj_vecs, noise], dim=-1))
+        masks_pred = scores.view(B, O, scores.shape[2], scores.shape[3]).sigmoid()
+    return obj_vecs, boxes_pred, masks_pred
 
 
 # --------------------------------------------------------------------------- layout
@@ -169,12 +190,16 @@ def masks_to_layout(vecs, boxes, masks, H, W=None):
     return out.unsqueeze(0)
 
 
-def batched_layout(obj_vecs, objs, boxes, vocab, H):
-    """The per-sample loop of spade/models/networks/generator.py:82-96 and discriminator.py:102-119."""
+def batched_layout(obj_vecs, objs, boxes, vocab, H, masks=None):
+    """The per-sample loop of spade/models/networks/generator.py:82-96 and discriminator.py:102-119
+    (masks layout when `masks` is given, else boxes layout)."""
     segs = []
     for b in range(obj_vecs.shape[0]):
         m = remove_dummy_objects(objs[b], vocab)
-        segs.append(boxes_to_layout(obj_vecs[b][m], boxes[b][m], H, H))
+        if masks is not None:
+            segs.append(masks_to_layout(obj_vecs[b][m], boxes[b][m], masks[b][m], H, H))
+        else:
+            segs.append(boxes_to_layout(obj_vecs[b][m], boxes[b][m], H, H))
     return torch.cat(segs, dim=0)
 
 
@@ -248,13 +273,13 @@ def spade_resblock(state, prefix, x, seg, training):
 
 
 def generator_forward(state, vocab, image_size, objs, layout_boxes, training=True, prefix="",
-                      num_upsampling_layers="normal"):
-    """`SPADEGenerator.forward` (spade/models/networks/generator.py:79-127), boxes layout."""
+                      num_upsampling_layers="normal", layout_masks=None):
+    """`SPADEGenerator.forward` (spade/models/networks/generator.py:79-127)."""
     H = image_size
     n_up = {"normal": 5, "more": 6, "most": 7}[num_upsampling_layers]                         # :64-77
     sw = H // (2 ** n_up)
     obj_vecs = attribute_embeddings(state, prefix + "attribute_embedding.", objs)             # :80
-    seg = batched_layout(obj_vecs, objs, layout_boxes, vocab, H)                              # :82-96
+    seg = batched_layout(obj_vecs, objs, layout_boxes, vocab, H, layout_masks)                # :82-96
     x = F.interpolate(seg, size=(sw, sw))                                                     # :99
     x = F.conv2d(x, state[prefix + "fc.weight"], state[prefix + "fc.bias"], padding=1)        # :100
     up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
@@ -302,16 +327,38 @@ def nlayer_discriminator(state, prefix, x, training):
     return outs
 
 
-def multiscale_discriminator(state, vocab, image_size, img, objs, layout_boxes, training=True, prefix=""):
+def multiscale_discriminator(state, vocab, image_size, img, objs, layout_boxes, training=True, prefix="",
+                             layout_masks=None):
     """`MultiscaleDiscriminator.forward` (discriminator.py:97-131): D's own embedding (with fc,
     :71-72) -> layout -> cat(img, layout) -> num_D scales, avg_pool(3,s2,p1, no pad count) between."""
     obj_vecs = attribute_embeddings(state, prefix + "attribute_embedding.", objs)
-    seg = batched_layout(obj_vecs, objs, layout_boxes, vocab, image_size)
+    seg = batched_layout(obj_vecs, objs, layout_boxes, vocab, image_size, layout_masks)
     inp = torch.cat([img, seg], dim=1)
     result, i = [], 0
     while (prefix + "discriminator_%d.model0.0.weight" % i) in state:
         result.append(nlayer_discriminator(state, prefix + "discriminator_%d." % i, inp, training))
         inp = F.avg_pool2d(inp, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)   # :92-93
+        i += 1
+    return result
+
+
+def mask_discriminator(state, vocab, objs, layout_masks, training=True, prefix=""):
+    """`MultiscaleMaskDiscriminator2.forward` (discriminator.py:264-308): per real object,
+    one-hot(class) broadcast over the mask grid ‖ mask -> NLayerMaskDiscriminator2 at num_D scales."""
+    ncls = max(vocab["object_name_to_idx"].values()) + 1
+    rows = []
+    for b in range(layout_masks.shape[0]):
+        m = remove_dummy_objects(objs[b], vocab)
+        mk = layout_masks[b][m]
+        lab = objs[b][m]
+        O, M = mk.shape[0], mk.shape[1]
+        one_hot = torch.zeros((O, ncls), dtype=mk.dtype).scatter_(1, lab.view(-1, 1).long(), 1.0)
+        rows.append(torch.cat([one_hot.view(O, -1, 1, 1).expand(-1, -1, M, M), mk.unsqueeze(1)], dim=1))
+    inp = torch.cat(rows, dim=0).float()
+    result, i = [], 0
+    while (prefix + "discriminator_%d.model0.0.weight" % i) in state:
+        result.append(nlayer_discriminator(state, prefix + "discriminator_%d." % i, inp, training))
+        inp = F.avg_pool2d(inp, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)
         i += 1
     return result
 
@@ -425,12 +472,13 @@ def vgg_loss(state, x, y):
     return loss
 
 
-def generator_losses(opt, d_state, batch, model_out, training=True, dobj_state=None, vgg_state=None):
+def generator_losses(opt, d_state, batch, model_out, training=True, dobj_state=None, vgg_state=None,
+                     dmask_state=None):
     """`Pix2PixModel.compute_generator_loss` (sg2im/pix2pix_model.py:65-143) with mask_size 0; the VGG
     term (:111-113) unless --no_vgg_loss; the object-discriminator terms (:115-121) when
     use_img_disc == 0."""
-    imgs, objs, boxes = batch[0], batch[1], batch[2]
-    imgs_pred, boxes_pred, _ = model_out
+    imgs, objs, boxes, masks = batch[0], batch[1], batch[2], batch[6]
+    imgs_pred, boxes_pred, masks_pred = model_out
     H = opt.image_size[0]
     G = {}
     if not opt.skip_graph_model:                                                              # :71-85
@@ -442,11 +490,17 @@ def generator_losses(opt, d_state, batch, model_out, training=True, dobj_state=N
         l = l * mask
         G["bbox_pred_all"] = l.view(boxes.shape).sum(dim=[1, 2]) / mask.view(boxes.shape[0], boxes.shape[1]).sum(dim=1)
         G["bbox_pred"] = G["bbox_pred_all"].mean()
+        if masks is not None:                                                                 # :88-92
+            M = masks.shape[-1]
+            bce = F.binary_cross_entropy(masks_pred.view(-1, M, M), masks.view(-1, M, M).float(),
+                                         reduction="none").mean(dim=(1, 2))
+            G["masks_pred"] = (bce[mask.bool().nonzero()[:, 0]] * opt.mask_pred_loss_weight).mean()
     if not opt.skip_generation:
-        fake = multiscale_discriminator(d_state, opt.vocab, H, imgs_pred, objs, boxes, training)   # :96
+        fake = multiscale_discriminator(d_state, opt.vocab, H, imgs_pred, objs, boxes, training,
+                                        layout_masks=masks)                                   # :96
         G["GAN_Img"] = gan_loss_multiscale(fake, True, False) * opt.discriminator_img_loss_weight
         if not opt.no_ganFeat_loss:                                                           # :99-109
-            real = multiscale_discriminator(d_state, opt.vocab, H, imgs, objs, boxes, training)
+            real = multiscale_discriminator(d_state, opt.vocab, H, imgs, objs, boxes, training, layout_masks=masks)
             feat = torch.zeros(())
             for i in range(len(fake)):
                 for j in range(len(fake[i]) - 1):
@@ -459,23 +513,33 @@ def generator_losses(opt, d_state, batch, model_out, training=True, dobj_state=N
                                                             opt.crop_size, training)
             G["GAN_Obj"] = hinge_loss(scores_fake, True, False) * opt.discriminator_obj_loss_weight
             G["GAN_Ac"] = ac_loss * opt.ac_loss_weight
+            if opt.mask_size > 0 and masks_pred is not None:                                  # :124-138
+                mfake = mask_discriminator(dmask_state, opt.vocab, objs, masks_pred, training)
+                G["GAN_Mask"] = gan_loss_multiscale(mfake, True, False) * opt.discriminator_img_loss_weight
+                if not opt.no_ganFeat_loss:
+                    mreal = mask_discriminator(dmask_state, opt.vocab, objs, masks, training)
+                    feat = torch.zeros(())
+                    for i in range(len(mfake)):
+                        for j in range(len(mfake[i]) - 1):
+                            feat = feat + F.l1_loss(mfake[i][j], mreal[i][j].detach()) * opt.lambda_feat / len(mfake)
+                    G["GAN_Mask_Feat"] = feat
     G["total_loss"] = torch.stack([v for k, v in G.items() if k != "bbox_pred_all"]).sum()    # :141-142
     return G
 
 
-def discriminator_losses(opt, d_state, batch, model_out, training=True, dobj_state=None):
+def discriminator_losses(opt, d_state, batch, model_out, training=True, dobj_state=None, dmask_state=None):
     """`Pix2PixModel.compute_discriminator_loss` (pix2pix_model.py:145-202)."""
-    imgs, objs, boxes = batch[0], batch[1], batch[2]
+    imgs, objs, boxes, masks = batch[0], batch[1], batch[2], batch[6]
     imgs_pred = model_out[0].detach()
     H = opt.image_size[0]
-    fake = multiscale_discriminator(d_state, opt.vocab, H, imgs_pred, objs, boxes, training)   # :159
-    real = multiscale_discriminator(d_state, opt.vocab, H, imgs, objs, boxes, training)        # :161
+    fake = multiscale_discriminator(d_state, opt.vocab, H, imgs_pred, objs, boxes, training, layout_masks=masks)  # :159
+    real = multiscale_discriminator(d_state, opt.vocab, H, imgs, objs, boxes, training, layout_masks=masks)       # :161
     D = {"D_img_fake": gan_loss_multiscale(fake, False, True),
          "D_img_real": gan_loss_multiscale(real, True, True)}
     D["total_img_loss"] = D["D_img_fake"] + D["D_img_real"]                                    # :166
     if not opt.use_img_disc:
         with torch.no_grad():                                                                  # :168-172: logged only
-            wrong = multiscale_discriminator(d_state, opt.vocab, H, imgs, objs, boxes, training)
+            wrong = multiscale_discriminator(d_state, opt.vocab, H, imgs, objs, boxes, training, layout_masks=masks)
             D["D_img_wrong"] = gan_loss_multiscale(wrong, False, True) * (1 / 2) * (.5)
         s_real, ac_real, _ = ac_crop_discriminator(dobj_state, opt.vocab, imgs, objs, boxes, opt.crop_size, training)
         s_fake, ac_fake, _ = ac_crop_discriminator(dobj_state, opt.vocab, imgs_pred, objs, boxes, opt.crop_size,
@@ -484,6 +548,12 @@ def discriminator_losses(opt, d_state, batch, model_out, training=True, dobj_sta
         D["D_obj"] = (bce_loss(r, torch.ones_like(r)) + bce_loss(f, torch.zeros_like(f))) * 0.5
         D["D_ac_real"], D["D_ac_fake"] = ac_real, ac_fake
         D["total_obj_loss"] = D["D_obj"] + D["D_ac_real"] + D["D_ac_fake"]                     # :185
+        if opt.mask_size > 0 and model_out[2] is not None:                                     # :188-196
+            mfake = mask_discriminator(dmask_state, opt.vocab, objs, model_out[2].detach(), training)
+            mreal = mask_discriminator(dmask_state, opt.vocab, objs, masks, training)
+            D["D_mask_fake"] = gan_loss_multiscale(mfake, False, True) * 0.5
+            D["D_mask_real"] = gan_loss_multiscale(mreal, True, True) * 0.5
+            D["total_mask_loss"] = D["D_mask_fake"] + D["D_mask_real"]
     return D
 
 
@@ -507,9 +577,14 @@ def make_adam_groups(sg_state, g_state, lr):
 class TrainState:
     """Leaf tensors + optimizers of one replica (what `scripts.train.main` builds at :312-329)."""
 
-    def __init__(self, opt, sg_state, g_state, d_state, dobj_state=None, vgg_state=None):
+    def __init__(self, opt, sg_state, g_state, d_state, dobj_state=None, vgg_state=None, dmask_state=None,
+                 mask_noise=None):
         self.opt, self.sg, self.g, self.d, self.dobj = opt, sg_state, g_state, d_state, dobj_state
         self.vgg = vgg_state                                   # frozen VGG19 weights (None with --no_vgg_loss)
+        self.dmask, self.mask_noise = dmask_state, mask_noise  # mask branch (--mask_size > 0)
+        if dmask_state is not None:
+            pm = [v for v in dmask_state.values() if torch.is_tensor(v) and v.requires_grad]
+            self.optimizer_d_mask = torch.optim.Adam(pm, lr=opt.mask_learning_rate, betas=(opt.beta1, 0.999))  # :88-90
         if dobj_state is not None:
             po = [v for v in dobj_state.values() if torch.is_tensor(v) and v.requires_grad]
             self.optimizer_d_obj = torch.optim.Adam(po, lr=opt.learning_rate, betas=(opt.beta1, 0.999))  # :79-81
@@ -523,20 +598,24 @@ def train_step(ts, batch):
     """One iteration of scripts/train.py:353-393 (+ :468-485) with learned_converse=0 (VGG term when
     `ts.vgg` is given and --no_vgg_loss is absent; object discriminator when use_img_disc=0).  Returns (G_losses, D_losses, imgs_pred)."""
     opt = ts.opt
-    imgs, objs, boxes, triplets, _, triplet_type = batch[:6]
+    imgs, objs, boxes, triplets, _, triplet_type, masks = batch[:7]
     H = opt.image_size[0]
-    _, boxes_pred, _ = sg2layout_forward(ts.sg, opt.vocab, objs, triplets, triplet_type)      # meta_models.py:43
+    _, boxes_pred, masks_pred = sg2layout_forward(ts.sg, opt.vocab, objs, triplets, triplet_type,
+                                                  mask_noise=ts.mask_noise)                   # meta_models.py:43
+    layout_masks = masks_pred if masks is None else masks                                     # :48
     imgs_pred = generator_forward(ts.g, opt.vocab, H, objs, boxes, True,
-                                  num_upsampling_layers=opt.num_upsampling_layers)            # :47-49 (GT boxes)
-    model_out = (imgs_pred, boxes_pred, None)
-    G = generator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj, vgg_state=ts.vgg)   # train.py:361
+                                  num_upsampling_layers=opt.num_upsampling_layers,
+                                  layout_masks=layout_masks)                                  # :47-49 (GT boxes)
+    model_out = (imgs_pred, boxes_pred, masks_pred)
+    G = generator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj, vgg_state=ts.vgg,
+                         dmask_state=ts.dmask)                                                # train.py:361
     ts.optimizer.zero_grad()
-    for v in list(ts.d.values()) + list((ts.dobj or {}).values()):
+    for v in list(ts.d.values()) + list((ts.dobj or {}).values()) + list((ts.dmask or {}).values()):
         if torch.is_tensor(v) and v.grad is not None:
             v.grad = None
     G["total_loss"].backward()                                                                # :366-368
     ts.optimizer.step()
-    D = discriminator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj)                 # :390
+    D = discriminator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj, dmask_state=ts.dmask)   # :390
     ts.optimizer_d_img.zero_grad()                                                            # :470-472
     D["total_img_loss"].backward()
     ts.optimizer_d_img.step()
@@ -544,4 +623,8 @@ def train_step(ts, batch):
         ts.optimizer_d_obj.zero_grad()
         D["total_obj_loss"].backward()
         ts.optimizer_d_obj.step()
+    if opt.mask_size > 0 and "total_mask_loss" in D:                                          # :482-485
+        ts.optimizer_d_mask.zero_grad()
+        D["total_mask_loss"].backward()
+        ts.optimizer_d_mask.step()
     return G, D, imgs_pred.detach()

@@ -245,12 +245,12 @@ def fx_syncbn():
 
 
 class _Holder(torch.nn.Module):
-    def __init__(self, d, dobj=None):
+    def __init__(self, d, dobj=None, dmask=None):
         super().__init__()
         self.img_discriminator = d
         if dobj is not None:
             self.obj_discriminator = dobj
-            self.mask_discriminator = None
+            self.mask_discriminator = dmask
 
 
 def fx_crops():
@@ -325,6 +325,79 @@ def fx_step_objdisc():
                                 "state": "deterministic_state seeds sg=21 g=22 d=23 dobj=24",
                                 "shapes": {"sg": shapes_of(sg), "g": shapes_of(G, unused), "d": shapes_of(D, unused),
                                            "dobj": shapes_of(Dobj)}}, **arrays)
+
+
+def fx_step_masks():
+    """--mask_size 8: mask net, masks layout in G and D, mask BCE + mask discriminator terms, all four
+    optimiser steps (scripts/train.py:353-393, 468-485)."""
+    from spade.models.networks.discriminator import MultiscaleMaskDiscriminator2
+    torch.manual_seed(27)
+    vocab = make_vocab("tiny")
+    argv = ["--image_size", "64,64", "--embedding_dim", "8", "--gconv_dim", "16", "--gconv_hidden_dim", "24",
+            "--gconv_num_layers", "2", "--ngf", "4", "--ndf", "4", "--no_vgg_loss", "--batch_size", "2",
+            "--crop_size", "32", "--d_obj_arch", "C4-8-2,C4-16-2,C4-32-2", "--mask_size", "8",
+            "--g_mask_dim", "24", "--mask_noise_dim", "8", "--mask_pred_loss_weight", "0.5"]
+    opt = ref_opt(vocab, argv)
+    sg, G, D = Sg2LayoutModel(opt), SPADEGenerator(opt), MultiscaleDiscriminator(opt)
+    Dobj = AcCropDiscriminator(vocab=vocab, arch=opt.d_obj_arch, normalization=opt.d_normalization,
+                               activation=opt.d_activation, padding=opt.d_padding, object_size=opt.crop_size)
+    Dmask = MultiscaleMaskDiscriminator2(opt)
+    unused = ("repr_net", "image_encoder")
+    sg.load_state_dict(deterministic_state(sg.state_dict(), seed=41))
+    G.load_state_dict(deterministic_state(G.state_dict(), seed=42))
+    D.load_state_dict(deterministic_state(D.state_dict(), seed=43))
+    Dobj.load_state_dict(deterministic_state(Dobj.state_dict(), seed=44))
+    Dmask.load_state_dict(deterministic_state(Dmask.state_dict(), seed=45))
+    batch = make_batch(vocab, BatchConfig(2, 64, 2, 5, "packed", mask_size=8), seed=29)
+    imgs, objs, boxes, triplets, _, tt, masks = batch[:7]
+    arrays = {"imgs": npy(imgs), "objs": npy(objs), "boxes": npy(boxes), "triplets": npy(triplets), "tt": npy(tt),
+              "masks": npy(masks)}
+    gans = Pix2PixModel(opt, discriminator=_Holder(D, Dobj, Dmask))
+    for m in (sg, G, D, Dobj, Dmask):
+        m.train()
+    trans = [p for n, p in sg.named_parameters() if n == "trans_candidates_weights"]
+    base = [p for n, p in sg.named_parameters() if n not in ("trans_candidates_weights", "converse_candidates_weights")]
+    base += list(G.parameters())
+    optimizer = torch.optim.Adam([{"params": base, "lr": opt.learning_rate}, {"params": trans, "lr": 1e-2}])
+    opt_d = torch.optim.Adam(list(D.parameters()), lr=opt.img_learning_rate, betas=(opt.beta1, 0.999))
+    opt_o = torch.optim.Adam(list(Dobj.parameters()), lr=opt.learning_rate, betas=(opt.beta1, 0.999))
+    opt_m = torch.optim.Adam(list(Dmask.parameters()), lr=opt.mask_learning_rate, betas=(opt.beta1, 0.999))
+    torch.manual_seed(123)
+    arrays["mask_noise"] = npy(torch.randn((1, opt.mask_noise_dim)))       # what create_mask_vecs draws next
+    torch.manual_seed(123)
+    _, boxes_pred, masks_pred = sg(objs, triplets, tt, boxes)
+    arrays["masks_pred"] = npy(masks_pred)
+    imgs_pred = G(objs, boxes, masks, test_mode=False)                     # meta_models.py:48: GT masks when given
+    arrays["imgs_pred"] = npy(imgs_pred)
+    model_out = (imgs_pred, boxes_pred, masks_pred)
+    G_losses = gans(batch, model_out, mode="compute_generator_loss")
+    for k, v in G_losses.items():
+        arrays["G:" + k] = npy(v)
+    optimizer.zero_grad()
+    {k: v.mean() for k, v in G_losses.items()}["total_loss"].backward()
+    for n, p in sg.named_parameters():
+        if n.startswith("mask_net") and p.grad is not None:
+            arrays["sggrad:" + n] = npy(p.grad)
+    optimizer.step()
+    D_losses = gans(batch, model_out, mode="compute_discriminator_loss")
+    for k, v in D_losses.items():
+        arrays["D:" + k] = npy(v)
+    Dm = {k: v.mean() for k, v in D_losses.items()}
+    opt_d.zero_grad(); Dm["total_img_loss"].backward(); opt_d.step()
+    opt_o.zero_grad(); Dm["total_obj_loss"].backward(); opt_o.step()
+    opt_m.zero_grad(); Dm["total_mask_loss"].backward()
+    for n, p in Dmask.named_parameters():
+        arrays["mgrad:" + n] = npy(p.grad)
+    opt_m.step()
+    for k, v in sg.state_dict().items():
+        if k.startswith("mask_net") and ("running_" in k or "num_batches" in k):
+            arrays["sg_after:" + k] = npy(v)
+    save("train_step_masks", {"ref": "scripts/train.py:353-393,468-485; sg2im/model.py:67-88,118-123; "
+                                     "spade/models/networks/discriminator.py:264-356",
+                              "argv": argv, "vocab": "tiny",
+                              "state": "deterministic_state seeds sg=41 g=42 d=43 dobj=44 dmask=45",
+                              "shapes": {"sg": shapes_of(sg), "g": shapes_of(G, unused), "d": shapes_of(D, unused),
+                                         "dobj": shapes_of(Dobj), "dmask": shapes_of(Dmask)}}, **arrays)
 
 
 def fx_model_and_step():
@@ -472,3 +545,5 @@ if __name__ == "__main__":
     fx_model_and_step()
     fx_crops()
     fx_step_objdisc()
+    fx_vgg()
+    fx_step_masks()

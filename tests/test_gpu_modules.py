@@ -185,6 +185,52 @@ def test_default_step_with_object_discriminator_vs_reference(cuda):
     assert n >= 12
 
 
+def test_step_with_masks_vs_reference(cuda):
+    """--mask_size 8: mask net, masks layout in G and D, mask BCE, mask discriminator
+    terms and its optimiser; against the reference's own outputs."""
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import make_vocab
+    meta, a = load_golden("train_step_masks")
+    opt = T.make_opt(make_vocab(meta["vocab"]), meta["argv"])
+    tr = T.Trainer(opt, cuda)
+    sh = meta["shapes"]
+    sgm = tr.model.sg_to_layout.module
+    assert set(k for k in sgm.state_dict() if k.startswith("mask_net")) == \
+        set(k for k in sh["sg"] if k.startswith("mask_net"))
+    _load(sgm, state_from_shapes(sh["sg"], 41, requires_grad=False))
+    _load(tr.model.layout_to_image_model.module, state_from_shapes(sh["g"], 42, requires_grad=False), strict=False)
+    _load(tr.discriminator.img_discriminator, state_from_shapes(sh["d"], 43, requires_grad=False), strict=False)
+    _load(tr.discriminator.obj_discriminator, state_from_shapes(sh["dobj"], 44, requires_grad=False))
+    _load(tr.discriminator.mask_discriminator, state_from_shapes(sh["dmask"], 45, requires_grad=False))
+    sgm.mask_noise = a["mask_noise"].cuda()
+    batch = [a["imgs"], a["objs"], a["boxes"], a["triplets"], None, a["tt"], a["masks"], None]
+    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    assert {k[2:] for k in a if k.startswith("G:")} == set(G.keys())
+    assert {k[2:] for k in a if k.startswith("D:")} == set(D.keys())
+    for k in G:
+        assert_close(G[k].reshape(a["G:" + k].shape), a["G:" + k], RTOL, 1e-5, "G " + k)
+    for k in D:
+        assert_close(D[k].reshape(a["D:" + k].shape), a["D:" + k], RTOL, 1e-5, "D " + k)
+    mnamed = dict(tr.discriminator.mask_discriminator.named_parameters())
+    sgnamed = dict(sgm.named_parameters())
+    sgsd = sgm.state_dict()
+    n = 0
+    for k, v in a.items():
+        if k.startswith("mgrad:"):
+            assert_close(mnamed[k[6:]].grad, v, 1e-3, 1e-6 + 1e-3 * float(v.abs().max()), k)
+            n += 1
+        elif k.startswith("sggrad:"):
+            if float(v.abs().max()) < 1e-6:      # conv bias in front of a BatchNorm: analytically zero, rounding noise
+                assert float(sgnamed[k[7:]].grad.abs().max()) < 1e-6, k
+            else:
+                assert_close(sgnamed[k[7:]].grad, v, 1e-3, 1e-7 + 1e-3 * float(v.abs().max()), k)
+            n += 1
+        elif k.startswith("sg_after:"):
+            assert_close(sgsd[k[9:]], v, 1e-3, 2e-6, k)
+            n += 1
+    assert n > 15
+
+
 def test_generated_image_vs_reference(cuda):
     meta, a, opt, tr, batch = _trainer_from_golden(cuda)
     with torch.no_grad():

@@ -250,3 +250,50 @@ def test_vgg_loss():
     assert_close(loss, a["loss"], RTOL, ATOL, "vgg loss")
     loss.backward()
     assert_close(x.grad, a["grad_x"], RTOL, 1e-6, "vgg dx")
+
+
+def _masks_fixture():
+    meta, a = load_golden("train_step_masks")
+    vocab = make_vocab(meta["vocab"])
+    opt = make_opt(vocab, meta["argv"])
+    sh = meta["shapes"]
+    sg = state_from_shapes(sh["sg"], seed=41)
+    w = sg["trans_candidates_weights"]
+    for k in list(sg):
+        if k.endswith("predicates_transitive_weights"):
+            sg[k] = w
+    g, d = state_from_shapes(sh["g"], seed=42), state_from_shapes(sh["d"], seed=43)
+    dobj, dmask = state_from_shapes(sh["dobj"], seed=44), state_from_shapes(sh["dmask"], seed=45)
+    batch = (a["imgs"], a["objs"], a["boxes"], a["triplets"], None, a["tt"], a["masks"], None)
+    return meta, a, opt, sg, g, d, dobj, dmask, batch
+
+
+def test_train_step_with_masks():
+    """--mask_size 8: mask net (incl. its BatchNorm over padded slots), masks layout in G and D, mask BCE,
+    mask discriminator G/D terms and its optimiser step, against the reference."""
+    meta, a, opt, sg, g, d, dobj, dmask, batch = _masks_fixture()
+    assert opt.mask_size == 8
+    _, _, masks_pred = oracle.sg2layout_forward({k: v.detach().clone() for k, v in sg.items()}, opt.vocab, batch[1],
+                                                batch[3], batch[5], mask_noise=a["mask_noise"])
+    assert_close(masks_pred, a["masks_pred"], RTOL, 1e-6, "masks_pred")
+    ts = oracle.TrainState(opt, sg, g, d, dobj, None, dmask, a["mask_noise"])
+    G, D, imgs_pred = oracle.train_step(ts, batch)
+    assert_close(imgs_pred, a["imgs_pred"], RTOL, 1e-5, "imgs_pred (masks layout)")
+    assert {k[2:] for k in a if k.startswith("G:")} == set(G.keys())
+    assert {k[2:] for k in a if k.startswith("D:")} == set(D.keys())
+    for k in G:
+        assert_close(G[k].reshape(a["G:" + k].shape), a["G:" + k], RTOL, 1e-5, "G " + k)
+    for k in D:
+        assert_close(D[k].reshape(a["D:" + k].shape), a["D:" + k], RTOL, 1e-5, "D " + k)
+    n = 0
+    for k, v in a.items():
+        if k.startswith("mgrad:"):
+            assert_close(dmask[k[6:]].grad, v, 1e-3, 1e-6 + 1e-3 * float(v.abs().max()), k)
+            n += 1
+        elif k.startswith("sggrad:"):
+            assert_close(sg[k[7:]].grad, v, 1e-3, 1e-7 + 1e-3 * float(v.abs().max()), k)
+            n += 1
+        elif k.startswith("sg_after:"):
+            assert_close(sg[k[9:]], v, 1e-3, 2e-6, k)
+            n += 1
+    assert n > 15
