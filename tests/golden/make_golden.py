@@ -52,7 +52,7 @@ _mod("torchvision.utils", save_image=_Any)
 for _n in ("cv2", "h5py", "pycocotools", "pycocotools.mask"):
     _mod(_n)
 _mod("tensorboardX", SummaryWriter=_Any)
-_mod("imageio", imwrite=_Any)
+_mod("imageio", imwrite=_Any, imread=_Any)
 
 import warnings  # noqa: E402
 warnings.filterwarnings("ignore")
@@ -398,6 +398,59 @@ def fx_step_masks():
                               "state": "deterministic_state seeds sg=41 g=42 d=43 dobj=44 dmask=45",
                               "shapes": {"sg": shapes_of(sg), "g": shapes_of(G, unused), "d": shapes_of(D, unused),
                                          "dobj": shapes_of(Dobj), "dmask": shapes_of(Dmask)}}, **arrays)
+
+
+def fx_canon_graph():
+    """Canonical graph construction of the packed datasets, by the reference's own functions:
+    BaseDataset.add_location_triplets / add_dummy_triplets / add_learnt_triplets
+    (sg2im/data/base_dataset.py:35-151) in the order of packed_clevr_dialog.py:205-209, then the padding
+    of packed_clevr_collate_fn (packed_clevr_dialog.py:249-330)."""
+    from sg2im.data.base_dataset import BaseDataset
+    try:
+        from sg2im.data.packed_clevr_dialog import packed_clevr_collate_fn
+    except Exception as e:                                   # pragma: no cover
+        raise SystemExit("cannot import the reference collate: %r" % (e,))
+    vocab = make_vocab("clevr")
+    rng = np.random.default_rng(2024)
+    arrays, cases = {}, []
+    for ci, (sizes, trans) in enumerate((((2, 3, 4, 6, 9, 14), 0), ((3, 5, 8, 12, 20, 33), 1), ((40, 17, 3), 1))):
+        ds = BaseDataset()
+        ds.vocab, ds.include_dummies = vocab, True
+        ds.learned_transitivity, ds.learned_converse, ds.learned_symmetry = bool(trans), False, False
+        batch = []
+        for n in sizes:
+            wh = rng.uniform(0.05, 0.6, size=(n, 2))
+            xy = rng.uniform(0.0, 1.0, size=(n, 2)) * (1.0 - wh)
+            if n >= 6:                                       # exact ties of centres / edges exercise the strict compares
+                xy[1] = xy[0]; wh[1] = wh[0]
+                xy[3, 0] = xy[2, 0]
+            bx = [tuple(float(v) for v in r) for r in np.concatenate([xy, wh], axis=1)]
+            centers = torch.FloatTensor([[x0 + 0.5 * w, y0 + 0.5 * h] for x0, y0, w, h in bx])   # packed_clevr_dialog.py:190-196
+            boxes = torch.FloatTensor(bx + [[-1, -1, -1, -1]])
+            objs = {a: torch.LongTensor(list(rng.integers(1, max(vocab["attributes"][a].values()) + 1, size=n)) + [0])
+                    for a in vocab["attributes"]}
+            triplets = []
+            ds.add_location_triplets(boxes, centers, objs["shape"], triplets)
+            ds.add_dummy_triplets(objs["shape"], triplets)
+            triplets, conv_counts, ttype = ds.add_learnt_triplets(triplets, boxes.size(0))
+            batch.append((torch.zeros(3, 4, 4), objs, boxes, torch.LongTensor(triplets), torch.LongTensor(conv_counts),
+                          torch.LongTensor(ttype), None, len(batch), centers))
+        out = packed_clevr_collate_fn(vocab, [b[:8] for b in batch])
+        _, all_objs, all_boxes, all_triplets, _, all_tt, _, _ = out
+        O = all_boxes.shape[1]
+        cen = torch.zeros(len(sizes), O, 2)
+        for b, n in enumerate(sizes):
+            cen[b, :n] = batch[b][8]
+        arrays.update({"c%d_objs" % ci: npy(all_objs), "c%d_boxes" % ci: npy(all_boxes), "c%d_triplets" % ci: npy(all_triplets),
+                       "c%d_tt" % ci: npy(all_tt), "c%d_n" % ci: np.asarray([n + 1 for n in sizes], np.int64),
+                       "c%d_counts" % ci: np.asarray([len(b[3]) for b in batch], np.int64), "c%d_centers" % ci: npy(cen)})
+        cases.append({"sizes": list(sizes), "learned_transitivity": trans})
+    save("canon_graph", {"ref": "sg2im/data/base_dataset.py:35-151; scripts/graphs_utils.py:15-100; "
+                                "sg2im/data/packed_clevr_dialog.py:205-209,249-330",
+                         "vocab": "clevr", "cases": cases,
+                         "note": "centres are an input: float32 of x0 + 0.5*w evaluated in python floats, as "
+                                 "packed_clevr_dialog.py:190-196 computes them before the boxes become a FloatTensor"},
+         **arrays)
 
 
 def fx_model_and_step():
