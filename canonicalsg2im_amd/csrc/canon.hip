@@ -1,0 +1,347 @@
+// Canonical scene-graph construction of the packed datasets, on the device.
+//
+// Reference (numpy / python loops, O(O^3) per sample, ~2.5 s per graph at O = 128):
+//   BaseDataset.add_location_triplets   sg2im/data/base_dataset.py:35-87
+//   triplets_to_minimal / path / hsu    scripts/graphs_utils.py:15-71
+//   BaseDataset.add_dummy_triplets      sg2im/data/base_dataset.py:141-151
+//   BaseDataset.add_learnt_triplets     sg2im/data/base_dataset.py:89-139 (learned_converse = 0)
+//   get_current_and_transitive_triplets scripts/graphs_utils.py:96-100
+//   triplet padding of the collate      sg2im/data/packed_clevr_dialog.py:309-315
+//
+// One workgroup per sample.  The six location relations are 256x256 bit matrices in LDS (one
+// 64-bit word = 64 objects of a row): the pair loop sets bits, Warshall's closure ORs whole rows
+// (one barrier per pivot), Hsu's reduction clears them with AND-NOT in the reference's pivot order.
+// Integer/bit work end to end: results are bit-identical to the reference's.  Emission order is
+// the one np.unique(axis=0) produces — (s, p, o) lexicographic — followed by the transitive extras
+// in (ascending predicate id, s, o) order.
+#include "csg_common.h"
+
+using namespace csg;
+
+namespace {
+
+constexpr int MAXN = 256;        // objects per sample (incl. the __image__ object)
+constexpr int W = MAXN / 64;     // 64-bit words per bit-matrix row
+constexpr int NREL = 6;          // __below__ __above__ __left of__ __right of__ __inside__ __surrounding__
+
+struct CanonParams {
+  int O;                  // padded objects per sample in the input tensors
+  int image_id;           // id of the __image__ object (first attribute)
+  int pid[NREL];          // predicate id of each location relation, in the order above
+  int pid_in_image;       // predicate id of __in_image__
+  int pid_padding;        // predicate id of __padding__
+  int order[NREL + 1];    // relation slots (0..5, 6 = __in_image__) sorted by ascending predicate id
+  int include_dummies;
+  int learned_transitivity;
+};
+
+// workspace per sample: R[NREL][MAXN][W] | X[NREL][MAXN][W] (u64) | off_orig[MAXN] | off_trans[NREL][MAXN] (i32)
+constexpr int64_t kBitWords = (int64_t)NREL * MAXN * W;
+constexpr int64_t kWsBytesPerSample = 2 * kBitWords * 8 + (int64_t)(MAXN + NREL * MAXN) * 4;
+
+__device__ __forceinline__ uint64_t* ws_R(void* ws, int b) { return (uint64_t*)((char*)ws + (int64_t)b * kWsBytesPerSample); }
+__device__ __forceinline__ uint64_t* ws_X(void* ws, int b) { return ws_R(ws, b) + kBitWords; }
+__device__ __forceinline__ int* ws_off(void* ws, int b) { return (int*)(ws_X(ws, b) + kBitWords); }
+
+// exclusive scan of one int per thread over the 256-thread block; returns the block total in *total
+__device__ int block_exscan(int v, int* sm, int* total) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  sm[tid] = v;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    int t = tid >= o ? sm[tid - o] : 0;
+    __syncthreads();
+    sm[tid] += t;
+    __syncthreads();
+  }
+  *total = sm[255];
+  return sm[tid] - v;
+}
+
+__global__ __launch_bounds__(256) void k_canon_build(CanonParams P, const int64_t* __restrict__ objs0,
+                                                      const float* __restrict__ boxes,
+                                                      const float* __restrict__ centers,
+                                                      const int64_t* __restrict__ n_objs, void* __restrict__ ws,
+                                                      int64_t* __restrict__ counts) {
+  __shared__ uint64_t adj[NREL][MAXN][W];      // 48 KB
+  __shared__ float gx0[MAXN], gy0[MAXN], gxc[MAXN], gyc[MAXN], gcx[MAXN], gcy[MAXN];
+  __shared__ int real[MAXN];
+  __shared__ int scan[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int n = (int)n_objs[b];
+  if (n > P.O) n = P.O;
+  if (n > MAXN) n = MAXN;
+  const int nw = (n + 63) >> 6;
+
+  for (int i = tid; i < NREL * MAXN * W; i += 256) (&adj[0][0][0])[i] = 0;
+  if (tid < MAXN) {
+    int r = 0;
+    float x0 = 0.f, y0 = 0.f, xc = 0.f, yc = 0.f, cx = 0.f, cy = 0.f;
+    if (tid < n) {
+      const float* bx = boxes + ((int64_t)b * P.O + tid) * 4;
+      x0 = bx[0];
+      y0 = bx[1];
+      xc = __fadd_rn(x0, bx[2] * 0.5f);          // `sx1 = sx0 + sw / 2` (base_dataset.py:47): the box CENTRE, fp32
+      yc = __fadd_rn(y0, bx[3] * 0.5f);
+      cx = centers[((int64_t)b * P.O + tid) * 2 + 0];
+      cy = centers[((int64_t)b * P.O + tid) * 2 + 1];
+      r = (n > 1) && (objs0[(int64_t)b * P.O + tid] != (int64_t)P.image_id);   // base_dataset.py:39-41
+    }
+    gx0[tid] = x0; gy0[tid] = y0; gxc[tid] = xc; gyc[tid] = yc; gcx[tid] = cx; gcy[tid] = cy;
+    real[tid] = r;
+  }
+  __syncthreads();
+
+  // ---- pair loop (base_dataset.py:42-81): thread s builds row s of the six matrices
+  if (tid < n && real[tid]) {
+    const int s = tid;
+    const float sx0 = gx0[s], sy0 = gy0[s], sxc = gxc[s], syc = gyc[s], scx = gcx[s], scy = gcy[s];
+    for (int w = 0; w < nw; ++w) {
+      uint64_t m[NREL] = {0, 0, 0, 0, 0, 0};
+      const int hi = min(64, n - w * 64);
+      for (int k = 0; k < hi; ++k) {
+        const int o = w * 64 + k;
+        if (o == s || !real[o]) continue;
+        const uint64_t bit = 1ull << k;
+        const float ox0 = gx0[o], oy0 = gy0[o], oxc = gxc[o], oyc = gyc[o];
+        if (sx0 < ox0 && sxc > oxc && sy0 < oy0 && syc > oyc) {
+          m[5] |= bit;                                            // __surrounding__
+        } else if (sx0 > ox0 && sxc < oxc && sy0 > oy0 && syc < oyc) {
+          m[4] |= bit;                                            // __inside__
+        } else {
+          // d = obj_centers[s] - obj_centers[o]; the sign of an IEEE difference is the comparison
+          const float ocx = gcx[o], ocy = gcy[o];
+          if (scx > ocx) m[3] |= bit; else if (scx < ocx) m[2] |= bit;      // __right of__ / __left of__
+          if (scy > ocy) m[0] |= bit; else if (scy < ocy) m[1] |= bit;      // __below__ / __above__
+        }
+      }
+      for (int r = 0; r < NREL; ++r) adj[r][s][w] = m[r];
+    }
+  }
+
+  // ---- path(): Warshall closure, pivot i (graphs_utils.py:15-27)
+  const int tasks = NREL * n;
+  for (int i = 0; i < n; ++i) {
+    __syncthreads();
+    for (int t = tid; t < tasks; t += 256) {
+      const int r = t / n, j = t - r * n;
+      if (j != i && ((adj[r][j][i >> 6] >> (i & 63)) & 1ull)) {
+        for (int w = 0; w < nw; ++w) adj[r][j][w] |= adj[r][i][w];
+      }
+    }
+  }
+  __syncthreads();
+  uint64_t* X = ws_X(ws, b);
+  uint64_t* R = ws_R(ws, b);
+  for (int t = tid; t < tasks * W; t += 256) {       // park the closure in X
+    const int w = t % W, rj = t / W;
+    const int r = rj / n, j = rj - r * n;
+    X[((int64_t)r * MAXN + j) * W + w] = adj[r][j][w];
+  }
+
+  // ---- hsu(): reduction in the reference's pivot order j (graphs_utils.py:30-38).  The location
+  // relations are strict orders, so m[j][j] is never set and row j is not written while it is read.
+  for (int j = 0; j < n; ++j) {
+    __syncthreads();
+    for (int t = tid; t < tasks; t += 256) {
+      const int r = t / n, i = t - r * n;
+      if (i != j && ((adj[r][i][j >> 6] >> (j & 63)) & 1ull)) {
+        for (int w = 0; w < nw; ++w) adj[r][i][w] &= ~adj[r][j][w];
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < tasks * W; t += 256) {
+    const int w = t % W, rj = t / W;
+    const int r = rj / n, j = rj - r * n;
+    const int64_t at = ((int64_t)r * MAXN + j) * W + w;
+    const uint64_t red = adj[r][j][w];
+    R[at] = red;
+    X[at] = X[at] & ~red;                             // closure - current (graphs_utils.py:96-100)
+  }
+
+  // ---- per-row counts -> offsets
+  int img = -1;
+  if (P.include_dummies) {                            // the __image__ object's index (base_dataset.py:144)
+    scan[tid] = (tid < n && objs0[(int64_t)b * P.O + tid] == (int64_t)P.image_id) ? tid : MAXN;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) scan[tid] = min(scan[tid], scan[tid + o]);
+      __syncthreads();
+    }
+    img = scan[0] < MAXN ? scan[0] : -1;
+  }
+  int c = 0;
+  if (tid < n) {
+    for (int r = 0; r < NREL; ++r)
+      for (int w = 0; w < nw; ++w) c += __popcll(adj[r][tid][w]);
+    if (img >= 0 && tid != img) c += 1;
+  }
+  int* off = ws_off(ws, b);
+  int total = 0;
+  int ex = block_exscan(c, scan, &total);
+  off[tid] = ex;
+  const int n_orig = total;
+  int n_trans = 0;
+  if (P.learned_transitivity) {
+    for (int q = 0; q < NREL + 1; ++q) {
+      const int r = P.order[q];
+      if (r >= NREL) continue;
+      int cx = 0;
+      if (tid < n)
+        for (int w = 0; w < nw; ++w) cx += __popcll(X[((int64_t)r * MAXN + tid) * W + w]);
+      int tot = 0;
+      int e = block_exscan(cx, scan, &tot);
+      off[MAXN + r * MAXN + tid] = n_trans + e;
+      n_trans += tot;
+    }
+  }
+  if (tid == 0) {
+    counts[b * 2 + 0] = n_orig;
+    counts[b * 2 + 1] = n_trans;
+  }
+}
+
+__device__ __forceinline__ void put(int64_t* trip, int64_t* tt, int64_t at, int s, int p, int o, int type) {
+  trip[at * 3 + 0] = s;
+  trip[at * 3 + 1] = p;
+  trip[at * 3 + 2] = o;
+  tt[at] = type;
+}
+
+__global__ __launch_bounds__(256) void k_canon_emit(CanonParams P, const int64_t* __restrict__ objs0,
+                                                     const int64_t* __restrict__ n_objs,
+                                                     const void* __restrict__ ws, const int64_t* __restrict__ counts,
+                                                     int64_t T, int64_t* __restrict__ triplets,
+                                                     int64_t* __restrict__ ttype) {
+  __shared__ int red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int n = (int)n_objs[b];
+  if (n > P.O) n = P.O;
+  if (n > MAXN) n = MAXN;
+  const int nw = (n + 63) >> 6;
+  const uint64_t* R = ws_R((void*)ws, b);
+  const uint64_t* X = ws_X((void*)ws, b);
+  const int* off = ws_off((void*)ws, b);
+  int64_t* trip = triplets + (int64_t)b * T * 3;
+  int64_t* tt = ttype + (int64_t)b * T;
+  const int n_orig = (int)counts[b * 2 + 0], n_trans = (int)counts[b * 2 + 1];
+
+  int img = -1;
+  if (P.include_dummies) {
+    red[tid] = (tid < n && objs0[(int64_t)b * P.O + tid] == (int64_t)P.image_id) ? tid : MAXN;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] = min(red[tid], red[tid + o]);
+      __syncthreads();
+    }
+    img = red[0] < MAXN ? red[0] : -1;
+  }
+  if (tid < n) {
+    const int s = tid;
+    int64_t at = off[s];
+    for (int q = 0; q < NREL + 1; ++q) {               // ascending predicate id: np.unique's (s, p, o) order
+      const int r = P.order[q];
+      if (r >= NREL) {
+        if (img >= 0 && s != img && at < T) put(trip, tt, at++, s, P.pid_in_image, img, 0);
+        continue;
+      }
+      for (int w = 0; w < nw; ++w) {
+        uint64_t m = R[((int64_t)r * MAXN + s) * W + w];
+        while (m) {
+          const int k = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          if (at < T) put(trip, tt, at, s, P.pid[r], w * 64 + k, 0);
+          ++at;
+        }
+      }
+    }
+    if (n_trans) {
+      for (int q = 0; q < NREL + 1; ++q) {
+        const int r = P.order[q];
+        if (r >= NREL) continue;
+        int64_t a2 = (int64_t)n_orig + off[MAXN + r * MAXN + s];
+        for (int w = 0; w < nw; ++w) {
+          uint64_t m = X[((int64_t)r * MAXN + s) * W + w];
+          while (m) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (a2 < T) put(trip, tt, a2, s, P.pid[r], w * 64 + k, 1);
+            ++a2;
+          }
+        }
+      }
+    }
+  }
+  for (int64_t t = (int64_t)n_orig + n_trans + tid; t < T; t += 256)      // packed_clevr_dialog.py:309-315
+    put(trip, tt, t, 0, P.pid_padding, 0, 0);
+}
+
+int fill_params(CanonParams* P, int64_t O, const int32_t* pred_ids, int64_t image_id, int include_dummies,
+                int learned_transitivity) {
+  P->O = (int)O;
+  P->image_id = (int)image_id;
+  P->pid_padding = pred_ids[0];
+  P->pid_in_image = pred_ids[1];
+  for (int r = 0; r < NREL; ++r) P->pid[r] = pred_ids[2 + r];
+  int key[NREL + 1];
+  for (int r = 0; r < NREL; ++r) key[r] = P->pid[r];
+  key[NREL] = P->pid_in_image;
+  for (int q = 0; q < NREL + 1; ++q) P->order[q] = q;
+  for (int a = 1; a < NREL + 1; ++a)            // insertion sort by predicate id
+    for (int c = a; c > 0 && key[P->order[c]] < key[P->order[c - 1]]; --c) {
+      int t = P->order[c];
+      P->order[c] = P->order[c - 1];
+      P->order[c - 1] = t;
+    }
+  for (int a = 0; a < NREL + 1; ++a)
+    for (int c = a + 1; c < NREL + 1; ++c)
+      if (key[a] == key[c] || key[a] == P->pid_padding) return 0;
+  P->include_dummies = include_dummies;
+  P->learned_transitivity = learned_transitivity;
+  return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t csg_canon_workspace(int64_t B) { return B > 0 ? B * kWsBytesPerSample : -1; }
+
+int csg_canon_build(const int64_t* objs0, const float* boxes, const float* centers, const int64_t* n_objs,
+                    int64_t B, int64_t O, const int32_t* pred_ids, int64_t image_id, int include_dummies,
+                    int learned_transitivity, void* workspace, int64_t workspace_bytes, int64_t* counts,
+                    void* stream) {
+  CSG_REQUIRE(B > 0 && O > 0, CSG_E_BADSHAPE, "csg_canon_build: bad shape B=%ld O=%ld", (long)B, (long)O);
+  CSG_REQUIRE(O <= MAXN, CSG_E_UNSUPPORTED, "csg_canon_build: at most %d objects per sample (got %ld)", MAXN, (long)O);
+  CSG_REQUIRE(workspace && workspace_bytes >= B * kWsBytesPerSample, CSG_E_BADSHAPE,
+              "csg_canon_build: workspace too small (%ld bytes, need %ld)", (long)workspace_bytes,
+              (long)(B * kWsBytesPerSample));
+  CanonParams P;
+  CSG_REQUIRE(fill_params(&P, O, pred_ids, image_id, include_dummies, learned_transitivity), CSG_E_BADSHAPE,
+              "csg_canon_build: the eight predicate ids must be distinct");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_CANON_BUILD, (double)B * O * O, s);
+  hipLaunchKernelGGL(k_canon_build, dim3((unsigned)B), dim3(256), 0, s, P, objs0, boxes, centers, n_objs, workspace,
+                     counts);
+  return check_launch("csg_canon_build");
+}
+
+int csg_canon_emit(const int64_t* objs0, const int64_t* n_objs, int64_t B, int64_t O, const int32_t* pred_ids,
+                   int64_t image_id, int include_dummies, int learned_transitivity, const void* workspace,
+                   const int64_t* counts, int64_t T, int64_t* triplets, int64_t* triplet_type, void* stream) {
+  CSG_REQUIRE(B > 0 && O > 0 && O <= MAXN && T >= 0, CSG_E_BADSHAPE, "csg_canon_emit: bad shape B=%ld O=%ld T=%ld",
+              (long)B, (long)O, (long)T);
+  if (T == 0) return CSG_OK;
+  CanonParams P;
+  CSG_REQUIRE(fill_params(&P, O, pred_ids, image_id, include_dummies, learned_transitivity), CSG_E_BADSHAPE,
+              "csg_canon_emit: the eight predicate ids must be distinct");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_CANON_EMIT, (double)B * T * 32, s);
+  hipLaunchKernelGGL(k_canon_emit, dim3((unsigned)B), dim3(256), 0, s, P, objs0, n_objs, workspace, counts, T,
+                     triplets, triplet_type);
+  return check_launch("csg_canon_emit");
+}
+
+}  // extern "C"

@@ -42,6 +42,8 @@ enum KernelId {
   K_MAXPOOL_BWD,
   K_L1_FWD,
   K_L1_BWD,
+  K_CANON_BUILD,
+  K_CANON_EMIT,
   K_COUNT
 };
 

@@ -205,6 +205,31 @@ int csg_l1_mean_fwd(const float* a, const float* b, int64_t n, float* out, void*
                     void* stream);
 int csg_l1_mean_bwd(const float* a, const float* b, const float* gout, int64_t n, float* da, void* stream);
 
+/* ---- canonical scene-graph construction of the packed datasets -----------------------------------
+ * Replaces, per batch, the per-sample numpy/python pipeline of the data loader:
+ * BaseDataset.add_location_triplets -> add_dummy_triplets -> add_learnt_triplets (learned_converse=0)
+ * (sg2im/data/base_dataset.py:35-151, scripts/graphs_utils.py:15-100; call order
+ * sg2im/data/packed_clevr_dialog.py:205-209) and the triplet padding of the collate function
+ * (packed_clevr_dialog.py:309-315).  Inputs are the padded batch tensors: objs0 (B,O) int64 ids of the
+ * first attribute, boxes (B,O,4) xywh fp32, centers (B,O,2) fp32 (the dataset's obj_centers), n_objs (B,)
+ * int64 number of objects of each sample INCLUDING its __image__ object (rows >= n are padding).
+ * pred_ids[8] = ids of __padding__, __in_image__, __below__, __above__, __left of__, __right of__,
+ * __inside__, __surrounding__.  At most 256 objects per sample.
+ *   csg_canon_build: relations, transitive closure and reduction as bit matrices (kept in `workspace`,
+ *     csg_canon_workspace(B) bytes) and counts[b] = {original triplets, transitive triplets}.
+ *   csg_canon_emit: triplets (B,T,3) int64 sorted by (s,p,o) as np.unique(axis=0) does, then the
+ *     transitive extras by (p,s,o); rows past a sample's count are [0, __padding__, 0];
+ *     triplet_type (B,T) int64 is 0 / 1 (ORIGINAL_EDGE / TRANSITIVE_EDGE) and 0 in the padding.
+ *     T is chosen by the caller: max_b(counts[b][0] + counts[b][1]) reproduces the collate. */
+int64_t csg_canon_workspace(int64_t B);
+int csg_canon_build(const int64_t* objs0, const float* boxes, const float* centers, const int64_t* n_objs,
+                    int64_t B, int64_t O, const int32_t* pred_ids, int64_t image_id, int include_dummies,
+                    int learned_transitivity, void* workspace, int64_t workspace_bytes, int64_t* counts,
+                    void* stream);
+int csg_canon_emit(const int64_t* objs0, const int64_t* n_objs, int64_t B, int64_t O, const int32_t* pred_ids,
+                   int64_t image_id, int include_dummies, int learned_transitivity, const void* workspace,
+                   const int64_t* counts, int64_t T, int64_t* triplets, int64_t* triplet_type, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
