@@ -45,8 +45,11 @@ SIGNATURES = {
     "csg_real_object_mask": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_graph_csr_build": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "csg_gather_concat_fwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
-    "csg_gather_concat_bwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
-    "csg_segment_avg_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p]),
+    "csg_gather_concat_bwd_workspace": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
+    "csg_gather_concat_bwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_segment_avg_fwd_workspace": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
+    "csg_segment_avg_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
+                                    c_i64, c_p]),
     "csg_segment_avg_bwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64,
                                     c_p, c_p, c_p, c_p]),
     "csg_layout_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64,

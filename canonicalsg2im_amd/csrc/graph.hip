@@ -142,27 +142,135 @@ __global__ void k_gather_concat_fwd(const float* __restrict__ obj, const float* 
   out[e] = v;
 }
 
-// dobj[b,i,:] = sum over the CSR row of the matching slice of dcat; dpred = middle slice.
-__global__ __launch_bounds__(128) void k_gather_concat_bwd_obj(const float* __restrict__ dcat,
-                                                               const int32_t* __restrict__ row_ptr,
-                                                               const int32_t* __restrict__ col, int O, int T, int Din,
-                                                               int Dp, float* __restrict__ dobj) {
-  const int i = blockIdx.x, b = blockIdx.y;
-  const int Dc = 2 * Din + Dp;
+// ---- CSR row sums (K5 forward, K2 backward) ---------------------------------------------------
+// out[b,i,0:D] = sum over the CSR row of object i of  w_e * src[t_e, off(role_e) + 0:D]
+//   role 0 (subject) reads the slice at off0, role 1 (object) at off1;
+//   WEIGHTED: w_e = conf[t_e] for valid triplets (invalid ones are skipped) and cnt = sum w_e;
+//   otherwise w_e = 1.
+// The reference's scatter_add loops (graph.py:98-106) give dense graphs rows of several hundred
+// edges (CLEVR closure graphs: ~2*(O-1) per object), so a row is split over `S` workgroups (grid.z)
+// and, inside a workgroup, over 256/LPE edge groups of LPE lanes; a lane owns one float4 of the D
+// columns, 4 edges are in flight per lane.  Group partials are combined through LDS and split
+// partials by k_rowsum_finish, both in a fixed order: results are bit-reproducible run to run.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_csr_rowsum(const float* __restrict__ src, const float* __restrict__ conf,
+                                                     const uint8_t* __restrict__ valid,
+                                                     const int32_t* __restrict__ row_ptr,
+                                                     const int32_t* __restrict__ col, int O, int T, int D, int stride,
+                                                     int off0, int off1, int LPE, int S, float* __restrict__ out,
+                                                     float* __restrict__ cnt_out, float* __restrict__ part,
+                                                     float* __restrict__ part_cnt) {
+  __shared__ float4 sm[256];
+  __shared__ float smc[256];
+  const int i = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
+  const int G = 256 / LPE, lane = tid % LPE, grp = tid / LPE;
   const int32_t* rp = row_ptr + (int64_t)b * (O + 1);
   const int32_t* cl = col + (int64_t)b * 2 * T;
-  const int beg = rp[i], end = rp[i + 1];
-  const float* base = dcat + (int64_t)b * T * Dc;
-  for (int d = threadIdx.x; d < Din; d += blockDim.x) {
-    float acc = 0.f;
-    for (int e = beg; e < end; ++e) {
-      int c = cl[e];
-      int t = c >> 1;
-      int off = (c & 1) ? (Din + Dp) : 0;
-      acc += base[(int64_t)t * Dc + off + d];
+  const int beg = rp[i], len = rp[i + 1] - beg;
+  const int e0 = beg + (int)(((int64_t)len * sp) / S), e1 = beg + (int)(((int64_t)len * (sp + 1)) / S);
+  const float* base = src + (int64_t)b * T * stride;
+  const float* cb = WEIGHTED ? conf + (int64_t)b * T : nullptr;
+  const uint8_t* vb = WEIGHTED ? valid + (int64_t)b * T : nullptr;
+  const int64_t orow = (int64_t)b * O + i;
+  float* dst = S > 1 ? part + (orow * S + sp) * D : out + orow * D;
+
+  float cnt = 0.f;
+  for (int d0 = 0; d0 < D; d0 += LPE * 4) {
+    const int d = d0 + lane * 4;
+    const bool live = d < D;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = e0 + grp;
+    for (; e + 3 * G < e1; e += 4 * G) {                 // 4 independent 16-byte loads per lane
+      int c[4];
+      float w[4];
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = cl[e + u * G];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = c[u] >> 1;
+        w[u] = WEIGHTED ? (vb[t] ? cb[t] : 0.f) : 1.f;
+        const bool take = live && (!WEIGHTED || vb[t]);
+        v[u] = take ? *(const float4*)(base + (int64_t)t * stride + ((c[u] & 1) ? off1 : off0) + d)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc.x += v[u].x * w[u]; acc.y += v[u].y * w[u]; acc.z += v[u].z * w[u]; acc.w += v[u].w * w[u];
+        if (WEIGHTED && d0 == 0) cnt += w[u];
+      }
     }
-    dobj[((int64_t)b * O + i) * Din + d] = acc;
+    for (; e < e1; e += G) {
+      const int c = cl[e], t = c >> 1;
+      const float w = WEIGHTED ? (vb[t] ? cb[t] : 0.f) : 1.f;
+      if (live && (!WEIGHTED || vb[t])) {
+        const float4 v = *(const float4*)(base + (int64_t)t * stride + ((c & 1) ? off1 : off0) + d);
+        acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+      }
+      if (WEIGHTED && d0 == 0) cnt += w;
+    }
+    __syncthreads();
+    sm[tid] = acc;
+    if (d0 == 0) smc[tid] = cnt;
+    __syncthreads();
+    if (grp == 0) {
+      float4 tot = sm[lane];
+      for (int g = 1; g < G; ++g) {                      // fixed order over the edge groups
+        const float4 o = sm[g * LPE + lane];
+        tot.x += o.x; tot.y += o.y; tot.z += o.z; tot.w += o.w;
+      }
+      float ctot = 0.f;
+      if (WEIGHTED) {
+        for (int g = 0; g < G; ++g) ctot += smc[g * LPE];
+        if (d0 == 0) cnt = ctot;                        // lanes of group 0 now hold the chunk's total
+        ctot = cnt;
+        if (S == 1 && ctot > 0.f) {                     // graph.py:105-106: a true division where count > 0
+          tot.x /= ctot; tot.y /= ctot; tot.z /= ctot; tot.w /= ctot;
+        }
+      }
+      if (live) *(float4*)(dst + d) = tot;
+    }
   }
+  if (WEIGHTED && tid == 0) {
+    if (S > 1) part_cnt[orow * S + sp] = cnt;
+    else cnt_out[orow] = cnt;
+  }
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(128) void k_rowsum_finish(const float* __restrict__ part,
+                                                        const float* __restrict__ part_cnt, int D, int S,
+                                                        float* __restrict__ out, float* __restrict__ cnt_out) {
+  const int64_t orow = blockIdx.x;
+  float cnt = 0.f;
+  if (WEIGHTED)
+    for (int sp = 0; sp < S; ++sp) cnt += part_cnt[orow * S + sp];
+  for (int d = threadIdx.x * 4; d < D; d += 128 * 4) {
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sp = 0; sp < S; ++sp) {
+      const float4 v = *(const float4*)(part + (orow * S + sp) * D + d);
+      tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+    }
+    if (WEIGHTED && cnt > 0.f) {
+      tot.x /= cnt; tot.y /= cnt; tot.z /= cnt; tot.w /= cnt;
+    }
+    *(float4*)(out + orow * D + d) = tot;
+  }
+  if (WEIGHTED && threadIdx.x == 0) cnt_out[orow] = cnt;
+}
+
+// lanes per edge (a power of two <= 256 covering D/4 float4 columns) and row splits for B*O rows of
+// average degree 2T/O
+static inline int rowsum_lpe(int64_t D) {
+  int l = 1;
+  while (l * 4 < D && l < 256) l <<= 1;
+  return l;
+}
+static inline int rowsum_splits(int64_t B, int64_t O, int64_t T) {
+  const int64_t deg = O > 0 ? (2 * T + O - 1) / O : 0;
+  int s = 1;
+  while (s < 32 && deg > 48 * (int64_t)s && B * O * s < 16384) s <<= 1;
+  return s;
 }
 
 __global__ void k_slice_copy(const float* __restrict__ src, int64_t rows, int src_stride, int src_off, int width,
@@ -175,42 +283,6 @@ __global__ void k_slice_copy(const float* __restrict__ src, int64_t rows, int sr
 }
 
 // ------------------------------------------------------------------------------------ K4+K5
-__global__ __launch_bounds__(128) void k_segment_avg_fwd(const float* __restrict__ h, const float* __restrict__ conf,
-                                                          const uint8_t* __restrict__ valid,
-                                                          const int32_t* __restrict__ row_ptr,
-                                                          const int32_t* __restrict__ col, int O, int T, int H, int Dp,
-                                                          float* __restrict__ pooled, float* __restrict__ cnt_out) {
-  const int i = blockIdx.x, b = blockIdx.y;
-  const int Dh = 2 * H + Dp;
-  const int32_t* rp = row_ptr + (int64_t)b * (O + 1);
-  const int32_t* cl = col + (int64_t)b * 2 * T;
-  const int beg = rp[i], end = rp[i + 1];
-  const float* hb = h + (int64_t)b * T * Dh;
-  const float* cb = conf + (int64_t)b * T;
-  const uint8_t* vb = valid + (int64_t)b * T;
-  float cnt = 0.f;
-  for (int e = beg; e < end; ++e) {
-    int t = cl[e] >> 1;
-    if (vb[t]) cnt += cb[t];
-  }
-  const float inv = cnt > 0.f ? 1.0f / cnt : 0.f;
-  for (int d = threadIdx.x; d < H; d += blockDim.x) {
-    float acc = 0.f;
-    for (int e = beg; e < end; ++e) {
-      int c = cl[e];
-      int t = c >> 1;
-      if (vb[t]) {
-        int off = (c & 1) ? (H + Dp) : 0;
-        acc += hb[(int64_t)t * Dh + off + d] * cb[t];
-      }
-    }
-    // sg2im/graph.py:105-106: divide only where count > 0 (a true division, like the reference)
-    pooled[((int64_t)b * O + i) * H + d] = cnt > 0.f ? acc / cnt : acc;
-  }
-  (void)inv;
-  if (threadIdx.x == 0) cnt_out[(int64_t)b * O + i] = cnt;
-}
-
 __global__ void k_scale_slice(const float* __restrict__ h, const float* __restrict__ conf, int64_t BT, int Dh,
                               int off, int Dp, float* __restrict__ out) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,13 +419,33 @@ int csg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* tr
   return check_launch("csg_gather_concat_fwd");
 }
 
+int64_t csg_gather_concat_bwd_workspace(int64_t B, int64_t O, int64_t T, int64_t Din) {
+  if (B <= 0 || O <= 0 || T < 0 || Din <= 0) return -1;
+  const int S = rowsum_splits(B, O, T);
+  return S > 1 ? B * O * S * Din * (int64_t)sizeof(float) : 0;
+}
+
 int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32_t* col, int64_t B, int64_t O,
-                          int64_t T, int64_t Din, int64_t Dp, float* dobj, float* dpred, void* stream) {
+                          int64_t T, int64_t Din, int64_t Dp, float* dobj, float* dpred, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
   CSG_REQUIRE(B > 0 && O > 0 && T >= 0 && Din > 0 && Dp > 0, CSG_E_BADSHAPE, "csg_gather_concat_bwd: bad shape");
+  CSG_REQUIRE(Din % 4 == 0 && Dp % 4 == 0, CSG_E_BADSHAPE,
+              "csg_gather_concat_bwd: Din=%ld and Dp=%ld must be multiples of 4", (long)Din, (long)Dp);
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_GATHER_BWD, (double)B * T * (2 * Din + Dp) * 8, s);
-  if (dobj) hipLaunchKernelGGL(k_gather_concat_bwd_obj, dim3((unsigned)O, (unsigned)B), dim3(128), 0, s, dcat, row_ptr,
-                               col, (int)O, (int)T, (int)Din, (int)Dp, dobj);
+  if (dobj) {
+    const int S = rowsum_splits(B, O, T);
+    const int64_t need = S > 1 ? B * O * S * Din * (int64_t)sizeof(float) : 0;
+    CSG_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), CSG_E_BADSHAPE,
+                "csg_gather_concat_bwd: workspace too small (%ld bytes, need %ld)", (long)workspace_bytes, (long)need);
+    hipLaunchKernelGGL(k_csr_rowsum<false>, dim3((unsigned)O, (unsigned)B, (unsigned)S), dim3(256), 0, s, dcat,
+                       (const float*)nullptr, (const uint8_t*)nullptr, row_ptr, col, (int)O, (int)T, (int)Din,
+                       (int)(2 * Din + Dp), 0, (int)(Din + Dp), rowsum_lpe(Din), S, dobj, (float*)nullptr,
+                       (float*)workspace, (float*)nullptr);
+    if (S > 1)
+      hipLaunchKernelGGL(k_rowsum_finish<false>, dim3((unsigned)(B * O)), dim3(128), 0, s, (const float*)workspace,
+                         (const float*)nullptr, (int)Din, S, dobj, (float*)nullptr);
+  }
   if (dpred && T > 0) {
     int64_t n = B * T * Dp;
     hipLaunchKernelGGL(k_slice_copy, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, dcat, B * T,
@@ -362,15 +454,33 @@ int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32
   return check_launch("csg_gather_concat_bwd");
 }
 
+int64_t csg_segment_avg_fwd_workspace(int64_t B, int64_t O, int64_t T, int64_t H) {
+  if (B <= 0 || O <= 0 || T < 0 || H <= 0) return -1;
+  const int S = rowsum_splits(B, O, T);
+  return S > 1 ? B * O * S * (H + 1) * (int64_t)sizeof(float) : 0;
+}
+
 int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid, const int32_t* row_ptr,
                         const int32_t* col, int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, float* pooled,
-                        float* cnt, float* new_p, void* stream) {
+                        float* cnt, float* new_p, void* workspace, int64_t workspace_bytes, void* stream) {
   CSG_REQUIRE(B > 0 && O > 0 && T >= 0 && H > 0 && Dp >= 0, CSG_E_BADSHAPE, "csg_segment_avg_fwd: bad shape");
+  CSG_REQUIRE(H % 4 == 0 && Dp % 4 == 0, CSG_E_BADSHAPE, "csg_segment_avg_fwd: H=%ld and Dp=%ld must be multiples of 4",
+              (long)H, (long)Dp);
   hipStream_t s = (hipStream_t)stream;
   // algorithmic bytes: messages 2*T*H*4 + indices + confidence, pooled O*H*4 written
   ProfScope p(K_SEGAVG_FWD, (double)B * (T * (2.0 * H * 4 + 16 + 4) + O * H * 4.0), s);
-  hipLaunchKernelGGL(k_segment_avg_fwd, dim3((unsigned)O, (unsigned)B), dim3(128), 0, s, h, conf, valid, row_ptr, col,
-                     (int)O, (int)T, (int)H, (int)Dp, pooled, cnt);
+  const int S = rowsum_splits(B, O, T);
+  const int64_t need = S > 1 ? B * O * S * (H + 1) * (int64_t)sizeof(float) : 0;
+  CSG_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), CSG_E_BADSHAPE,
+              "csg_segment_avg_fwd: workspace too small (%ld bytes, need %ld)", (long)workspace_bytes, (long)need);
+  float* part = (float*)workspace;
+  float* part_cnt = part ? part + B * O * S * H : nullptr;
+  hipLaunchKernelGGL(k_csr_rowsum<true>, dim3((unsigned)O, (unsigned)B, (unsigned)S), dim3(256), 0, s, h, conf, valid,
+                     row_ptr, col, (int)O, (int)T, (int)H, (int)(2 * H + Dp), 0, (int)(H + Dp), rowsum_lpe(H), S, pooled,
+                     cnt, part, part_cnt);
+  if (S > 1)
+    hipLaunchKernelGGL(k_rowsum_finish<true>, dim3((unsigned)(B * O)), dim3(128), 0, s, (const float*)part,
+                       (const float*)part_cnt, (int)H, S, pooled, cnt);
   if (new_p && Dp > 0 && T > 0) {
     int64_t n = B * T * Dp;
     hipLaunchKernelGGL(k_scale_slice, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, h, conf, B * T,

@@ -481,8 +481,10 @@ class _GatherConcat(torch.autograd.Function):
         dcat = dcat.contiguous()
         dobj = torch.empty((B, O, Din), device=dcat.device, dtype=torch.float32)
         dpred = torch.empty((B, T, Dp), device=dcat.device, dtype=torch.float32)
+        nbytes = lib.csg_gather_concat_bwd_workspace(B, O, T, Din)
+        ws = torch.empty(nbytes // 4, device=dcat.device, dtype=torch.float32) if nbytes > 0 else None
         check(lib.csg_gather_concat_bwd(ptr(dcat), ptr(row_ptr), ptr(col), B, O, T, Din, Dp, ptr(dobj), ptr(dpred),
-                                        stream()), "gather_concat_bwd")
+                                        ptr(ws), nbytes, stream()), "gather_concat_bwd")
         return dobj, dpred, None, None, None
 
 
@@ -501,8 +503,10 @@ class _SegmentAvg(torch.autograd.Function):
         pooled = torch.empty((B, O, H), device=h.device, dtype=torch.float32)
         cnt = torch.empty((B, O), device=h.device, dtype=torch.float32)
         new_p = torch.empty((B, T, Dp), device=h.device, dtype=torch.float32)
+        nbytes = lib.csg_segment_avg_fwd_workspace(B, O, T, H)
+        ws = torch.empty(nbytes // 4, device=h.device, dtype=torch.float32) if nbytes > 0 else None
         check(lib.csg_segment_avg_fwd(ptr(h), ptr(conf), ptr(valid), ptr(row_ptr), ptr(col), B, O, T, H, Dp,
-                                      ptr(pooled), ptr(cnt), ptr(new_p), stream()), "segment_avg_fwd")
+                                      ptr(pooled), ptr(cnt), ptr(new_p), ptr(ws), nbytes, stream()), "segment_avg_fwd")
         ctx.save_for_backward(h, conf, valid, triplets, pooled, cnt)
         ctx.dims = (B, O, T, H, Dp)
         return pooled, new_p

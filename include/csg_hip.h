@@ -77,15 +77,24 @@ int csg_graph_csr_build(const int64_t* triplets, int64_t B, int64_t T, int64_t O
 /* K2: cur_t = cat(obj[s], pred, obj[o])   (sg2im/graph.py:63-66) */
 int csg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* triplets, int64_t B, int64_t O,
                           int64_t T, int64_t Din, int64_t Dp, float* out, void* stream);
+/* dobj[b,i] = sum over object i's CSR row of the matching slice of dcat; dpred = the middle slice.
+ * Dense graphs split each row over several workgroups: the partial sums live in `workspace`
+ * (csg_gather_concat_bwd_workspace bytes, 0 for sparse graphs) and are combined in a fixed order.
+ * Din and Dp must be multiples of 4 (16-byte rows). */
+int64_t csg_gather_concat_bwd_workspace(int64_t B, int64_t O, int64_t T, int64_t Din);
 int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32_t* col, int64_t B, int64_t O,
-                          int64_t T, int64_t Din, int64_t Dp, float* dobj, float* dpred, void* stream);
+                          int64_t T, int64_t Din, int64_t Dp, float* dobj, float* dpred, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* K4+K5: confidence gate + masked segment average (sg2im/graph.py:69-109).
  * h = net1 output (B,T,2H+Dp) = [s | p | o]; conf (B,T); valid (B,T) = pred_indicators.
- * pooled (B,O,H), cnt (B,O), new_p (B,T,Dp) = conf * h[:, H:H+Dp]                               */
+ * pooled (B,O,H), cnt (B,O), new_p (B,T,Dp) = conf * h[:, H:H+Dp]
+ * H and Dp multiples of 4.  `workspace`: csg_segment_avg_fwd_workspace bytes (row-split partials of
+ * dense graphs; 0 for sparse ones).                                                             */
+int64_t csg_segment_avg_fwd_workspace(int64_t B, int64_t O, int64_t T, int64_t H);
 int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid, const int32_t* row_ptr,
                         const int32_t* col, int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, float* pooled,
-                        float* cnt, float* new_p, void* stream);
+                        float* cnt, float* new_p, void* workspace, int64_t workspace_bytes, void* stream);
 /* dcnt_scratch (B,O) float workspace */
 int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* h, const float* conf,
                         const uint8_t* valid, const int64_t* triplets, const float* pooled, const float* cnt,

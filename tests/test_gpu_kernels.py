@@ -412,6 +412,61 @@ def test_gather_concat_and_segment_avg_vs_golden(ops):
         assert_close(sd[k].grad, a["grad:" + k], RTOL, 1e-5, "d" + k)
 
 
+@pytest.mark.parametrize("O,H,Dp,Din", [(70, 512, 128, 128), (130, 64, 32, 32), (9, 2048, 16, 12)])
+def test_dense_graph_rows_vs_oracle(ops, O, H, Dp, Din):
+    """CLEVR-style closure graphs (every ordered pair: rows of ~2(O-1) edges, split over several workgroups),
+    padded triplets, transitive confidences: gather + weighted segment average, forward and backward,
+    against the oracle's GraphTripleConv arithmetic (sg2im/graph.py:63-109)."""
+    g = torch.Generator().manual_seed(O)
+    B = 2
+    pairs = [(s, o) for s in range(O) for o in range(O) if s != o]
+    T = len(pairs) + 7                                                    # 7 padded triplets at the end
+    tr = torch.zeros(B, T, 3, dtype=torch.int64)
+    for b in range(B):
+        keep = len(pairs) if b == 0 else len(pairs) // 2                 # the second sample is half padding
+        tr[b, :keep, 0] = torch.tensor([p[0] for p in pairs[:keep]])
+        tr[b, :keep, 2] = torch.tensor([p[1] for p in pairs[:keep]])
+        tr[b, :keep, 1] = torch.randint(2, 8, (keep,), generator=g)
+    p = tr[..., 1]
+    tt = (torch.rand(B, T, generator=g) < 0.7).long() * (p != 0).long()
+    obj = torch.randn(B, O, Din, generator=g)
+    pred = torch.randn(B, T, Dp if Dp % 4 == 0 else Dp, generator=g)
+    h = torch.randn(B, T, 2 * H + Dp, generator=g)
+    w_trans = torch.randn(8, generator=g)
+    conf = (tt == 0).float() + (tt == 1).float() * torch.sigmoid(w_trans)[p]
+    valid = p != 0
+    wo, wc = torch.randn(B, O, H, generator=g), torch.randn(B, T, 2 * Din + Dp, generator=g)
+    # ---- CPU restatement (graph.py:63-66, 88-106)
+    objr, hr, confr = obj.clone().requires_grad_(True), h.clone().requires_grad_(True), conf.clone().requires_grad_(True)
+    cat_ref = torch.cat([torch.gather(objr, 1, tr[..., 0:1].expand(-1, -1, Din)), pred,
+                         torch.gather(objr, 1, tr[..., 2:3].expand(-1, -1, Din))], dim=-1)
+    pooled_ref = torch.zeros(B, O, H)
+    cnt_ref = torch.zeros(B, O)
+    for b in range(B):
+        m = valid[b]
+        s_i, o_i = tr[b, m, 0], tr[b, m, 2]
+        hs, ho = hr[b, m, :H] * confr[b, m, None], hr[b, m, H + Dp:] * confr[b, m, None]
+        pooled_b = torch.zeros(O, H).index_add(0, s_i, hs).index_add(0, o_i, ho)
+        cnt_b = torch.zeros(O).index_add(0, s_i, confr[b, m]).index_add(0, o_i, confr[b, m])
+        nz = cnt_b > 0
+        pooled_b = torch.where(nz[:, None], pooled_b / cnt_b.clamp_min(1e-30)[:, None], pooled_b)
+        pooled_ref[b], cnt_ref[b] = pooled_b, cnt_b.detach()
+    ((pooled_ref * wo).sum() + (cat_ref * wc).sum()).backward()
+    # ---- kernels
+    trd = tr.cuda()
+    rp, col = ops.graph_csr(trd, O)
+    objd, hd, confd = dev(obj, True), dev(h, True), dev(conf, True)
+    cat = ops.gather_concat(objd, pred.cuda(), trd, rp, col)
+    pooled, new_p = ops.segment_avg(hd, confd, valid.to(torch.uint8).cuda(), trd, rp, col, H, Dp)
+    assert_close(cat, cat_ref, 0, 0, "gather (bit exact)")
+    assert_close(pooled, pooled_ref, RTOL, 2e-5, "pooled")
+    assert_close(new_p, h[..., H:H + Dp] * conf[..., None], RTOL, 1e-6, "new_p")
+    ((pooled * wo.cuda()).sum() + (cat * wc.cuda()).sum()).backward()
+    assert_close(objd.grad, objr.grad, RTOL, 2e-4 * float(objr.grad.abs().max()), "dobj (row-split sums)")
+    assert_close(hd.grad, hr.grad, RTOL, 1e-5, "dh")
+    assert_close(confd.grad, confr.grad, 1e-3, 2e-4 * float(confr.grad.abs().max()), "dconf")
+
+
 def test_object_crops_golden(ops):
     """crop_bbox_batch of the reference (expand + grid_sample) vs the gather kernel, fwd + d(image)."""
     from canonicalsg2im_amd.synth import make_vocab
