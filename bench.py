@@ -184,11 +184,20 @@ def main():
             kern[name] = {"ms_per_step": round(ms / args.steps, 3), "launches_per_step": round(n / args.steps, 1),
                           "avg_us": round(1000.0 * ms / n, 2)}
         ms, n, work = prof.get("igemm_fwd", (0.0, 0, 0.0))
+        traffic = None                      # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if args.config == "C3" and H == 256 and args.batch == 16 and not args.use_img_disc and not args.vgg_loss:
+                traffic = pmc["kernels"]["k_igemm_fwd<128>"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         if n:
             ach = work / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_igemm_fwd (conv forward + backward-data, all shapes)",
                                "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                               "traffic_note": "HBM bytes per launch (read x2-corrected FETCH_SIZE + WRITE_SIZE, two "
+                                               "rocprofv3 --pmc passes of this workload, profiles/pmc_traffic.json)",
                                "launches": n, "avg_launch_us": round(1000.0 * ms / n, 2),
                                "algorithmic_gflop_per_launch": round(work / n / 1e9, 3)}
         wms, wn, wwork = prof.get("igemm_wgrad", (0.0, 0, 0.0))
@@ -196,6 +205,17 @@ def main():
             out["roofline_wgrad"] = {"bound": "mfma", "achieved": round(wwork / (wms * 1e-3) / 1e12, 2),
                                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(wwork / (wms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        # HBM-bound kernels: algorithmic bytes (K5 messages+indices+output, K6 the layout written
+        # once, K9 the activation passes) over their HIP-event time
+        hbm = {}
+        for name in ("segment_avg_fwd", "segment_avg_bwd", "gather_concat_fwd", "gather_concat_bwd", "layout_fwd",
+                     "layout_bwd", "norm_stats", "norm_apply_fwd", "norm_bwd_reduce", "norm_bwd_dx", "act_bwd"):
+            kms, kn, kwork = prof.get(name, (0.0, 0, 0.0))
+            if kn and kms > 0:
+                gbs = kwork / (kms * 1e-3) / 1e9
+                hbm[name] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": round(gbs / PEAK_HBM_GBS, 4)}
+        out["hbm_kernels"] = hbm
         out["kernels"] = kern
     if gen_ms is not None:
         # algorithmic work of SPADEGenerator fwd+bwd per image (FlopCounterMode; S = 32 or 128)
