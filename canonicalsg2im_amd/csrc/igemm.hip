@@ -25,6 +25,8 @@
 // reduction over pixels, split across blocks into slabs + ordered reduction as well.
 #include <stddef.h>
 
+#include <type_traits>
+
 #include "csg_common.h"
 
 using namespace csg;
@@ -501,22 +503,31 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
   const int wi = BI == 32 ? 0 : (wave >> 1), wj = BI == 32 ? wave : (wave & 1);
   const int r = lane & 31, hh = lane >> 5;
 
+  // Fragment rows are INTERLEAVED: lane r of tile mi holds channel wi*(MI*32) + r*MI + mi (and column
+  // r*NJ + nj of the X tile), so one ds_read_b64 fetches a lane's operands for MI (NJ) tiles at once —
+  // half the LDS instructions of one ds_read_b32 per tile.  The epilogue undoes the permutation.
+  auto frag = [&](const float* ptr, float* dst, auto n_tag) {
+    constexpr int N = decltype(n_tag)::value;
+    if constexpr (N == 2) {
+      const float2 t = *(const float2*)ptr;
+      dst[0] = t.x;
+      dst[1] = t.y;
+    } else {
+      dst[0] = *ptr;
+    }
+  };
   auto compute_tile = [&](int buf) {
-    const float* Ab = As + buf * 32 * BI + hh * BI + wi * (MI * 32) + r;
-    const float* Bb = Bs + buf * 32 * WG_LDB + hh * WG_LDB + wj * (NJ * 32) + r;
+    const float* Ab = As + buf * 32 * BI + hh * BI + wi * (MI * 32) + r * MI;
+    const float* Bb = Bs + buf * 32 * WG_LDB + hh * WG_LDB + wj * (NJ * 32) + r * NJ;
     // fragments of pixel pair kp+1 are fetched from LDS before the MFMAs of pair kp are issued
     float a[2][MI], b[2][NJ];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a[0][mi] = Ab[mi * 32];
-#pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) b[0][nj] = Bb[nj * 32];
+    frag(Ab, a[0], std::integral_constant<int, MI>());
+    frag(Bb, b[0], std::integral_constant<int, NJ>());
 #pragma unroll
     for (int kp = 0; kp < 16; ++kp) {
       if (kp + 1 < 16) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[(kp + 1) & 1][mi] = Ab[(kp + 1) * 2 * BI + mi * 32];
-#pragma unroll
-        for (int nj = 0; nj < NJ; ++nj) b[(kp + 1) & 1][nj] = Bb[(kp + 1) * 2 * WG_LDB + nj * 32];
+        frag(Ab + (kp + 1) * 2 * BI, a[(kp + 1) & 1], std::integral_constant<int, MI>());
+        frag(Bb + (kp + 1) * 2 * WG_LDB, b[(kp + 1) & 1], std::integral_constant<int, NJ>());
       }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
@@ -563,24 +574,30 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
     compute_tile(buf);
   }
 
-  // D[i = kk][j = n]: a lane owns output channel n and runs of 4 consecutive (tap,c) columns, which
-  // are contiguous in the slab row [split][Cout][wrow] (Cin % 4 == 0, so a run never straddles taps)
+  // D[i = kk][j = n]: a lane owns output channel n and, per (g, hh), a run of 4*NJ consecutive (tap,c)
+  // columns (row rho = 8g+4hh+q of tile nj is column rho*NJ + nj), contiguous in the slab row
+  // [split][Cout][wrow] (Cin % 4 == 0, so a float4 never straddles taps)
   float* slab = out + (long long)sp * d.Cout * p.wrow;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int n = it * BI + wi * (MI * 32) + mi * 32 + r;
+    const int n = it * BI + wi * (MI * 32) + r * MI + mi;
     if (n >= d.Cout) continue;
     float* srow = slab + (long long)n * p.wrow;
 #pragma unroll
-    for (int nj = 0; nj < NJ; ++nj)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int kk = jt * 128 + wj * (NJ * 32) + nj * 32 + 8 * g + 4 * hh;
+      for (int f = 0; f < NJ; ++f) {
+        const int kk = jt * 128 + wj * (NJ * 32) + (8 * g + 4 * hh) * NJ + 4 * f;
         if (kk < p.Ktot) {
           const int sl = kk / d.Cin;
           const int col = s_tap[32 + sl] * d.Cin + (kk - sl * d.Cin);
-          *(float4*)(srow + col) = make_float4(acc[mi][nj][4 * g], acc[mi][nj][4 * g + 1], acc[mi][nj][4 * g + 2],
-                                               acc[mi][nj][4 * g + 3]);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int L = 4 * f + e;
+            v[e] = acc[mi][L % NJ][4 * g + L / NJ];
+          }
+          *(float4*)(srow + col) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
   }
