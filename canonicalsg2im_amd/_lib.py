@@ -79,6 +79,10 @@ SIGNATURES = {
     "csg_l1_mean_workspace": (c_i64, [c_i64]),
     "csg_l1_mean_fwd": (c_i32, [c_p, c_p, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_l1_mean_bwd": (c_i32, [c_p, c_p, c_p, c_i64, c_p, c_p]),
+    "csg_spectral_norm_workspace": (c_i64, [c_i64, c_i64]),
+    "csg_spectral_norm_fwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f32, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_spectral_norm_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
+                                      c_p, c_p, c_i64, c_p]),
     "csg_canon_workspace": (c_i64, [c_i64]),
     "csg_canon_build": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, ctypes.POINTER(c_i32), c_i64, c_i32, c_i32, c_p, c_i64,
                                 c_p, c_p]),

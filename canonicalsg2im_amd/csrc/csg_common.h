@@ -44,6 +44,8 @@ enum KernelId {
   K_L1_BWD,
   K_CANON_BUILD,
   K_CANON_EMIT,
+  K_SPECTRAL_FWD,
+  K_SPECTRAL_BWD,
   K_COUNT
 };
 

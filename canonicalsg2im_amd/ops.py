@@ -18,7 +18,7 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, check, lib, ptr, stre
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
     "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "disc_input", "crop_objects", "maxpool2", "l1_mean",
-    "pack_conv_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
+    "pack_conv_weight", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
 
 
@@ -206,6 +206,65 @@ def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
         x2 = x2.contiguous()
     y = conv2d(x2.view(-1, K, 1, 1), weight.view(N, K, 1, 1), bias, 1, 0, act, slope)
     return y.reshape(*lead, N)
+
+
+class _SpectralWeight(torch.autograd.Function):
+    """W_eff = W / sigma(W, u, v) with torch.nn.utils.spectral_norm's power iteration (one step, in place on
+    the u / v buffers) — csrc/spectral.hip.  u and v are constants of the graph, as in PyTorch."""
+
+    @staticmethod
+    def forward(ctx, w, u, v, iterate, eps):
+        w = _f32(w).contiguous()
+        Cout = w.shape[0]
+        K = w.numel() // Cout
+        nbytes = lib.csg_spectral_norm_workspace(Cout, K)
+        if nbytes < 0:
+            raise RuntimeError("spectral_weight: weight (%d x %d) needs K %% 4 == 0" % (Cout, K))
+        dev = w.device
+        ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        w_eff = torch.empty_like(w)
+        small = torch.empty(1 + Cout + K, device=dev, dtype=torch.float32)      # sigma | u_used | v_used
+        sigma, u_used, v_used = small[:1], small[1:1 + Cout], small[1 + Cout:]
+        check(lib.csg_spectral_norm_fwd(ptr(w), ptr(u), ptr(v), Cout, K, 1 if iterate else 0, eps, ptr(w_eff),
+                                        ptr(sigma), ptr(u_used), ptr(v_used), ptr(ws), nbytes, stream()),
+              "spectral_norm_fwd")
+        ctx.save_for_backward(w, small)                 # u, v are buffers (no grad): updated in place by the kernel
+        return w_eff
+
+    @staticmethod
+    def backward(ctx, dweff):
+        w, small = ctx.saved_tensors
+        Cout = w.shape[0]
+        K = w.numel() // Cout
+        Cin, KH, KW = (w.shape[1], w.shape[2], w.shape[3]) if w.dim() == 4 else (K, 1, 1)
+        dweff = _f32(dweff)
+        st = dweff.stride() if dweff.dim() == 4 else (K, 1, 1, 1)
+        if not _rows_dense(st, (Cin, KH, KW), K):       # e.g. a slice of a channel-padded gradient
+            dweff = dweff.contiguous()
+            st = dweff.stride() if dweff.dim() == 4 else (K, 1, 1, 1)
+        sigma, u_used, v_used = small[:1], small[1:1 + Cout], small[1 + Cout:]
+        nbytes = lib.csg_spectral_norm_workspace(Cout, K)
+        ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+        dw = torch.empty_like(w)
+        check(lib.csg_spectral_norm_bwd(ptr(dweff), Cout, Cin, KH, KW, st[0], st[1], st[2], st[3], ptr(w), ptr(u_used),
+                                        ptr(v_used), ptr(sigma), ptr(dw), ptr(ws), nbytes, stream()),
+              "spectral_norm_bwd")
+        return dw, None, None, None, None
+
+
+def _rows_dense(st, dims, K):
+    """True if a (Cout, Cin, KH, KW) tensor with element strides `st` stores every Cout-row as a dense
+    permutation of its K elements (contiguous, or the weight-gradient kernel's [Cout][KH][KW][Cin])."""
+    run = 1
+    for i in sorted(range(3), key=lambda i: st[1 + i]):
+        if dims[i] > 1 and st[1 + i] != run:
+            return False
+        run *= dims[i]
+    return st[0] == K
+
+
+def spectral_weight(w, u, v, iterate, eps=1e-12):
+    return _SpectralWeight.apply(w, u, v, bool(iterate), float(eps))
 
 
 # ------------------------------------------------------------------------------------ normalisation

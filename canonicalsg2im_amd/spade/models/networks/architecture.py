@@ -1,9 +1,9 @@
 """SPADE residual block and the VGG19 feature stack (reference: spade/models/networks/architecture.py:21-68, 93-123)."""
 import torch
 import torch.nn as nn
-import torch.nn.utils.spectral_norm as spectral_norm
 
 from .... import ops
+from ....spectral_norm import spectral_norm
 from ....sg2im.layers import Conv2d
 from .normalization import SPADE
 

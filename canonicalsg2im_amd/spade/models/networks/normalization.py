@@ -8,9 +8,9 @@ import re
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-import torch.nn.utils.spectral_norm as spectral_norm
 
 from .... import ops
+from ....spectral_norm import spectral_norm
 from ....sg2im.layers import Conv2d, _FusedActivation
 from .sync_batchnorm import LocalBatchNorm2d, SynchronizedBatchNorm2d
 

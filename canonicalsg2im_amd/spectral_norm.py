@@ -1,0 +1,30 @@
+"""`spectral_norm(module)` with the reference's semantics (torch.nn.utils.spectral_norm: parameters
+`weight_orig`, buffers `weight_u` / `weight_v`, one power iteration per training-mode forward call,
+state_dict hooks) whose per-call arithmetic runs on the HIP kernels of csrc/spectral.hip.
+
+Registration is torch's own (`SpectralNorm.apply`), so checkpoints, `remove_spectral_norm` and the
+state-dict version hooks behave exactly as in the reference; only `compute_weight` is replaced."""
+import torch
+from torch.nn.utils.spectral_norm import SpectralNorm
+from torch.nn.utils.spectral_norm import spectral_norm as _torch_spectral_norm
+
+from . import ops
+
+
+class HipSpectralNorm(SpectralNorm):
+    def compute_weight(self, module, do_power_iteration):
+        weight = getattr(module, self.name + "_orig")
+        if not weight.is_cuda or self.dim != 0 or self.n_power_iterations != 1:
+            # construction-time call on CPU tensors / exotic settings: torch's own arithmetic
+            return super().compute_weight(module, do_power_iteration)
+        u = getattr(module, self.name + "_u")
+        v = getattr(module, self.name + "_v")
+        return ops.spectral_weight(weight, u, v, do_power_iteration, self.eps)
+
+
+def spectral_norm(module, name='weight', n_power_iterations=1, eps=1e-12, dim=None):
+    module = _torch_spectral_norm(module, name, n_power_iterations, eps, dim)
+    for hook in module._forward_pre_hooks.values():
+        if isinstance(hook, SpectralNorm) and hook.name == name:
+            hook.__class__ = HipSpectralNorm
+    return module

@@ -239,6 +239,25 @@ int csg_canon_emit(const int64_t* objs0, const int64_t* n_objs, int64_t B, int64
                    int64_t image_id, int include_dummies, int learned_transitivity, const void* workspace,
                    const int64_t* counts, int64_t T, int64_t* triplets, int64_t* triplet_type, void* stream);
 
+/* ---- spectral normalisation of a conv weight (a13) ----------------------------------------------
+ * torch.nn.utils.spectral_norm's forward pre-hook (reference call sites architecture.py:35-39,
+ * normalization.py:27; SpectralNorm.compute_weight, n_power_iterations = 1, dim = 0):
+ *   iterate != 0 (training): v <- normalize(W^T u); u <- normalize(W v), both buffers updated in place;
+ *   sigma = u.(W v); w_eff = w / sigma.   normalize(x) = x / max(||x||, eps).
+ * w is weight_orig viewed (Cout, K = Cin*KH*KW), K % 4 == 0.  u_used / v_used receive the vectors the
+ * graph keeps for backward (PyTorch clones them for the same reason).
+ * Backward: dw = (dweff - (sum dweff.w_eff) u v^T) / sigma; dweff is given with its element strides
+ * along (Cout, Cin, KH, KW) — rows must be dense, e.g. contiguous or the [Cout][KH][KW][Cin] layout of
+ * csg_conv_bwd_weight.  One workspace size serves both calls. */
+int64_t csg_spectral_norm_workspace(int64_t Cout, int64_t K);
+int csg_spectral_norm_fwd(const float* w, float* u, float* v, int64_t Cout, int64_t K, int iterate, float eps,
+                          float* w_eff, float* sigma, float* u_used, float* v_used, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+int csg_spectral_norm_bwd(const float* dweff, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW, int64_t s0,
+                          int64_t s1, int64_t s2, int64_t s3, const float* w, const float* u_used,
+                          const float* v_used, const float* sigma, float* dw, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

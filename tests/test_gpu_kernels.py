@@ -467,6 +467,50 @@ def test_dense_graph_rows_vs_oracle(ops, O, H, Dp, Din):
     assert_close(confd.grad, confr.grad, 1e-3, 2e-4 * float(confr.grad.abs().max()), "dconf")
 
 
+@pytest.mark.parametrize("shape", [(64, 32, 3, 3), (128, 64, 4, 4), (1024, 1024, 3, 3), (20, 12, 1, 1)])
+def test_spectral_norm_vs_torch(ops, shape):
+    """csrc/spectral.hip against torch.nn.utils.spectral_norm (the function the reference calls,
+    architecture.py:35-39): three training-mode calls (u/v evolve in place), one eval call, and the
+    gradient w.r.t. weight_orig for a cotangent handed over in the weight-gradient kernel's layout."""
+    import torch.nn as nn
+    from canonicalsg2im_amd.spectral_norm import spectral_norm
+    torch.manual_seed(sum(shape))
+    Cout, Cin, KH, KW = shape
+    ref = nn.Conv2d(Cin, Cout, (KH, KW), bias=False)
+    mine = nn.Conv2d(Cin, Cout, (KH, KW), bias=False)
+    mine.load_state_dict(ref.state_dict())
+    ref = torch.nn.utils.spectral_norm(ref)
+    mine = spectral_norm(mine)
+    mine.load_state_dict(ref.state_dict())
+    assert list(mine.state_dict()) == list(ref.state_dict()) == ["weight_orig", "weight_u", "weight_v"]
+    mine = mine.cuda()
+    hook_r = next(iter(ref._forward_pre_hooks.values()))
+    hook_m = next(iter(mine._forward_pre_hooks.values()))
+    for it in range(3):
+        hook_r(ref, None)
+        hook_m(mine, None)
+        assert_close(mine.weight, ref.weight, RTOL, 1e-7, "W_eff call %d" % it)
+        assert_close(mine.weight_u, ref.weight_u, RTOL, 1e-6, "u call %d" % it)
+        assert_close(mine.weight_v, ref.weight_v, RTOL, 1e-6, "v call %d" % it)
+    g = torch.randn(Cout, KH, KW, Cin)                       # [Cout][KH][KW][Cin] memory, as csg_conv_bwd_weight writes
+    ref.weight.backward(g.permute(0, 3, 1, 2))
+    mine.weight.backward(g.cuda().permute(0, 3, 1, 2))
+    scale = float(ref.weight_orig.grad.abs().max())
+    assert_close(mine.weight_orig.grad, ref.weight_orig.grad, RTOL, 2e-5 * scale, "dW_orig")
+    mine.weight_orig.grad = None
+    ref.weight_orig.grad = None
+    g2 = torch.randn(Cout, Cin, KH, KW)                       # contiguous cotangent
+    hook_r(ref, None); hook_m(mine, None)
+    ref.weight.backward(g2); mine.weight.backward(g2.cuda())
+    assert_close(mine.weight_orig.grad, ref.weight_orig.grad, RTOL, 2e-5 * float(ref.weight_orig.grad.abs().max()),
+                 "dW_orig (contiguous)")
+    ref.eval(); mine.eval()
+    u_before = mine.weight_u.clone()
+    hook_r(ref, None); hook_m(mine, None)
+    assert_close(mine.weight, ref.weight, RTOL, 1e-7, "W_eff eval")
+    assert torch.equal(mine.weight_u, u_before)               # no power iteration in eval mode
+
+
 def test_object_crops_golden(ops):
     """crop_bbox_batch of the reference (expand + grid_sample) vs the gather kernel, fwd + d(image)."""
     from canonicalsg2im_amd.synth import make_vocab
