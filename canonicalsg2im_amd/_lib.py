@@ -132,7 +132,8 @@ def stream():
 
 # ---------------------------------------------------------------- per-kernel timing
 def prof_enable(on=True):
-    check(lib.csg_prof_enable(1 if on else 0), "prof_enable")
+    """True / 1: time every launch; 2: only the dominant kernel (k_igemm_fwd<128>); False / 0: off."""
+    check(lib.csg_prof_enable(int(on)), "prof_enable")
 
 
 def prof_reset():

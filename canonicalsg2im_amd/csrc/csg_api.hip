@@ -33,7 +33,7 @@ struct Rec {
   double work;
   hipEvent_t e0, e1;
 };
-static bool g_prof = false;
+static int g_prof = 0;   // 0 off, 1 every kernel, 2 only the dominant one (k_igemm_fwd<128>)
 static std::mutex g_mu;
 static std::vector<Rec> g_pending;
 static std::vector<hipEvent_t> g_free;
@@ -42,7 +42,7 @@ static double g_work[K_COUNT];
 static int64_t g_n[K_COUNT];
 static Rec g_cur;
 
-bool prof_on() { return g_prof; }
+bool prof_on(int kid) { return g_prof == 1 || (g_prof == 2 && kid == K_IGEMM_FWD); }
 
 static hipEvent_t get_event() {
   if (!g_free.empty()) {
@@ -102,7 +102,7 @@ const char* csg_last_error(void) { return csg::g_err; }
 
 int csg_prof_enable(int on) {
   csg::resolve();
-  csg::g_prof = on != 0;
+  csg::g_prof = on < 0 ? 0 : (on > 2 ? 1 : on);
   return CSG_OK;
 }
 

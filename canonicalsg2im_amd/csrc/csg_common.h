@@ -53,14 +53,14 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
 // profiling hooks (csg_api.hip)
-bool prof_on();
+bool prof_on(int kid);
 void prof_begin(int kid, double work, hipStream_t s);
 void prof_end(hipStream_t s);
 
 struct ProfScope {
   hipStream_t s;
   bool on;
-  ProfScope(int kid, double work, hipStream_t st) : s(st), on(prof_on()) {
+  ProfScope(int kid, double work, hipStream_t st) : s(st), on(prof_on(kid)) {
     if (on) prof_begin(kid, work, s);
   }
   ~ProfScope() {

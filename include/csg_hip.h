@@ -44,8 +44,10 @@ extern "C" {
 int csg_version(void);
 const char* csg_last_error(void);
 
-/* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline) ------- */
-int csg_prof_enable(int on);
+/* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline) -------
+ * mode 0 = off, 1 = every launch, 2 = only the dominant kernel (k_igemm_fwd<128>): an event pair costs
+ * ~9 us of queue time, 10 ms per step when all ~1100 launches carry one, 2 ms in mode 2. */
+int csg_prof_enable(int mode);
 int csg_prof_reset(void);
 int csg_prof_num_kernels(void);
 const char* csg_prof_kernel_name(int kernel_id);
