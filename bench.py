@@ -170,6 +170,8 @@ def main():
         gen_ms = e0.elapsed_time(e1) / reps
 
     if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
     imgs = args.batch * world * args.steps
     out = {
@@ -240,9 +242,11 @@ def main():
                                         "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                                         "note": "SPADEGenerator forward+backward on one %d-image batch, all kernels "
                                                 "(convs, norms, layout, resampling) included" % args.batch}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # the CPU leg runs at N = 1 only
         out["cpu_baseline"] = cpu_baseline(opt_argv, vocab, cfg, args.cpu_image_size or H)
     print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
