@@ -14,9 +14,12 @@ from . import ops
 class HipSpectralNorm(SpectralNorm):
     def compute_weight(self, module, do_power_iteration):
         weight = getattr(module, self.name + "_orig")
-        if not weight.is_cuda or self.dim != 0 or self.n_power_iterations != 1:
-            # construction-time call on CPU tensors / exotic settings: torch's own arithmetic
-            return super().compute_weight(module, do_power_iteration)
+        if not weight.is_cuda:
+            raise RuntimeError("canonicalsg2im_amd ops need HIP (cuda) tensors; got a %s tensor — there is no CPU path"
+                               % weight.device)
+        if self.dim != 0 or self.n_power_iterations != 1:
+            raise NotImplementedError("spectral_norm: only dim=0, n_power_iterations=1 (the reference's settings, "
+                                      "architecture.py:35-39) are on the hot path")
         u = getattr(module, self.name + "_u")
         v = getattr(module, self.name + "_v")
         return ops.spectral_weight(weight, u, v, do_power_iteration, self.eps)
