@@ -59,7 +59,7 @@ SIGNATURES = {
     "csg_conv_fwd_workspace": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "csg_conv_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_conv_bwd_weight_workspace": (c_i64, [ctypes.POINTER(ConvDesc)]),
-    "csg_conv_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_conv_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_act_bwd": (c_i32, [c_p, c_p, c_i64, c_i32, c_f32, c_p, c_p]),
     "csg_colsum": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_norm_stats": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),

@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(IgemmParams p, const fl
 template <int BI>
 __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const float* __restrict__ x,
                                                          const float* __restrict__ dy, float* __restrict__ out,
-                                                         int itiles, int jtiles, int nsplit, int cps) {
+                                                         int itiles, int jtiles, int nsplit, int cps,
+                                                         float* __restrict__ dbp) {
   constexpr int WI = BI == 32 ? 1 : 2;          // waves along i
   constexpr int WJ = 4 / WI;                    // waves along j
   constexpr int MI = BI / (WI * 32);            // 32x32 tiles per wave along i
@@ -485,9 +486,17 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
       rb[i] = csg_buffer_load_f32x4(rsX, (int)(inb ? off : OOB_OFF), 0, 0);
     }
   };
+  // bias gradient (column sums of dY) for free: the j-tile-0 block of every (channel tile, split) adds up
+  // the dY values it stages anyway (rows past M arrive as zeros)
+  const bool do_db = dbp != nullptr && jt == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   auto store_tile = [&](int buf, const f32x4* ra, const f32x4* rb) {
 #pragma unroll
     for (int i = 0; i < AIT; ++i) *(f32x4*)(As + buf * 32 * BI + (apr + RP * i) * BI + ac4 * 4) = ra[i];
+    if (do_db) {
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) csum += ra[i];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + buf * 32 * WG_LDB + (pr + 8 * i) * WG_LDB + c4 * 4) = rb[i];
   };
@@ -601,6 +610,17 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
         }
       }
   }
+  if (do_db) {                               // uniform per block
+    __syncthreads();                         // every wave is done with the LDS tiles
+    f32x4* red = (f32x4*)smem;               // [RP][CQ]
+    red[apr * CQ + ac4] = csum;
+    __syncthreads();
+    if (apr == 0 && n0 < d.Cout) {
+      f32x4 tot = red[ac4];
+      for (int q = 1; q < RP; ++q) tot += red[q * CQ + ac4];      // fixed order
+      *(f32x4*)(dbp + (long long)sp * d.Cout + n0) = tot;
+    }
+  }
 }
 
 __global__ void k_wgrad_reduce(const float* __restrict__ ws, int64_t n4, int nsplit, float* __restrict__ dw) {
@@ -713,7 +733,7 @@ static void wgrad_plan(const IgemmParams& p, int bi, int& itiles, int& jtiles, i
 
 template <int BI>
 static int launch_wgrad(IgemmParams& p, const float* x, const float* dy, float* out, int itiles, int jtiles,
-                        int nsplit, int cps, hipStream_t s) {
+                        int nsplit, int cps, float* dbp, hipStream_t s) {
   static bool attr_set = false;
   size_t shm = (size_t)(2 * 32 * BI + 2 * 32 * WG_LDB) * 4 + 48 * 4;
   if (!attr_set) {
@@ -721,7 +741,7 @@ static int launch_wgrad(IgemmParams& p, const float* x, const float* dy, float* 
     attr_set = true;
   }
   hipLaunchKernelGGL(k_igemm_wgrad<BI>, dim3((unsigned)(itiles * jtiles * nsplit)), dim3(256), shm, s, p, x, dy, out,
-                     itiles, jtiles, nsplit, cps);
+                     itiles, jtiles, nsplit, cps, dbp);
   return check_launch("csg_conv_bwd_weight");
 }
 
@@ -781,11 +801,11 @@ int64_t csg_conv_bwd_weight_workspace(const csg_conv_desc* d) {
   fill(p, d);
   int it, jt, ns, cps;
   wgrad_plan(p, pick_bi(d->Cout), it, jt, ns, cps);
-  return ns > 1 ? (int64_t)ns * d->Cout * p.wrow * 4 : 0;
+  return ns > 1 ? (int64_t)ns * d->Cout * (p.wrow + 1) * 4 : 0;      // dW slabs + one bias-gradient row per split
 }
 
-int csg_conv_bwd_weight(const csg_conv_desc* d, const float* x, const float* dy, float* dw, float* workspace,
-                        int64_t workspace_bytes, void* stream) {
+int csg_conv_bwd_weight(const csg_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                        float* workspace, int64_t workspace_bytes, void* stream) {
   int rc = validate(d, "csg_conv_bwd_weight");
   if (rc) return rc;
   CSG_REQUIRE(d->Cout % 4 == 0 && d->y_cs % 4 == 0, CSG_E_UNSUPPORTED,
@@ -807,25 +827,33 @@ int csg_conv_bwd_weight(const csg_conv_desc* d, const float* x, const float* dy,
     const int64_t span = (((int64_t)cps * 32 + npix - 1) / npix + 1) * (int64_t)p.img_bytes;
     CSG_REQUIRE(span < MAX_RECORDS, CSG_E_UNSUPPORTED, "csg_conv_bwd_weight: split spans more than 2 GB of input");
   }
-  const int64_t need = nsplit > 1 ? (int64_t)nsplit * d->Cout * p.wrow * 4 : 0;
+  const int64_t need = nsplit > 1 ? (int64_t)nsplit * d->Cout * (p.wrow + 1) * 4 : 0;
+  CSG_REQUIRE(db == nullptr || ((uintptr_t)db % 16) == 0, CSG_E_UNSUPPORTED,
+              "csg_conv_bwd_weight: db must be 16-byte aligned");
   CSG_REQUIRE(workspace_bytes >= need && (need == 0 || workspace != nullptr), CSG_E_WORKSPACE,
               "csg_conv_bwd_weight: workspace %ld < %ld bytes", (long)workspace_bytes, (long)need);
   hipStream_t s = (hipStream_t)stream;
   {
     ProfScope ps(K_IGEMM_WGRAD, 2.0 * p.M * (double)p.Ktot * d->Cout, s);
     float* out = nsplit > 1 ? workspace : dw;
+    float* dbp = db == nullptr ? nullptr : (nsplit > 1 ? workspace + (int64_t)nsplit * d->Cout * p.wrow : db);
     if (bi == 32)
-      rc = launch_wgrad<32>(p, x, dy, out, itiles, jtiles, nsplit, cps, s);
+      rc = launch_wgrad<32>(p, x, dy, out, itiles, jtiles, nsplit, cps, dbp, s);
     else if (bi == 64)
-      rc = launch_wgrad<64>(p, x, dy, out, itiles, jtiles, nsplit, cps, s);
+      rc = launch_wgrad<64>(p, x, dy, out, itiles, jtiles, nsplit, cps, dbp, s);
     else
-      rc = launch_wgrad<128>(p, x, dy, out, itiles, jtiles, nsplit, cps, s);
+      rc = launch_wgrad<128>(p, x, dy, out, itiles, jtiles, nsplit, cps, dbp, s);
     if (rc) return rc;
   }
   if (nsplit > 1) {
     const int64_t n4 = (int64_t)d->Cout * p.wrow / 4;
     ProfScope ps(K_WGRAD_REDUCE, (double)(nsplit + 1) * n4 * 16, s);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, s, workspace, n4, nsplit, dw);
+    if (db != nullptr) {
+      const int64_t b4 = d->Cout / 4;
+      hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv(b4, 256)), dim3(256), 0, s,
+                         workspace + (int64_t)nsplit * d->Cout * p.wrow, b4, nsplit, db);
+    }
     rc = check_launch("csg_conv_bwd_weight(reduce)");
   }
   return rc;

@@ -147,6 +147,7 @@ class _Conv2d(torch.autograd.Function):
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
             for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
                 _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             d, _, _ = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad)
             nbytes = lib.csg_conv_bwd_weight_workspace(d)
@@ -154,9 +155,12 @@ class _Conv2d(torch.autograd.Function):
                 raise RuntimeError("conv_bwd_weight_workspace: " + _lib.last_error())
             ws = torch.empty(max(nbytes // 4, 4), device=dy.device, dtype=torch.float32)
             dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
-            check(lib.csg_conv_bwd_weight(d, ptr(x), ptr(dpre), ptr(dwp), ptr(ws), nbytes, stream()), "conv_bwd_weight")
+            if want_db:                                   # column sums of dY ride along in the same kernel
+                db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
+            check(lib.csg_conv_bwd_weight(d, ptr(x), ptr(dpre), ptr(dwp), ptr(db), ptr(ws), nbytes, stream()),
+                  "conv_bwd_weight")
             dw = dwp.permute(0, 3, 1, 2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        elif want_db:
             rows = B * OH * OW
             nch = _chunks(rows)
             part = torch.empty(nch * 2 * Cout, device=dy.device, dtype=torch.float32)

@@ -149,10 +149,12 @@ int64_t csg_conv_fwd_workspace(const csg_conv_desc* d);
 int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
                  float* y, float* workspace, int64_t workspace_bytes, void* stream);
 /* dw[n][tap][c] = sum_m dy[m][n] * x[src(m,tap)][c]; `d` is the FORWARD descriptor (y_cs = floats per
- * pixel of dy).  Deterministic split-K: partial slabs in `workspace`, then an ordered reduction. */
+ * pixel of dy).  Deterministic split-K: partial slabs in `workspace`, then an ordered reduction.
+ * db (Cout floats, may be NULL) receives the bias gradient sum_m dy[m][n], accumulated from the dY
+ * tiles the kernel stages anyway (no separate pass over dy). */
 int64_t csg_conv_bwd_weight_workspace(const csg_conv_desc* d);
-int csg_conv_bwd_weight(const csg_conv_desc* d, const float* x, const float* dy, float* dw, float* workspace,
-                        int64_t workspace_bytes, void* stream);
+int csg_conv_bwd_weight(const csg_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                        float* workspace, int64_t workspace_bytes, void* stream);
 
 /* dpre = dy * act'(.) evaluated from the OUTPUT y (leaky: y>0 ? 1 : slope; tanh: 1-y^2)          */
 int csg_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float slope, float* dpre, void* stream);
