@@ -343,6 +343,38 @@ def test_step_with_vgg_loss_vs_oracle(cuda, monkeypatch):
     assert_close(w, wo, 0, 2.2 * opt.learning_rate, "conv_img.weight after step")
 
 
+def test_ragged_batch_vs_oracle(cuda):
+    """Ragged inputs: a sample with ONE object and no triplets at all (only padding), a sample whose boxes
+    leave the image, duplicate triplets, and heavy object padding — default recipe, HIP trainer vs oracle."""
+    import oracle
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
+    vocab = make_vocab("coco")
+    opt = T.make_opt(vocab, ["--image_size", "64,64", "--ngf", "8", "--ndf", "8", "--batch_size", "3", "--no_vgg_loss",
+                             "--gconv_hidden_dim", "64", "--gconv_dim", "32", "--crop_size", "32"])
+    torch.manual_seed(9)
+    tr = T.Trainer(opt, cuda)
+    ts = T.oracle_state_from(tr, oracle)
+    imgs, objs, boxes, triplets, cc, tt, masks, ids = make_batch(vocab, BatchConfig(3, 64, 6, 6, "random", pad_objects_to=11,
+                                                                                   pad_triplets_to=9), seed=77)
+    objs[1, 1:] = 0                      # sample 1: a single object ...
+    boxes[1, 1:] = -1
+    triplets[1] = 0                      # ... and only padded triplets ([0, __padding__, 0])
+    tt[1] = 0
+    boxes[2, 0] = torch.tensor([0.8, -0.2, 0.6, 0.5])      # partly outside the image
+    boxes[2, 1] = torch.tensor([-0.3, 0.9, 0.2, 0.4])
+    triplets[2, 1] = triplets[2, 0]                        # duplicate edge
+    batch = (imgs, objs, boxes, triplets, cc, tt, masks, ids)
+    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    Go, Do, img_o = oracle.train_step(ts, batch)
+    for k in Go:
+        if k != "bbox_pred_all":
+            assert_close(G[k].reshape(()), Go[k].reshape(()), 3e-4, 1e-5, "G %s" % k)
+    assert_close(G["bbox_pred_all"], Go["bbox_pred_all"], 3e-4, 1e-6, "bbox_pred_all")
+    for k in Do:
+        assert_close(D[k].reshape(()), Do[k].reshape(()), 3e-4, 1e-5, "D %s" % k)
+
+
 # ----------------------------------------------------------------------------- full-size properties
 def test_layout_full_size_checksum_and_linearity(cuda):
     """256x256, S=32, 30 objects/img, B=16 (config C3): (1) sum over pixels of the layout equals
