@@ -1,61 +1,72 @@
-"""Trainer-level containers (reference: sg2im/meta_models.py:9-90).  Same attribute names and
-state_dict prefixes (`sg_to_layout.module.*`, `layout_to_image_model.module.*`)."""
+"""Trainer-level containers with the reference's surface (sg2im/meta_models.py:9-90): attribute names
+`sg_to_layout`, `layout_to_image_model`, `img_/obj_/mask_discriminator`, `optimizer_d_img/_obj/_mask`
+and the state_dict prefixes `sg_to_layout.module.*`, `layout_to_image_model.module.*`.
+
+One process drives one GPU here, so `DataParallelWithCallback` is a transparent wrapper that only
+contributes the `.module` level of the checkpoint keys."""
 import torch
 import torch.nn as nn
 
-from ..spade.models.networks import (AcCropDiscriminator, MultiscaleDiscriminator, MultiscaleMaskDiscriminator2,
-                                     SPADEGenerator)
+from ..spade.models import networks as spade_nets
 from ..spade.models.networks.sync_batchnorm import DataParallelWithCallback
 from .model import Sg2LayoutModel
 
 
+def _wrapped(net, opt, device):
+    return DataParallelWithCallback(net, device_ids=opt.gpu_ids).to(device)
+
+
 class MetaGeneratorModel(nn.Module):
+    """Scene graph -> (boxes, masks) -> image.  Either half can be switched off with
+    `--skip_graph_model` / `--skip_generation` (reference :13-23)."""
+
     def __init__(self, opt, device):
         super().__init__()
         self.args = vars(opt)
-        self.vocab = self.args["vocab"]
-        if not self.args['skip_graph_model']:
-            self.sg_to_layout = DataParallelWithCallback(Sg2LayoutModel(opt), device_ids=self.args['gpu_ids']).to(device)
-        if not self.args['skip_generation']:
-            self.layout_to_image_model = DataParallelWithCallback(SPADEGenerator(opt),
-                                                                  device_ids=self.args['gpu_ids']).to(device)
+        self.vocab = opt.vocab
+        self.has_graph = not opt.skip_graph_model
+        self.has_image = not opt.skip_generation
+        if self.has_graph:
+            self.sg_to_layout = _wrapped(Sg2LayoutModel(opt), opt, device)
+        if self.has_image:
+            self.layout_to_image_model = _wrapped(spade_nets.SPADEGenerator(opt), opt, device)
 
     def forward(self, objs, triplets, triplet_type, boxes_gt=None, masks_gt=None, test_mode=False):
-        boxes_pred = masks_pred = img = None
-        if not self.args['skip_graph_model']:
-            _, boxes_pred, masks_pred = self.sg_to_layout(objs, triplets, triplet_type, boxes_gt)
-        if not self.args["skip_generation"]:
-            layout_boxes = boxes_pred if boxes_gt is None else boxes_gt
-            layout_masks = masks_pred if masks_gt is None else masks_gt
-            img = self.layout_to_image_model(objs, layout_boxes, layout_masks, test_mode=test_mode)
+        img = boxes_pred = masks_pred = None
+        if self.has_graph:
+            boxes_pred, masks_pred = self.sg_to_layout(objs, triplets, triplet_type, boxes_gt)[1:]
+        if self.has_image:
+            # ground truth wins over the prediction wherever it is given (reference :47-49)
+            img = self.layout_to_image_model(objs, boxes_gt if boxes_gt is not None else boxes_pred,
+                                             masks_gt if masks_gt is not None else masks_pred, test_mode=test_mode)
         return img, boxes_pred, masks_pred
 
 
 class MetaDiscriminatorModel(nn.Module):
+    """Image discriminator always; object-crop and mask discriminators unless `--use_img_disc 1`
+    (reference :56-90).  Optimisers are created by `build_optimizers` once the module is on its device —
+    the reference hard-codes `torch.cuda.FloatTensor` in the constructor instead."""
+
     def __init__(self, opt):
         super().__init__()
         self.args = vars(opt)
-        self.img_discriminator = MultiscaleDiscriminator(opt)
-        self.img_discriminator.train()
+        self.img_discriminator = spade_nets.MultiscaleDiscriminator(opt)
         if not opt.use_img_disc:
-            self.obj_discriminator = AcCropDiscriminator(vocab=opt.vocab, arch=opt.d_obj_arch,
-                                                         normalization=opt.d_normalization,
-                                                         activation=opt.d_activation, padding=opt.d_padding,
-                                                         object_size=opt.crop_size)
-            self.obj_discriminator.train()
-            self.mask_discriminator = MultiscaleMaskDiscriminator2(opt)
-            self.mask_discriminator.train()
+            self.obj_discriminator = spade_nets.AcCropDiscriminator(
+                vocab=opt.vocab, arch=opt.d_obj_arch, normalization=opt.d_normalization, activation=opt.d_activation,
+                padding=opt.d_padding, object_size=opt.crop_size)
+            self.mask_discriminator = spade_nets.MultiscaleMaskDiscriminator2(opt)
+        self.train()
 
     def build_optimizers(self, opt):
-        """Adam(betas=(beta1, 0.999)) per discriminator (reference meta_models.py:67-69,79-81,88-90);
-        called after the module sits on its device."""
-        on_gpu = next(self.img_discriminator.parameters()).is_cuda
-        fused = {'fused': True} if on_gpu else {}
-        self.optimizer_d_img = torch.optim.Adam(list(self.img_discriminator.parameters()),
-                                                lr=opt.img_learning_rate, betas=(opt.beta1, 0.999), **fused)
+        """Adam with betas (beta1, 0.999); learning rates `img_learning_rate`, `learning_rate`,
+        `mask_learning_rate` for the image / object / mask discriminator (reference :67-69, :79-81, :88-90)."""
+        extra = {'fused': True} if next(self.parameters()).is_cuda else {}        # one multi-tensor kernel per step
+        plan = [("img", opt.img_learning_rate)]
         if not opt.use_img_disc:
-            self.optimizer_d_obj = torch.optim.Adam(list(self.obj_discriminator.parameters()),
-                                                    lr=opt.learning_rate, betas=(opt.beta1, 0.999), **fused)
-            self.optimizer_d_mask = torch.optim.Adam(list(self.mask_discriminator.parameters()),
-                                                     lr=opt.mask_learning_rate, betas=(opt.beta1, 0.999), **fused)
+            plan += [("obj", opt.learning_rate), ("mask", opt.mask_learning_rate)]
+        for tag, lr in plan:
+            net = getattr(self, tag + "_discriminator")
+            setattr(self, "optimizer_d_" + tag,
+                    torch.optim.Adam(list(net.parameters()), lr=lr, betas=(opt.beta1, 0.999), **extra))
         return self

@@ -1,7 +1,10 @@
-"""Loss module of the trainer (reference: sg2im/pix2pix_model.py:12-223).
+"""Loss module of the trainer — the surface of the reference's `Pix2PixModel` (sg2im/pix2pix_model.py:12-223):
+`forward(batch, model_out, mode)` with modes `compute_generator_loss` / `compute_discriminator_loss` returning
+the same loss dictionaries (same keys, same weighting).
 
-The discriminator passes run on the HIP kernels; the loss arithmetic on their outputs is
-elementwise + small reductions and stays as tensor ops."""
+All discriminator passes, the VGG features and the L1 feature-matching distances run on the HIP kernels; what
+is left for torch are scalar combinations and three tiny elementwise losses (smooth-L1 on (B,O,4) boxes, BCE on
+the (B,O,M,M) masks, cross-entropy on the crop logits — SURVEY.md §2.2 K12)."""
 import torch
 import torch.nn.functional as F
 
@@ -17,120 +20,118 @@ class _L1Loss(torch.nn.Module):
         return ops.l1_mean(input, target)
 
 
+def _total(losses, skip=()):
+    return torch.stack([v for k, v in losses.items() if k not in skip], dim=0).sum()
+
+
 class Pix2PixModel(torch.nn.Module):
     def __init__(self, opt, discriminator, netE=None):
         super().__init__()
-        self.opt = opt
-        self.discriminator = discriminator
-        if hasattr(discriminator, 'img_discriminator'):
-            self.netD_img = discriminator.img_discriminator
-        if hasattr(opt, 'use_img_disc') and not opt.use_img_disc:
-            if hasattr(discriminator, 'obj_discriminator'):
-                self.netD_obj = discriminator.obj_discriminator
-            if hasattr(discriminator, 'mask_discriminator'):
-                self.netD_mask = discriminator.mask_discriminator
-        if opt.isTrain:
-            self.criterionGAN = networks.GANLoss(opt.gan_mode, opt=self.opt)
-            self.criterionFeat = _L1Loss()
-            self.gan_g_loss, self.gan_d_loss = get_gan_losses(opt.gan_loss_type)
-            if not opt.no_vgg_loss:
-                self.criterionVGG = networks.VGGLoss(self.opt.gpu_ids)
-            if opt.use_vae:
-                self.KLDLoss = networks.KLDLoss()
+        self.opt, self.discriminator = opt, discriminator
+        self.netD_img = getattr(discriminator, 'img_discriminator', None)
+        self.netD_obj = self.netD_mask = None
+        if not getattr(opt, 'use_img_disc', 1):
+            self.netD_obj = getattr(discriminator, 'obj_discriminator', None)
+            self.netD_mask = getattr(discriminator, 'mask_discriminator', None)
+        if not opt.isTrain:
+            return
+        self.criterionGAN = networks.GANLoss(opt.gan_mode, opt=opt)
+        self.criterionFeat = _L1Loss()
+        self.gan_g_loss, self.gan_d_loss = get_gan_losses(opt.gan_loss_type)
+        if not opt.no_vgg_loss:
+            self.criterionVGG = networks.VGGLoss(opt.gpu_ids)
+        if opt.use_vae:
+            self.KLDLoss = networks.KLDLoss()
 
     def use_gpu(self):
         return len(self.opt.gpu_ids) > 0
 
-    # ------------------------------------------------------------------ generator side (:65-143)
-    def compute_generator_loss(self, batch, model_out):
-        imgs, objs, boxes, triplets, _, _, masks, _ = batch
-        imgs_pred, boxes_pred, masks_pred = model_out
-        G = {}
-        if not self.opt.skip_graph_model:
-            l = F.smooth_l1_loss(boxes_pred.reshape(-1, 4), boxes.reshape(-1, 4), reduction='none') \
-                * self.opt.bbox_pred_loss_weight
-            flat = objs.reshape(-1, objs.size(-1))
-            mask = (flat.sum(1, keepdim=True) != 0) if objs.size(-1) > 1 else (flat != 0)
-            mask = mask.to(l.dtype)
-            l = l * mask
-            G["bbox_pred_all"] = l.view(boxes.shape).sum(dim=[1, 2]) / mask.view(boxes.shape[0], boxes.shape[1]).sum(dim=1)
-            G["bbox_pred"] = G["bbox_pred_all"].mean()
-            if masks is not None:                                   # :88-92 — BCE over the real objects' masks
-                M = masks.size(-1)
-                bce = F.binary_cross_entropy(masks_pred.reshape(-1, M, M), masks.reshape(-1, M, M).float(),
-                                             reduction='none').mean(dim=(1, 2))
-                # mean over real objects, as masks_loss[object_mask.nonzero()[:, 0]].mean() without the host sync
-                G["masks_pred"] = (bce * mask.view(-1)).sum() / mask.sum() * self.opt.mask_pred_loss_weight
-        if not self.opt.skip_generation:
-            pred_fake = self.netD_img(imgs_pred, objs, boxes, layout_masks=masks, gt_train=True, fool=False)
-            G['GAN_Img'] = self.criterionGAN(pred_fake, True, for_discriminator=False).squeeze(0) \
-                * self.opt.discriminator_img_loss_weight
-            if not self.opt.no_ganFeat_loss:
-                pred_real = self.netD_img(imgs, objs, boxes, layout_masks=masks, gt_train=True, fool=False)
-                num_D = len(pred_fake)
-                feat = imgs.new_zeros(1)
-                for i in range(num_D):
-                    for j in range(len(pred_fake[i]) - 1):       # last output is the final prediction
-                        feat = feat + self.criterionFeat(pred_fake[i][j], pred_real[i][j].detach()) \
-                            * self.opt.lambda_feat / num_D
-                G['GAN_Feat'] = feat.squeeze(0)
-            if not self.opt.no_vgg_loss:
-                G['VGG'] = self.criterionVGG(imgs_pred, imgs) * self.opt.lambda_vgg
-            if not self.opt.use_img_disc:                      # object discriminator (:115-121)
-                scores_fake, ac_loss, _ = self.netD_obj(imgs_pred, objs, boxes)
-                G['GAN_Obj'] = self.criterionGAN(scores_fake, True, for_discriminator=False).squeeze(0) \
-                    * self.opt.discriminator_obj_loss_weight
-                G['GAN_Ac'] = ac_loss * self.opt.ac_loss_weight
-                if getattr(self, 'netD_mask', None) is not None and self.opt.mask_size > 0 and masks_pred is not None:
-                    scores_fake = self.netD_mask(objs, masks_pred)                                # :124-138
-                    G['GAN_Mask'] = self.criterionGAN(scores_fake, True, for_discriminator=False).squeeze(0) \
-                        * self.opt.discriminator_img_loss_weight
-                    if not self.opt.no_ganFeat_loss:
-                        scores_real = self.netD_mask(objs, masks)
-                        num_D = len(scores_fake)
-                        feat = imgs.new_zeros(1)
-                        for i in range(num_D):
-                            for j in range(len(scores_fake[i]) - 1):
-                                feat = feat + self.criterionFeat(scores_fake[i][j], scores_real[i][j].detach()) \
-                                    * self.opt.lambda_feat / num_D
-                        G['GAN_Mask_Feat'] = feat.squeeze(0)
-        scalars = [k for k in G if k != "bbox_pred_all"]
-        G['total_loss'] = torch.stack([G[k] for k in scalars], dim=0).sum()
-        return G
-
-    # ------------------------------------------------------------------ discriminator side (:145-202)
-    def compute_discriminator_loss(self, batch, model_out):
-        imgs, objs, boxes, _, _, _, masks, _ = batch
-        imgs_pred = model_out[0].detach()
-        D = {}
-        pred_fake = self.netD_img(imgs_pred, objs, boxes, layout_masks=masks, gt_train=True, fool=False)
-        gt_real = self.netD_img(imgs, objs, boxes, layout_masks=masks, gt_train=True, fool=False)
-        D["D_img_fake"] = self.criterionGAN(pred_fake, False, for_discriminator=True)
-        D["D_img_real"] = self.criterionGAN(gt_real, True, for_discriminator=True)
-        D["total_img_loss"] = torch.stack(list(D.values()), dim=0).sum()
-        if not self.opt.use_img_disc:
-            # "wrong layout" pass: `fool` is ignored by the discriminator, the value is logged but never
-            # back-propagated; it still advances the spectral-norm state, so it is replayed (:168-172)
-            with torch.no_grad():
-                pred_wrong = self.netD_img(imgs, objs, boxes, layout_masks=masks, gt_train=True, fool=True)
-                D["D_img_wrong"] = self.criterionGAN(pred_wrong, False, for_discriminator=True) * (1 / 2) * (.5)
-            scores_real, ac_loss_real, self.d_real_crops = self.netD_obj(imgs, objs, boxes)       # :178-185
-            scores_fake, ac_loss_fake, self.d_fake_crops = self.netD_obj(imgs_pred, objs, boxes)
-            D["D_obj"] = self.gan_d_loss(scores_real, scores_fake) * 0.5
-            D["D_ac_real"] = ac_loss_real
-            D["D_ac_fake"] = ac_loss_fake
-            D["total_obj_loss"] = torch.stack([D["D_obj"], D["D_ac_real"], D["D_ac_fake"]], dim=0).sum()
-            if self.opt.mask_size > 0 and model_out[2] is not None:                               # :188-196
-                scores_fake = self.netD_mask(objs, model_out[2].detach())
-                scores_real = self.netD_mask(objs, masks)
-                D["D_mask_fake"] = self.criterionGAN(scores_fake, False, for_discriminator=True) * 0.5
-                D["D_mask_real"] = self.criterionGAN(scores_real, True, for_discriminator=True) * 0.5
-                D["total_mask_loss"] = torch.stack([D["D_mask_fake"], D["D_mask_real"]], dim=0).sum()
-        return D
-
     def forward(self, batch, model_out, mode):
-        if mode == "compute_discriminator_loss":
-            return self.compute_discriminator_loss(batch, model_out)
-        if mode == "compute_generator_loss":
-            return self.compute_generator_loss(batch, model_out)
-        raise ValueError("unknown mode %r" % mode)
+        handlers = {"compute_generator_loss": self.compute_generator_loss,
+                    "compute_discriminator_loss": self.compute_discriminator_loss}
+        if mode not in handlers:
+            raise ValueError("unknown mode %r" % mode)
+        return handlers[mode](batch, model_out)
+
+    # ---------------------------------------------------------------------------------------- pieces
+    def _fool(self, scores, weight):
+        """Generator-side GAN term: the discriminator should call `scores` real."""
+        return self.criterionGAN(scores, True, for_discriminator=False).squeeze(0) * weight
+
+    def _feature_matching(self, fake, real):
+        """lambda_feat * mean over scales of the L1 distances of every intermediate map (reference :99-109)."""
+        total = fake[0][0].new_zeros(1)
+        for f_scale, r_scale in zip(fake, real):
+            for f, r in zip(f_scale[:-1], r_scale[:-1]):            # the last entry is the prediction itself
+                total = total + self.criterionFeat(f, r.detach()) * self.opt.lambda_feat / len(fake)
+        return total.squeeze(0)
+
+    def _layout_terms(self, out, objs, boxes, boxes_pred, masks, masks_pred):
+        """Box regression (:71-85) and mask BCE (:88-92), both averaged over the REAL objects only."""
+        opt = self.opt
+        per_coord = F.smooth_l1_loss(boxes_pred.reshape(-1, 4), boxes.reshape(-1, 4), reduction='none')
+        ids = objs.reshape(-1, objs.size(-1))
+        real = ((ids.sum(1, keepdim=True) != 0) if ids.size(1) > 1 else (ids != 0)).to(per_coord.dtype)     # (B*O, 1)
+        per_coord = per_coord * opt.bbox_pred_loss_weight * real
+        B, O = boxes.shape[0], boxes.shape[1]
+        out["bbox_pred_all"] = per_coord.view(B, O, 4).sum(dim=[1, 2]) / real.view(B, O).sum(dim=1)
+        out["bbox_pred"] = out["bbox_pred_all"].mean()
+        if masks is not None:
+            M = masks.size(-1)
+            bce = F.binary_cross_entropy(masks_pred.reshape(-1, M, M), masks.reshape(-1, M, M).float(),
+                                         reduction='none').mean(dim=(1, 2))
+            # == masks_loss[object_mask.nonzero()[:, 0]].mean() of the reference, without the host round trip
+            out["masks_pred"] = (bce * real.view(-1)).sum() / real.sum() * opt.mask_pred_loss_weight
+
+    # ---------------------------------------------------------------------------------------- generator
+    def compute_generator_loss(self, batch, model_out):
+        imgs, objs, boxes, masks = batch[0], batch[1], batch[2], batch[6]
+        imgs_pred, boxes_pred, masks_pred = model_out
+        opt, out = self.opt, {}
+        if not opt.skip_graph_model:
+            self._layout_terms(out, objs, boxes, boxes_pred, masks, masks_pred)
+        if not opt.skip_generation:
+            d_args = dict(layout_masks=masks, gt_train=True, fool=False)
+            fake = self.netD_img(imgs_pred, objs, boxes, **d_args)
+            out['GAN_Img'] = self._fool(fake, opt.discriminator_img_loss_weight)
+            if not opt.no_ganFeat_loss:
+                out['GAN_Feat'] = self._feature_matching(fake, self.netD_img(imgs, objs, boxes, **d_args))
+            if not opt.no_vgg_loss:
+                out['VGG'] = self.criterionVGG(imgs_pred, imgs) * opt.lambda_vgg
+            if not opt.use_img_disc:
+                crop_scores, ac_loss, _ = self.netD_obj(imgs_pred, objs, boxes)                   # :115-121
+                out['GAN_Obj'] = self._fool(crop_scores, opt.discriminator_obj_loss_weight)
+                out['GAN_Ac'] = ac_loss * opt.ac_loss_weight
+                if self.netD_mask is not None and opt.mask_size > 0 and masks_pred is not None:   # :124-138
+                    m_fake = self.netD_mask(objs, masks_pred)
+                    out['GAN_Mask'] = self._fool(m_fake, opt.discriminator_img_loss_weight)
+                    if not opt.no_ganFeat_loss:
+                        out['GAN_Mask_Feat'] = self._feature_matching(m_fake, self.netD_mask(objs, masks))
+        out['total_loss'] = _total(out, skip=("bbox_pred_all",))
+        return out
+
+    # ---------------------------------------------------------------------------------------- discriminators
+    def compute_discriminator_loss(self, batch, model_out):
+        imgs, objs, boxes, masks = batch[0], batch[1], batch[2], batch[6]
+        fake_img = model_out[0].detach()
+        opt, crit = self.opt, self.criterionGAN
+        d_args = dict(layout_masks=masks, gt_train=True)
+        out = {"D_img_fake": crit(self.netD_img(fake_img, objs, boxes, fool=False, **d_args), False, for_discriminator=True),
+               "D_img_real": crit(self.netD_img(imgs, objs, boxes, fool=False, **d_args), True, for_discriminator=True)}
+        out["total_img_loss"] = _total(out)
+        if opt.use_img_disc:
+            return out
+        # "wrong layout" pass (:168-172): `fool` is ignored by the discriminator and the value is only logged,
+        # but the call advances the spectral-norm vectors, so it is replayed — without autograd
+        with torch.no_grad():
+            wrong = self.netD_img(imgs, objs, boxes, fool=True, **d_args)
+            out["D_img_wrong"] = crit(wrong, False, for_discriminator=True) * (1 / 2) * (.5)
+        s_real, out["D_ac_real"], self.d_real_crops = self.netD_obj(imgs, objs, boxes)            # :178-185
+        s_fake, out["D_ac_fake"], self.d_fake_crops = self.netD_obj(fake_img, objs, boxes)
+        out["D_obj"] = self.gan_d_loss(s_real, s_fake) * 0.5
+        out["total_obj_loss"] = out["D_obj"] + out["D_ac_real"] + out["D_ac_fake"]
+        if opt.mask_size > 0 and model_out[2] is not None:                                        # :188-196
+            out["D_mask_fake"] = crit(self.netD_mask(objs, model_out[2].detach()), False, for_discriminator=True) * 0.5
+            out["D_mask_real"] = crit(self.netD_mask(objs, masks), True, for_discriminator=True) * 0.5
+            out["total_mask_loss"] = out["D_mask_fake"] + out["D_mask_real"]
+        return out
