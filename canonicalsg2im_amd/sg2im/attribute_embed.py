@@ -1,4 +1,7 @@
-"""Per-attribute embedding tables (reference: sg2im/attribute_embed.py:18-48)."""
+"""One embedding table per attribute (`att_emb_0`, `att_emb_1`, ...: the reference's names,
+sg2im/attribute_embed.py:18-48) looked up and concatenated by ONE gather kernel; an optional Linear over
+the concatenation (`attribute_fc_gen`) exists iff there are several attributes or the caller asks for it
+(the discriminator does, discriminator.py:71-72)."""
 import torch.nn as nn
 
 from .. import ops
@@ -8,17 +11,15 @@ from .layers import Linear
 class AttributeEmbeddings(nn.Module):
     def __init__(self, attributes, embedding_dim, use_attr_fc_gen=False):
         super().__init__()
-        names = list(attributes)
-        if len(names) > 1 or use_attr_fc_gen:
-            self.attribute_fc_gen = Linear(len(names) * embedding_dim, len(names) * embedding_dim)
-        for i, name in enumerate(names):
-            self.add_module("att_emb_%d" % i, nn.Embedding(max(attributes[name].values()) + 1, embedding_dim))
-        self.num_attributes = len(names)
+        self.num_attributes = len(attributes)
+        width = self.num_attributes * embedding_dim
+        if self.num_attributes > 1 or use_attr_fc_gen:
+            self.attribute_fc_gen = Linear(width, width)
+        for k, values in enumerate(attributes.values()):
+            self.add_module("att_emb_%d" % k, nn.Embedding(max(values.values()) + 1, embedding_dim))
 
     def forward(self, x):
-        """x int64 [B, O, A] -> [B, O, A*E]: one fused gather for all attribute columns."""
-        tables = [self._modules["att_emb_%d" % k].weight for k in range(x.size(-1))]
-        vecs = ops.embed(x, tables)
-        if hasattr(self, 'attribute_fc_gen'):
-            vecs = self.attribute_fc_gen(vecs)
-        return vecs
+        """ids (B, O, A) int64 -> vectors (B, O, A*E)."""
+        out = ops.embed(x, [getattr(self, "att_emb_%d" % k).weight for k in range(x.size(-1))])
+        fc = getattr(self, 'attribute_fc_gen', None)
+        return out if fc is None else fc(out)

@@ -28,42 +28,46 @@ class AppearanceEncoder(nn.Module):
         return self.cnn(crops)
 
 
+# (attribute name, input width, output width) in units of ngf, in execution order — the attribute
+# names are the reference's (generator.py:30-44) and therefore the checkpoint keys
+_BLOCKS = (("head_0", 16, 16), ("G_middle_0", 16, 16), ("G_middle_1", 16, 16),
+           ("up_0", 16, 8), ("up_1", 8, 4), ("up_2", 4, 2), ("up_3", 2, 1))
+_LATENT_HALVINGS = {'normal': 5, 'more': 6, 'most': 7}          # generator.py:64-77
+
+
 class SPADEGenerator(BaseNetwork):
+    """layout -> fc on the coarsest pyramid level -> 7 (8) SPADE residual blocks with nearest x2 upsampling in
+    between -> LeakyReLU -> conv -> tanh (reference generator.py:79-127).  The layout is produced once, at every
+    resolution the blocks need, by one kernel (`ops.layout_pyramid`)."""
+
     def __init__(self, opt):
         super().__init__()
+        if opt.use_vae:
+            raise NotImplementedError("--use_vae is never wired in the reference trainer (SURVEY.md §2 row 22)")
         self.attribute_embedding = AttributeEmbeddings(opt.vocab['attributes'], opt.embedding_dim)
         self.opt = opt
         nf = opt.ngf
         self.sw, self.sh = self.compute_latent_vector_size(opt)
-        if opt.use_vae:
-            raise NotImplementedError("--use_vae is never wired in the reference trainer (SURVEY.md §2 row 22)")
         self.fc = Conv2d(opt.semantic_nc, 16 * nf, 3, padding=1)
-        self.head_0 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
-        self.G_middle_0 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
-        self.G_middle_1 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
-        self.up_0 = SPADEResnetBlock(16 * nf, 8 * nf, opt)
-        self.up_1 = SPADEResnetBlock(8 * nf, 4 * nf, opt)
-        self.up_2 = SPADEResnetBlock(4 * nf, 2 * nf, opt)
-        self.up_3 = SPADEResnetBlock(2 * nf, 1 * nf, opt)
-        final_nc = nf
+        blocks = list(_BLOCKS)
         if opt.num_upsampling_layers == 'most':
-            self.up_4 = SPADEResnetBlock(1 * nf, nf // 2, opt)
-            final_nc = nf // 2
-        self.conv_img = Conv2d(final_nc, 3, 3, padding=1, act=ops.ACT_TANH)      # tanh fused (generator.py:124)
-        self.up = nn.Upsample(scale_factor=2)
-        # unused sub-modules of the reference, kept for checkpoint compatibility (generator.py:50-62)
+            blocks.append(("up_4", 1, 0.5))
+        for name, win, wout in blocks:
+            setattr(self, name, SPADEResnetBlock(int(win * nf), int(wout * nf), opt))
+        self._block_names = [b[0] for b in blocks]
+        self.conv_img = Conv2d(int(blocks[-1][2] * nf), 3, 3, padding=1, act=ops.ACT_TANH)   # tanh fused (:124)
+        self.up = nn.Upsample(scale_factor=2)       # parameter-free; kept because the reference registers it
+        # never executed by the reference either (generator.py:50-62): present for checkpoint compatibility
         self.repr_input = opt.g_mask_dim
         self.repr_net = build_mlp([self.repr_input, 64, opt.rep_size], batch_norm=opt.mlp_normalization)
-        self.image_encoder = AppearanceEncoder(vocab=opt.vocab, arch='C4-64-2,C4-128-2,C4-256-2',
+        self.image_encoder = AppearanceEncoder(vocab=opt.vocab, arch='C4-64-2,C4-128-2,C4-256-2', padding='valid',
                                                normalization=opt.appearance_normalization,
-                                               activation=opt.a_activation, padding='valid',
-                                               vecs_size=opt.g_mask_dim)
+                                               activation=opt.a_activation, vecs_size=opt.g_mask_dim)
 
     def compute_latent_vector_size(self, opt):
-        n = {'normal': 5, 'more': 6, 'most': 7}.get(opt.num_upsampling_layers)
-        if n is None:
+        if opt.num_upsampling_layers not in _LATENT_HALVINGS:
             raise ValueError('opt.num_upsampling_layers [%s] not recognized' % opt.num_upsampling_layers)
-        sw = opt.image_size[0] // (2 ** n)
+        sw = opt.image_size[0] >> _LATENT_HALVINGS[opt.num_upsampling_layers]
         return sw, round(sw / opt.aspect_ratio)
 
     def forward(self, objs, layout_boxes, layout_masks, test_mode=False):
@@ -72,24 +76,15 @@ class SPADEGenerator(BaseNetwork):
         if self.sw != self.sh:
             raise NotImplementedError("aspect_ratio != 1 is not on the hot path")
         H = self.opt.image_size[0]
-        obj_vecs = self.attribute_embedding(objs)
-        valid = real_object_mask(objs, self.opt.vocab)
-        sizes, h = [], self.sw
-        while h <= H:
-            sizes.append(h)
-            h *= 2
-        seg = SegPyramid(zip(sizes, ops.layout_pyramid(obj_vecs, layout_boxes, valid, H, sizes, masks=layout_masks)))
-        x = self.fc(seg.at(self.sw))          # F.interpolate(seg, (sh,sw)) == pyramid level sw
-        x = self.head_0(x, seg)
-        x = ops.upsample2x(x)
-        x = self.G_middle_0(x, seg)
-        if self.opt.num_upsampling_layers in ('more', 'most'):
-            x = ops.upsample2x(x)
-        x = self.G_middle_1(x, seg)
-        for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
-            x = ops.upsample2x(x)
-            x = blk(x, seg)
-        if self.opt.num_upsampling_layers == 'most':
-            x = ops.upsample2x(x)
-            x = self.up_4(x, seg)
+        levels = [self.sw << k for k in range(H.bit_length()) if (self.sw << k) <= H]
+        maps = ops.layout_pyramid(self.attribute_embedding(objs), layout_boxes, real_object_mask(objs, self.opt.vocab),
+                                  H, levels, masks=layout_masks)
+        seg = SegPyramid(zip(levels, maps))
+        x = self.fc(seg.at(self.sw))                 # nearest resize to (sh, sw) == the coarsest pyramid level
+        # x2 upsampling precedes every block except head_0 and — unless 'more'/'most' — G_middle_1
+        no_upsample = {"head_0"} | (set() if self.opt.num_upsampling_layers in ('more', 'most') else {"G_middle_1"})
+        for name in self._block_names:
+            if name not in no_upsample:
+                x = ops.upsample2x(x)
+            x = getattr(self, name)(x, seg)
         return self.conv_img(F.leaky_relu(x, 2e-1))

@@ -6,37 +6,41 @@ import torch.nn.functional as F
 
 
 class GANLoss(nn.Module):
+    """`GANLoss(gan_mode)(prediction, target_is_real, for_discriminator)` of the reference (loss.py:13-98).
+    A multiscale prediction (list over scales of lists of feature maps) is reduced to the mean over scales
+    of the loss on each scale's LAST map, kept as a 1-element tensor like the reference's."""
+
+    MODES = ('ls', 'original', 'w', 'hinge')
+
     def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0, tensor=torch.FloatTensor, opt=None):
         super().__init__()
-        if gan_mode not in ('ls', 'original', 'w', 'hinge'):
+        if gan_mode not in self.MODES:
             raise ValueError('Unexpected gan_mode {}'.format(gan_mode))
-        self.real_label, self.fake_label = target_real_label, target_fake_label
         self.gan_mode, self.opt = gan_mode, opt
+        self.real_label, self.fake_label = target_real_label, target_fake_label
 
     def loss(self, input, target_is_real, for_discriminator=True):
-        if self.gan_mode == 'original':
-            target = torch.full_like(input, self.real_label if target_is_real else self.fake_label)
-            return F.binary_cross_entropy_with_logits(input, target)
-        if self.gan_mode == 'ls':
-            target = torch.full_like(input, self.real_label if target_is_real else self.fake_label)
-            return F.mse_loss(input, target)
-        if self.gan_mode == 'hinge':
-            if for_discriminator:
-                x = input - 1 if target_is_real else -input - 1
-                return -torch.mean(torch.clamp(x, max=0.0))
-            assert target_is_real, "The generator's hinge loss must be aiming for real"
-            return -torch.mean(input)
-        return -input.mean() if target_is_real else input.mean()
+        mode = self.gan_mode
+        if mode == 'hinge':
+            if not for_discriminator:
+                assert target_is_real, "The generator's hinge loss must be aiming for real"
+                return -input.mean()
+            margin = (input - 1) if target_is_real else (-input - 1)
+            return -torch.clamp(margin, max=0.0).mean()
+        if mode == 'w':
+            return -input.mean() if target_is_real else input.mean()
+        label = torch.full_like(input, self.real_label if target_is_real else self.fake_label)
+        return F.binary_cross_entropy_with_logits(input, label) if mode == 'original' else F.mse_loss(input, label)
 
     def __call__(self, input, target_is_real, for_discriminator=True):
-        if isinstance(input, list):
-            loss = 0
-            for pred_i in input:
-                if isinstance(pred_i, list):
-                    pred_i = pred_i[-1]
-                loss = loss + self.loss(pred_i, target_is_real, for_discriminator).reshape(1)
-            return loss / len(input)
-        return self.loss(input, target_is_real, for_discriminator)
+        if not isinstance(input, list):
+            return self.loss(input, target_is_real, for_discriminator)
+        per_scale = [self.loss(p[-1] if isinstance(p, list) else p, target_is_real, for_discriminator).reshape(1)
+                     for p in input]
+        total = 0
+        for term in per_scale:
+            total = total + term
+        return total / len(input)
 
 
 class VGGLoss(nn.Module):

@@ -39,27 +39,28 @@ class InstanceNormAct(nn.InstanceNorm2d):
 
 
 def get_nonspade_norm_layer(opt, norm_type='instance'):
-    def get_out_channel(layer):
-        return getattr(layer, 'out_channels', None) or layer.weight.size(0)
+    """Returns `wrap(conv)` for the PatchGAN layers (reference normalization.py:16-50): an optional
+    `spectral` prefix applies spectral normalisation, the remainder names the activation norm that
+    follows the conv (whose bias is then dropped).  Only 'instance' (fused with the LeakyReLU behind
+    it) and 'none' are on the hot path."""
+    use_sn = norm_type.startswith('spectral')
+    after = norm_type[len('spectral'):] if use_sn else norm_type
 
-    def add_norm_layer(layer):
-        subnorm_type = norm_type
-        if norm_type.startswith('spectral'):
-            layer = spectral_norm(layer)
-            subnorm_type = norm_type[len('spectral'):]
-        if subnorm_type == 'none' or len(subnorm_type) == 0:
-            return layer
-        if getattr(layer, 'bias', None) is not None:     # bias is meaningless before a normalisation
-            delattr(layer, 'bias')
-            layer.register_parameter('bias', None)
-        if subnorm_type == 'instance':
-            norm_layer = InstanceNormAct(get_out_channel(layer))
-        else:
+    def wrap(conv):
+        if use_sn:
+            conv = spectral_norm(conv)
+        if after in ('', 'none'):
+            return conv
+        if after != 'instance':
             raise NotImplementedError('normalization layer %s is not on the hot path (norm_D default is '
-                                      'spectralinstance)' % subnorm_type)
-        return nn.Sequential(layer, norm_layer)
+                                      'spectralinstance)' % after)
+        if getattr(conv, 'bias', None) is not None:          # a bias in front of a normalisation is a no-op
+            del conv.bias
+            conv.register_parameter('bias', None)
+        width = getattr(conv, 'out_channels', None) or conv.weight.size(0)
+        return nn.Sequential(conv, InstanceNormAct(width))
 
-    return add_norm_layer
+    return wrap
 
 
 class SPADE(nn.Module):
