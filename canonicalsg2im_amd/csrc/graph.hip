@@ -31,6 +31,32 @@ __global__ void k_embed_bwd(const int64_t* __restrict__ idx, int64_t rows, int64
   if (i >= 0 && i < num_emb) atomicAdd(&dtable[i * dim + d], dout[r * out_stride + out_off + d]);
 }
 
+// Small tables (predicate / attribute embeddings: <= 8192 floats) receive hundreds of thousands of rows on
+// dense graphs; per-block accumulation in LDS first cuts the global atomics by the rows-per-block factor.
+#define EMB_ROWS_PER_BLOCK 2048
+__global__ __launch_bounds__(256) void k_embed_bwd_lds(const int64_t* __restrict__ idx, int64_t rows,
+                                                        int64_t idx_stride, const float* __restrict__ dout,
+                                                        int64_t out_stride, int64_t out_off, int num_emb, int dim,
+                                                        float* __restrict__ dtable) {
+  extern __shared__ float acc[];                               // [num_emb * dim]
+  const int n = num_emb * dim;
+  for (int i = threadIdx.x; i < n; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS_PER_BLOCK;
+  const int64_t r1 = min(rows, r0 + EMB_ROWS_PER_BLOCK);
+  for (int64_t e = r0 * dim + threadIdx.x; e < r1 * dim; e += 256) {
+    const int64_t r = e / dim;
+    const int d = (int)(e - r * dim);
+    const int64_t i = idx[r * idx_stride];
+    if (i >= 0 && i < num_emb) atomicAdd(&acc[i * dim + d], dout[r * out_stride + out_off + d]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = acc[i];
+    if (v != 0.f) atomicAdd(&dtable[i], v);
+  }
+}
+
 __global__ void k_obj_mask(const int64_t* __restrict__ objs, int64_t n, int64_t A, int64_t image_id,
                            uint8_t* __restrict__ mask) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -119,6 +145,73 @@ __global__ __launch_bounds__(256) void k_csr_build(const int64_t* __restrict__ t
   }
 }
 
+// Counting-sort variant for dense graphs (O <= 254, a few 10^4 triplets per image): the (s, o) columns are
+// staged in LDS as bytes, 64 chunk owners count their contiguous range of triplets into a per-(role, object,
+// chunk) table, a prefix over chunks turns the table into write offsets, and the owners walk their range a
+// second time to emit the entries — O(T) work per image instead of O(T*O), same output order (inside a row:
+// subject entries in triplet order, then object entries in triplet order).
+#define CSR_NCH 64
+__global__ __launch_bounds__(256) void k_csr_build_sorted(const int64_t* __restrict__ triplets, int T, int O,
+                                                           int32_t* __restrict__ row_ptr, int32_t* __restrict__ col) {
+  extern __shared__ unsigned char lds[];
+  uint16_t* tab = (uint16_t*)lds;                               // [2][O][CSR_NCH]
+  int* tot = (int*)(lds + (size_t)2 * O * CSR_NCH * 2);        // [2*O]
+  int* rows = tot + 2 * O;                                      // [O+1]
+  unsigned char* so = (unsigned char*)(rows + O + 1);           // [T][2]: s, o (255 = not an object of this image)
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t* tr = triplets + (int64_t)b * T * 3;
+  int32_t* rp = row_ptr + (int64_t)b * (O + 1);
+  int32_t* cl = col + (int64_t)b * 2 * T;
+  for (int i = tid; i < 2 * O * CSR_NCH; i += 256) tab[i] = 0;
+  for (int t = tid; t < T; t += 256) {
+    const int64_t sv = tr[(int64_t)t * 3], ov = tr[(int64_t)t * 3 + 2];
+    so[2 * t] = (sv >= 0 && sv < O) ? (unsigned char)sv : 255;
+    so[2 * t + 1] = (ov >= 0 && ov < O) ? (unsigned char)ov : 255;
+  }
+  __syncthreads();
+  const int L = (T + CSR_NCH - 1) / CSR_NCH;
+  const int t0 = min(T, tid * L), t1 = min(T, t0 + L);
+  if (tid < CSR_NCH) {
+    for (int t = t0; t < t1; ++t) {
+      const int sv = so[2 * t], ov = so[2 * t + 1];
+      if (sv != 255) tab[sv * CSR_NCH + tid]++;
+      if (ov != 255) tab[(O + ov) * CSR_NCH + tid]++;
+    }
+  }
+  __syncthreads();
+  for (int task = tid; task < 2 * O; task += 256) {              // exclusive prefix over the chunks
+    int run = 0;
+    for (int c = 0; c < CSR_NCH; ++c) {
+      const int v = tab[task * CSR_NCH + c];
+      tab[task * CSR_NCH + c] = (uint16_t)run;
+      run += v;
+    }
+    tot[task] = run;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < O; ++i) {
+      rows[i] = run;
+      run += tot[i] + tot[O + i];
+    }
+    rows[O] = run;
+  }
+  __syncthreads();
+  for (int i = tid; i <= O; i += 256) rp[i] = rows[i];
+  if (tid < CSR_NCH) {
+    for (int t = t0; t < t1; ++t) {
+      const int sv = so[2 * t], ov = so[2 * t + 1];
+      if (sv != 255) cl[rows[sv] + tab[sv * CSR_NCH + tid]++] = 2 * t;
+      if (ov != 255) cl[rows[ov] + tot[ov] + tab[(O + ov) * CSR_NCH + tid]++] = 2 * t + 1;
+    }
+  }
+}
+
+static inline size_t csr_sorted_lds(int64_t T, int64_t O) {
+  return (size_t)2 * O * CSR_NCH * 2 + (size_t)(2 * O + O + 1) * 4 + (size_t)2 * T;
+}
+
 // ------------------------------------------------------------------------------------ K2
 __global__ void k_gather_concat_fwd(const float* __restrict__ obj, const float* __restrict__ pred,
                                     const int64_t* __restrict__ triplets, int64_t BT, int O, int T, int Din, int Dp,
@@ -148,31 +241,87 @@ __global__ void k_gather_concat_fwd(const float* __restrict__ obj, const float* 
 //   WEIGHTED: w_e = conf[t_e] for valid triplets (invalid ones are skipped) and cnt = sum w_e;
 //   otherwise w_e = 1.
 // The reference's scatter_add loops (graph.py:98-106) give dense graphs rows of several hundred
-// edges (CLEVR closure graphs: ~2*(O-1) per object), so a row is split over `S` workgroups (grid.z)
-// and, inside a workgroup, over 256/LPE edge groups of LPE lanes; a lane owns one float4 of the D
-// columns, 4 edges are in flight per lane.  Group partials are combined through LDS and split
-// partials by k_rowsum_finish, both in a fixed order: results are bit-reproducible run to run.
+// edges (CLEVR closure graphs: ~2*(O-1) per object) and hub rows of thousands (the padded triplets of
+// a short sample all point at object 0), so rows are cut into 64-edge segments, one workgroup each;
+// inside a workgroup 256/LPE edge groups of LPE lanes work on different edges, a lane owns one float4
+// of the D columns, 4 edges are in flight per lane.  Group partials are combined through LDS and
+// segment partials by k_rowsum_finish, both in a fixed order: results are bit-reproducible run to run.
+#define ROWSUM_SEG 64        // edges per segment in edge-balanced mode
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void k_csr_rowsum(const float* __restrict__ src, const float* __restrict__ conf,
                                                      const uint8_t* __restrict__ valid,
                                                      const int32_t* __restrict__ row_ptr,
                                                      const int32_t* __restrict__ col, int O, int T, int D, int stride,
-                                                     int off0, int off1, int LPE, int S, float* __restrict__ out,
-                                                     float* __restrict__ cnt_out, float* __restrict__ part,
-                                                     float* __restrict__ part_cnt) {
+                                                     int off0, int off1, int LPE, int nseg_max,
+                                                     float* __restrict__ out, float* __restrict__ cnt_out,
+                                                     float* __restrict__ part, float* __restrict__ part_cnt,
+                                                     int32_t* __restrict__ seg_info) {
   __shared__ float4 sm[256];
   __shared__ float smc[256];
-  const int i = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
+  __shared__ int s_seg[1024 + 1];
+  __shared__ int s_scan[256];
+  const int b = blockIdx.y, tid = threadIdx.x;
   const int G = 256 / LPE, lane = tid % LPE, grp = tid / LPE;
   const int32_t* rp = row_ptr + (int64_t)b * (O + 1);
   const int32_t* cl = col + (int64_t)b * 2 * T;
-  const int beg = rp[i], len = rp[i + 1] - beg;
-  const int e0 = beg + (int)(((int64_t)len * sp) / S), e1 = beg + (int)(((int64_t)len * (sp + 1)) / S);
+  int i, sp = 0, S = 1, e0, e1;
+  int64_t pidx = 0;                       // index of this block's partial
+  if (nseg_max == 0) {                    // sparse graphs: one workgroup per row
+    i = blockIdx.x;
+    e0 = rp[i];
+    e1 = rp[i + 1];
+  } else {
+    // Edge-balanced mode: rows are cut into segments of ROWSUM_SEG edges (an empty row keeps one, so that it
+    // is written) and block g takes segment g of the image, whatever row it belongs to — a hub row (the
+    // __image__ object, or object 0 of a heavily padded sample) is spread over as many workgroups as it
+    // needs.  Every block rebuilds the row -> first-segment prefix (O <= 1024 ints) and bisects it.
+    int n4[4], run = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = tid * 4 + q;
+      n4[q] = r < O ? max(1, (rp[r + 1] - rp[r] + ROWSUM_SEG - 1) / ROWSUM_SEG) : 0;
+      run += n4[q];
+    }
+    s_scan[tid] = run;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int t = tid >= o ? s_scan[tid - o] : 0;
+      __syncthreads();
+      s_scan[tid] += t;
+      __syncthreads();
+    }
+    int ex = s_scan[tid] - run;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = tid * 4 + q;
+      if (r < O) s_seg[r] = ex;
+      ex += n4[q];
+    }
+    if (tid == 255) s_seg[O] = s_scan[255];
+    __syncthreads();
+    const int g = blockIdx.x;
+    if (g >= s_seg[O]) return;            // uniform
+    int lo = 0, hi = O;                   // largest i with s_seg[i] <= g
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_seg[mid] <= g) lo = mid; else hi = mid;
+    }
+    i = lo;
+    sp = g - s_seg[i];
+    S = s_seg[i + 1] - s_seg[i];
+    e0 = rp[i] + sp * ROWSUM_SEG;
+    e1 = min(rp[i + 1], e0 + ROWSUM_SEG);
+    pidx = (int64_t)b * nseg_max + g;
+    if (sp == 0 && tid == 0) {            // tell the finish pass where the row's partials are
+      seg_info[((int64_t)b * O + i) * 2 + 0] = g;
+      seg_info[((int64_t)b * O + i) * 2 + 1] = S;
+    }
+  }
   const float* base = src + (int64_t)b * T * stride;
   const float* cb = WEIGHTED ? conf + (int64_t)b * T : nullptr;
   const uint8_t* vb = WEIGHTED ? valid + (int64_t)b * T : nullptr;
   const int64_t orow = (int64_t)b * O + i;
-  float* dst = S > 1 ? part + (orow * S + sp) * D : out + orow * D;
+  float* dst = S > 1 ? part + pidx * D : out + orow * D;
 
   float cnt = 0.f;
   for (int d0 = 0; d0 < D; d0 += LPE * 4) {
@@ -232,23 +381,29 @@ __global__ __launch_bounds__(256) void k_csr_rowsum(const float* __restrict__ sr
     }
   }
   if (WEIGHTED && tid == 0) {
-    if (S > 1) part_cnt[orow * S + sp] = cnt;
+    if (S > 1) part_cnt[pidx] = cnt;
     else cnt_out[orow] = cnt;
   }
 }
 
+// rows that were cut into several segments: sum their partials in segment order (rows with one segment were
+// written directly by k_csr_rowsum)
 template <bool WEIGHTED>
 __global__ __launch_bounds__(128) void k_rowsum_finish(const float* __restrict__ part,
-                                                        const float* __restrict__ part_cnt, int D, int S,
+                                                        const float* __restrict__ part_cnt,
+                                                        const int32_t* __restrict__ seg_info, int O, int D, int nseg_max,
                                                         float* __restrict__ out, float* __restrict__ cnt_out) {
   const int64_t orow = blockIdx.x;
+  const int g0 = seg_info[orow * 2], S = seg_info[orow * 2 + 1];
+  if (S <= 1) return;
+  const int64_t p0 = (orow / O) * nseg_max + g0;
   float cnt = 0.f;
   if (WEIGHTED)
-    for (int sp = 0; sp < S; ++sp) cnt += part_cnt[orow * S + sp];
+    for (int sp = 0; sp < S; ++sp) cnt += part_cnt[p0 + sp];
   for (int d = threadIdx.x * 4; d < D; d += 128 * 4) {
     float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int sp = 0; sp < S; ++sp) {
-      const float4 v = *(const float4*)(part + (orow * S + sp) * D + d);
+      const float4 v = *(const float4*)(part + (p0 + sp) * D + d);
       tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
     }
     if (WEIGHTED && cnt > 0.f) {
@@ -266,11 +421,18 @@ static inline int rowsum_lpe(int64_t D) {
   while (l * 4 < D && l < 256) l <<= 1;
   return l;
 }
-static inline int rowsum_splits(int64_t B, int64_t O, int64_t T) {
+// segments per image in edge-balanced mode (0 = sparse graph: one workgroup per row).  Dense mode is chosen
+// from the PADDED triplet count, so a batch whose longest sample is dense uses it for every sample.
+static inline int64_t rowsum_nseg(int64_t O, int64_t T) {
   const int64_t deg = O > 0 ? (2 * T + O - 1) / O : 0;
-  int s = 1;
-  while (s < 32 && deg > 48 * (int64_t)s && B * O * s < 16384) s <<= 1;
-  return s;
+  if (deg <= 48 || O > 1024) return 0;
+  return cdiv(2 * T, ROWSUM_SEG) + O;
+}
+// workspace: partial rows (+ counts when weighted) and the (first segment, segments) pair of every row
+static inline int64_t rowsum_ws_bytes(int64_t B, int64_t O, int64_t T, int64_t D, bool weighted) {
+  const int64_t ns = rowsum_nseg(O, T);
+  if (ns == 0) return 0;
+  return (B * ns * (D + (weighted ? 1 : 0))) * (int64_t)sizeof(float) + B * O * 2 * (int64_t)sizeof(int32_t);
 }
 
 __global__ void k_slice_copy(const float* __restrict__ src, int64_t rows, int src_stride, int src_off, int width,
@@ -379,8 +541,14 @@ int csg_embed_bwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const fl
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_EMBED_BWD, (double)rows * dim * 8, s);
   int64_t n = rows * dim;
-  hipLaunchKernelGGL(k_embed_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, idx, rows, idx_stride, dout,
-                     out_stride, out_off, num_emb, dim, dtable);
+  if (num_emb * dim <= 8192 && rows >= 4 * EMB_ROWS_PER_BLOCK) {
+    hipLaunchKernelGGL(k_embed_bwd_lds, dim3((unsigned)cdiv(rows, EMB_ROWS_PER_BLOCK)), dim3(256),
+                       (size_t)(num_emb * dim) * sizeof(float), s, idx, rows, idx_stride, dout, out_stride, out_off,
+                       (int)num_emb, (int)dim, dtable);
+  } else {
+    hipLaunchKernelGGL(k_embed_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, idx, rows, idx_stride, dout,
+                       out_stride, out_off, num_emb, dim, dtable);
+  }
   return check_launch("csg_embed_bwd");
 }
 
@@ -403,7 +571,18 @@ int csg_graph_csr_build(const int64_t* triplets, int64_t B, int64_t T, int64_t O
   CSG_REQUIRE(T < (1 << 29), CSG_E_UNSUPPORTED, "csg_graph_csr_build: T too large");
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_CSR_BUILD, (double)B * T * (24 + 8), s);
-  hipLaunchKernelGGL(k_csr_build, dim3((unsigned)B), dim3(256), 0, s, triplets, (int)T, (int)O, row_ptr, col);
+  const size_t shm = csr_sorted_lds(T, O);
+  if (O <= 254 && T >= 512 && T <= 65535 && shm <= 150 * 1024) {      // dense graphs: counting sort
+    static size_t attr = 0;
+    if (shm > attr) {
+      (void)hipFuncSetAttribute((const void*)k_csr_build_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      attr = shm;
+    }
+    hipLaunchKernelGGL(k_csr_build_sorted, dim3((unsigned)B), dim3(256), shm, s, triplets, (int)T, (int)O, row_ptr,
+                       col);
+  } else {
+    hipLaunchKernelGGL(k_csr_build, dim3((unsigned)B), dim3(256), 0, s, triplets, (int)T, (int)O, row_ptr, col);
+  }
   return check_launch("csg_graph_csr_build");
 }
 
@@ -421,8 +600,7 @@ int csg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* tr
 
 int64_t csg_gather_concat_bwd_workspace(int64_t B, int64_t O, int64_t T, int64_t Din) {
   if (B <= 0 || O <= 0 || T < 0 || Din <= 0) return -1;
-  const int S = rowsum_splits(B, O, T);
-  return S > 1 ? B * O * S * Din * (int64_t)sizeof(float) : 0;
+  return rowsum_ws_bytes(B, O, T, Din, false);
 }
 
 int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32_t* col, int64_t B, int64_t O,
@@ -434,17 +612,20 @@ int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_GATHER_BWD, (double)B * T * (2 * Din + Dp) * 8, s);
   if (dobj) {
-    const int S = rowsum_splits(B, O, T);
-    const int64_t need = S > 1 ? B * O * S * Din * (int64_t)sizeof(float) : 0;
+    const int64_t ns = rowsum_nseg(O, T);
+    const int64_t need = rowsum_ws_bytes(B, O, T, Din, false);
     CSG_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), CSG_E_BADSHAPE,
                 "csg_gather_concat_bwd: workspace too small (%ld bytes, need %ld)", (long)workspace_bytes, (long)need);
-    hipLaunchKernelGGL(k_csr_rowsum<false>, dim3((unsigned)O, (unsigned)B, (unsigned)S), dim3(256), 0, s, dcat,
+    float* part = (float*)workspace;
+    int32_t* seg_info = ns ? (int32_t*)(part + B * ns * Din) : nullptr;
+    hipLaunchKernelGGL(k_csr_rowsum<false>, dim3((unsigned)(ns ? ns : O), (unsigned)B), dim3(256), 0, s, dcat,
                        (const float*)nullptr, (const uint8_t*)nullptr, row_ptr, col, (int)O, (int)T, (int)Din,
-                       (int)(2 * Din + Dp), 0, (int)(Din + Dp), rowsum_lpe(Din), S, dobj, (float*)nullptr,
-                       (float*)workspace, (float*)nullptr);
-    if (S > 1)
-      hipLaunchKernelGGL(k_rowsum_finish<false>, dim3((unsigned)(B * O)), dim3(128), 0, s, (const float*)workspace,
-                         (const float*)nullptr, (int)Din, S, dobj, (float*)nullptr);
+                       (int)(2 * Din + Dp), 0, (int)(Din + Dp), rowsum_lpe(Din), (int)ns, dobj, (float*)nullptr, part,
+                       (float*)nullptr, seg_info);
+    if (ns)
+      hipLaunchKernelGGL(k_rowsum_finish<false>, dim3((unsigned)(B * O)), dim3(128), 0, s, (const float*)part,
+                         (const float*)nullptr, (const int32_t*)seg_info, (int)O, (int)Din, (int)ns, dobj,
+                         (float*)nullptr);
   }
   if (dpred && T > 0) {
     int64_t n = B * T * Dp;
@@ -456,8 +637,7 @@ int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32
 
 int64_t csg_segment_avg_fwd_workspace(int64_t B, int64_t O, int64_t T, int64_t H) {
   if (B <= 0 || O <= 0 || T < 0 || H <= 0) return -1;
-  const int S = rowsum_splits(B, O, T);
-  return S > 1 ? B * O * S * (H + 1) * (int64_t)sizeof(float) : 0;
+  return rowsum_ws_bytes(B, O, T, H, true);
 }
 
 int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid, const int32_t* row_ptr,
@@ -469,18 +649,19 @@ int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid,
   hipStream_t s = (hipStream_t)stream;
   // algorithmic bytes: messages 2*T*H*4 + indices + confidence, pooled O*H*4 written
   ProfScope p(K_SEGAVG_FWD, (double)B * (T * (2.0 * H * 4 + 16 + 4) + O * H * 4.0), s);
-  const int S = rowsum_splits(B, O, T);
-  const int64_t need = S > 1 ? B * O * S * (H + 1) * (int64_t)sizeof(float) : 0;
+  const int64_t ns = rowsum_nseg(O, T);
+  const int64_t need = rowsum_ws_bytes(B, O, T, H, true);
   CSG_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), CSG_E_BADSHAPE,
               "csg_segment_avg_fwd: workspace too small (%ld bytes, need %ld)", (long)workspace_bytes, (long)need);
   float* part = (float*)workspace;
-  float* part_cnt = part ? part + B * O * S * H : nullptr;
-  hipLaunchKernelGGL(k_csr_rowsum<true>, dim3((unsigned)O, (unsigned)B, (unsigned)S), dim3(256), 0, s, h, conf, valid,
-                     row_ptr, col, (int)O, (int)T, (int)H, (int)(2 * H + Dp), 0, (int)(H + Dp), rowsum_lpe(H), S, pooled,
-                     cnt, part, part_cnt);
-  if (S > 1)
+  float* part_cnt = ns ? part + B * ns * H : nullptr;
+  int32_t* seg_info = ns ? (int32_t*)(part_cnt + B * ns) : nullptr;
+  hipLaunchKernelGGL(k_csr_rowsum<true>, dim3((unsigned)(ns ? ns : O), (unsigned)B), dim3(256), 0, s, h, conf, valid,
+                     row_ptr, col, (int)O, (int)T, (int)H, (int)(2 * H + Dp), 0, (int)(H + Dp), rowsum_lpe(H), (int)ns,
+                     pooled, cnt, part, part_cnt, seg_info);
+  if (ns)
     hipLaunchKernelGGL(k_rowsum_finish<true>, dim3((unsigned)(B * O)), dim3(128), 0, s, (const float*)part,
-                       (const float*)part_cnt, (int)H, S, pooled, cnt);
+                       (const float*)part_cnt, (const int32_t*)seg_info, (int)O, (int)H, (int)ns, pooled, cnt);
   if (new_p && Dp > 0 && T > 0) {
     int64_t n = B * T * Dp;
     hipLaunchKernelGGL(k_scale_slice, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, h, conf, B * T,
@@ -496,7 +677,7 @@ int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* 
   CSG_REQUIRE(B > 0 && O > 0 && T >= 0 && H > 0 && Dp >= 0, CSG_E_BADSHAPE, "csg_segment_avg_bwd: bad shape");
   if (T == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope p(K_SEGAVG_BWD, (double)B * T * (2.0 * H + Dp) * 12, s);
+  ProfScope p(K_SEGAVG_BWD, (double)B * T * (2.0 * H + Dp) * 8, s);   // h read + dh written (dpooled rows are L2 hits)
   hipLaunchKernelGGL(k_segavg_dcnt, dim3((unsigned)(B * O)), dim3(64), 0, s, dpooled, pooled, cnt, (int)H,
                      dcnt_scratch);
   hipLaunchKernelGGL(k_segment_avg_bwd, dim3((unsigned)(B * T)), dim3(64), 0, s, dpooled, dnew_p, h, conf, valid,

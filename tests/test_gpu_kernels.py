@@ -357,7 +357,8 @@ def _csr_reference(triplets, O):
     return rp, col
 
 
-@pytest.mark.parametrize("B,T,O", [(2, 9, 5), (3, 700, 40), (2, 5000, 300), (1, 1, 1)])
+@pytest.mark.parametrize("B,T,O", [(2, 9, 5), (3, 700, 40), (2, 5000, 300), (1, 1, 1), (4, 16256, 129), (2, 40000, 254),
+                                   (2, 513, 1)])
 def test_graph_csr_bit_exact(ops, B, T, O):
     g = torch.Generator().manual_seed(T)
     tr = torch.stack([torch.randint(0, O, (B, T), generator=g), torch.randint(0, 8, (B, T), generator=g),
@@ -382,6 +383,18 @@ def test_embed(ops):
     out.backward(gy.cuda())
     for k in range(4):
         assert_close(td[k].grad, tr[k].grad, RTOL, 1e-5, "dtable %d" % k)
+    # dense-graph regime: tens of thousands of rows onto a tiny table (per-block LDS accumulation)
+    tab = torch.randn(8, 32, generator=g)
+    idx = torch.randint(0, 8, (3, 9000, 1), generator=g)
+    t_ref = tab.clone().requires_grad_(True)
+    ref = F.embedding(idx[..., 0], t_ref)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    t_dev = dev(tab, True)
+    out = ops.embed(idx.cuda(), [t_dev])
+    assert_close(out, ref, 0, 0, "embedding, many rows")
+    out.backward(gy.cuda())
+    assert_close(t_dev.grad, t_ref.grad, RTOL, 2e-4 * float(t_ref.grad.abs().max()), "dtable, many rows")
 
 
 def test_gather_concat_and_segment_avg_vs_golden(ops):
