@@ -186,8 +186,9 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
   }
 }
 
-// One block per (object, image): reduce dout over the box's support only.
-__global__ __launch_bounds__(256) void k_layout_bwd(const float* __restrict__ dout, int out_cs, int out_off,
+// One block per (object, image): reduce dout over the box's support only.  256 threads for small layouts,
+// 1024 for >= 64x64 ones (S/4 lanes per pixel, blockDim/(S/4) pixels in flight, two loads per lane in flight).
+__global__ __launch_bounds__(1024) void k_layout_bwd(const float* __restrict__ dout, int out_cs, int out_off,
                                                      const float* __restrict__ boxes,
                                                      const uint8_t* __restrict__ valid,
                                                      const float* __restrict__ masks, int M, int O, int S, int H,
@@ -198,19 +199,19 @@ __global__ __launch_bounds__(256) void k_layout_bwd(const float* __restrict__ do
   float* s_wx = sm + OH;       // [OW]
   int* s_rng = (int*)(s_wx + OW);  // ylo, yhi, xlo, xhi
   float* s_red = sm + (((OH + OW + 4) + 3) & ~3);  // [npl][S], 16-byte aligned
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, BD = blockDim.x;
   const int o = blockIdx.x, b = blockIdx.y;
   float* dv = dvecs + ((int64_t)b * O + o) * S;
   if (!valid[(int64_t)b * O + o]) {
     if (!accumulate)
-      for (int d = tid; d < S; d += 256) dv[d] = 0.f;
+      for (int d = tid; d < S; d += BD) dv[d] = 0.f;
     return;
   }
   const float* bx = boxes + ((int64_t)b * O + o) * 4;
   const float x0 = bx[0], y0 = bx[1], ww = bx[2], hh = bx[3];
   if (tid < 4) s_rng[tid] = (tid & 1) ? -1 : (1 << 30);
   __syncthreads();
-  for (int y = tid; y < OH; y += 256) {
+  for (int y = tid; y < OH; y += BD) {
     int ysrc = min((int)(((int64_t)y * H) / OH), H - 1);
     float w = masks == nullptr ? coverage(lin01(ysrc, H), y0, hh) : coverage_n(lin01(ysrc, H), y0, hh, M);
     s_wy[y] = w;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void k_layout_bwd(const float* __restrict__ do
       atomicMax(&s_rng[1], y);
     }
   }
-  for (int x = tid; x < OW; x += 256) {
+  for (int x = tid; x < OW; x += BD) {
     int xsrc = min((int)(((int64_t)x * W) / OW), W - 1);
     float w = masks == nullptr ? coverage(lin01(xsrc, W), x0, ww) : coverage_n(lin01(xsrc, W), x0, ww, M);
     s_wx[x] = w;
@@ -231,36 +232,43 @@ __global__ __launch_bounds__(256) void k_layout_bwd(const float* __restrict__ do
   __syncthreads();
   const int ylo = s_rng[0], yhi = s_rng[1], xlo = s_rng[2], xhi = s_rng[3];
   const int qpp = S >> 2;
-  const int npl = 256 / qpp;
+  const int npl = BD / qpp;
   const int q = tid % qpp, pl = tid / qpp;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (yhi >= ylo && xhi >= xlo && pl < npl) {
     const int nx = xhi - xlo + 1, npix = (yhi - ylo + 1) * nx;
     const float* base = dout + (int64_t)b * OH * OW * out_cs + out_off + q * 4;
-    for (int i = pl; i < npix; i += npl) {
-      int yy = i / nx;
-      int xx = xlo + (i - yy * nx);
-      yy += ylo;
-      float w;
-      if (masks == nullptr) {
-        w = s_wy[yy] * s_wx[xx];
-      } else {
-        int iy0;
-        float wy0, wy1;
-        axis_taps(lin01(min((int)(((int64_t)yy * H) / OH), H - 1), H), y0, hh, M, iy0, wy0, wy1);
-        w = mask_weight(masks + ((int64_t)b * O + o) * M * M, M, iy0, wy0, wy1,
-                        lin01(min((int)(((int64_t)xx * W) / OW), W - 1), W), x0, ww);
-      }
-      float4 g = *(const float4*)&base[((int64_t)yy * OW + xx) * out_cs];
-      acc.x += g.x * w;
-      acc.y += g.y * w;
-      acc.z += g.z * w;
-      acc.w += g.w * w;
+    auto weight = [&](int yy, int xx) -> float {
+      if (masks == nullptr) return s_wy[yy] * s_wx[xx];
+      int iy0;
+      float wy0, wy1;
+      axis_taps(lin01(min((int)(((int64_t)yy * H) / OH), H - 1), H), y0, hh, M, iy0, wy0, wy1);
+      return mask_weight(masks + ((int64_t)b * O + o) * M * M, M, iy0, wy0, wy1,
+                         lin01(min((int)(((int64_t)xx * W) / OW), W - 1), W), x0, ww);
+    };
+    float4 acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = pl;
+    for (; i + npl < npix; i += 2 * npl) {            // two independent loads in flight per lane
+      const int ya = i / nx, xa = xlo + (i - ya * nx);
+      const int j = i + npl;
+      const int yb = j / nx, xb = xlo + (j - yb * nx);
+      const float4 ga = *(const float4*)&base[((int64_t)(ya + ylo) * OW + xa) * out_cs];
+      const float4 gb = *(const float4*)&base[((int64_t)(yb + ylo) * OW + xb) * out_cs];
+      const float wa = weight(ya + ylo, xa), wb = weight(yb + ylo, xb);
+      acc.x += ga.x * wa; acc.y += ga.y * wa; acc.z += ga.z * wa; acc.w += ga.w * wa;
+      acc1.x += gb.x * wb; acc1.y += gb.y * wb; acc1.z += gb.z * wb; acc1.w += gb.w * wb;
     }
+    if (i < npix) {
+      const int ya = i / nx, xa = xlo + (i - ya * nx);
+      const float4 ga = *(const float4*)&base[((int64_t)(ya + ylo) * OW + xa) * out_cs];
+      const float wa = weight(ya + ylo, xa);
+      acc.x += ga.x * wa; acc.y += ga.y * wa; acc.z += ga.z * wa; acc.w += ga.w * wa;
+    }
+    acc.x += acc1.x; acc.y += acc1.y; acc.z += acc1.z; acc.w += acc1.w;
   }
   if (pl < npl) *(float4*)&s_red[pl * S + q * 4] = acc;
   __syncthreads();
-  for (int d = tid; d < S; d += 256) {
+  for (int d = tid; d < S; d += BD) {
     float t = 0.f;
     for (int p = 0; p < npl; ++p) t += s_red[p * S + d];
     dv[d] = accumulate ? dv[d] + t : t;
@@ -305,11 +313,12 @@ int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const flo
   if (O == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
   const int qpp = (int)(S / 4);
-  const int npl = 256 / qpp;
+  const int bd = (OH * OW >= 64 * 64) ? 1024 : 256;
+  const int npl = bd / qpp;
   CSG_REQUIRE(npl >= 1, CSG_E_UNSUPPORTED, "csg_layout_bwd: S too large");
   size_t shm = (size_t)(((OH + OW + 4) + 3) & ~3) * 4 + (size_t)npl * S * 4;
   ProfScope p(K_LAYOUT_BWD, (double)B * OH * OW * S * 4, s);
-  hipLaunchKernelGGL(k_layout_bwd, dim3((unsigned)O, (unsigned)B), dim3(256), shm, s, dout, (int)out_cs, (int)out_off,
+  hipLaunchKernelGGL(k_layout_bwd, dim3((unsigned)O, (unsigned)B), dim3((unsigned)bd), shm, s, dout, (int)out_cs, (int)out_off,
                      boxes, valid, masks, (int)M, (int)O, (int)S, (int)H, (int)W, (int)OH, (int)OW, dvecs, accumulate);
   return check_launch("csg_layout_bwd");
 }
