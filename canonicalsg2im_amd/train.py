@@ -12,6 +12,8 @@ import torch
 
 from . import dist as csg_dist
 from .scripts.args import make_opt  # noqa: F401  (re-exported)
+from .scripts.graphs_utils import calc_log_p
+from .sg2im.model import get_conv_converse
 from .sg2im.meta_models import MetaDiscriminatorModel, MetaGeneratorModel
 from .sg2im.pix2pix_model import Pix2PixModel
 
@@ -33,7 +35,11 @@ class Trainer:
         fused = {'fused': True} if torch.device(device).type == 'cuda' else {}   # one multi-tensor kernel per step
         self.optimizer = torch.optim.Adam([{'params': base, 'lr': opt.learning_rate},
                                            {'params': [p for n, p in named if n in trans], 'lr': 1e-2}], **fused)
-        self.optimizer_converse = torch.optim.Adam([{'params': [p for n, p in named if n in converse], 'lr': 1e-2}])
+        self.converse_params = [p for n, p in named if n in converse]
+        self.optimizer_converse = torch.optim.Adam([{'params': self.converse_params, 'lr': 1e-2}])
+        meta = [opt.vocab['pred_name_to_idx'][p] for p in ("__padding__", "__in_image__")]          # train.py:343-345
+        self.non_meta_relations = sorted(set(opt.vocab['pred_name_to_idx'].values()) - set(meta))
+        self.converse_buckets = csg_dist.GradBuckets(self.converse_params)
         self.g_buckets = csg_dist.GradBuckets(base + [p for n, p in named if n in trans])
         self.d_params = list(self.discriminator.img_discriminator.parameters())
         self.d_buckets = csg_dist.GradBuckets(self.d_params)
@@ -52,11 +58,28 @@ class Trainer:
         for p in self.d_params + self.dobj_params + self.dmask_params:
             p.requires_grad_(flag)
 
+    def _converse_step(self, r, conv_counts):
+        """REINFORCE update of `converse_candidates_weights` (scripts/train.py:370-381): the per-sample box loss,
+        normalised over the GLOBAL batch, weights the log-probability of the converse edges the data loader
+        sampled for that sample (`conv_counts`).  The data loader reads the updated weights back on the host."""
+        eps = float(torch.finfo(torch.float32).eps)                              # np.finfo(np.float32).eps (:345)
+        r_all = r
+        if csg_dist.world_size() > 1:
+            parts = [torch.empty_like(r) for _ in range(csg_dist.world_size())]
+            torch.distributed.all_gather(parts, r.contiguous())
+            r_all = torch.cat(parts)
+        if r_all.numel() > 1:
+            r = (r - r_all.mean()) / (r_all.std() + eps)
+        log_prob = calc_log_p(get_conv_converse(self.model), self.non_meta_relations, conv_counts)
+        loss_conv = torch.mean(r * log_prob)
+        self.optimizer_converse.zero_grad(set_to_none=True)
+        loss_conv.backward()
+        self.converse_buckets.all_reduce_mean()
+        self.optimizer_converse.step()
+        return loss_conv.detach()
+
     def step(self, batch):
         opt = self.opt
-        if opt.learned_converse:
-            raise NotImplementedError("--learned_converse (REINFORCE on the data loader's converse weights) is a "
-                                      "data-loader feature outside the hot path")
         imgs, objs, boxes, triplets, conv_counts, triplet_type, masks, image_ids = batch
         if not opt.use_img_disc and objs.is_cuda:
             self.discriminator.obj_discriminator.prefetch_index(objs)
@@ -70,6 +93,8 @@ class Trainer:
         self.g_buckets.all_reduce_mean()
         self.optimizer.step()
         self._d_requires_grad(True)
+        if opt.learned_converse:
+            G["loss_conv"] = self._converse_step(G["bbox_pred_all"].detach(), conv_counts)
         # ---- discriminator update (train.py:388-393, 468-472)
         D = {}
         if not opt.skip_generation and opt.freeze_options != "generation":

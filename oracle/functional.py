@@ -20,7 +20,7 @@ __all__ = [
     "spectral_weight", "batch_norm_train", "syncbn_multi_replica", "spade", "spade_resblock",
     "generator_forward", "instance_norm", "nlayer_discriminator", "multiscale_discriminator",
     "hinge_loss", "gan_loss_multiscale", "generator_losses", "discriminator_losses", "TrainState",
-    "train_step", "make_adam_groups", "crop_objects", "ac_crop_discriminator", "bce_loss", "vgg19_features", "vgg_loss", "mask_net", "mask_discriminator",
+    "train_step", "make_adam_groups", "crop_objects", "ac_crop_discriminator", "bce_loss", "vgg19_features", "vgg_loss", "mask_net", "mask_discriminator", "calc_log_p", "converse_loss",
 ]
 
 ORIGINAL_EDGE, TRANSITIVE_EDGE = 0, 1          # sg2im/data/base_dataset.py:7-8
@@ -557,6 +557,30 @@ def discriminator_losses(opt, d_state, batch, model_out, training=True, dobj_sta
     return D
 
 
+# --------------------------------------------------------------------------- converse REINFORCE
+def calc_log_p(converse_weights, rels, rel_mat):
+    """`calc_prob(log=True)` + `calc_log_p` (scripts/graphs_utils.py:109-123): per-sample log-probability
+    of the converse edges the data loader drew; rel_mat (B,P,P+1) holds the draw counts."""
+    P = converse_weights.shape[0]
+    w = torch.cat([converse_weights, torch.zeros(P, 1).to(converse_weights)], dim=-1)
+    e = torch.exp(w)
+    w_sum = torch.sum(e[:, list(rels) + [P]], dim=1) - torch.diagonal(e)
+    log_prob = w - torch.log(w_sum.view(P, 1))
+    return torch.sum(log_prob * rel_mat, dim=[1, 2])
+
+
+def converse_loss(converse_param, vocab, bbox_pred_all, conv_counts):
+    """scripts/train.py:343-345,370-378: normalised per-sample box loss x log-probability of the draws."""
+    meta = [vocab["pred_name_to_idx"][p] for p in ("__padding__", "__in_image__")]
+    non_meta = set(vocab["pred_name_to_idx"].values()) - set(meta)
+    eps = float(torch.finfo(torch.float32).eps)
+    r = bbox_pred_all.detach()
+    if r.shape[0] > 1:
+        r = (r - r.mean()) / (r.std() + eps)
+    triu = torch.triu(converse_param, diagonal=0)                       # get_conv_converse (sg2im/model.py:10-13)
+    return torch.mean(r * calc_log_p(triu + triu.t(), non_meta, conv_counts))
+
+
 # --------------------------------------------------------------------------- train step
 def make_adam_groups(sg_state, g_state, lr):
     """Param groups of scripts/train.py:316-322: everything at `lr`, except
@@ -589,6 +613,8 @@ class TrainState:
             po = [v for v in dobj_state.values() if torch.is_tensor(v) and v.requires_grad]
             self.optimizer_d_obj = torch.optim.Adam(po, lr=opt.learning_rate, betas=(opt.beta1, 0.999))  # :79-81
         self.optimizer = torch.optim.Adam(make_adam_groups(sg_state, g_state, opt.learning_rate))
+        if "converse_candidates_weights" in sg_state:                      # scripts/train.py:312-323
+            self.optimizer_converse = torch.optim.Adam([{"params": [sg_state["converse_candidates_weights"]], "lr": 1e-2}])
         d_params = [v for v in d_state.values() if torch.is_tensor(v) and v.requires_grad]
         self.optimizer_d_img = torch.optim.Adam(d_params, lr=opt.img_learning_rate,
                                                 betas=(opt.beta1, 0.999))          # meta_models.py:67-69
@@ -615,6 +641,12 @@ def train_step(ts, batch):
             v.grad = None
     G["total_loss"].backward()                                                                # :366-368
     ts.optimizer.step()
+    if opt.learned_converse:                                                                  # :370-381
+        G["loss_conv"] = converse_loss(ts.sg["converse_candidates_weights"], opt.vocab, G["bbox_pred_all"], batch[4])
+        ts.optimizer_converse.zero_grad()
+        G["loss_conv"].backward()
+        ts.optimizer_converse.step()
+        G["loss_conv"] = G["loss_conv"].detach()
     D = discriminator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj, dmask_state=ts.dmask)   # :390
     ts.optimizer_d_img.zero_grad()                                                            # :470-472
     D["total_img_loss"].backward()

@@ -453,6 +453,30 @@ def fx_canon_graph():
          **arrays)
 
 
+def fx_converse():
+    """REINFORCE signal of --learned_converse (scripts/train.py:343-345,370-378) from the reference's own
+    calc_log_p / get_conv_converse on seeded inputs."""
+    from scripts.graphs_utils import calc_log_p
+    from sg2im.model import get_conv_converse
+    vocab = make_vocab("coco")
+    P = len(vocab["pred_idx_to_name"])
+    g = torch.Generator().manual_seed(61)
+    w = (torch.rand(P, P, generator=g) * 2 - 1).requires_grad_(True)
+    counts = torch.randint(0, 4, (5, P, P + 1), generator=g).float()
+    counts[:, :2] = 0                                                      # meta relations never sample
+    r = torch.rand(5, generator=g) * 3
+    meta = [vocab["pred_name_to_idx"][p] for p in ("__padding__", "__in_image__")]
+    non_meta = set(vocab["pred_name_to_idx"].values()) - set(meta)
+    eps = np.finfo(np.float32).eps.item()
+    rn = (r - r.mean()) / (r.std() + eps)
+    log_prob = calc_log_p(get_conv_converse({"sg_to_layout.module.converse_candidates_weights": w}), non_meta, counts)
+    loss = torch.mean(rn * log_prob)
+    loss.backward()
+    save("converse", {"ref": "scripts/train.py:343-345,370-378; scripts/graphs_utils.py:109-123; sg2im/model.py:10-13",
+                      "vocab": "coco"}, w=npy(w), counts=npy(counts), r=npy(r), log_prob=npy(log_prob), loss=npy(loss),
+         grad_w=npy(w.grad))
+
+
 def fx_model_and_step():
     """Sg2Layout + SPADEGenerator + MultiscaleDiscriminator at 64^2, ngf=2, ndf=4: forward
     outputs, loss dicts, gradients of the G step, and the state after one full train step
@@ -600,3 +624,5 @@ if __name__ == "__main__":
     fx_step_objdisc()
     fx_vgg()
     fx_step_masks()
+    fx_canon_graph()
+    fx_converse()

@@ -375,6 +375,36 @@ def test_ragged_batch_vs_oracle(cuda):
         assert_close(D[k].reshape(()), Do[k].reshape(()), 3e-4, 1e-5, "D %s" % k)
 
 
+def test_learned_converse_step_vs_oracle(cuda):
+    """--learned_converse 1: after the generator update the trainer takes the REINFORCE step on
+    `converse_candidates_weights` (scripts/train.py:370-381) from the batch's conv_counts."""
+    import oracle
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
+    vocab = make_vocab("coco")
+    opt = T.make_opt(vocab, ["--image_size", "64,64", "--ngf", "8", "--ndf", "8", "--batch_size", "4", "--no_vgg_loss",
+                             "--use_img_disc", "1", "--gconv_hidden_dim", "64", "--gconv_dim", "32",
+                             "--learned_converse", "1"])
+    torch.manual_seed(12)
+    tr = T.Trainer(opt, cuda)
+    ts = T.oracle_state_from(tr, oracle)
+    imgs, objs, boxes, triplets, cc, tt, masks, ids = make_batch(vocab, BatchConfig(4, 64, 3, 6, "random"), seed=5)
+    cc = torch.randint(0, 3, cc.shape, generator=torch.Generator().manual_seed(1)).float()
+    cc[:, :2] = 0
+    batch = (imgs, objs, boxes, triplets, cc, tt, masks, ids)
+    before = tr.model.sg_to_layout.module.converse_candidates_weights.detach().clone()
+    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    Go, Do, _ = oracle.train_step(ts, batch)
+    assert_close(G["loss_conv"], Go["loss_conv"], 2e-3, 1e-5, "loss_conv")
+    after = tr.model.sg_to_layout.module.converse_candidates_weights.detach()
+    assert not torch.equal(after, before)
+    # Adam's first step is lr * sign(g): compare where the gradient is clearly non-zero
+    assert_close(after, ts.sg["converse_candidates_weights"], 0, 2.2e-2, "converse weights after the step")
+    moved = (ts.sg["converse_candidates_weights"].detach() - before.cpu()).abs() > 5e-3
+    assert moved.any() and torch.equal((after.cpu() - before.cpu())[moved].sign(),
+                                       (ts.sg["converse_candidates_weights"].detach() - before.cpu())[moved].sign())
+
+
 # ----------------------------------------------------------------------------- full-size properties
 def test_layout_full_size_checksum_and_linearity(cuda):
     """256x256, S=32, 30 objects/img, B=16 (config C3): (1) sum over pixels of the layout equals

@@ -297,3 +297,20 @@ def test_train_step_with_masks():
             assert_close(sg[k[9:]], v, 1e-3, 2e-6, k)
             n += 1
     assert n > 15
+
+
+def test_converse_reinforce_signal():
+    """--learned_converse (scripts/train.py:370-378): log-probability of the sampled converse edges and the
+    REINFORCE loss / gradient, oracle and product helpers against the reference's own functions."""
+    from canonicalsg2im_amd.scripts import graphs_utils as product
+    meta, a = load_golden("converse")
+    vocab = make_vocab(meta["vocab"])
+    w = a["w"].clone().requires_grad_(True)
+    loss = oracle.converse_loss(w, vocab, a["r"], a["counts"])
+    assert_close(loss, a["loss"], RTOL, 1e-6, "loss_conv")
+    loss.backward()
+    assert_close(w.grad, a["grad_w"], RTOL, 1e-6, "d converse weights")
+    non_meta = sorted(set(vocab["pred_name_to_idx"].values()) - {0, 1})
+    triu = torch.triu(a["w"], diagonal=0)
+    assert_close(product.calc_log_p(triu + triu.t(), non_meta, a["counts"]), a["log_prob"], RTOL, 1e-5, "log_prob")
+    assert_close(oracle.calc_log_p(triu + triu.t(), non_meta, a["counts"]), a["log_prob"], RTOL, 1e-5, "log_prob (oracle)")
