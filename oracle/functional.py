@@ -629,9 +629,11 @@ def train_step(ts, batch):
     _, boxes_pred, masks_pred = sg2layout_forward(ts.sg, opt.vocab, objs, triplets, triplet_type,
                                                   mask_noise=ts.mask_noise)                   # meta_models.py:43
     layout_masks = masks_pred if masks is None else masks                                     # :48
-    imgs_pred = generator_forward(ts.g, opt.vocab, H, objs, boxes, True,
-                                  num_upsampling_layers=opt.num_upsampling_layers,
-                                  layout_masks=layout_masks)                                  # :47-49 (GT boxes)
+    imgs_pred = None
+    if not opt.skip_generation:                                                               # meta_models.py:44
+        imgs_pred = generator_forward(ts.g, opt.vocab, H, objs, boxes, True,
+                                      num_upsampling_layers=opt.num_upsampling_layers,
+                                      layout_masks=layout_masks)                              # :47-49 (GT boxes)
     model_out = (imgs_pred, boxes_pred, masks_pred)
     G = generator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj, vgg_state=ts.vgg,
                          dmask_state=ts.dmask)                                                # train.py:361
@@ -647,6 +649,8 @@ def train_step(ts, batch):
         G["loss_conv"].backward()
         ts.optimizer_converse.step()
         G["loss_conv"] = G["loss_conv"].detach()
+    if opt.skip_generation or opt.freeze_options == "generation":                             # train.py:388
+        return G, {}, None
     D = discriminator_losses(opt, ts.d, batch, model_out, dobj_state=ts.dobj, dmask_state=ts.dmask)   # :390
     ts.optimizer_d_img.zero_grad()                                                            # :470-472
     D["total_img_loss"].backward()

@@ -375,6 +375,30 @@ def test_ragged_batch_vs_oracle(cuda):
         assert_close(D[k].reshape(()), Do[k].reshape(()), 3e-4, 1e-5, "D %s" % k)
 
 
+def test_graph_only_step_config_c1_vs_oracle(cuda):
+    """BASELINE config C1: packed-COCO scene graph -> layout only (--skip_generation 1), 64x64, batch 4,
+    16-40 objects per image with the 4-neighbour canonical graph: box loss and the encoder update."""
+    import oracle
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import BASELINE_CONFIGS, make_batch, make_vocab
+    base = BASELINE_CONFIGS["C1"]
+    vocab = make_vocab(base["vocab"])
+    opt = T.make_opt(vocab, ["--image_size", "64,64", "--batch_size", "4", "--skip_generation", "1", "--no_vgg_loss"])
+    torch.manual_seed(3)
+    tr = T.Trainer(opt, cuda)
+    assert not hasattr(tr.model, "layout_to_image_model")
+    ts = T.oracle_state_from(tr, oracle)
+    batch = make_batch(vocab, base["cfg"], seed=8)
+    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    Go, Do, _ = oracle.train_step(ts, batch)
+    assert D == {} and Do == {} and set(G) == set(Go) == {"bbox_pred_all", "bbox_pred", "total_loss"}
+    assert_close(G["bbox_pred_all"], Go["bbox_pred_all"], 2e-4, 1e-6, "bbox_pred_all")
+    assert_close(G["total_loss"].reshape(()), Go["total_loss"].reshape(()), 2e-4, 1e-6, "total_loss")
+    sg = T.split_state(tr)[0]
+    for k in ("box_net.2.weight", "gconvs.4.net2.0.weight", "gconvs.0.net1.0.weight", "attribute_embedding.att_emb_0.weight"):
+        assert_close(sg[k], ts.sg[k], 0, 2.2 * opt.learning_rate, k + " after the step")
+
+
 def test_learned_converse_step_vs_oracle(cuda):
     """--learned_converse 1: after the generator update the trainer takes the REINFORCE step on
     `converse_candidates_weights` (scripts/train.py:370-381) from the batch's conv_counts."""
