@@ -399,6 +399,35 @@ def test_graph_only_step_config_c1_vs_oracle(cuda):
         assert_close(sg[k], ts.sg[k], 0, 2.2 * opt.learning_rate, k + " after the step")
 
 
+@pytest.mark.parametrize("kind,graph,objs", [("clevr", "closure", (9, 14)), ("vg", "random", (3, 12))])
+def test_other_vocab_steps_vs_oracle(cuda, kind, graph, objs):
+    """Shapes of BASELINE configs C5 (CLEVR: 4 attributes -> 128 layout channels, closure graphs with transitive
+    edges) and C4 (VG: 179 classes, 46 predicates) at 64x64 with narrow nets: one default-recipe step, every
+    loss term of the HIP trainer against the oracle."""
+    import oracle
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
+    vocab = make_vocab(kind)
+    opt = T.make_opt(vocab, ["--image_size", "64,64", "--ngf", "8", "--ndf", "8", "--batch_size", "3", "--no_vgg_loss",
+                             "--gconv_hidden_dim", "64", "--gconv_dim", "32", "--crop_size", "32"])
+    assert opt.semantic_nc == 32 * len(vocab["attributes"])
+    torch.manual_seed(21)
+    tr = T.Trainer(opt, cuda)
+    ts = T.oracle_state_from(tr, oracle)
+    batch = make_batch(vocab, BatchConfig(3, 64, objs[0], objs[1], graph), seed=31)
+    if graph == "closure":
+        assert set(batch[5].unique().tolist()) == {0, 1}          # original and transitive edges
+    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    Go, Do, _ = oracle.train_step(ts, batch)
+    for k in Go:
+        if k != "bbox_pred_all":
+            assert_close(G[k].reshape(()), Go[k].reshape(()), 3e-4, 1e-5, "%s G %s" % (kind, k))
+    for k in Do:
+        assert_close(D[k].reshape(()), Do[k].reshape(()), 3e-4, 1e-5, "%s D %s" % (kind, k))
+    w, wo = tr.model.sg_to_layout.module.trans_candidates_weights, ts.sg["trans_candidates_weights"]
+    assert_close(w, wo, 0, 2.2e-2, "transitive weights after the step (lr 1e-2)")
+
+
 def test_learned_converse_step_vs_oracle(cuda):
     """--learned_converse 1: after the generator update the trainer takes the REINFORCE step on
     `converse_candidates_weights` (scripts/train.py:370-381) from the batch's conv_counts."""
