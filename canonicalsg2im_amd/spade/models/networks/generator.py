@@ -1,5 +1,4 @@
 """AttSPADE generator (reference: spade/models/networks/generator.py:13-147)."""
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 

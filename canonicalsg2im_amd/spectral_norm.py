@@ -4,7 +4,6 @@ state_dict hooks) whose per-call arithmetic runs on the HIP kernels of csrc/spec
 
 Registration is torch's own (`SpectralNorm.apply`), so checkpoints, `remove_spectral_norm` and the
 state-dict version hooks behave exactly as in the reference; only `compute_weight` is replaced."""
-import torch
 from torch.nn.utils.spectral_norm import SpectralNorm
 from torch.nn.utils.spectral_norm import spectral_norm as _torch_spectral_norm
 

@@ -8,8 +8,6 @@ Conventions
 * `prefix` selects a sub-module ("gconvs.0.", "up_3.norm_s.", ...).
 * All citations are relative to /root/reference.
 """
-import math
-import re
 
 import torch
 import torch.nn.functional as F
