@@ -225,8 +225,12 @@ def main():
             if kn and kms > 0:
                 gbs = kwork / (kms * 1e-3) / 1e9
                 hbm[name] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": round(gbs / PEAK_HBM_GBS, 4)}
+                             "frac": round(gbs / PEAK_HBM_GBS, 4), "mb_per_launch": round(kwork / kn / 1e6, 2),
+                             "us_per_launch": round(1000.0 * kms / kn, 1)}
         out["hbm_kernels"] = hbm
+        out["hbm_kernels_note"] = ("algorithmic bytes / HIP-event time; launches that move a few MB (the graph kernels on "
+                                   "COCO-sized graphs: ~30 triplets per image) are launch-latency bound — their rates on "
+                                   "dense graphs are in profiles/r01i_bench_C5_dense_graphs.json")
         out["kernels"] = kern
         out["kernels_note"] = ("per-kernel table, roofline_wgrad and hbm_kernels: %d untimed steps after the timed region "
                                "with a HIP event pair on every launch; `roofline`: events on k_igemm_fwd<128> only, "
