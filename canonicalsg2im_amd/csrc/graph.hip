@@ -386,32 +386,58 @@ __global__ __launch_bounds__(256) void k_csr_rowsum(const float* __restrict__ sr
   }
 }
 
-// rows that were cut into several segments: sum their partials in segment order (rows with one segment were
-// written directly by k_csr_rowsum)
+// rows that were cut into several segments: combine their partials (rows with one segment were written
+// directly by k_csr_rowsum).  1024 threads = 1024/LPE groups of LPE lanes; group g adds segments g, g+G, ...
+// (a hub row has hundreds), the groups are combined through LDS in a fixed order.
 template <bool WEIGHTED>
-__global__ __launch_bounds__(128) void k_rowsum_finish(const float* __restrict__ part,
-                                                        const float* __restrict__ part_cnt,
-                                                        const int32_t* __restrict__ seg_info, int O, int D, int nseg_max,
-                                                        float* __restrict__ out, float* __restrict__ cnt_out) {
+__global__ __launch_bounds__(1024) void k_rowsum_finish(const float* __restrict__ part,
+                                                         const float* __restrict__ part_cnt,
+                                                         const int32_t* __restrict__ seg_info, int O, int D, int LPE,
+                                                         int nseg_max, float* __restrict__ out,
+                                                         float* __restrict__ cnt_out) {
+  __shared__ float4 sm[1024];
   const int64_t orow = blockIdx.x;
   const int g0 = seg_info[orow * 2], S = seg_info[orow * 2 + 1];
   if (S <= 1) return;
+  const int tid = threadIdx.x, G = 1024 / LPE, lane = tid % LPE, grp = tid / LPE;
   const int64_t p0 = (orow / O) * nseg_max + g0;
   float cnt = 0.f;
   if (WEIGHTED)
-    for (int sp = 0; sp < S; ++sp) cnt += part_cnt[p0 + sp];
-  for (int d = threadIdx.x * 4; d < D; d += 128 * 4) {
-    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int sp = 0; sp < S; ++sp) {
-      const float4 v = *(const float4*)(part + (p0 + sp) * D + d);
-      tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+    for (int sp = 0; sp < S; ++sp) cnt += part_cnt[p0 + sp];          // S floats, same order in every thread
+  for (int d0 = 0; d0 < D; d0 += LPE * 4) {
+    const int d = d0 + lane * 4;
+    const bool live = d < D;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int sp = grp;
+    for (; sp + G < S; sp += 2 * G) {
+      if (live) {
+        const float4 u = *(const float4*)(part + (p0 + sp) * D + d);
+        const float4 v = *(const float4*)(part + (p0 + sp + G) * D + d);
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+        a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+      }
     }
-    if (WEIGHTED && cnt > 0.f) {
-      tot.x /= cnt; tot.y /= cnt; tot.z /= cnt; tot.w /= cnt;
+    if (sp < S && live) {
+      const float4 u = *(const float4*)(part + (p0 + sp) * D + d);
+      a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
     }
-    *(float4*)(out + orow * D + d) = tot;
+    a0.x += a1.x; a0.y += a1.y; a0.z += a1.z; a0.w += a1.w;
+    __syncthreads();
+    sm[tid] = a0;
+    __syncthreads();
+    if (grp == 0 && live) {
+      float4 tot = sm[lane];
+      for (int g = 1; g < G; ++g) {
+        const float4 o = sm[g * LPE + lane];
+        tot.x += o.x; tot.y += o.y; tot.z += o.z; tot.w += o.w;
+      }
+      if (WEIGHTED && cnt > 0.f) {
+        tot.x /= cnt; tot.y /= cnt; tot.z /= cnt; tot.w /= cnt;
+      }
+      *(float4*)(out + orow * D + d) = tot;
+    }
   }
-  if (WEIGHTED && threadIdx.x == 0) cnt_out[orow] = cnt;
+  if (WEIGHTED && tid == 0) cnt_out[orow] = cnt;
 }
 
 // lanes per edge (a power of two <= 256 covering D/4 float4 columns) and row splits for B*O rows of
@@ -623,8 +649,8 @@ int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32
                        (int)(2 * Din + Dp), 0, (int)(Din + Dp), rowsum_lpe(Din), (int)ns, dobj, (float*)nullptr, part,
                        (float*)nullptr, seg_info);
     if (ns)
-      hipLaunchKernelGGL(k_rowsum_finish<false>, dim3((unsigned)(B * O)), dim3(128), 0, s, (const float*)part,
-                         (const float*)nullptr, (const int32_t*)seg_info, (int)O, (int)Din, (int)ns, dobj,
+      hipLaunchKernelGGL(k_rowsum_finish<false>, dim3((unsigned)(B * O)), dim3(1024), 0, s, (const float*)part,
+                         (const float*)nullptr, (const int32_t*)seg_info, (int)O, (int)Din, rowsum_lpe(Din), (int)ns, dobj,
                          (float*)nullptr);
   }
   if (dpred && T > 0) {
@@ -660,8 +686,9 @@ int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid,
                      row_ptr, col, (int)O, (int)T, (int)H, (int)(2 * H + Dp), 0, (int)(H + Dp), rowsum_lpe(H), (int)ns,
                      pooled, cnt, part, part_cnt, seg_info);
   if (ns)
-    hipLaunchKernelGGL(k_rowsum_finish<true>, dim3((unsigned)(B * O)), dim3(128), 0, s, (const float*)part,
-                       (const float*)part_cnt, (const int32_t*)seg_info, (int)O, (int)H, (int)ns, pooled, cnt);
+    hipLaunchKernelGGL(k_rowsum_finish<true>, dim3((unsigned)(B * O)), dim3(1024), 0, s, (const float*)part,
+                       (const float*)part_cnt, (const int32_t*)seg_info, (int)O, (int)H, rowsum_lpe(H), (int)ns, pooled,
+                       cnt);
   if (new_p && Dp > 0 && T > 0) {
     int64_t n = B * T * Dp;
     hipLaunchKernelGGL(k_scale_slice, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, h, conf, B * T,
