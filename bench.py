@@ -179,9 +179,9 @@ def main():
         "value": round(imgs / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE config %s: COCO-shaped AttSPADE %dx%d, batch %d/GPU, %d-%d objects/img, "
+        "config": {"workload": "BASELINE config %s: %s-shaped AttSPADE %dx%d, batch %d/GPU, %d-%d objects/img, "
                                "ngf=%d ndf=%d, %s --use_img_disc %d; Sg2Layout GCN + SPADE G + 2-scale "
-                               "PatchGAN D%s, fwd+bwd+Adam" % (args.config, H, H, args.batch, cfg.min_objects,
+                               "PatchGAN D%s, fwd+bwd+Adam" % (args.config, base["vocab"].upper(), H, H, args.batch, cfg.min_objects,
                                                                  cfg.max_objects, args.ngf, args.ndf,
                                                                  "VGG loss (random features)" if args.vgg_loss
                                                                  else "--no_vgg_loss", args.use_img_disc,
