@@ -94,6 +94,36 @@ class GradBuckets:
         return nbytes
 
 
+    # ---- split form: start the collectives now, finish them later (overlap with independent work)
+    def all_reduce_start(self):
+        """Flatten the gradients into buckets and launch one ASYNC all-reduce per bucket.  Returns the
+        pending list for `all_reduce_finish` (None on a single rank)."""
+        if world_size() == 1:
+            return None
+        pending = []
+        grads = [p.grad for p in self.params if p.grad is not None]
+        for bucket in self._buckets(grads):
+            flat = torch.cat([g.reshape(-1) for g in bucket])
+            pending.append((flat, bucket, dist.all_reduce(flat, async_op=True)))
+        return pending
+
+    def all_reduce_finish(self, pending):
+        """Wait for the collectives of `all_reduce_start`, average, and scatter back into the .grad tensors."""
+        if not pending:
+            return 0
+        n, nbytes = world_size(), 0
+        for flat, bucket, work in pending:
+            work.wait()
+            flat.div_(n)
+            off = 0
+            for g in bucket:
+                k = g.numel()
+                g.copy_(flat[off:off + k].view_as(g))
+                off += k
+            nbytes += flat.numel() * 4
+        return nbytes
+
+
 def broadcast_module(module, src=0):
     """Make every replica start from rank `src`'s parameters and buffers."""
     if world_size() == 1:

@@ -90,8 +90,12 @@ class Trainer:
         G = {k: (v if k == "bbox_pred_all" else v.mean()) for k, v in G.items()}
         self.optimizer.zero_grad(set_to_none=True)
         G["total_loss"].backward()
-        self.g_buckets.all_reduce_mean()
-        self.optimizer.step()
+        # N > 1: the generator's gradient all-reduce (~375 MB) runs on RCCL's stream while the discriminator
+        # losses below are computed — they read neither the generator's parameters nor its gradients
+        # (imgs_pred is detached), so applying the generator's Adam step after them changes nothing.
+        g_pending = self.g_buckets.all_reduce_start()
+        if g_pending is None:
+            self.optimizer.step()
         self._d_requires_grad(True)
         if opt.learned_converse:
             G["loss_conv"] = self._converse_step(G["bbox_pred_all"].detach(), conv_counts)
@@ -114,6 +118,9 @@ class Trainer:
                 D["total_mask_loss"].backward()
                 self.dmask_buckets.all_reduce_mean()
                 self.discriminator.optimizer_d_mask.step()
+        if g_pending is not None:
+            self.g_buckets.all_reduce_finish(g_pending)
+            self.optimizer.step()
         return G, D
 
 

@@ -37,7 +37,17 @@ def _worker(rank, world, port, out):
     loss = net(x).pow(2).mean()
     loss.backward()
     buckets = D.GradBuckets(list(net.parameters()) + list(unused.parameters()), bucket_bytes=256)
+    before = [p.grad.clone() for p in net.parameters()]
     nbytes = buckets.all_reduce_mean()
+    # the split (asynchronous) form must give the same averages
+    averaged = [p.grad.clone() for p in net.parameters()]
+    for p, g in zip(net.parameters(), before):
+        p.grad.copy_(g)
+    pending = buckets.all_reduce_start()
+    assert pending is not None and len(pending) >= 2          # 256-byte buckets: several collectives in flight
+    assert buckets.all_reduce_finish(pending) == nbytes
+    for p, g in zip(net.parameters(), averaged):
+        assert torch.equal(p.grad, g)
     # SyncBN message
     xs = torch.randn(2, 5, 4, 4, generator=torch.Generator().manual_seed(7 + rank)) * (1 + rank) + rank
     C = 5
