@@ -261,33 +261,63 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
         }
     }
   };
+  // MFMAs of tile `buf` with the LDS refill of the other buffer spread between the four k-groups, so that
+  // the ds_writes drain under the MFMAs instead of queueing up in front of the barrier
+  auto compute_store = [&](int buf, const f32x4* ra, const f32x4* rb) {
+    const float* Ab = As + buf * IG_BM * IG_LD + (wm * WROWS + r) * IG_LD + 4 * hh;
+    const float* Bb = Bs + buf * BN * IG_LD + (wn * WCOLS + r) * IG_LD + 4 * hh;
+    float* sa = As + (buf ^ 1) * IG_BM * IG_LD + r0 * IG_LD + kc * 4;
+    float* sb = Bs + (buf ^ 1) * BN * IG_LD + r0 * IG_LD + kc * 4;
+    // fragments of k-group g+1 are fetched before the MFMAs of group g are issued
+    float4 a[2][MI], b[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[0][mi] = *(const float4*)(Ab + mi * 32 * IG_LD);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b[0][ni] = *(const float4*)(Bb + ni * 32 * IG_LD);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g + 1 < 4) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[(g + 1) & 1][mi] = *(const float4*)(Ab + mi * 32 * IG_LD + (g + 1) * 8);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[(g + 1) & 1][ni] = *(const float4*)(Bb + ni * 32 * IG_LD + (g + 1) * 8);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[g & 1][ni].x, a[g & 1][mi].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[g & 1][ni].y, a[g & 1][mi].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[g & 1][ni].z, a[g & 1][mi].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[g & 1][ni].w, a[g & 1][mi].w, acc[mi][ni], 0, 0, 0);
+        }
+      *(f32x4*)(sa + 32 * g * IG_LD) = ra[g];
+      if (g < BROWS) *(f32x4*)(sb + 32 * g * IG_LD) = rb[g];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   // steady state: branch-free body, two K tiles per trip.  Invariant at the top: tile kt is in
   // LDS[buf] and tile kt+1 is in flight in register set 1; the loads issued in a half-trip are only
   // consumed (LDS refill) one half-trip later, so their latency hides behind 64 MFMAs.
   int kt = kt0, buf = 0;
   for (; kt + 3 < kt1; kt += 2) {
     load_tile(ra0, rb0);
-    compute_tile(buf);
-    store_tile(buf ^ 1, ra1, rb1);
+    compute_store(buf, ra1, rb1);
     __syncthreads();
     load_tile(ra1, rb1);
-    compute_tile(buf ^ 1);
-    store_tile(buf, ra0, rb0);
+    compute_store(buf ^ 1, ra0, rb0);
     __syncthreads();
   }
   const int left = kt1 - kt;            // 0..3 tiles remain
   if (left == 3) {
     load_tile(ra0, rb0);
-    compute_tile(buf);
-    store_tile(buf ^ 1, ra1, rb1);
+    compute_store(buf, ra1, rb1);
     __syncthreads();
-    compute_tile(buf ^ 1);
-    store_tile(buf, ra0, rb0);
+    compute_store(buf ^ 1, ra0, rb0);
     __syncthreads();
     compute_tile(buf);
   } else if (left == 2) {
-    compute_tile(buf);
-    store_tile(buf ^ 1, ra1, rb1);
+    compute_store(buf, ra1, rb1);
     __syncthreads();
     compute_tile(buf ^ 1);
   } else if (left == 1) {
@@ -546,6 +576,40 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
     }
   };
 
+  // the same MFMAs with the LDS refill of the other buffer (AIT dY pieces + 4 X pieces) spread over the 16 pixel
+  // pairs: the ds_writes drain under the MFMAs instead of queueing up in front of the barrier
+  auto compute_store = [&](int buf, const f32x4* ra, const f32x4* rb) {
+    const float* Ab = As + buf * 32 * BI + hh * BI + wi * (MI * 32) + r * MI;
+    const float* Bb = Bs + buf * 32 * WG_LDB + hh * WG_LDB + wj * (NJ * 32) + r * NJ;
+    float* sa = As + (buf ^ 1) * 32 * BI + apr * BI + ac4 * 4;
+    float* sb = Bs + (buf ^ 1) * 32 * WG_LDB + pr * WG_LDB + c4 * 4;
+    float a[2][MI], b[2][NJ];
+    frag(Ab, a[0], std::integral_constant<int, MI>());
+    frag(Bb, b[0], std::integral_constant<int, NJ>());
+#pragma unroll
+    for (int kp = 0; kp < 16; ++kp) {
+      if (kp + 1 < 16) {
+        frag(Ab + (kp + 1) * 2 * BI, a[(kp + 1) & 1], std::integral_constant<int, MI>());
+        frag(Bb + (kp + 1) * 2 * WG_LDB, b[(kp + 1) & 1], std::integral_constant<int, NJ>());
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[kp & 1][nj], a[kp & 1][mi], acc[mi][nj], 0, 0, 0);
+      if ((kp & 1) == 1) {                       // 8 slots: kp = 1, 3, ..., 15
+        const int slot = kp >> 1;
+        if (slot < AIT) {
+          *(f32x4*)(sa + RP * slot * BI) = ra[slot];
+          if (do_db) csum += ra[slot];
+        }
+        if (slot >= 4) *(f32x4*)(sb + 8 * (slot - 4) * WG_LDB) = rb[slot - 4];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    static_assert(AIT <= 4, "the refill slots cover at most 4 dY pieces");
+  };
+
   // invariant at the top of the steady loop: chunk `ch` is in LDS[buf], chunk ch+1 is in flight in set 1
   int ch = ch0, buf = 0;
   if (ch0 < ch1) {
@@ -556,27 +620,22 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
   __syncthreads();
   for (; ch + 3 < ch1; ch += 2) {      // branch-free body: two chunks per trip
     load_tile(ch + 2, ra0, rb0);
-    compute_tile(buf);
-    store_tile(buf ^ 1, ra1, rb1);
+    compute_store(buf, ra1, rb1);
     __syncthreads();
     load_tile(ch + 3, ra1, rb1);
-    compute_tile(buf ^ 1);
-    store_tile(buf, ra0, rb0);
+    compute_store(buf ^ 1, ra0, rb0);
     __syncthreads();
   }
   const int left = ch1 - ch;            // 0..3 chunks remain
   if (left == 3) {
     load_tile(ch + 2, ra0, rb0);
-    compute_tile(buf);
-    store_tile(buf ^ 1, ra1, rb1);
+    compute_store(buf, ra1, rb1);
     __syncthreads();
-    compute_tile(buf ^ 1);
-    store_tile(buf, ra0, rb0);
+    compute_store(buf ^ 1, ra0, rb0);
     __syncthreads();
     compute_tile(buf);
   } else if (left == 2) {
-    compute_tile(buf);
-    store_tile(buf ^ 1, ra1, rb1);
+    compute_store(buf, ra1, rb1);
     __syncthreads();
     compute_tile(buf ^ 1);
   } else if (left == 1) {
