@@ -230,7 +230,7 @@ def main():
         out["hbm_kernels"] = hbm
         out["hbm_kernels_note"] = ("algorithmic bytes / HIP-event time; launches that move a few MB (the graph kernels on "
                                    "COCO-sized graphs: ~30 triplets per image) are launch-latency bound — their rates on "
-                                   "dense graphs are in profiles/r01i_bench_C5_dense_graphs.json")
+                                   "dense graphs are in profiles/r01j_bench_C5_dense_graphs.json")
         out["kernels"] = kern
         out["kernels_note"] = ("per-kernel table, roofline_wgrad and hbm_kernels: %d untimed steps after the timed region "
                                "with a HIP event pair on every launch; `roofline`: events on k_igemm_fwd<128> only, "
