@@ -111,7 +111,7 @@ class _Conv2d(torch.autograd.Function):
     include/csg_hip.h (K8/K11)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, pad, act, slope, packs=None):
+    def forward(ctx, x, weight, bias, residual, stride, pad, act, slope, packs=None, dx_range=None):
         x = nhwc(_f32(x))
         B, Cin, IH, IW = x.shape
         Cout, Cin_w, KH, KW = weight.shape
@@ -119,7 +119,7 @@ class _Conv2d(torch.autograd.Function):
             Cin_w = packs[0].shape[3]              # packed weights carry their own channel padding
         if Cin_w != Cin:
             raise RuntimeError("conv2d: weight expects %d input channels, x has %d" % (Cin_w, Cin))
-        ctx.packs = packs
+        ctx.packs, ctx.dx_range = packs, dx_range
         wp = packs[0] if packs is not None else weight.detach().permute(0, 2, 3, 1).contiguous()   # [Cout][KH][KW][Cin]
         d, OH, OW = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad, act, slope)
         y = empty_nhwc(B, Cout, OH, OW, x.device)
@@ -141,7 +141,22 @@ class _Conv2d(torch.autograd.Function):
         else:
             dpre = dy
         dx = dw = db = dres = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.dx_range is not None:
+            # only input channels [lo, hi) are wanted by the consumer of dx (the discriminator's packed
+            # [layout | img | pad] input: the image part in the generator pass, the layout part in the
+            # discriminator passes): the transposed convolution runs over that slice of the weight only
+            lo, hi = ctx.dx_range
+            wt = weight.detach()[:, lo:hi].permute(1, 2, 3, 0).contiguous()      # [hi-lo][KH][KW][Cout]
+            dx = empty_nhwc(B, Cin, IH, IW, dy.device, zero=True)
+            for d in _descs_backward_data(B, IH, IW, hi - lo, Cout, KH, KW, stride, pad, OH, OW):
+                d.y_cs = Cin
+                nbytes = lib.csg_conv_fwd_workspace(d)
+                if nbytes < 0:
+                    raise RuntimeError("conv_fwd_workspace: " + _lib.last_error())
+                ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32) if nbytes > 0 else None
+                check(lib.csg_conv_fwd(d, ptr(dpre), ptr(wt), None, None, ctypes_ptr_off(dx, lo), ptr(ws), nbytes,
+                                       stream()), "conv_bwd_data")
+        elif ctx.needs_input_grad[0]:
             wt = ctx.packs[1] if ctx.packs is not None else \
                 weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
@@ -168,7 +183,7 @@ class _Conv2d(torch.autograd.Function):
             check(lib.csg_colsum(ptr(dpre), rows, Cout, Cout, ptr(db), ptr(part), nch, stream()), "colsum")
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dpre
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
 def pack_conv_weight(weight):
@@ -180,7 +195,8 @@ def pack_conv_weight(weight):
     return w.permute(0, 2, 3, 1).contiguous(), w.permute(1, 2, 3, 0).contiguous()
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, residual=None, packs=None):
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, residual=None, packs=None,
+           dx_range=None):
     """Channel counts that are not multiples of 4 (conv_img: 3 outputs, the PatchGAN head: 1) are
     zero-padded to 16-byte pixel rows; the result is a channel-slice view of the padded output."""
     Cout, Cin = weight.shape[0], weight.shape[1]
@@ -196,7 +212,9 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, r
         weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, po))
         bias = F.pad(bias, (0, po)) if bias is not None else None
         residual = F.pad(residual, (0, 0, 0, 0, 0, po)) if residual is not None else None
-    y = _Conv2d.apply(x, weight, bias, residual, int(stride), int(padding), int(act), float(slope), packs)
+    if dx_range is not None and (dx_range[0] % 4 or dx_range[1] % 4 or pc):
+        raise RuntimeError("conv2d: dx_range must be 4-aligned channel bounds of an unpadded input")
+    y = _Conv2d.apply(x, weight, bias, residual, int(stride), int(padding), int(act), float(slope), packs, dx_range)
     return y[:, :Cout] if po else y
 
 

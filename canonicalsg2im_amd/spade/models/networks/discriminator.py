@@ -40,9 +40,10 @@ class NLayerDiscriminator(BaseNetwork):
     def compute_D_input_nc(self):
         return self.opt.semantic_nc + 3
 
-    def forward(self, input, seg_first=0):
+    def forward(self, input, seg_first=0, grad_channels=None):
         """`seg_first=S`: `input` is the packed buffer of ops.disc_input ([layout(S)|img(3)|pad]); the
-        first conv's weight (trained on cat([img, layout])) is permuted to that channel order."""
+        first conv's weight (trained on cat([img, layout])) is permuted to that channel order.
+        `grad_channels=(lo, hi)`: the only input channels whose gradient anybody reads."""
         results = [input]
         for name, sub in self.named_children():
             x = results[-1]
@@ -54,7 +55,7 @@ class NLayerDiscriminator(BaseNetwork):
                 if pad:
                     parts.append(w.new_zeros(w.size(0), pad, w.size(2), w.size(3)))
                 x = ops.conv2d(x, torch.cat(parts, dim=1), conv.bias, conv.stride[0], conv.padding[0], conv.act,
-                               conv.slope)
+                               conv.slope, dx_range=grad_channels)
             else:
                 x = sub(x)
             results.append(x)
@@ -86,10 +87,17 @@ class MultiscaleDiscriminator(BaseNetwork):
         valid = real_object_mask(objs, self.opt.vocab)
         S = obj_vecs.size(-1)
         x = ops.disc_input(img, obj_vecs, layout_boxes, valid, self.opt.image_size[0], masks=layout_masks)
+        # Who reads d(input)?  In the generator pass only the image (the discriminator is frozen), in the
+        # discriminator passes only the layout (through D's own embedding): the first conv's backward-data
+        # is restricted to those channels.
+        want_img, want_seg = img.requires_grad, obj_vecs.requires_grad
+        grad_channels = None
+        if want_img != want_seg and S % 4 == 0:
+            grad_channels = (S, x.size(1)) if want_img else (0, S)
         result = []
         for name, D in self.named_children():
             if name.startswith('discriminator'):
-                out = D(x, seg_first=S)
+                out = D(x, seg_first=S, grad_channels=grad_channels)
                 result.append(out if not self.opt.no_ganFeat_loss else [out])
                 x = self.downsample(x)
         return result
