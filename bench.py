@@ -86,6 +86,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    if os.environ.get("CSG_SINGLE_DEVICE") == "1":        # test hook: every rank on cuda:0 (with CSG_DIST_BACKEND=gloo)
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 

@@ -85,3 +85,27 @@ def test_two_ranks_on_one_gpu_match_and_track_single_process():
     sg, g, d = T.split_state(tr)
     rv = g["up_2.norm_0.param_free_norm.running_var"].cpu()
     assert torch.allclose(r0["probe"]["up_2.norm_0.param_free_norm.running_var"], rv, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.timeout(600)
+def test_bench_contract_with_two_ranks():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), with
+    both ranks on cuda:0 over gloo (test hooks CSG_DIST_BACKEND / CSG_SINGLE_DEVICE): rendezvous, parameter
+    broadcast, sharded steps with the SyncBN and gradient collectives, max-over-ranks timing, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CSG_DIST_BACKEND="gloo", CSG_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "2", "--image_size", "64", "--ngf", "8", "--ndf", "8"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=540)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["losses_finite"] and d["value"] > 0 and "cpu_baseline" not in d
+    assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 / 1000.0)) / d["value"] < 0.02
