@@ -84,6 +84,7 @@ def build_parser():
     p.add_argument('--use_img_disc', type=int, default=0)
     p.add_argument('--use_cuda', action='store_true')
     p.add_argument('--gpu_ids', type=str, default='0')
+    p.add_argument('--freeze', default=0, type=int)
     p.add_argument('--freeze_options', default=None)
     p.add_argument('--print_every', default=10, type=int)
     p.add_argument('--min_objects', type=int)

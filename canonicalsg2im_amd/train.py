@@ -25,6 +25,9 @@ class Trainer:
         self.discriminator = MetaDiscriminatorModel(opt).to(device).build_optimizers(opt)
         self.gans_model = Pix2PixModel(opt, discriminator=self.discriminator).to(device)
         self.model.train()
+        self.d_frozen = False
+        if getattr(opt, "freeze", 0):
+            self.freeze_weights(opt.freeze_options)
         csg_dist.broadcast_module(self.model)
         csg_dist.broadcast_module(self.discriminator)
         # param groups of scripts/train.py:312-322
@@ -54,7 +57,21 @@ class Trainer:
             self.dmask_params = list(self.discriminator.mask_discriminator.parameters())
             self.dmask_buckets = csg_dist.GradBuckets(self.dmask_params)
 
+    def freeze_weights(self, module):
+        """`--freeze 1 --freeze_options generation` (scripts/train.py:104-117, 337-338): the layout-to-image model and
+        every discriminator stop training; only the graph encoder is updated."""
+        if module != 'generation':
+            raise NotImplementedError('Unrecognized option, you can freeze either graph module or I3D module')
+        if hasattr(self.model, 'layout_to_image_model'):
+            for p in self.model.layout_to_image_model.parameters():
+                p.requires_grad = False
+        for p in self.discriminator.parameters():
+            p.requires_grad = False
+        self.d_frozen = True
+
     def _d_requires_grad(self, flag):
+        if self.d_frozen:
+            return
         for p in self.d_params + self.dobj_params + self.dmask_params:
             p.requires_grad_(flag)
 

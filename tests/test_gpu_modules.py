@@ -428,6 +428,29 @@ def test_other_vocab_steps_vs_oracle(cuda, kind, graph, objs):
     assert_close(w, wo, 0, 2.2e-2, "transitive weights after the step (lr 1e-2)")
 
 
+def test_freeze_generation(cuda):
+    """--freeze 1 --freeze_options generation (scripts/train.py:104-117,388): generator and discriminators keep
+    their weights, no discriminator step is taken, the graph encoder still learns from the box loss."""
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
+    vocab = make_vocab("coco")
+    opt = T.make_opt(vocab, ["--image_size", "64,64", "--ngf", "8", "--ndf", "8", "--batch_size", "2", "--no_vgg_loss",
+                             "--gconv_hidden_dim", "64", "--gconv_dim", "32", "--crop_size", "32", "--freeze", "1",
+                             "--freeze_options", "generation"])
+    torch.manual_seed(2)
+    tr = T.Trainer(opt, cuda)
+    snap = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point() and "running" not in k
+                      and "weight_u" not in k and "weight_v" not in k}
+    g0, d0, sg0 = snap(tr.model.layout_to_image_model), snap(tr.discriminator), snap(tr.model.sg_to_layout)
+    batch = make_batch(vocab, BatchConfig(2, 64, 3, 6, "random"), seed=4)
+    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    assert D == {} and "GAN_Img" in G and torch.isfinite(G["total_loss"])
+    assert all(torch.equal(v, g0[k]) for k, v in snap(tr.model.layout_to_image_model).items())
+    assert all(torch.equal(v, d0[k]) for k, v in snap(tr.discriminator).items())
+    assert any(not torch.equal(v, sg0[k]) for k, v in snap(tr.model.sg_to_layout).items())
+    assert not any(p.requires_grad for p in tr.discriminator.parameters())
+
+
 def test_learned_converse_step_vs_oracle(cuda):
     """--learned_converse 1: after the generator update the trainer takes the REINFORCE step on
     `converse_candidates_weights` (scripts/train.py:370-381) from the batch's conv_counts."""
