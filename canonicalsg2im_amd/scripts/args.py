@@ -16,6 +16,37 @@ def bool_flag(s):
     raise ValueError('Invalid value "%s" for bool flag (should be 0 or 1)' % s)
 
 
+_OFF_PATH_FLAGS = {
+    # data
+    'img_deprocess': ('decode_img', 'str'), 'num_train_samples': (None, 'int'), 'num_val_samples': (1024, 'int'),
+    'shuffle_val': (True, 'bool'), 'loader_num_workers': (1, 'int'), 'include_relationships': (True, 'bool'),
+    'vg_image_dir': ('datasets/vg/images', 'str'), 'train_h5': ('datasets/vg/train.h5', 'str'),
+    'val_h5': ('datasets/vg/val.h5', 'str'), 'vocab_json': ('datasets/vg/vocab.json', 'str'),
+    'max_objects_per_image': (10, 'int'), 'vg_use_orphaned_objects': (True, 'bool'), 'dataroot': ('./datasets', 'str'),
+    'preprocess_mode': ('scale_width_and_crop', 'str'), 'no_flip': (False, 'flag'), 'nThreads': (0, 'int'),
+    'cache_filelist_write': (False, 'flag'), 'cache_filelist_read': (False, 'flag'), 'dense_scenes': (0, 'int'),
+    'max_objects_val': (None, 'int'), 'min_object_size': (0.02, 'float'), 'use_attributes': (1, 'int'),
+    'include_dummies': (0, 'int'), 'use_transitivity': (0, 'int'), 'all_transitive_baseline': (0, 'int'),
+    'use_all_relations': (0, 'int'), 'learned_symmetry': (0, 'int'), 'use_converse': (0, 'int'),
+    # run control, logging, checkpoints
+    'timing': (False, 'bool'), 'checkpoint_every': (10000, 'int'), 'output_dir': (None, 'str'), 'run_name': ('debug', 'str'),
+    'checkpoint_name': ('checkpoint', 'str'), 'checkpoint_gan_name': ('checkpoint', 'str'),
+    'checkpoint_graph_name': ('checkpoint', 'str'), 'restore_checkpoint': (0, 'int'), 'checkpoint_start_from': (None, 'str'), 'name': ('label2coco', 'str'),
+    'checkpoints_dir': ('./checkpoints', 'str'), 'phase': ('train', 'str'), 'load_from_opt_file': (False, 'flag'),
+    'display_winsize': (400, 'int'), 'debug': (False, 'flag'), 'niter': (50, 'int'), 'niter_decay': (0, 'int'),
+    'full_test': (1000000, 'int'), 'resolution': (256, 'int'),
+    # model options the reference declares but its trainer never reads on this path
+    'graph_model': ('jj', 'str'), 'heads': (1, 'int'), 'normalization': ('batch', 'str'), 'activation': ('leakyrelu-0.2', 'str'),
+    'use_boxes_pred_after': (-1, 'int'), 'netD_subarch': ('n_layer', 'str'), 'model': ('pix2pix', 'str'),
+    'norm_E': ('spectralinstance', 'str'), 'label_nc': (182, 'int'), 'contain_dontcare_label': (False, 'flag'),
+    'output_nc': (131, 'int'), 'netG': ('spade', 'str'), 'init_type': ('xavier', 'str'), 'init_variance': (0.02, 'float'),
+    'no_instance': (False, 'flag'), 'nef': (16, 'int'), 'optimizer': ('adam', 'str'), 'D_steps_per_G': (1, 'int'),
+    'netD': ('multiscale', 'str'), 'no_TTUR': (False, 'flag'), 'lambda_kld': (0.05, 'float'), 'ndf_mask': (64, 'int'),
+    'num_D_mask': (1, 'int'), 'norm_D_mask': ('instance', 'str'), 'n_layers_D_mask': (2, 'int'),
+    'transformer_hidden_dim': (32, 'int'),
+}
+
+
 def build_parser():
     p = argparse.ArgumentParser()
     p.add_argument('--dataset', default='coco',
@@ -89,6 +120,13 @@ def build_parser():
     p.add_argument('--print_every', default=10, type=int)
     p.add_argument('--min_objects', type=int)
     p.add_argument('--max_objects', type=int)
+    # every other flag of the reference's command line (data loading, logging, checkpointing, evaluation, unused SPADE
+    # options): accepted with the reference's defaults so that its recipes parse unchanged; none is read on the hot path
+    for name, (default, kind) in _OFF_PATH_FLAGS.items():
+        if kind == 'flag':
+            p.add_argument('--' + name, action='store_true')
+        else:
+            p.add_argument('--' + name, default=default, type={'int': int, 'float': float, 'str': str, 'bool': bool_flag}[kind])
     return p
 
 

@@ -170,3 +170,16 @@ def test_out_of_scope_components_fail_loudly(built, monkeypatch):
             "discriminator.obj_classifier.bias"} <= keys
     assert "discriminator_1.model1.0.0.weight_orig" in tr.discriminator.mask_discriminator.state_dict()
     assert tr.discriminator.optimizer_d_obj.param_groups[0]["lr"] == 1e-4
+
+
+def test_reference_command_lines_parse():
+    """Every flag of the reference's scripts/args.py is accepted (README recipes parse unchanged)."""
+    from canonicalsg2im_amd.scripts.args import build_parser
+    p = build_parser()
+    clevr = ("--dataset packed_clevr --batch_size 48 --image_size 256,256 --learned_transitivity 1 --use_img_disc 1 "
+             "--loader_num_workers 8 --include_dummies 1 --output_dir out --checkpoint_every 5000 --print_every 100").split()
+    a = p.parse_args(clevr)
+    assert a.dataset == "packed_clevr" and a.batch_size == 48 and a.use_img_disc == 1 and a.loader_num_workers == 8
+    coco = "--dataset coco --max_objects 1000 --image_size 256,256 --no_flip --shuffle_val 0 --timing 1".split()
+    b = p.parse_args(coco)
+    assert b.no_flip is True and b.shuffle_val is False and b.timing is True and b.use_img_disc == 0
