@@ -141,6 +141,54 @@ class Trainer:
         return G, D
 
 
+    # ------------------------------------------------------------------ checkpoints (scripts/train.py:488-520)
+    def checkpoint_dict(self, t=0, epoch=0):
+        """The reference's checkpoint dictionary: same top-level keys, same state_dict keys inside (its
+        `gans_model` is wrapped in DataParallel, hence the `module.` prefix of `gans_model_state`)."""
+        d, opt = self.discriminator, self.opt
+        out = {
+            'model_state': self.model.state_dict(),
+            'gans_model_state': {'module.' + k: v for k, v in self.gans_model.state_dict().items()},
+            'd_img_state': d.img_discriminator.state_dict(),
+            'd_img_optim_state': d.optimizer_d_img.state_dict(),
+            'optim_state': self.optimizer.state_dict(),
+            'vocab': opt.vocab,
+            'counters': {'t': t, 'epoch': epoch},
+        }
+        if not opt.use_img_disc:
+            out.update({'d_obj_state': d.obj_discriminator.state_dict(), 'd_mask_state': d.mask_discriminator.state_dict(),
+                        'd_obj_optim_state': d.optimizer_d_obj.state_dict(),
+                        'd_mask_optim_state': d.optimizer_d_mask.state_dict()})
+        return out
+
+    def save_checkpoint(self, path, t=0, epoch=0):
+        if csg_dist.rank() == 0:
+            torch.save(self.checkpoint_dict(t, epoch), path)
+
+    def load_checkpoint(self, ckpt, optimizers=True):
+        """Restore from a checkpoint dictionary (or a path to one) written by this trainer or by the reference's
+        `save_checkpoint`.  Returns (t, epoch)."""
+        if not isinstance(ckpt, dict):
+            ckpt = torch.load(ckpt, map_location=self.device)
+        d = self.discriminator
+        self.model.load_state_dict(ckpt['model_state'], strict=False)
+        d.img_discriminator.load_state_dict(ckpt['d_img_state'])
+        if not self.opt.use_img_disc:
+            if 'd_obj_state' in ckpt:
+                d.obj_discriminator.load_state_dict(ckpt['d_obj_state'])
+            if 'd_mask_state' in ckpt:
+                d.mask_discriminator.load_state_dict(ckpt['d_mask_state'], strict=False)
+        if optimizers:
+            self.optimizer.load_state_dict(ckpt['optim_state'])
+            d.optimizer_d_img.load_state_dict(ckpt['d_img_optim_state'])
+            if not self.opt.use_img_disc and 'd_obj_optim_state' in ckpt:
+                d.optimizer_d_obj.load_state_dict(ckpt['d_obj_optim_state'])
+                if 'd_mask_optim_state' in ckpt:
+                    d.optimizer_d_mask.load_state_dict(ckpt['d_mask_optim_state'])
+        c = ckpt.get('counters', {})
+        return c.get('t', 0), c.get('epoch', 0)
+
+
 # ------------------------------------------------------------------ test / smoke helpers
 def split_state(trainer):
     """(sg, g, d) state dicts with the reference's un-prefixed keys."""

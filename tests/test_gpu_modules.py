@@ -428,6 +428,40 @@ def test_other_vocab_steps_vs_oracle(cuda, kind, graph, objs):
     assert_close(w, wo, 0, 2.2e-2, "transitive weights after the step (lr 1e-2)")
 
 
+def test_checkpoint_round_trip(cuda, tmp_path):
+    """Save after one step in the reference's checkpoint layout, restore into a fresh trainer, and the next step
+    matches the uninterrupted run (weights, Adam moments, spectral-norm vectors, BatchNorm statistics)."""
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
+    vocab = make_vocab("coco")
+    argv = ["--image_size", "64,64", "--ngf", "8", "--ndf", "8", "--batch_size", "2", "--no_vgg_loss",
+            "--gconv_hidden_dim", "64", "--gconv_dim", "32", "--crop_size", "32"]
+    b1 = [None if t is None else t.cuda() for t in make_batch(vocab, BatchConfig(2, 64, 3, 6, "random"), seed=1)]
+    b2 = [None if t is None else t.cuda() for t in make_batch(vocab, BatchConfig(2, 64, 3, 6, "random"), seed=2)]
+    torch.manual_seed(8)
+    a = T.Trainer(T.make_opt(vocab, argv), cuda)
+    a.step(b1)
+    path = str(tmp_path / "ckpt.pt")
+    a.save_checkpoint(path, t=1, epoch=0)
+    ck = torch.load(path, map_location="cpu")
+    assert {"model_state", "gans_model_state", "d_img_state", "d_obj_state", "d_mask_state", "d_img_optim_state",
+            "d_obj_optim_state", "d_mask_optim_state", "optim_state", "vocab", "counters"} == set(ck)
+    assert "sg_to_layout.module.gconvs.0.net1.0.weight" in ck["model_state"]
+    assert "module.netD_img.discriminator_0.model1.0.0.weight_orig" in ck["gans_model_state"]
+    Ga, Da = a.step(b2)
+    torch.manual_seed(99)                                    # a differently initialised trainer
+    b = T.Trainer(T.make_opt(vocab, argv), cuda)
+    assert b.load_checkpoint(path) == (1, 0)
+    Gb, Db = b.step(b2)
+    for k in Ga:
+        assert_close(Gb[k], Ga[k], 1e-5, 1e-6, "resumed G " + k)
+    for k in Da:
+        assert_close(Db[k], Da[k], 1e-5, 1e-6, "resumed D " + k)
+    wa = a.model.layout_to_image_model.module.conv_img.weight
+    wb = b.model.layout_to_image_model.module.conv_img.weight
+    assert_close(wb, wa, 0, 3e-5, "weights after the resumed step")     # crop-gradient atomics: not bit-identical
+
+
 def test_freeze_generation(cuda):
     """--freeze 1 --freeze_options generation (scripts/train.py:104-117,388): generator and discriminators keep
     their weights, no discriminator step is taken, the graph encoder still learns from the box loss."""
