@@ -55,7 +55,10 @@ SIGNATURES = {
     "csg_layout_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64,
                                c_i64, c_p]),
     "csg_layout_bwd": (c_i32, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
-                               c_i64, c_p, c_i32, c_p]),
+                               c_i64, c_p, c_i32, c_p, c_p, c_p]),
+    "csg_layout_mass": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_layout_paint": (c_i32, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64,
+                                 c_i64, c_p]),
     "csg_conv_fwd_workspace": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "csg_conv_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_conv_bwd_weight_workspace": (c_i64, [ctypes.POINTER(ConvDesc)]),

@@ -80,6 +80,41 @@ __device__ __forceinline__ float mask_weight(const float* __restrict__ mk, int M
   return acc;
 }
 
+// d coverage / d ix of grid_sample's bilinear interpolation on a constant n-pixel line (what ATen's
+// grid_sampler backward accumulates into the grid gradient): +1 while only the upper tap is inside the line
+// (ix in [-1, 0)), -1 while only the lower one is (ix in [n-1, n)), 0 elsewhere.
+__device__ __forceinline__ float coverage_dix(float t, float lo, float size, int n) {
+  float g = ((t - lo) / size) * 2.0f - 1.0f;
+  float ix = ((g + 1.0f) * (float)n - 1.0f) / 2.0f;
+  float i0 = floorf(ix);
+  float v0 = (i0 >= 0.0f && i0 <= (float)(n - 1)) ? 1.0f : 0.0f;
+  float v1 = (i0 + 1.0f >= 0.0f && i0 + 1.0f <= (float)(n - 1)) ? 1.0f : 0.0f;
+  return v1 - v0;
+}
+
+// mask_weight together with its derivatives w.r.t. the un-normalised sample coordinates (ix, iy)
+__device__ __forceinline__ void mask_weight_grad(const float* __restrict__ mk, int M, float ty, float y0, float hh,
+                                                 float tx, float x0, float ww, float& w, float& dwdix, float& dwdiy) {
+  float gy = ((ty - y0) / hh) * 2.0f - 1.0f, gx = ((tx - x0) / ww) * 2.0f - 1.0f;
+  float fy = ((gy + 1.0f) * (float)M - 1.0f) / 2.0f, fx = ((gx + 1.0f) * (float)M - 1.0f) / 2.0f;
+  float y0f = floorf(fy), x0f = floorf(fx);
+  float ry = fy - y0f, rx = fx - x0f;
+  y0f = fminf(fmaxf(y0f, -2.0f), (float)M);
+  x0f = fminf(fmaxf(x0f, -2.0f), (float)M);
+  const int iy = (int)y0f, ix = (int)x0f;
+  float m[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int yy = iy + a, xx = ix + c;
+      m[a][c] = (yy >= 0 && yy < M && xx >= 0 && xx < M) ? mk[yy * M + xx] : 0.f;
+    }
+  w = m[0][0] * (1.f - ry) * (1.f - rx) + m[0][1] * (1.f - ry) * rx + m[1][0] * ry * (1.f - rx) + m[1][1] * ry * rx;
+  dwdix = (m[0][1] - m[0][0]) * (1.f - ry) + (m[1][1] - m[1][0]) * ry;
+  dwdiy = (m[1][0] - m[0][0]) * (1.f - rx) + (m[1][1] - m[0][1]) * rx;
+}
+
 #define LAY_OB 32    // objects per LDS batch
 #define LAY_PXC 256  // max pixels per block chunk
 #define LAY_EPT 8    // float4 elements per thread
@@ -193,18 +228,24 @@ __global__ __launch_bounds__(1024) void k_layout_bwd(const float* __restrict__ d
                                                      const uint8_t* __restrict__ valid,
                                                      const float* __restrict__ masks, int M, int O, int S, int H,
                                                      int W, int OH, int OW, float* __restrict__ dvecs,
-                                                     int accumulate) {
+                                                     int accumulate, const float* __restrict__ vecs,
+                                                     float* __restrict__ dboxes) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_wy = sm;            // [OH]
   float* s_wx = sm + OH;       // [OW]
   int* s_rng = (int*)(s_wx + OW);  // ylo, yhi, xlo, xhi
-  float* s_red = sm + (((OH + OW + 4) + 3) & ~3);  // [npl][S], 16-byte aligned
+  float* s_red = sm + (((OH + OW + 4) + 3) & ~3);  // [max(npl * S, BD * 4)], 16-byte aligned
+  float* s_dwy = s_red + max((blockDim.x / (S >> 2)) * S, blockDim.x * 4);   // [OH]  box gradients only
+  float* s_dwx = s_dwy + OH;                                                    // [OW]
   const int tid = threadIdx.x, BD = blockDim.x;
   const int o = blockIdx.x, b = blockIdx.y;
   float* dv = dvecs + ((int64_t)b * O + o) * S;
+  float* db = dboxes != nullptr ? dboxes + ((int64_t)b * O + o) * 4 : nullptr;
   if (!valid[(int64_t)b * O + o]) {
-    if (!accumulate)
+    if (!accumulate) {
       for (int d = tid; d < S; d += BD) dv[d] = 0.f;
+      if (db != nullptr && tid < 4) db[tid] = 0.f;
+    }
     return;
   }
   const float* bx = boxes + ((int64_t)b * O + o) * 4;
@@ -215,7 +256,13 @@ __global__ __launch_bounds__(1024) void k_layout_bwd(const float* __restrict__ d
     int ysrc = min((int)(((int64_t)y * H) / OH), H - 1);
     float w = masks == nullptr ? coverage(lin01(ysrc, H), y0, hh) : coverage_n(lin01(ysrc, H), y0, hh, M);
     s_wy[y] = w;
-    if (w != 0.f) {
+    bool in = w != 0.f;
+    if (db != nullptr) {                     // the derivative's support includes the (measure-zero) points where
+      const float dw = coverage_dix(lin01(ysrc, H), y0, hh, masks == nullptr ? 8 : M);     // the coverage itself is 0
+      s_dwy[y] = dw;
+      in = in || dw != 0.f;
+    }
+    if (in) {
       atomicMin(&s_rng[0], y);
       atomicMax(&s_rng[1], y);
     }
@@ -224,7 +271,13 @@ __global__ __launch_bounds__(1024) void k_layout_bwd(const float* __restrict__ d
     int xsrc = min((int)(((int64_t)x * W) / OW), W - 1);
     float w = masks == nullptr ? coverage(lin01(xsrc, W), x0, ww) : coverage_n(lin01(xsrc, W), x0, ww, M);
     s_wx[x] = w;
-    if (w != 0.f) {
+    bool in = w != 0.f;
+    if (db != nullptr) {
+      const float dw = coverage_dix(lin01(xsrc, W), x0, ww, masks == nullptr ? 8 : M);
+      s_dwx[x] = dw;
+      in = in || dw != 0.f;
+    }
+    if (in) {
       atomicMin(&s_rng[2], x);
       atomicMax(&s_rng[3], x);
     }
@@ -273,9 +326,169 @@ __global__ __launch_bounds__(1024) void k_layout_bwd(const float* __restrict__ d
     for (int p = 0; p < npl; ++p) t += s_red[p * S + d];
     dv[d] = accumulate ? dv[d] + t : t;
   }
+  if (db == nullptr) return;
+  // ---- gradient w.r.t. the box (reference layout.py:98-110 is differentiable in x0, y0, w, h): with
+  // G(y,x) = sum_d dout[d,y,x] * vec[d] and ix = n (t - lo) / size - 1/2 (n = 8 or M),
+  //   d/dx0 = -n/ww   * sum G * dweight/dix,          d/dww = -n/ww^2 * sum G * dweight/dix * (tx - x0)   (same in y)
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);       // A1, A2 (x), B1, B2 (y)
+  if (yhi >= ylo && xhi >= xlo && pl < npl) {
+    const int nx = xhi - xlo + 1, npix = (yhi - ylo + 1) * nx;
+    const float* base = dout + (int64_t)b * OH * OW * out_cs + out_off + q * 4;
+    const float4 v4 = *(const float4*)&vecs[((int64_t)b * O + o) * S + q * 4];
+    for (int i = pl; i < npix; i += npl) {
+      const int yy = i / nx + ylo, xx = xlo + (i - (i / nx) * nx);
+      const float ty = lin01(min((int)(((int64_t)yy * H) / OH), H - 1), H);
+      const float tx = lin01(min((int)(((int64_t)xx * W) / OW), W - 1), W);
+      float cx, cy;                                   // dweight/dix, dweight/diy at this pixel
+      if (masks == nullptr) {
+        cx = s_wy[yy] * s_dwx[xx];
+        cy = s_dwy[yy] * s_wx[xx];
+      } else {
+        float w;
+        mask_weight_grad(masks + ((int64_t)b * O + o) * M * M, M, ty, y0, hh, tx, x0, ww, w, cx, cy);
+      }
+      if (cx == 0.f && cy == 0.f) continue;
+      const float4 ga = *(const float4*)&base[((int64_t)yy * OW + xx) * out_cs];
+      const float g = ga.x * v4.x + ga.y * v4.y + ga.z * v4.z + ga.w * v4.w;
+      bsum.x += g * cx;
+      bsum.y += g * cx * (tx - x0);
+      bsum.z += g * cy;
+      bsum.w += g * cy * (ty - y0);
+    }
+  }
+  __syncthreads();                                     // the dvecs reduction is done with s_red
+  *(float4*)&s_red[tid * 4] = bsum;
+  __syncthreads();
+  if (tid < 4) {
+    float t = 0.f;
+    for (int p = 0; p < BD; ++p) t += s_red[p * 4 + tid];       // fixed order
+    const float n = masks == nullptr ? 8.0f : (float)M;
+    const float size = (tid < 2) ? ww : hh;
+    const float sc = (tid & 1) ? -n / (size * size) : -n / size;
+    // (A1, A2, B1, B2) -> (dx0, dww, dy0, dhh); boxes are stored [x0, y0, w, h]
+    const int slot = tid == 0 ? 0 : (tid == 1 ? 2 : (tid == 2 ? 1 : 3));
+    db[slot] = accumulate ? db[slot] + t * sc : t * sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------- test mode
+// masks_to_layout(test_mode=True) (reference sg2im/layout.py:71-74,135-151): objects are painted in ascending
+// order of their "mass" sum(samples[j]); a pixel belongs to the FIRST object in that order whose bilinearly
+// sampled mask exceeds 0.5 there, and receives that object's sample vec[j] * mask_sample — one object per pixel.
+
+// mass[b,o] = sum_{d,y,x} vec[d] * mask_sample(y,x) at full resolution; one block per (object, image)
+__global__ __launch_bounds__(256) void k_layout_mass(const float* __restrict__ vecs, const float* __restrict__ boxes,
+                                                      const uint8_t* __restrict__ valid,
+                                                      const float* __restrict__ masks, int M, int O, int S, int H,
+                                                      int W, float* __restrict__ mass) {
+  __shared__ float s_red[256];
+  const int tid = threadIdx.x, o = blockIdx.x, b = blockIdx.y;
+  float acc = 0.f;
+  const bool ok = valid[(int64_t)b * O + o] != 0;
+  if (ok) {
+    const float* bx = boxes + ((int64_t)b * O + o) * 4;
+    const float x0 = bx[0], y0 = bx[1], ww = bx[2], hh = bx[3];
+    const float* mk = masks + ((int64_t)b * O + o) * M * M;
+    for (int i = tid; i < H * W; i += 256) {
+      const int y = i / W, x = i - y * W;
+      int iy0;
+      float wy0, wy1;
+      axis_taps(lin01(y, H), y0, hh, M, iy0, wy0, wy1);
+      if (wy0 == 0.f && wy1 == 0.f) continue;
+      acc += mask_weight(mk, M, iy0, wy0, wy1, lin01(x, W), x0, ww);
+    }
+  }
+  s_red[tid] = acc;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) s_red[tid] += s_red[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float vs = 0.f;
+    if (ok)
+      for (int d = 0; d < S; ++d) vs += vecs[((int64_t)b * O + o) * S + d];
+    mass[(int64_t)b * O + o] = ok ? vs * s_red[0] : __builtin_inff();
+  }
+}
+
+// one thread per output pixel finds the owner; the block then writes the S channels cooperatively
+__global__ __launch_bounds__(256) void k_layout_paint(const float* __restrict__ vecs, const float* __restrict__ boxes,
+                                                       const float* __restrict__ masks, int M,
+                                                       const int* __restrict__ order, int O, int S, int H, int W, int OH,
+                                                       int OW, float* __restrict__ out, int out_cs, int out_off) {
+  __shared__ int s_own[256];
+  __shared__ float s_w[256];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, y = blockIdx.y, xb = blockIdx.x * 256;
+  const int npx = min(256, OW - xb);
+  const int ysrc = min((int)(((int64_t)y * H) / OH), H - 1);
+  const float ty = lin01(ysrc, H);
+  int own = -1;
+  float wv = 0.f;
+  if (tid < npx) {
+    const int xsrc = min((int)(((int64_t)(xb + tid) * W) / OW), W - 1);
+    const float tx = lin01(xsrc, W);
+    for (int k = 0; k < O; ++k) {
+      const int o = order[(int64_t)b * O + k];
+      if (o < 0) break;
+      const float* bx = boxes + ((int64_t)b * O + o) * 4;
+      int iy0;
+      float wy0, wy1;
+      axis_taps(ty, bx[1], bx[3], M, iy0, wy0, wy1);
+      if (wy0 == 0.f && wy1 == 0.f) continue;
+      const float c = mask_weight(masks + ((int64_t)b * O + o) * M * M, M, iy0, wy0, wy1, tx, bx[0], bx[2]);
+      if (c > 0.5f) {
+        own = o;
+        wv = c;
+        break;
+      }
+    }
+  }
+  s_own[tid] = own;
+  s_w[tid] = wv;
+  __syncthreads();
+  const int qpp = S >> 2;
+  float* orow = out + ((int64_t)(b * OH + y) * OW + xb) * out_cs + out_off;
+  for (int e = tid; e < npx * qpp; e += 256) {
+    const int px = e / qpp, q = e - px * qpp;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int o = s_own[px];
+    if (o >= 0) {
+      const float4 u = *(const float4*)&vecs[((int64_t)b * O + o) * S + q * 4];
+      const float w = s_w[px];
+      v = make_float4(u.x * w, u.y * w, u.z * w, u.w * w);
+    }
+    *(float4*)&orow[(int64_t)px * out_cs + q * 4] = v;
+  }
 }
 
 extern "C" {
+
+int csg_layout_mass(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M,
+                    int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, float* mass, void* stream) {
+  CSG_REQUIRE(masks != nullptr && M >= 1 && M <= 1024, CSG_E_BADSHAPE, "csg_layout_mass: bad mask size %ld", (long)M);
+  CSG_REQUIRE(B > 0 && B <= 65535 && O >= 0 && S > 0 && H > 0 && W > 0, CSG_E_BADSHAPE, "csg_layout_mass: bad shape");
+  if (O == 0) return CSG_OK;
+  hipLaunchKernelGGL(k_layout_mass, dim3((unsigned)O, (unsigned)B), dim3(256), 0, (hipStream_t)stream, vecs, boxes, valid,
+                     masks, (int)M, (int)O, (int)S, (int)H, (int)W, mass);
+  return check_launch("csg_layout_mass");
+}
+
+int csg_layout_paint(const float* vecs, const float* boxes, const float* masks, int64_t M, const int32_t* order,
+                     int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* out,
+                     int64_t out_cs, int64_t out_off, void* stream) {
+  CSG_REQUIRE(masks != nullptr && M >= 1 && M <= 1024, CSG_E_BADSHAPE, "csg_layout_paint: bad mask size %ld", (long)M);
+  CSG_REQUIRE(B > 0 && O >= 0 && S > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, CSG_E_BADSHAPE,
+              "csg_layout_paint: bad shape");
+  CSG_REQUIRE(S % 4 == 0 && out_cs % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)out % 16) == 0, CSG_E_UNSUPPORTED,
+              "csg_layout_paint: S, out_cs, out_off must be multiples of 4 (16-byte rows)");
+  CSG_REQUIRE(OH <= 65535 && B <= 65535, CSG_E_UNSUPPORTED, "csg_layout_paint: OH/B too large");
+  hipLaunchKernelGGL(k_layout_paint, dim3((unsigned)cdiv(OW, 256), (unsigned)OH, (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, vecs, boxes, masks, (int)M, order, (int)O, (int)S, (int)H, (int)W, (int)OH,
+                     (int)OW, out, (int)out_cs, (int)out_off);
+  return check_launch("csg_layout_paint");
+}
 
 int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M,
                    int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* out,
@@ -303,7 +516,7 @@ int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, 
 
 int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,
                    const float* masks, int64_t M, int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH,
-                   int64_t OW, float* dvecs, int accumulate, void* stream) {
+                   int64_t OW, float* dvecs, int accumulate, const float* vecs, float* dboxes, void* stream) {
   CSG_REQUIRE(masks == nullptr || (M >= 1 && M <= 1024), CSG_E_BADSHAPE, "csg_layout_bwd: bad mask size %ld", (long)M);
   CSG_REQUIRE(B > 0 && O >= 0 && S > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, CSG_E_BADSHAPE,
               "csg_layout_bwd: bad shape");
@@ -316,10 +529,13 @@ int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const flo
   const int bd = (OH * OW >= 64 * 64) ? 1024 : 256;
   const int npl = bd / qpp;
   CSG_REQUIRE(npl >= 1, CSG_E_UNSUPPORTED, "csg_layout_bwd: S too large");
-  size_t shm = (size_t)(((OH + OW + 4) + 3) & ~3) * 4 + (size_t)npl * S * 4;
+  CSG_REQUIRE(dboxes == nullptr || vecs != nullptr, CSG_E_BADSHAPE, "csg_layout_bwd: box gradients need vecs");
+  const size_t red = (size_t)npl * S > (size_t)bd * 4 ? (size_t)npl * S : (size_t)bd * 4;
+  size_t shm = (size_t)(((OH + OW + 4) + 3) & ~3) * 4 + red * 4 + (dboxes != nullptr ? (size_t)(OH + OW) * 4 : 0);
   ProfScope p(K_LAYOUT_BWD, (double)B * OH * OW * S * 4, s);
   hipLaunchKernelGGL(k_layout_bwd, dim3((unsigned)O, (unsigned)B), dim3((unsigned)bd), shm, s, dout, (int)out_cs, (int)out_off,
-                     boxes, valid, masks, (int)M, (int)O, (int)S, (int)H, (int)W, (int)OH, (int)OW, dvecs, accumulate);
+                     boxes, valid, masks, (int)M, (int)O, (int)S, (int)H, (int)W, (int)OH, (int)OW, dvecs, accumulate,
+                     vecs, dboxes);
   return check_launch("csg_layout_bwd");
 }
 

@@ -17,7 +17,7 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, check, lib, ptr, stre
 
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
-    "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "disc_input", "crop_objects", "maxpool2", "l1_mean",
+    "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "l1_mean",
     "pack_conv_weight", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
 
@@ -182,7 +182,7 @@ class _Conv2d(torch.autograd.Function):
             db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
             check(lib.csg_colsum(ptr(dpre), rows, Cout, Cout, ptr(db), ptr(part), nch, stream()), "colsum")
         if ctx.has_res and ctx.needs_input_grad[3]:
-            dres = dpre
+            dres = dy                            # the residual is added AFTER the activation (igemm.hip epilogue)
         return dx, dw, db, dres, None, None, None, None, None, None
 
 
@@ -201,6 +201,10 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, r
     zero-padded to 16-byte pixel rows; the result is a channel-slice view of the padded output."""
     Cout, Cin = weight.shape[0], weight.shape[1]
     pc, po = (-Cin) % 4, (-Cout) % 4
+    if residual is not None and act != ACT_NONE:
+        # the epilogue adds the residual AFTER the activation and the backward recovers the activation mask from the
+        # saved output, which would then include the residual; the only user (SPADEResnetBlock.conv_1) has no activation
+        raise NotImplementedError("conv2d: a fused residual needs act == ACT_NONE")
     if packs is not None and po:
         raise RuntimeError("conv2d: packed weights need an output-channel count that is a multiple of 4")
     if pc:
@@ -612,12 +616,6 @@ def segment_avg(h, conf, valid, triplets, row_ptr, col, H, Dp):
 
 
 # ------------------------------------------------------------------------------------ layout
-def _check_boxes(boxes):
-    if boxes.requires_grad:
-        raise NotImplementedError("layout: gradients w.r.t. boxes are not implemented (training feeds GT boxes, "
-                                  "scripts/train.py:358; SURVEY.md §9 item 16)")
-
-
 def _prep_masks(masks):
     """(B,O,M,M) int64/float masks -> contiguous fp32 (what the reference's `.float()` does), or None."""
     if masks is None:
@@ -628,43 +626,75 @@ def _prep_masks(masks):
     return m, int(m.shape[-1])
 
 
+def _hw(size):
+    return (int(size[0]), int(size[1])) if isinstance(size, (tuple, list)) else (int(size), int(size))
+
+
 class _LayoutPyramid(torch.autograd.Function):
-    """boxes_to_layout / masks_to_layout for a whole batch at several output sizes at once: size h
-    samples the full-resolution layout at rows floor(y*H/h) (= F.interpolate(seg, (h,h), 'nearest'))."""
+    """boxes_to_layout / masks_to_layout for a whole batch at several output sizes at once: size (h,w)
+    samples the full-resolution (H,W) layout at rows floor(y*H/h), columns floor(x*W/w)
+    (= F.interpolate(seg, (h,w), 'nearest')).  Differentiable in vecs and in the boxes (layout.py:98-110)."""
 
     @staticmethod
-    def forward(ctx, vecs, boxes, valid, masks, H, sizes):
+    def forward(ctx, vecs, boxes, valid, masks, H, W, sizes):
         vecs = _f32(vecs).contiguous()
         boxes = _f32(boxes).contiguous()
         masks, M = _prep_masks(masks)
         B, O, S = vecs.shape
         outs = []
-        for h in sizes:
-            seg = empty_nhwc(B, S, h, h, vecs.device)
-            check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, h, h, ptr(seg), S,
+        for (h, w) in sizes:
+            seg = empty_nhwc(B, S, h, w, vecs.device)
+            check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, W, h, w, ptr(seg), S,
                                      0, stream()), "layout_fwd")
             outs.append(seg)
-        ctx.save_for_backward(boxes, valid, masks)
-        ctx.meta = (B, O, S, H, M, tuple(sizes))
+        ctx.save_for_backward(boxes, valid, masks, vecs if ctx.needs_input_grad[1] else None)
+        ctx.meta = (B, O, S, H, W, M, tuple(sizes))
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        boxes, valid, masks = ctx.saved_tensors
-        B, O, S, H, M, sizes = ctx.meta
+        boxes, valid, masks, vecs = ctx.saved_tensors
+        B, O, S, H, W, M, sizes = ctx.meta
         dvecs = torch.zeros((B, O, S), device=boxes.device, dtype=torch.float32)
-        for h, g in zip(sizes, douts):
+        dboxes = torch.zeros((B, O, 4), device=boxes.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        for (h, w), g in zip(sizes, douts):
             if g is None:
                 continue
             g = nhwc(g)
-            check(lib.csg_layout_bwd(ptr(g), S, 0, ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, h, h,
-                                     ptr(dvecs), 1, stream()), "layout_bwd")
-        return dvecs, None, None, None, None, None
+            check(lib.csg_layout_bwd(ptr(g), S, 0, ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, W, h, w,
+                                     ptr(dvecs), 1, ptr(vecs), ptr(dboxes), stream()), "layout_bwd")
+        return dvecs, dboxes, None, None, None, None, None
 
 
-def layout_pyramid(vecs, boxes, valid, H, sizes, masks=None):
-    _check_boxes(boxes)
-    return _LayoutPyramid.apply(vecs, boxes, valid, masks, int(H), tuple(int(s) for s in sizes))
+def layout_pyramid(vecs, boxes, valid, H, sizes, masks=None, W=None):
+    """sizes: ints (square) or (h, w) pairs."""
+    W = int(H) if W is None else int(W)
+    return _LayoutPyramid.apply(vecs, boxes, valid, masks, int(H), W, tuple(_hw(s) for s in sizes))
+
+
+def layout_paint(vecs, boxes, valid, masks, H, sizes, W=None):
+    """masks_to_layout(..., test_mode=True) for a batch (reference layout.py:71-74,135-151): painter's-algorithm
+    compositing in ascending order of each object's mass; inference only, so no autograd graph is recorded."""
+    W = int(H) if W is None else int(W)
+    with torch.no_grad():
+        vecs = _f32(vecs.detach()).contiguous()
+        boxes = _f32(boxes.detach()).contiguous()
+        masks, M = _prep_masks(masks.detach() if masks is not None else None)
+        if masks is None:
+            raise RuntimeError("layout_paint needs masks")
+        B, O, S = vecs.shape
+        mass = torch.empty((B, O), device=vecs.device, dtype=torch.float32)
+        check(lib.csg_layout_mass(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, W, ptr(mass), stream()),
+              "layout_mass")
+        srt, idx = torch.sort(mass, dim=1, stable=True)               # np.argsort(mass) of layout.py:141
+        order = torch.where(torch.isinf(srt), torch.full_like(idx, -1), idx).to(torch.int32).contiguous()
+        outs = []
+        for (h, w) in (_hw(s) for s in sizes):
+            seg = empty_nhwc(B, S, h, w, vecs.device)
+            check(lib.csg_layout_paint(ptr(vecs), ptr(boxes), ptr(masks), M, ptr(order), B, O, S, H, W, h, w, ptr(seg), S,
+                                       0, stream()), "layout_paint")
+            outs.append(seg)
+    return tuple(outs)
 
 
 class _DiscInput(torch.autograd.Function):
@@ -683,27 +713,28 @@ class _DiscInput(torch.autograd.Function):
         buf[..., S:S + 3] = img.permute(0, 2, 3, 1)
         check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, H, H, ptr(buf), Ct, 0,
                                  stream()), "layout_fwd")
-        ctx.save_for_backward(boxes, valid, masks)
+        ctx.save_for_backward(boxes, valid, masks, vecs if ctx.needs_input_grad[2] else None)
         ctx.meta = (B, O, S, H, Ct, M)
         return buf.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dbuf):
-        boxes, valid, masks = ctx.saved_tensors
+        boxes, valid, masks, vecs = ctx.saved_tensors
         B, O, S, H, Ct, M = ctx.meta
         dbuf = nhwc(dbuf)
-        dimg = dvecs = None
+        dimg = dvecs = dboxes = None
         if ctx.needs_input_grad[0]:
             dimg = dbuf[:, S:S + 3].contiguous()
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dvecs = torch.empty((B, O, S), device=dbuf.device, dtype=torch.float32)
+            if ctx.needs_input_grad[2]:
+                dboxes = torch.empty((B, O, 4), device=dbuf.device, dtype=torch.float32)
             check(lib.csg_layout_bwd(ptr(dbuf), Ct, 0, ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, H, H,
-                                     ptr(dvecs), 0, stream()), "layout_bwd")
-        return dimg, dvecs, None, None, None, None
+                                     ptr(dvecs), 0, ptr(vecs), ptr(dboxes), stream()), "layout_bwd")
+        return dimg, dvecs, dboxes, None, None, None
 
 
 def disc_input(img, vecs, boxes, valid, H, masks=None):
-    _check_boxes(boxes)
     return _DiscInput.apply(_f32(img), vecs, boxes, valid, masks, int(H))
 
 
@@ -741,5 +772,7 @@ class _CropObjects(torch.autograd.Function):
 
 def crop_objects(img, boxes, img_idx, HH):
     """img (B,C,H,W); boxes (N,4) xywh of the real objects in (image, object) order; img_idx (N,) int64."""
-    _check_boxes(boxes)
+    if boxes.requires_grad:
+        raise NotImplementedError("crop_objects: gradients w.r.t. boxes are not implemented (the object discriminator "
+                                  "crops GT boxes, sg2im/pix2pix_model.py:115,178)")
     return _CropObjects.apply(img, boxes, img_idx.contiguous(), int(HH))

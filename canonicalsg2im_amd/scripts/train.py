@@ -41,7 +41,11 @@ def main(argv=None):
     torch.manual_seed(0)
     trainer = T.Trainer(args, dev)
     t0 = epoch = 0
-    if args.restore_checkpoint and args.checkpoint_name and os.path.exists(args.checkpoint_name):
+    if args.restore_checkpoint:
+        # scripts/train.py:29-60: `--checkpoint_name` is the PATH of the checkpoint file; a failed restore raises
+        if not args.checkpoint_name or not os.path.isfile(args.checkpoint_name):
+            raise NotImplementedError("Could not restore weights for checkpoint %s because `no such file` (pass the path "
+                                      "of a checkpoint, e.g. <output_dir>/itr_<t>.pt)" % args.checkpoint_name)
         t0, epoch = trainer.load_checkpoint(args.checkpoint_name)
     packed = args.dataset.startswith("packed")
     lo = args.min_objects or (16 if packed else 3)
@@ -70,7 +74,7 @@ def main(argv=None):
             print("t = %d / %d  [%.1f img/s]  %s" % (t, args.num_iterations, rate, terms), flush=True)
         if args.output_dir and t % args.checkpoint_every == 0:
             os.makedirs(args.output_dir, exist_ok=True)
-            trainer.save_checkpoint(os.path.join(args.output_dir, "%s_with_model.pt" % args.checkpoint_name), t, epoch)
+            trainer.save_checkpoint(os.path.join(args.output_dir, "itr_%s.pt" % t), t, epoch)      # scripts/train.py:427
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -50,16 +50,23 @@ def get_activation(name):
 
 
 def build_mlp(dim_list, activation='relu', batch_norm='none', dropout=0, final_nonlinearity='relu'):
-    """[Linear, ReLU]* Linear [ReLU] (reference sg2im/layers.py:6-25) with every ReLU fused."""
-    if batch_norm != 'none' or dropout > 0 or activation != 'relu' or final_nonlinearity not in (None, 'relu'):
-        raise NotImplementedError("build_mlp: only the trainer defaults (mlp_normalization='none', relu, no "
-                                  "dropout) are on the hot path")
+    """[Linear, (BatchNorm1d), ReLU]* Linear [ReLU] (reference sg2im/layers.py:6-25) with the same nn.Sequential
+    indices (state_dict keys `net.0`, `net.2` — or `net.0`, `net.1`, `net.3` with batch_norm='batch').  Every ReLU is
+    fused: into the GEMM epilogue, or into the BatchNorm apply pass when a BatchNorm1d sits in between."""
+    if dropout > 0 or activation != 'relu' or final_nonlinearity not in (None, 'relu'):
+        raise NotImplementedError("build_mlp: only relu activations without dropout (the trainer's settings) are "
+                                  "on the hot path")
+    if batch_norm not in ('none', 'batch'):
+        raise ValueError('Invalid mlp normalization "%s"' % batch_norm)
     layers = []
     n = len(dim_list) - 1
     for i in range(n):
         last = i == n - 1
+        bn = (not last) and batch_norm == 'batch'
         relu = (not last) or final_nonlinearity == 'relu'
-        layers.append(Linear(dim_list[i], dim_list[i + 1], fused_relu=relu))
+        layers.append(Linear(dim_list[i], dim_list[i + 1], fused_relu=relu and not bn))
+        if bn:
+            layers.append(BatchNorm1dAct(dim_list[i + 1], fused_slope=0.0))
         if relu:
             layers.append(_FusedActivation())
     return nn.Sequential(*layers)
@@ -82,24 +89,53 @@ class Interpolate(nn.Module):
                                          align_corners=self.align_corners)
 
 
+def affine_batch_norm(x, weight, bias, running_mean, running_var, training, slope, eps, momentum, sync):
+    """Batch normalisation with a per-channel affine on the HIP statistics + apply kernels.  x is (N,C), (N,C,L) or
+    (N,C,H,W) — channels in dim 1, as torch's BatchNorm{1,2}d.  The affine is fed to the modulation kernel as a
+    broadcast gamma||beta map (y = xhat * (1 + (w - 1)) + b): these layers only see small tensors (object crops,
+    per-object vectors), so the extra map costs nothing measurable."""
+    if not x.is_cuda:
+        raise RuntimeError("canonicalsg2im_amd ops need HIP (cuda) tensors; there is no CPU path")
+    shape = x.shape
+    x4 = x if x.dim() == 4 else x.reshape(shape[0], shape[1], -1, 1)
+    B, C, H, W = x4.shape
+    gb = torch.cat([weight - 1.0, bias]).view(1, 2 * C, 1, 1).expand(B, 2 * C, H, W)
+    y = ops.norm_act(x4, gb, running_mean, running_var, instance=False, training=training, slope=slope, eps=eps,
+                     momentum=momentum, sync=sync)
+    return y if x.dim() == 4 else y.reshape(shape)
+
+
 class BatchNormAct(nn.BatchNorm2d):
     """nn.BatchNorm2d (affine, running stats) whose forward is the fused HIP statistics + apply pass;
-    a following LeakyReLU can be folded in with `fused_slope`.  The per-channel affine is fed to the
-    kernel as a broadcast gamma||beta map (these layers only see the small object crops)."""
+    a following LeakyReLU can be folded in with `fused_slope`."""
 
     def __init__(self, num_features, fused_slope=1.0):
         super().__init__(num_features)
         self.fused_slope = fused_slope
 
     def forward(self, x):
-        if not x.is_cuda:
-            raise RuntimeError("canonicalsg2im_amd ops need HIP (cuda) tensors; there is no CPU path")
         if self.training and self.track_running_stats:
             self.num_batches_tracked.add_(1)
-        B, C, H, W = x.shape
-        gb = torch.cat([self.weight - 1.0, self.bias]).view(1, 2 * C, 1, 1).expand(B, 2 * C, H, W)
-        return ops.norm_act(x, gb, self.running_mean, self.running_var, instance=False, training=self.training,
-                            slope=self.fused_slope, eps=self.eps, momentum=self.momentum, sync=False)
+        return affine_batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                 self.fused_slope, self.eps, self.momentum, sync=False)
+
+
+class BatchNorm1dAct(nn.BatchNorm1d):
+    """nn.BatchNorm1d of `build_mlp(batch_norm='batch')` (reference sg2im/layers.py:13-14) with the ReLU behind it
+    folded in (`fused_slope=0`)."""
+
+    def __init__(self, num_features, fused_slope=1.0):
+        super().__init__(num_features)
+        self.fused_slope = fused_slope
+
+    def forward(self, x):
+        self._check_input_dim(x)
+        if x.size(1) != self.num_features:          # what F.batch_norm reports for the reference's module
+            raise RuntimeError("running_mean should contain %d elements not %d" % (x.size(1), self.num_features))
+        if self.training and self.track_running_stats:
+            self.num_batches_tracked.add_(1)
+        return affine_batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                 self.fused_slope, self.eps, self.momentum, sync=False)
 
 
 def build_hot_cnn(arch, normalization='batch', activation='leakyrelu-0.2', padding='valid'):

@@ -152,6 +152,12 @@ class AcCropDiscriminator(nn.Module):
         ev.record()
         self._index_cache = (objs.data_ptr(), objs._version, tuple(objs.shape), host, ev, None)
 
+    def release_index(self):
+        """Forget the prefetched list (called by Trainer.step once the step's last object-discriminator pass has
+        consumed it): the cache is keyed by the tensor's address, and the caching allocator hands the next batch's
+        `objs` the same address."""
+        self._index_cache = None
+
     def _object_index(self, objs):
         c = getattr(self, "_index_cache", None)
         if c is not None and c[:3] == (objs.data_ptr(), objs._version, tuple(objs.shape)):

@@ -70,14 +70,15 @@ class SPADEGenerator(BaseNetwork):
         return sw, round(sw / opt.aspect_ratio)
 
     def forward(self, objs, layout_boxes, layout_masks, test_mode=False):
-        if layout_masks is not None and test_mode:
-            raise NotImplementedError("masks_to_layout(test_mode=True) compositing is an inference-only path")
         if self.sw != self.sh:
             raise NotImplementedError("aspect_ratio != 1 is not on the hot path")
         H = self.opt.image_size[0]
         levels = [self.sw << k for k in range(H.bit_length()) if (self.sw << k) <= H]
-        maps = ops.layout_pyramid(self.attribute_embedding(objs), layout_boxes, real_object_mask(objs, self.opt.vocab),
-                                  H, levels, masks=layout_masks)
+        valid = real_object_mask(objs, self.opt.vocab)
+        if layout_masks is not None and test_mode:          # painter's compositing (layout.py:135-151), inference only
+            maps = ops.layout_paint(self.attribute_embedding(objs), layout_boxes, valid, layout_masks, H, levels)
+        else:
+            maps = ops.layout_pyramid(self.attribute_embedding(objs), layout_boxes, valid, H, levels, masks=layout_masks)
         seg = SegPyramid(zip(levels, maps))
         x = self.fc(seg.at(self.sw))                 # nearest resize to (sh, sw) == the coarsest pyramid level
         # x2 upsampling precedes every block except head_0 and — unless 'more'/'most' — G_middle_1

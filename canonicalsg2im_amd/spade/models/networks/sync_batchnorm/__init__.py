@@ -27,8 +27,12 @@ class _SynchronizedBatchNorm(_BatchNorm):
         pass
 
     def forward(self, input, gb=None, fused_slope=1.0):
-        if self.affine:
-            raise NotImplementedError("affine SynchronizedBatchNorm is not on the hot path (SPADE uses affine=False)")
+        if self.affine:                               # batchnorm.py:51-93 with weight and bias (SPADE itself uses affine=False)
+            if gb is not None:
+                raise RuntimeError("an affine SynchronizedBatchNorm cannot take a SPADE modulation map as well")
+            from .....sg2im.layers import affine_batch_norm
+            return affine_batch_norm(input, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                     fused_slope, self.eps, self.momentum, sync=self.sync)
         x = input if input.dim() == 4 else input.reshape(input.size(0), self.num_features, -1, 1)
         y = ops.norm_act(x, gb, self.running_mean, self.running_var, instance=False, training=self.training,
                          slope=fused_slope, eps=self.eps, momentum=self.momentum, sync=self.sync)

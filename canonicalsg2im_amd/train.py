@@ -101,6 +101,7 @@ class Trainer:
         if not opt.use_img_disc and objs.is_cuda:
             self.discriminator.obj_discriminator.prefetch_index(objs)
         model_out = self.model(objs, triplets, triplet_type, boxes_gt=boxes, masks_gt=masks, test_mode=False)
+        self.last_model_out = tuple(None if t is None else t.detach() for t in model_out)
         # ---- generator update (train.py:361-368)
         self._d_requires_grad(False)
         G = self.gans_model(batch, model_out, mode="compute_generator_loss")
@@ -138,6 +139,8 @@ class Trainer:
         if g_pending is not None:
             self.g_buckets.all_reduce_finish(g_pending)
             self.optimizer.step()
+        if not opt.use_img_disc:
+            self.discriminator.obj_discriminator.release_index()        # the prefetched object list dies with its batch
         return G, D
 
 
@@ -171,13 +174,14 @@ class Trainer:
         if not isinstance(ckpt, dict):
             ckpt = torch.load(ckpt, map_location=self.device)
         d = self.discriminator
-        self.model.load_state_dict(ckpt['model_state'], strict=False)
+        # strict, as the reference's restore_checkpoint (scripts/train.py:40-43): a checkpoint written with other
+        # flags (--skip_graph_model, --mask_size, num_upsampling_layers ...) must not load partially
+        self.model.load_state_dict(ckpt['model_state'])
         d.img_discriminator.load_state_dict(ckpt['d_img_state'])
         if not self.opt.use_img_disc:
-            if 'd_obj_state' in ckpt:
-                d.obj_discriminator.load_state_dict(ckpt['d_obj_state'])
-            if 'd_mask_state' in ckpt:
-                d.mask_discriminator.load_state_dict(ckpt['d_mask_state'], strict=False)
+            d.obj_discriminator.load_state_dict(ckpt['d_obj_state'])
+            if 'd_mask_state' in ckpt:                  # absent from the reference's own save_checkpoint (:488-520)
+                d.mask_discriminator.load_state_dict(ckpt['d_mask_state'])
         if optimizers:
             self.optimizer.load_state_dict(ckpt['optim_state'])
             d.optimizer_d_img.load_state_dict(ckpt['d_img_optim_state'])

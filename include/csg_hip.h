@@ -112,10 +112,21 @@ int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* 
 int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M,
                    int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* out,
                    int64_t out_cs, int64_t out_off, void* stream);
-/* dvecs (B,O,S) = (accumulate ? dvecs : 0) + sum_{y,x} dout * cov * cov                        */
+/* dvecs (B,O,S) = (accumulate ? dvecs : 0) + sum_{y,x} dout * cov * cov.  With `dboxes` (B,O,4) non-NULL (needs
+ * `vecs`) the gradient w.r.t. [x0,y0,w,h] is produced too: the grid of layout.py:98-110 is differentiable in the
+ * box, and grid_sample's backward w.r.t. its grid is the bilinear weights' derivative.          */
 int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,
                    const float* masks, int64_t M, int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH,
-                   int64_t OW, float* dvecs, int accumulate, void* stream);
+                   int64_t OW, float* dvecs, int accumulate, const float* vecs, float* dboxes, void* stream);
+/* masks_to_layout(test_mode=True) (layout.py:71-74,135-151): painter's compositing, one object per pixel.
+ * csg_layout_mass: mass[b,o] = sum(samples[o]) at full resolution (+inf for invalid objects) — the caller sorts it
+ * (ascending, stable) into `order` (B,O) int32, -1 after the last valid object.
+ * csg_layout_paint: pixel -> first object of `order` whose sampled mask is > 0.5, value vec * mask sample.  */
+int csg_layout_mass(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M,
+                    int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, float* mass, void* stream);
+int csg_layout_paint(const float* vecs, const float* boxes, const float* masks, int64_t M, const int32_t* order,
+                     int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* out,
+                     int64_t out_cs, int64_t out_off, void* stream);
 
 /* ---- K3/K8/K11: implicit-GEMM convolution on fp32 MFMA ---------------------------------------
  * replaces nn.Conv2d (generator.py:28,46; architecture.py:29-32; normalization.py:89-94;

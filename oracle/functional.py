@@ -19,6 +19,7 @@ __all__ = [
     "generator_forward", "instance_norm", "nlayer_discriminator", "multiscale_discriminator",
     "hinge_loss", "gan_loss_multiscale", "generator_losses", "discriminator_losses", "TrainState",
     "train_step", "make_adam_groups", "crop_objects", "ac_crop_discriminator", "bce_loss", "vgg19_features", "vgg_loss", "mask_net", "mask_discriminator", "calc_log_p", "converse_loss",
+    "mlp2_batchnorm", "syncbn_affine_single_device",
 ]
 
 ORIGINAL_EDGE, TRANSITIVE_EDGE = 0, 1          # sg2im/data/base_dataset.py:7-8
@@ -43,6 +44,25 @@ def mlp2(state, prefix, x, final_relu):
     h = F.relu(F.linear(x, state[prefix + "0.weight"], state[prefix + "0.bias"]))
     y = F.linear(h, state[prefix + "2.weight"], state[prefix + "2.bias"])
     return F.relu(y) if final_relu else y
+
+
+def mlp2_batchnorm(state, prefix, x, training, final_relu=True):
+    """`build_mlp([d0,d1,d2], batch_norm='batch')` (sg2im/layers.py:6-25): Linear(net.0) BatchNorm1d(net.1) ReLU
+    Linear(net.3) [ReLU].  nn.BatchNorm1d normalises dim 1, so the input is (N, d0) (or (N, d0, L))."""
+    h = F.linear(x, state[prefix + "0.weight"], state[prefix + "0.bias"])
+    if training:
+        state[prefix + "1.num_batches_tracked"].add_(1)
+    h = F.batch_norm(h, state[prefix + "1.running_mean"], state[prefix + "1.running_var"], state[prefix + "1.weight"],
+                     state[prefix + "1.bias"], training, 0.1, 1e-5)
+    y = F.linear(F.relu(h), state[prefix + "3.weight"], state[prefix + "3.bias"])
+    return F.relu(y) if final_relu else y
+
+
+def syncbn_affine_single_device(state, prefix, x, training, momentum=0.1, eps=1e-5):
+    """`_SynchronizedBatchNorm.forward` with affine=True on one device (sync_batchnorm/batchnorm.py:63-68):
+    F.batch_norm with weight and bias; `num_batches_tracked` is not advanced (the forward bypasses _BatchNorm's)."""
+    return F.batch_norm(x, state[prefix + "running_mean"], state[prefix + "running_var"], state[prefix + "weight"],
+                        state[prefix + "bias"], training, momentum, eps)
 
 
 def triplet_confidence(w_trans, triplet_type, predicate_ids):
@@ -170,21 +190,41 @@ def _axis_taps(lo, size, n_out, n_src):
     return i0.clamp(-1, n_src - 1).long(), w0, w1
 
 
-def masks_to_layout(vecs, boxes, masks, H, W=None):
-    """`masks_to_layout`, train mode (sg2im/layout.py:48-77): vec[o] x bilinear sample of mask[o]
-    over box o, summed over objects.  masks (O,M,M) int or float."""
-    W = H if W is None else W
+def _mask_samples(boxes, masks, H, W, dtype):
+    """(O,H,W): bilinear sample of each object's (M,M) mask over its box — `F.grid_sample(masks, grid)` of
+    sg2im/layout.py:70-73 (align_corners=False, zeros padding) in closed form."""
     O, M = masks.shape[0], masks.shape[1]
-    mk = F.pad(masks.to(vecs.dtype), (1, 1, 1, 1))                  # index -1 and M read zeros
+    mk = F.pad(masks.to(dtype), (1, 1, 1, 1))                       # index -1 and M read zeros
     ix0, wx0, wx1 = _axis_taps(boxes[:, 0], boxes[:, 2], W, M)
     iy0, wy0, wy1 = _axis_taps(boxes[:, 1], boxes[:, 3], H, M)
-    out = torch.zeros(vecs.shape[1], H, W, dtype=vecs.dtype)
+    out = []
     for o in range(O):
         r0, r1 = mk[o][iy0[o] + 1], mk[o][iy0[o] + 2]               # (H, M+2) source rows of each output row
         c0, c1 = ix0[o] + 1, ix0[o] + 2
-        w = wy0[o].view(H, 1) * (r0[:, c0] * wx0[o].view(1, W) + r0[:, c1] * wx1[o].view(1, W)) + \
-            wy1[o].view(H, 1) * (r1[:, c0] * wx0[o].view(1, W) + r1[:, c1] * wx1[o].view(1, W))
-        out = out + vecs[o].view(-1, 1, 1) * w.unsqueeze(0)
+        out.append(wy0[o].view(H, 1) * (r0[:, c0] * wx0[o].view(1, W) + r0[:, c1] * wx1[o].view(1, W)) +
+                   wy1[o].view(H, 1) * (r1[:, c0] * wx0[o].view(1, W) + r1[:, c1] * wx1[o].view(1, W)))
+    return torch.stack(out) if out else torch.zeros(0, H, W, dtype=dtype)
+
+
+def masks_to_layout(vecs, boxes, masks, H, W=None, test_mode=False):
+    """`masks_to_layout` (sg2im/layout.py:48-77): vec[o] x bilinear sample of mask[o] over box o.  Train mode sums
+    the objects; `test_mode` composites them with the painter's algorithm of `_pool_mask_samples` (:135-151):
+    ascending order of mass = sum(samples[j]); a pixel goes to the first object whose sampled mask is > 0.5.
+    masks (O,M,M) int or float."""
+    W = H if W is None else W
+    w = _mask_samples(boxes, masks, H, W, vecs.dtype)               # (O,H,W)
+    out = torch.zeros(vecs.shape[1], H, W, dtype=vecs.dtype)
+    if not test_mode:
+        for o in range(vecs.shape[0]):
+            out = out + vecs[o].view(-1, 1, 1) * w[o].unsqueeze(0)
+        return out.unsqueeze(0)
+    samples = vecs.view(vecs.shape[0], -1, 1, 1) * w.unsqueeze(1)   # (O,D,H,W)
+    mass = [float(samples[j].sum()) for j in range(vecs.shape[0])]
+    taken = torch.zeros(H, W, dtype=vecs.dtype)
+    for j in sorted(range(len(mass)), key=lambda i: mass[i]):       # np.argsort (:141); stable for ties
+        claim = (taken == 0).to(vecs.dtype) * (w[j] > 0.5).to(vecs.dtype)
+        taken = taken + claim
+        out = out + samples[j] * claim
     return out.unsqueeze(0)
 
 

@@ -607,6 +607,69 @@ def fx_vgg():
                       "shapes": shapes_of(crit.vgg)}, **arrays)
 
 
+def fx_row_gaps():
+    """Reference outputs for the parts of rows a4, a7, a8, a12 that were missing after round 1: painter's
+    compositing (`masks_to_layout(test_mode=True)`), box gradients of both layouts, non-square layouts,
+    `build_mlp(batch_norm='batch')`, affine SynchronizedBatchNorm2d."""
+    from sg2im.layers import build_mlp
+    torch.manual_seed(61)
+    arrays = {}
+    # ---- painter's compositing, square and non-square, binary and soft masks (layout.py:71-74, 135-151)
+    vecs = torch.randn(6, 8)
+    boxes = torch.tensor([[0.10, 0.20, 0.50, 0.40], [0.05, 0.05, 0.90, 0.90], [0.60, 0.55, 0.35, 0.30],
+                          [0.30, 0.30, 0.17, 0.60], [-0.2, 0.40, 0.60, 0.20], [0.45, 0.05, 0.50, 0.31]])
+    yy, xx = torch.meshgrid((torch.arange(16) + 0.5) / 16, (torch.arange(16) + 0.5) / 16, indexing="ij")
+    cen, rad = torch.rand(6, 2) * 0.3 + 0.35, torch.rand(6, 2) * 0.25 + 0.25
+    ell = torch.stack([((xx - cen[i, 0]) / rad[i, 0]) ** 2 + ((yy - cen[i, 1]) / rad[i, 1]) ** 2 for i in range(6)])
+    binm = (ell <= 1.0).long()
+    soft = torch.sigmoid(4.0 * (1.0 - ell))                              # mask-net style probabilities
+    arrays.update({"p_vecs": npy(vecs), "p_boxes": npy(boxes), "p_bin": npy(binm), "p_soft": npy(soft)})
+    for (H, W) in ((32, 32), (24, 40)):
+        for tag, m in (("bin", binm), ("soft", soft)):
+            arrays["paint_%s_%dx%d" % (tag, H, W)] = npy(masks_to_layout(vecs, boxes, m, H, W, test_mode=True))
+    # ---- box gradients of the masks layout (train mode), square and non-square
+    v2 = vecs.clone().requires_grad_(True)
+    b2 = boxes.clone().requires_grad_(True)
+    for (H, W) in ((32, 32), (24, 40)):
+        out = masks_to_layout(v2, b2, soft, H, W)
+        w = torch.randn_like(out)
+        gv, gb = torch.autograd.grad((out * w).sum(), [v2, b2])
+        tag = "%dx%d" % (H, W)
+        arrays.update({"m_out_" + tag: npy(out), "m_w_" + tag: npy(w), "m_gvecs_" + tag: npy(gv), "m_gboxes_" + tag: npy(gb)})
+    # ---- build_mlp(batch_norm='batch') on a 2-D input (sg2im/layers.py:6-25): Linear, BatchNorm1d, ReLU, Linear, ReLU
+    mlp = build_mlp([12, 24, 8], batch_norm='batch')
+    mlp.load_state_dict(deterministic_state(mlp.state_dict(), seed=62))
+    mlp.train()
+    x = torch.randn(10, 12, requires_grad=True)
+    y = mlp(x)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    arrays.update({"mlp_x": npy(x), "mlp_y": npy(y), "mlp_w": npy(w), "mlp_gx": npy(x.grad)})
+    arrays.update(grads_np(mlp, "mlp_grad:"))
+    arrays.update(sd_np(mlp, "mlp_after:"))
+    mlp.eval()
+    arrays["mlp_y_eval"] = npy(mlp(x))
+    # ---- affine SynchronizedBatchNorm2d on one device (batchnorm.py:51-68): train step, then eval
+    bn = SynchronizedBatchNorm2d(8)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(8) + 0.5)
+        bn.bias.copy_(torch.randn(8) * 0.3)
+    arrays.update({"bn_weight": npy(bn.weight), "bn_bias": npy(bn.bias)})
+    bn.train()
+    xb = (torch.randn(3, 8, 5, 6) * 1.5 + 0.4).requires_grad_(True)
+    yb = bn(xb)
+    wb = torch.randn_like(yb)
+    (yb * wb).sum().backward()
+    arrays.update({"bn_x": npy(xb), "bn_y": npy(yb), "bn_w": npy(wb), "bn_gx": npy(xb.grad), "bn_gweight": npy(bn.weight.grad),
+                   "bn_gbias": npy(bn.bias.grad), "bn_running_mean": npy(bn.running_mean),
+                   "bn_running_var": npy(bn.running_var)})
+    bn.eval()
+    arrays["bn_y_eval"] = npy(bn(xb))
+    save("row_gaps", {"ref": "sg2im/layout.py:48-77,98-110,135-151; sg2im/layers.py:6-25; "
+                             "spade/models/networks/sync_batchnorm/batchnorm.py:51-68",
+                      "mlp_shapes": shapes_of(mlp)}, **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1:                      # regenerate selected fixtures: make_golden.py fx_vgg ...
@@ -626,3 +689,4 @@ if __name__ == "__main__":
     fx_step_masks()
     fx_canon_graph()
     fx_converse()
+    fx_row_gaps()

@@ -158,8 +158,12 @@ def test_out_of_scope_components_fail_loudly(built, monkeypatch):
     assert list(vgg.state_dict())[:6] == ["slice1.0.weight", "slice1.0.bias", "slice2.2.weight", "slice2.2.bias",
                                           "slice2.5.weight", "slice2.5.bias"]
     assert len(vgg.state_dict()) == 26 and "slice5.28.weight" in vgg.state_dict()
-    with pytest.raises(NotImplementedError):          # inference-time compositing only
+    with pytest.raises(RuntimeError, match="no CPU path"):          # compositing is a HIP kernel too: no CPU fallback
         masks_to_layout(torch.zeros(1, 4), torch.zeros(1, 4), torch.zeros(1, 2, 2), 8, test_mode=True)
+    from canonicalsg2im_amd.sg2im.layers import build_mlp
+    mlp = build_mlp([6, 12, 4], batch_norm='batch')                   # reference keys: Linear 0, BatchNorm1d 1, Linear 3
+    assert set(mlp.state_dict()) == {"0.weight", "0.bias", "1.weight", "1.bias", "1.running_mean", "1.running_var",
+                                     "1.num_batches_tracked", "3.weight", "3.bias"}
     with pytest.raises(RuntimeError, match="CSG_VGG19_WEIGHTS"):     # default flags keep the VGG loss on
         T.Trainer(T.make_opt(make_vocab("tiny"), ["--image_size", "64,64", "--ngf", "4"]), torch.device("cpu"))
     tr = T.Trainer(T.make_opt(make_vocab("tiny"), ["--no_vgg_loss", "--image_size", "64,64", "--ngf", "4"]),
@@ -183,3 +187,28 @@ def test_reference_command_lines_parse():
     coco = "--dataset coco --max_objects 1000 --image_size 256,256 --no_flip --shuffle_val 0 --timing 1".split()
     b = p.parse_args(coco)
     assert b.no_flip is True and b.shuffle_val is False and b.timing is True and b.use_img_disc == 0
+
+
+def test_dropin_aliases_resolve_the_reference_import_paths(built):
+    """after `dropin.install()` the reference trainer's imports (scripts/train.py:18-24)
+    resolve to the HIP-backed modules — the SAME module objects, not second copies.  Run in a child process so
+    that the aliases do not leak into this test session."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import canonicalsg2im_amd.dropin as dropin; dropin.install(scripts=True)\n"
+        "from sg2im.meta_models import MetaGeneratorModel, MetaDiscriminatorModel\n"
+        "from sg2im.model import get_conv_converse\n"
+        "from sg2im.pix2pix_model import Pix2PixModel\n"
+        "from sg2im.layout import boxes_to_layout, masks_to_layout\n"
+        "from spade.models.networks.sync_batchnorm import DataParallelWithCallback\n"
+        "from spade.models.networks import SPADEGenerator, MultiscaleDiscriminator, GANLoss\n"
+        "from scripts.graphs_utils import calc_log_p\n"
+        "import canonicalsg2im_amd.sg2im.meta_models as real\n"
+        "assert MetaGeneratorModel is real.MetaGeneratorModel\n"
+        "assert sys.modules['sg2im.meta_models'] is real\n"
+        "assert SPADEGenerator.__module__ == 'canonicalsg2im_amd.spade.models.networks.generator'\n"
+        "print('ALIASES_OK')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ALIASES_OK" in out.stdout, out.stderr[-2000:]

@@ -87,6 +87,12 @@ def test_conv2d_forward_backward(ops, case):
         assert_close(rd.grad, rr.grad, RTOL, 1e-5, "conv dres %s" % (case,))
 
 
+def test_conv2d_rejects_activation_with_residual(ops):
+    x, w = dev(torch.randn(1, 8, 6, 6)), dev(torch.randn(8, 8, 3, 3))
+    with pytest.raises(NotImplementedError, match="residual"):
+        ops.conv2d(x, w, None, 1, 1, ops.ACT_LEAKY, 0.2, residual=dev(torch.randn(1, 8, 6, 6)))
+
+
 @pytest.mark.parametrize("M,K,N,relu", [(37, 24, 64, True), (300, 128, 512, True), (1000, 512, 1152, True),
                                         (64, 128, 4, False), (5, 8, 12, False)])
 def test_linear(ops, M, K, N, relu):
@@ -234,7 +240,8 @@ def test_layout_golden(ops):
         assert_close(out.permute(0, 3, 1, 2), a["out_" + tag], RTOL, 2e-6, "layout " + tag)
         dv = torch.empty(1, O, S).cuda()
         gw = a["w_" + tag].permute(0, 2, 3, 1).contiguous().cuda()
-        check(lib.csg_layout_bwd(ptr(gw), S, 0, ptr(bd), ptr(valid), None, 0, 1, O, S, H, W, H, W, ptr(dv), 0, stream()))
+        check(lib.csg_layout_bwd(ptr(gw), S, 0, ptr(bd), ptr(valid), None, 0, 1, O, S, H, W, H, W, ptr(dv), 0, None, None,
+                                 stream()))
         assert_close(dv[0], a["gvecs_" + tag], RTOL, 1e-5, "layout dvecs " + tag)
 
 
@@ -249,8 +256,6 @@ def test_masks_to_layout_golden(ops):
             assert_close(out, a["out_%s_%d" % (tag, H)], RTOL, 2e-6, "masks layout %s %d" % (tag, H))
             (out * a["w_%s_%d" % (tag, H)].cuda()).sum().backward()
             assert_close(vd.grad, a["gvecs_%s_%d" % (tag, H)], RTOL, 1e-5, "masks layout dvecs %s %d" % (tag, H))
-    with pytest.raises(NotImplementedError):
-        masks_to_layout(vd, a["boxes"].cuda(), a["masks"].cuda(), 32, 32, test_mode=True)
 
 
 def test_masked_pyramid_and_disc_input_vs_oracle(ops):

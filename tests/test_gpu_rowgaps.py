@@ -1,0 +1,155 @@
+"""Rows a4 / a7 / a8 / a12 of SURVEY.md §8, the parts that were missing after round 1, on a real MI355X against the
+reference's own outputs (tests/golden/row_gaps.npz, layout.npz) and the oracle: box gradients of `boxes_to_layout`
+and `masks_to_layout`, non-square layouts through the Python surface, `masks_to_layout(test_mode=True)`
+(painter's compositing), `build_mlp(batch_norm='batch')`, the affine SynchronizedBatchNorm2d."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close, load_golden, state_from_shapes
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def test_boxes_to_layout_box_gradients_and_non_square_vs_reference():
+    """sg2im/layout.py:12-45 through the drop-in function: (H, W) = 16x16, 32x32 and 24x40; gradients w.r.t. the
+    vectors AND the boxes (the grid of layout.py:98-110 is differentiable in x0, y0, w, h)."""
+    from canonicalsg2im_amd.sg2im.layout import boxes_to_layout
+    meta, a = load_golden("layout")
+    for H, W in meta["sizes"]:
+        tag = "%dx%d" % (H, W)
+        vecs = a["vecs"].cuda().requires_grad_(True)
+        boxes = a["boxes"].cuda().requires_grad_(True)
+        out = boxes_to_layout(vecs, boxes, H, W)
+        assert out.shape == (1, 8, H, W)
+        assert_close(out, a["out_" + tag], RTOL, 2e-6, "layout " + tag)
+        gv, gb = torch.autograd.grad((out * a["w_" + tag].cuda()).sum(), [vecs, boxes])
+        assert_close(gv, a["gvecs_" + tag], RTOL, 1e-5, "layout dvecs " + tag)
+        # a box gradient multiplies O(H*W) border terms by 8/w (up to 8/0.07 here): absolute term scaled to its size
+        assert_close(gb, a["gboxes_" + tag], RTOL, 1e-5 * float(a["gboxes_" + tag].abs().max()), "layout dboxes " + tag)
+
+
+def test_masks_to_layout_box_gradients_vs_reference():
+    from canonicalsg2im_amd.sg2im.layout import masks_to_layout
+    meta, a = load_golden("row_gaps")
+    for (H, W) in ((32, 32), (24, 40)):
+        t = "%dx%d" % (H, W)
+        vecs = a["p_vecs"].cuda().requires_grad_(True)
+        boxes = a["p_boxes"].cuda().requires_grad_(True)
+        out = masks_to_layout(vecs, boxes, a["p_soft"].cuda(), H, W)
+        assert_close(out, a["m_out_" + t], RTOL, 2e-6, "masks layout " + t)
+        gv, gb = torch.autograd.grad((out * a["m_w_" + t].cuda()).sum(), [vecs, boxes])
+        assert_close(gv, a["m_gvecs_" + t], RTOL, 1e-5, "masks layout dvecs " + t)
+        assert_close(gb, a["m_gboxes_" + t], RTOL, 1e-5 * float(a["m_gboxes_" + t].abs().max()), "masks layout dboxes " + t)
+
+
+def test_masks_to_layout_test_mode_vs_reference():
+    """Painter's compositing (layout.py:135-151): binary and soft masks, square and non-square."""
+    from canonicalsg2im_amd.sg2im.layout import masks_to_layout
+    meta, a = load_golden("row_gaps")
+    for (H, W) in ((32, 32), (24, 40)):
+        for tag, key in (("bin", "p_bin"), ("soft", "p_soft")):
+            out = masks_to_layout(a["p_vecs"].cuda(), a["p_boxes"].cuda(), a[key].cuda(), H, W, test_mode=True)
+            want = a["paint_%s_%dx%d" % (tag, H, W)]
+            assert out.shape == want.shape and not out.requires_grad
+            assert_close(out, want, RTOL, 2e-6, "paint %s %dx%d" % (tag, H, W))
+
+
+def test_generator_test_mode_layout_pyramid_vs_oracle():
+    """SPADEGenerator.forward(test_mode=True) with masks (generator.py:88-90): every pyramid level the SPADE blocks
+    read equals F.interpolate(nearest) of the oracle's full-resolution composited layout; ragged batch (padded rows)."""
+    import oracle
+    from canonicalsg2im_amd import ops
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
+    vocab = make_vocab("coco")
+    imgs, objs, boxes, _, _, _, masks, _ = make_batch(vocab, BatchConfig(3, 64, 2, 7, "random", mask_size=16), seed=9)
+    g = torch.Generator().manual_seed(3)
+    vecs = torch.randn(3, objs.shape[1], 32, generator=g)
+    valid = ((objs[..., 0] != 0)).to(torch.uint8)
+    levels = (2, 4, 8, 16, 32, 64)
+    maps = ops.layout_paint(vecs.cuda(), boxes.cuda(), valid.cuda(), masks.cuda(), 64, levels)
+    for b in range(3):
+        m = oracle.remove_dummy_objects(objs[b], vocab)
+        full = oracle.masks_to_layout(vecs[b][m], boxes[b][m], masks[b][m], 64, 64, test_mode=True)
+        for h, got in zip(levels, maps):
+            want = F.interpolate(full, size=(h, h), mode="nearest")
+            assert_close(got[b:b + 1], want, RTOL, 2e-6, "painted pyramid level %d sample %d" % (h, b))
+
+
+def test_layout_box_gradients_random_vs_oracle():
+    """A denser random case than the fixture (12 objects, S=32, 64x48 and the discriminator's packed input buffer)."""
+    import oracle
+    from canonicalsg2im_amd import ops
+    g = torch.Generator().manual_seed(12)
+    O, S, H, W = 12, 32, 64, 48
+    vecs = torch.randn(1, O, S, generator=g)
+    wh = torch.rand(1, O, 2, generator=g) * 0.5 + 0.08
+    boxes = torch.cat([torch.rand(1, O, 2, generator=g) * (1.1 - wh) - 0.05, wh], -1)
+    valid = torch.ones(1, O, dtype=torch.uint8)
+    valid[0, 5] = 0
+    vr, br = vecs[0].clone().requires_grad_(True), boxes[0].clone().requires_grad_(True)
+    keep = valid[0].bool()
+    ref = oracle.boxes_to_layout(vr[keep], br[keep], H, W)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    vd, bd = vecs.cuda().requires_grad_(True), boxes.cuda().requires_grad_(True)
+    (out,) = ops.layout_pyramid(vd, bd, valid.cuda(), H, ((H, W),), W=W)
+    assert_close(out, ref, RTOL, 1e-5, "layout")
+    (out * w.cuda()).sum().backward()
+    assert_close(vd.grad[0], vr.grad, RTOL, 1e-5 * float(vr.grad.abs().max()), "dvecs")
+    assert_close(bd.grad[0], br.grad, RTOL, 1e-5 * float(br.grad.abs().max()), "dboxes")
+    assert float(bd.grad[0, 5].abs().max()) == 0.0                      # masked-out object: no gradient
+
+
+def test_build_mlp_batch_norm_vs_reference():
+    """build_mlp([12, 24, 8], batch_norm='batch') (sg2im/layers.py:6-25): train step, gradients, running stats, eval."""
+    from canonicalsg2im_amd.sg2im.layers import build_mlp
+    meta, a = load_golden("row_gaps")
+    mlp = build_mlp([12, 24, 8], batch_norm='batch')
+    mlp.load_state_dict({k: v.detach().clone() for k, v in state_from_shapes(meta["mlp_shapes"], seed=62, requires_grad=False).items()})
+    mlp = mlp.cuda().train()
+    x = a["mlp_x"].cuda().requires_grad_(True)
+    y = mlp(x)
+    assert_close(y, a["mlp_y"], RTOL, 2e-6, "mlp(batch) y")
+    (y * a["mlp_w"].cuda()).sum().backward()
+    assert_close(x.grad, a["mlp_gx"], RTOL, 1e-5, "mlp(batch) dx")
+    for k, p in mlp.named_parameters():
+        gref = a["mlp_grad:" + k]
+        if float(gref.abs().max()) < 1e-6:             # Linear bias in front of BatchNorm: analytically zero
+            assert float(p.grad.abs().max()) < 1e-5, k
+        else:
+            assert_close(p.grad, gref, RTOL, 1e-5, "mlp(batch) d" + k)
+    sd = mlp.state_dict()
+    for k in ("1.running_mean", "1.running_var", "1.num_batches_tracked"):
+        assert_close(sd[k], a["mlp_after:" + k], RTOL, 1e-6, "mlp(batch) " + k)
+    mlp.eval()
+    with torch.no_grad():
+        assert_close(mlp(a["mlp_x"].cuda()), a["mlp_y_eval"], RTOL, 2e-6, "mlp(batch) eval")
+    # the reference's module refuses (B, T, D) inputs whose dim 1 is not the feature count (nn.BatchNorm1d)
+    with pytest.raises(RuntimeError, match="running_mean should contain"):
+        mlp.train()(torch.randn(2, 5, 12).cuda())
+
+
+def test_affine_synchronized_batchnorm_vs_reference():
+    """SynchronizedBatchNorm2d(8) with weight and bias on one device (sync_batchnorm/batchnorm.py:51-68)."""
+    from canonicalsg2im_amd.spade.models.networks.sync_batchnorm import SynchronizedBatchNorm2d
+    meta, a = load_golden("row_gaps")
+    bn = SynchronizedBatchNorm2d(8)
+    with torch.no_grad():
+        bn.weight.copy_(a["bn_weight"])
+        bn.bias.copy_(a["bn_bias"])
+    bn = bn.cuda().train()
+    x = a["bn_x"].cuda().requires_grad_(True)
+    y = bn(x)
+    assert_close(y, a["bn_y"], RTOL, 2e-6, "affine syncbn y")
+    (y * a["bn_w"].cuda()).sum().backward()
+    assert_close(x.grad, a["bn_gx"], RTOL, 1e-5, "affine syncbn dx")
+    assert_close(bn.weight.grad, a["bn_gweight"], RTOL, 1e-5, "affine syncbn dweight")
+    assert_close(bn.bias.grad, a["bn_gbias"], RTOL, 1e-5, "affine syncbn dbias")
+    assert_close(bn.running_mean, a["bn_running_mean"], RTOL, 1e-6, "running_mean")
+    assert_close(bn.running_var, a["bn_running_var"], RTOL, 1e-6, "running_var")
+    assert int(bn.num_batches_tracked) == 0               # the reference's forward never advances it
+    bn.eval()
+    with torch.no_grad():
+        assert_close(bn(a["bn_x"].cuda()), a["bn_y_eval"], RTOL, 2e-6, "affine syncbn eval")

@@ -186,6 +186,53 @@ def test_masks_to_layout():
             assert_close(gv, a["gvecs_%s_%d" % (tag, H)], RTOL, 1e-5, "masks layout dvecs %s %d" % (tag, H))
 
 
+def test_row_gap_fixtures():
+    """Painter's compositing (`test_mode`), box gradients of the masks layout, non-square sizes,
+    build_mlp(batch_norm='batch') and the affine SynchronizedBatchNorm2d — oracle vs the reference's outputs."""
+    meta, a = load_golden("row_gaps")
+    for (H, W) in ((32, 32), (24, 40)):
+        for tag, key in (("bin", "p_bin"), ("soft", "p_soft")):
+            out = oracle.masks_to_layout(a["p_vecs"], a["p_boxes"], a[key], H, W, test_mode=True)
+            assert_close(out, a["paint_%s_%dx%d" % (tag, H, W)], RTOL, ATOL, "paint %s %dx%d" % (tag, H, W))
+        vecs = a["p_vecs"].clone().requires_grad_(True)
+        boxes = a["p_boxes"].clone().requires_grad_(True)
+        out = oracle.masks_to_layout(vecs, boxes, a["p_soft"], H, W)
+        t = "%dx%d" % (H, W)
+        assert_close(out, a["m_out_" + t], RTOL, ATOL, "masks layout " + t)
+        gv, gb = torch.autograd.grad((out * a["m_w_" + t]).sum(), [vecs, boxes])
+        assert_close(gv, a["m_gvecs_" + t], RTOL, 1e-5, "masks layout dvecs " + t)
+        assert_close(gb, a["m_gboxes_" + t], RTOL, 1e-5 * float(a["m_gboxes_" + t].abs().max()), "masks layout dboxes " + t)
+    st = state_from_shapes(meta["mlp_shapes"], seed=62)  # the state the fixture was generated from
+    x = a["mlp_x"].clone().requires_grad_(True)
+    y = oracle.mlp2_batchnorm(st, "", x, True)
+    assert_close(y, a["mlp_y"], RTOL, ATOL, "mlp(batch) y")
+    (y * a["mlp_w"]).sum().backward()
+    assert_close(x.grad, a["mlp_gx"], RTOL, 1e-5, "mlp(batch) dx")
+    for k in ("0.weight", "0.bias", "1.weight", "1.bias", "3.weight", "3.bias"):
+        g = a["mlp_grad:" + k]
+        if float(g.abs().max()) < 1e-6:                  # Linear bias in front of BatchNorm: analytically zero
+            assert float(st[k].grad.abs().max()) < 1e-5
+        else:
+            assert_close(st[k].grad, g, RTOL, 1e-5, "mlp(batch) d" + k)
+    for k in ("1.running_mean", "1.running_var", "1.num_batches_tracked"):
+        assert_close(st[k], a["mlp_after:" + k], RTOL, 1e-6, "mlp(batch) " + k)
+    with torch.no_grad():
+        assert_close(oracle.mlp2_batchnorm(st, "", a["mlp_x"], False), a["mlp_y_eval"], RTOL, ATOL, "mlp(batch) eval")
+    bn = {"weight": a["bn_weight"].clone().requires_grad_(True), "bias": a["bn_bias"].clone().requires_grad_(True),
+          "running_mean": torch.zeros(8), "running_var": torch.ones(8)}
+    xb = a["bn_x"].clone().requires_grad_(True)
+    yb = oracle.syncbn_affine_single_device(bn, "", xb, True)
+    assert_close(yb, a["bn_y"], RTOL, ATOL, "affine syncbn y")
+    (yb * a["bn_w"]).sum().backward()
+    assert_close(xb.grad, a["bn_gx"], RTOL, 1e-5, "affine syncbn dx")
+    assert_close(bn["weight"].grad, a["bn_gweight"], RTOL, 1e-5, "affine syncbn dweight")
+    assert_close(bn["bias"].grad, a["bn_gbias"], RTOL, 1e-5, "affine syncbn dbias")
+    assert_close(bn["running_mean"], a["bn_running_mean"], RTOL, 1e-6, "affine syncbn running_mean")
+    assert_close(bn["running_var"], a["bn_running_var"], RTOL, 1e-6, "affine syncbn running_var")
+    with torch.no_grad():
+        assert_close(oracle.syncbn_affine_single_device(bn, "", a["bn_x"], False), a["bn_y_eval"], RTOL, ATOL, "eval")
+
+
 def test_object_crops():
     meta, a = load_golden("crops")
     vocab = make_vocab(meta["vocab"])
