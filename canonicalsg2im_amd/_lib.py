@@ -31,6 +31,12 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class WinoDesc(ctypes.Structure):
+    """Mirror of `csg_wino_desc` (include/csg_hip.h)."""
+    _fields_ = [("B", c_i32), ("H", c_i32), ("W", c_i32), ("Cin", c_i32), ("x_cs", c_i32), ("Cout", c_i32),
+                ("y_cs", c_i32), ("act", c_i32), ("slope", c_f32)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/csg_hip.h
 SIGNATURES = {
     "csg_version": (c_i32, []),
@@ -63,6 +69,9 @@ SIGNATURES = {
     "csg_conv_fwd": (c_i32, [ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_conv_bwd_weight_workspace": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "csg_conv_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_wino_pack_bytes": (c_i64, [c_i64, c_i64]),
+    "csg_wino_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
+    "csg_wino_conv": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_p]),
     "csg_act_bwd": (c_i32, [c_p, c_p, c_i64, c_i32, c_f32, c_p, c_p]),
     "csg_colsum": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_norm_stats": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),

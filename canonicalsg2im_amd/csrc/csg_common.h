@@ -46,6 +46,8 @@ enum KernelId {
   K_CANON_EMIT,
   K_SPECTRAL_FWD,
   K_SPECTRAL_BWD,
+  K_WINO_CONV,
+  K_WINO_PACK,
   K_COUNT
 };
 

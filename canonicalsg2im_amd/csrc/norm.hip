@@ -19,41 +19,53 @@ __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : 
 __device__ __forceinline__ float lrelu_g(float pre, float s) { return pre > 0.f ? 1.f : s; }
 
 // --------------------------------------------------------------------------------- statistics
-// grid (nchunk, G); partial[(g*nchunk + chunk)*2C + {c | C + c}] = {sum x, sum x^2} over the chunk
+// grid (nchunk, G); partial[(g*nchunk + chunk)*2C + {c | C + c}] = {sum x, sum x^2} over the chunk.
+// Sums are carried in fp64 from the first addition on: var = E[x^2] - E[x]^2 cancels mean^2 / var leading digits,
+// and the discriminator's InstanceNorm maps (mean^2 >> var on 16 641-pixel planes) lost 3-4 digits of inv_std
+// with fp32 partial sums (profiles/r02_band_*.txt: 1e-4 gradient error where the fp32 reference has 1e-6).
+// x and x*x are exact in fp64, so the result is the correctly rounded statistic whatever the chunking.
+struct d4 {
+  double x, y, z, w;
+};
+__device__ __forceinline__ d4 d4zero() { return d4{0.0, 0.0, 0.0, 0.0}; }
+
 __global__ __launch_bounds__(256) void k_norm_stats_partial(const float* __restrict__ x, int64_t P, int C,
-                                                             int64_t x_cs, int nchunk, float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // [R][Qc][8]
+                                                             int64_t x_cs, int nchunk, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double smd[];  // [R][Qc][8]
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, g = blockIdx.y;
   const int64_t per = (P + nchunk - 1) / nchunk;
   const int64_t p0 = chunk * per, p1 = min(P, p0 + per);
   const int Q = C >> 2;
-  float* out = partial + ((int64_t)g * nchunk + chunk) * 2 * C;
+  double* out = partial + ((int64_t)g * nchunk + chunk) * 2 * C;
   for (int qb = 0; qb < Q; qb += 256) {
     const int Qc = min(256, Q - qb);
     const int R = 256 / Qc;
     const int q = tid % Qc, rr = tid / Qc;
-    float4 s = f4(0.f), ss = f4(0.f);
+    d4 s = d4zero(), ss = d4zero();
     if (rr < R) {
       const float* xp = x + ((int64_t)g * P) * x_cs + (qb + q) * 4;
       for (int64_t p = p0 + rr; p < p1; p += R) {
-        float4 v = ld4(xp + p * x_cs);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
+        const float4 v = ld4(xp + p * x_cs);
+        const double a = v.x, b = v.y, c = v.z, d = v.w;
+        s.x += a; s.y += b; s.z += c; s.w += d;
+        ss.x += a * a; ss.y += b * b; ss.z += c * c; ss.w += d * d;
       }
-      st4(&sm[(rr * Qc + q) * 8], s);
-      st4(&sm[(rr * Qc + q) * 8 + 4], ss);
+      double* o = &smd[(rr * Qc + q) * 8];
+      o[0] = s.x; o[1] = s.y; o[2] = s.z; o[3] = s.w;
+      o[4] = ss.x; o[5] = ss.y; o[6] = ss.z; o[7] = ss.w;
     }
     __syncthreads();
     if (tid < Qc) {
-      float4 a = f4(0.f), b = f4(0.f);
-      for (int r = 0; r < R; ++r) {
-        float4 u = ld4(&sm[(r * Qc + tid) * 8]), v = ld4(&sm[(r * Qc + tid) * 8 + 4]);
-        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += smd[(r * Qc + tid) * 8 + e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        out[(qb + tid) * 4 + e] = a[e];
+        out[C + (qb + tid) * 4 + e] = a[4 + e];
       }
-      st4(&out[(qb + tid) * 4], a);
-      st4(&out[C + (qb + tid) * 4], b);
     }
     __syncthreads();
   }
@@ -62,24 +74,24 @@ __global__ __launch_bounds__(256) void k_norm_stats_partial(const float* __restr
 // Second stage of every two-stage reduction: out[g][j] = sum over chunks of partial[g][chunk][j],
 // accumulated in fp64 in a fixed order.  Block = 32 columns x 8 chunk lanes, 4 loads in flight.
 template <typename OutT>
-__global__ __launch_bounds__(256) void k_partial_reduce(const float* __restrict__ partial, int ncols, int nchunk,
+__global__ __launch_bounds__(256) void k_partial_reduce(const double* __restrict__ partial, int ncols, int nchunk,
                                                          int out_cols, OutT* __restrict__ out) {
   __shared__ double sm[8][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + cl, g = blockIdx.y;
   double a = 0.0;
   if (j < out_cols) {
-    const float* p = partial + (int64_t)g * nchunk * ncols + j;
+    const double* p = partial + (int64_t)g * nchunk * ncols + j;
     int c = rl;
     for (; c + 24 < nchunk; c += 32) {
-      const float v0 = p[(int64_t)c * ncols], v1 = p[(int64_t)(c + 8) * ncols];
-      const float v2 = p[(int64_t)(c + 16) * ncols], v3 = p[(int64_t)(c + 24) * ncols];
-      a += (double)v0;
-      a += (double)v1;
-      a += (double)v2;
-      a += (double)v3;
+      const double v0 = p[(int64_t)c * ncols], v1 = p[(int64_t)(c + 8) * ncols];
+      const double v2 = p[(int64_t)(c + 16) * ncols], v3 = p[(int64_t)(c + 24) * ncols];
+      a += v0;
+      a += v1;
+      a += v2;
+      a += v3;
     }
-    for (; c < nchunk; c += 8) a += (double)p[(int64_t)c * ncols];
+    for (; c < nchunk; c += 8) a += p[(int64_t)c * ncols];
   }
   sm[rl][cl] = a;
   __syncthreads();
@@ -142,19 +154,19 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const float* __restrict
                                                           const float* __restrict__ invstd,
                                                           const float* __restrict__ gb, float slope, int64_t P, int C,
                                                           int nchunk, float* __restrict__ dgb,
-                                                          float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+                                                          double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double smd[];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, g = blockIdx.y;
   const int64_t per = (P + nchunk - 1) / nchunk;
   const int64_t p0 = chunk * per, p1 = min(P, p0 + per);
   const int Q = C >> 2;
-  float* out = partial + ((int64_t)g * nchunk + chunk) * 2 * C;
+  double* out = partial + ((int64_t)g * nchunk + chunk) * 2 * C;
   for (int qb = 0; qb < Q; qb += 256) {
     const int Qc = min(256, Q - qb);
     const int R = 256 / Qc;
     const int q = tid % Qc, rr = tid / Qc;
-    float4 s = f4(0.f), ss = f4(0.f);
+    d4 s = d4zero(), ss = d4zero();
     if (rr < R) {
       const int co = (qb + q) * 4;
       const float4 m = ld4(mean + (int64_t)g * C + co), r = ld4(invstd + (int64_t)g * C + co);
@@ -177,21 +189,23 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const float* __restrict
           dn.x *= lrelu_g(xh.x, slope); dn.y *= lrelu_g(xh.y, slope); dn.z *= lrelu_g(xh.z, slope); dn.w *= lrelu_g(xh.w, slope);
         }
         s.x += dn.x; s.y += dn.y; s.z += dn.z; s.w += dn.w;
-        ss.x += dn.x * xh.x; ss.y += dn.y * xh.y; ss.z += dn.z * xh.z; ss.w += dn.w * xh.w;
+        ss.x += (double)dn.x * xh.x; ss.y += (double)dn.y * xh.y; ss.z += (double)dn.z * xh.z; ss.w += (double)dn.w * xh.w;
       }
-      st4(&sm[(rr * Qc + q) * 8], s);
-      st4(&sm[(rr * Qc + q) * 8 + 4], ss);
+      double* o = &smd[(rr * Qc + q) * 8];
+      o[0] = s.x; o[1] = s.y; o[2] = s.z; o[3] = s.w;
+      o[4] = ss.x; o[5] = ss.y; o[6] = ss.z; o[7] = ss.w;
     }
     __syncthreads();
     if (tid < Qc) {
-      float4 a = f4(0.f), b = f4(0.f);
-      for (int r = 0; r < R; ++r) {
-        float4 u = ld4(&sm[(r * Qc + tid) * 8]), v = ld4(&sm[(r * Qc + tid) * 8 + 4]);
-        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += smd[(r * Qc + tid) * 8 + e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        out[(qb + tid) * 4 + e] = a[e];
+        out[C + (qb + tid) * 4 + e] = a[4 + e];
       }
-      st4(&out[(qb + tid) * 4], a);
-      st4(&out[C + (qb + tid) * 4], b);
     }
     __syncthreads();
   }
@@ -348,7 +362,7 @@ static inline unsigned ew_grid(int64_t n) {
 
 extern "C" {
 
-int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums, float* partial, int64_t nchunk,
+int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums, double* partial, int64_t nchunk,
                    void* stream) {
   CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_norm_stats: bad shape G=%ld P=%ld C=%ld",
               (long)G, (long)P, (long)C);
@@ -356,7 +370,7 @@ int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums
   hipStream_t s = (hipStream_t)stream;
   {
     ProfScope p(K_NORM_STATS, (double)G * P * C * 4, s);
-    hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 4, s, x, P,
+    hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 8, s, x, P,
                        (int)C, C, (int)nchunk, partial);
   }
   hipLaunchKernelGGL(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
@@ -387,14 +401,14 @@ int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, c
 
 int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
                               const float* gb, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
-                              double* dsums, float* partial, int64_t nchunk, void* stream) {
+                              double* dsums, double* partial, int64_t nchunk, void* stream) {
   CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: bad shape");
   CSG_REQUIRE((gb == nullptr) == (dgb == nullptr), CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: gb/dgb mismatch");
   CSG_REQUIRE(nchunk >= 1 && nchunk <= 65535 && G <= 65535, CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: bad nchunk");
   hipStream_t s = (hipStream_t)stream;
   {
     ProfScope p(K_NORM_BWD_REDUCE, (double)G * P * C * 4 * (gb ? 6 : 2), s);
-    hipLaunchKernelGGL(k_norm_bwd_reduce, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 4, s, dy, x, mean,
+    hipLaunchKernelGGL(k_norm_bwd_reduce, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 8, s, dy, x, mean,
                        invstd, gb, slope, P, (int)C, (int)nchunk, dgb, partial);
   }
   hipLaunchKernelGGL(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
@@ -423,13 +437,13 @@ int csg_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float s
   return check_launch("csg_act_bwd");
 }
 
-int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out, float* partial, int64_t nchunk,
+int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out, double* partial, int64_t nchunk,
                void* stream) {
   CSG_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && x_cs % 4 == 0, CSG_E_BADSHAPE, "csg_colsum: bad shape");
   CSG_REQUIRE(nchunk >= 1 && nchunk <= 65535, CSG_E_BADSHAPE, "csg_colsum: bad nchunk");
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_COLSUM, (double)rows * C * 4, s);
-  hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, 1), dim3(256), 256 * 8 * 4, s, x, rows, (int)C, x_cs,
+  hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, 1), dim3(256), 256 * 8 * 8, s, x, rows, (int)C, x_cs,
                      (int)nchunk, partial);
   hipLaunchKernelGGL(k_partial_reduce<float>, dim3((unsigned)cdiv(C, 32), 1), dim3(256), 0, s, partial, (int)(2 * C),
                      (int)nchunk, (int)C, out);

@@ -13,12 +13,14 @@ import torch.nn.functional as F
 
 from . import _lib
 from . import dist as csg_dist
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, check, lib, ptr, stream
+import os
+
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, WinoDesc, check, lib, ptr, stream
 
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
     "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "l1_mean",
-    "pack_conv_weight", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
+    "pack_conv_weight", "wino_pack", "wino_eligible", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
 
 
@@ -106,6 +108,34 @@ def _conv_launch(d, x, w, bias, res, y, what):
     check(lib.csg_conv_fwd(d, ptr(x), ptr(w), ptr(bias), ptr(res), ptr(y), ptr(ws), nbytes, stream()), what)
 
 
+# ---- Winograd F(2x2,3x3) path (csrc/wino.hip): 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip
+WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "16384"))     # B*H*W below which the direct kernel stays
+WINO_ENABLED = os.environ.get("CSG_WINOGRAD", "1") != "0"
+
+
+def wino_eligible(B, H, W, Cin, Cout, KH, KW, stride, pad):
+    return (WINO_ENABLED and KH == 3 and KW == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 and W >= 8
+            and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 16 and Cout >= 32 and B * H * W >= WINO_MIN_PIXELS)
+
+
+def wino_pack(weight, backward_data, sigma=None):
+    """Transformed weights U = G g G^T of a (Cout,Cin,3,3) weight in the MFMA operand order of k_wino_conv."""
+    w = _f32(weight.detach()).contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    N, K = (Cin, Cout) if backward_data else (Cout, Cin)
+    nbytes = lib.csg_wino_pack_bytes(N, K)
+    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    check(lib.csg_wino_pack_weights(ptr(w), Cout, Cin, 1 if backward_data else 0, ptr(sigma), ptr(packed), stream()),
+          "wino_pack_weights")
+    return packed
+
+
+def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what):
+    d = WinoDesc()
+    d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, act, slope
+    check(lib.csg_wino_conv(d, ptr(x), ptr(packed), ptr(bias), ptr(res), ptr(y), stream()), what)
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv2d(x, w) + b) [+ residual] — reference nn.Conv2d call sites listed in
     include/csg_hip.h (K8/K11)."""
@@ -120,11 +150,18 @@ class _Conv2d(torch.autograd.Function):
         if Cin_w != Cin:
             raise RuntimeError("conv2d: weight expects %d input channels, x has %d" % (Cin_w, Cin))
         ctx.packs, ctx.dx_range = packs, dx_range
-        wp = packs[0] if packs is not None else weight.detach().permute(0, 2, 3, 1).contiguous()   # [Cout][KH][KW][Cin]
-        d, OH, OW = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad, act, slope)
-        y = empty_nhwc(B, Cout, OH, OW, x.device)
         res = nhwc(residual) if residual is not None else None
-        _conv_launch(d, x, wp, bias.detach() if bias is not None else None, res, y, "conv_fwd")
+        if dx_range is None and wino_eligible(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
+            OH, OW = IH, IW
+            y = empty_nhwc(B, Cout, OH, OW, x.device)
+            up = packs[2] if (packs is not None and len(packs) > 2) else wino_pack(weight, False)
+            _wino_launch(x, up, bias.detach() if bias is not None else None, res, y, B, IH, IW, Cin, Cout, act, slope,
+                         "wino_conv_fwd")
+        else:
+            wp = packs[0] if packs is not None else weight.detach().permute(0, 2, 3, 1).contiguous()   # [Cout][KH][KW][Cin]
+            d, OH, OW = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad, act, slope)
+            y = empty_nhwc(B, Cout, OH, OW, x.device)
+            _conv_launch(d, x, wp, bias.detach() if bias is not None else None, res, y, "conv_fwd")
         ctx.geom = (B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW, act, slope)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
@@ -156,6 +193,11 @@ class _Conv2d(torch.autograd.Function):
                 ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32) if nbytes > 0 else None
                 check(lib.csg_conv_fwd(d, ptr(dpre), ptr(wt), None, None, ctypes_ptr_off(dx, lo), ptr(ws), nbytes,
                                        stream()), "conv_bwd_data")
+        elif ctx.needs_input_grad[0] and wino_eligible(B, IH, IW, Cout, Cin, KH, KW, stride, pad):
+            # dX = conv3x3(dY, flipped W^T): the same Winograd kernel with the roles of the channel counts swapped
+            ut = ctx.packs[3] if (ctx.packs is not None and len(ctx.packs) > 3) else wino_pack(weight, True)
+            dx = empty_nhwc(B, Cin, IH, IW, dy.device)
+            _wino_launch(dpre, ut, None, None, dx, B, IH, IW, Cout, Cin, ACT_NONE, 0.0, "wino_conv_bwd_data")
         elif ctx.needs_input_grad[0]:
             wt = ctx.packs[1] if ctx.packs is not None else \
                 weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]
@@ -178,7 +220,7 @@ class _Conv2d(torch.autograd.Function):
         elif want_db:
             rows = B * OH * OW
             nch = _chunks(rows)
-            part = torch.empty(nch * 2 * Cout, device=dy.device, dtype=torch.float32)
+            part = torch.empty(nch * 2 * Cout, device=dy.device, dtype=torch.float64)
             db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
             check(lib.csg_colsum(ptr(dpre), rows, Cout, Cout, ptr(db), ptr(part), nch, stream()), "colsum")
         if ctx.has_res and ctx.needs_input_grad[3]:
@@ -187,12 +229,16 @@ class _Conv2d(torch.autograd.Function):
 
 
 def pack_conv_weight(weight):
-    """The two kernel-side layouts of a FROZEN (Cout,Cin,KH,KW) weight, for `conv2d(..., packs=)`:
+    """The kernel-side layouts of a FROZEN (Cout,Cin,KH,KW) weight, for `conv2d(..., packs=)`:
     [Cout][KH][KW][Cin] for the forward and [Cin][KH][KW][Cout] for backward-data, input channels
-    zero-padded to a multiple of 4.  Trainable weights are repacked per call instead."""
+    zero-padded to a multiple of 4 — plus, for 3x3 weights, the two Winograd operands (csrc/wino.hip).
+    Trainable weights are repacked per call instead."""
     pc = (-weight.shape[1]) % 4
     w = F.pad(weight.detach(), (0, 0, 0, 0, 0, pc)) if pc else weight.detach()
-    return w.permute(0, 2, 3, 1).contiguous(), w.permute(1, 2, 3, 0).contiguous()
+    out = (w.permute(0, 2, 3, 1).contiguous(), w.permute(1, 2, 3, 0).contiguous())
+    if WINO_ENABLED and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[0] % 4 == 0:
+        out = out + (wino_pack(w, False), wino_pack(w, True))
+    return out
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, residual=None, packs=None,
@@ -319,7 +365,7 @@ class _NormAct(torch.autograd.Function):
         count = float(P * world)
         if use_batch_stats:
             nch = _chunks(P, G)
-            part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float32)
+            part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float64)
             sums = torch.empty(G * 2 * C, device=dev, dtype=torch.float64)
             check(lib.csg_norm_stats(ptr(x), G, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
             if world > 1:
@@ -347,7 +393,7 @@ class _NormAct(torch.autograd.Function):
         dev = dy.device
         dgb = torch.empty_like(gb) if gb is not None else None
         nch = _chunks(P, G)
-        part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float32)
+        part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float64)
         dsums = torch.empty(G * 2 * C, device=dev, dtype=torch.float64)
         check(lib.csg_norm_apply_bwd_reduce(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, G, P, C, ptr(dgb),
                                             ptr(dsums), ptr(part), nch, stream()), "norm_bwd_reduce")

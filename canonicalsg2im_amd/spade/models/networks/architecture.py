@@ -59,9 +59,9 @@ class _VGGConv(nn.Module):
     def forward(self, x):
         if self.weight.requires_grad:
             return ops.conv2d(x, self.weight, self.bias, 1, 1, act=ops.ACT_LEAKY, slope=0.0)
-        if self._packs is None or self._packs[2] != self.weight._version or self._packs[0].device != x.device:
+        if self._packs is None or self._packs[-1] != self.weight._version or self._packs[0].device != x.device:
             self._packs = ops.pack_conv_weight(self.weight) + (self.weight._version,)
-        return ops.conv2d(x, self.weight, self.bias, 1, 1, act=ops.ACT_LEAKY, slope=0.0, packs=self._packs[:2])
+        return ops.conv2d(x, self.weight, self.bias, 1, 1, act=ops.ACT_LEAKY, slope=0.0, packs=self._packs[:-1])
 
 
 class _VGGPool(nn.Module):

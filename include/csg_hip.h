@@ -167,10 +167,33 @@ int64_t csg_conv_bwd_weight_workspace(const csg_conv_desc* d);
 int csg_conv_bwd_weight(const csg_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                         float* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- K8w: 3x3 / stride 1 / pad 1 convolution by Winograd F(2x2,3x3) on fp32 MFMA (csrc/wino.hip) ----
+ * The same nn.Conv2d call sites as above restricted to 3x3 kernels (generator.py:28; architecture.py:29-31;
+ * normalization.py:89-94) and their backward-data passes: 16 instead of 36 multiplications per 2x2 output tile
+ * and (cin,cout) pair, fp32 throughout.  x (B,H,W,Cin) NHWC with channel stride x_cs, y likewise with y_cs;
+ * H, W even; channel counts multiples of 4.  y = act(conv + bias) [+ residual] exactly as csg_conv_fwd.
+ * `packed`: the transformed weights U = G g G^T in MFMA operand order, csg_wino_pack_bytes(N, K) bytes, produced by
+ * csg_wino_pack_weights from the (Cout,Cin,3,3) contiguous weight: backward_data = 0 -> operand of the forward
+ * (N = Cout, K = Cin); 1 -> operand of dX = conv(dY, flipped W^T) (N = Cin, K = Cout: call csg_wino_conv with
+ * Cin := Cout, Cout := Cin).  `sigma` (device scalar or NULL) divides every weight first — W / sigma of spectral
+ * normalisation — so a spectrally normalised layer needs no materialised W_eff.                            */
+typedef struct csg_wino_desc {
+  int32_t B, H, W;
+  int32_t Cin, x_cs;
+  int32_t Cout, y_cs;
+  int32_t act;
+  float slope;
+} csg_wino_desc;
+int64_t csg_wino_pack_bytes(int64_t N, int64_t K);
+int csg_wino_pack_weights(const float* w, int64_t Cout, int64_t Cin, int32_t backward_data, const float* sigma,
+                          float* packed, void* stream);
+int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, const float* bias,
+                  const float* residual, float* y, void* stream);
+
 /* dpre = dy * act'(.) evaluated from the OUTPUT y (leaky: y>0 ? 1 : slope; tanh: 1-y^2)          */
 int csg_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float slope, float* dpre, void* stream);
-/* out[c] = sum_rows x[r, c] over (rows, C) with row stride x_cs — bias gradients; partial (nchunk,C) */
-int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out, float* partial, int64_t nchunk,
+/* out[c] = sum_rows x[r, c] over (rows, C) with row stride x_cs — bias gradients; partial (nchunk,2C) fp64 */
+int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out, double* partial, int64_t nchunk,
                void* stream);
 
 /* ---- K9/K11: BatchNorm / InstanceNorm statistics + SPADE modulation + LeakyReLU ---------------
@@ -179,8 +202,9 @@ int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out
  * LeakyReLU (normalization.py:44, discriminator.py:181-185).
  * x is (G groups, P pixels, C channels): BatchNorm G=1, P=B*h*w; InstanceNorm G=B, P=h*w.
  * sums (G,2C) double = [sum x | sum x^2]; it is the message SyncBN all-reduces
- * (batchnorm.py:74-83).                                                                          */
-int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums, float* partial, int64_t nchunk,
+ * (batchnorm.py:74-83).  Accumulated in fp64 throughout (partial: (G,nchunk,2C) doubles): x and x*x are
+ * exact in fp64, so E[x^2]-E[x]^2 loses nothing to the chunking.                                 */
+int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums, double* partial, int64_t nchunk,
                    void* stream);
 /* mode 0: invstd = 1/sqrt(var+eps) (F.batch_norm); mode 1: invstd = clamp(var,eps)^-1/2
  * (batchnorm.py:145, N-replica path).  running_* may be NULL; running_var gets the unbiased var. */
@@ -192,7 +216,7 @@ int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, c
 /* pass 1: dgb (if gb) and dsums (G,2C) double = [sum dn | sum dn*xhat]                          */
 int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
                               const float* gb, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
-                              double* dsums, float* partial, int64_t nchunk, void* stream);
+                              double* dsums, double* partial, int64_t nchunk, void* stream);
 /* pass 2: dx = invstd*(dn - dsum0/count - xhat*dsum1/count)                                     */
 int csg_norm_apply_bwd_dx(const float* dy, const float* x, const float* mean, const float* invstd, const float* gb,
                           float slope, const double* dsums, double count, int64_t G, int64_t P, int64_t C, float* dx,

@@ -50,8 +50,12 @@ def errors(x, ref64):
 class Band:
     """Collects (name, hip-vs-fp64 error, fp32-reference-vs-fp64 error) rows and judges them."""
 
-    def __init__(self, k_l2=5.0, k_max=10.0, floor=1e-4):
-        self.k_l2, self.k_max, self.floor = k_l2, k_max, floor
+    def __init__(self, k_l2=5.0, max_cap=0.05, floor=1e-4):
+        """L2 criterion: hip_l2 <= k_l2 * ref_l2 + floor.  The max-norm is only capped (no single entry off by more
+        than 5 % of the tensor's largest): one flipped gate in front of a large activation moves ONE entry of a
+        weight gradient by percents of the maximum in either implementation (the fp32 oracle shows 1.4e-1 on
+        G_middle_1.conv_0 against its own fp64 evaluation), so a ratio of max-norms says nothing."""
+        self.k_l2, self.max_cap, self.floor = k_l2, max_cap, floor
         self.rows, self.bad = [], []
 
     def add(self, name, hip, ref32, ref64):
@@ -62,7 +66,7 @@ class Band:
         h_l2, h_mx = errors(hip, ref64)
         r_l2, r_mx = errors(ref32, ref64)
         self.rows.append((name, h_l2, r_l2, h_mx, r_mx))
-        if h_l2 > self.k_l2 * r_l2 + self.floor or h_mx > self.k_max * r_mx + self.floor:
+        if h_l2 > self.k_l2 * r_l2 + self.floor or h_mx > max(self.max_cap, 3.0 * r_mx):
             self.bad.append("%s: hip l2 %.2e (fp32 ref %.2e), hip max %.2e (fp32 ref %.2e)" % (name, h_l2, r_l2, h_mx, r_mx))
 
     def table(self):

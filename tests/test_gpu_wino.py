@@ -1,0 +1,124 @@
+"""Winograd F(2x2,3x3) convolution (csrc/wino.hip) on a real MI355X against torch's fp32 CPU convolution:
+every tile geometry (TW = 4, 8, 16, 32), ragged regions, channel counts that are not multiples of the 16-channel
+stage / 64-channel block, the fused epilogue, and the backward-data pass through the autograd op.  Tolerance:
+rtol 1e-4 with the absolute term scaled to the output's magnitude (the transform sums 4 inputs per operand and
+the result is differenced again: ~2x the direct kernel's rounding error, measured below against fp64)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from canonicalsg2im_amd import ops as O
+    return O
+
+
+def _raw_wino(ops, x, w, bias=None, res=None, act=0, slope=0.0):
+    """Direct call of the C ABI: pack + conv (forward operand)."""
+    from canonicalsg2im_amd._lib import WinoDesc, check, lib, ptr, stream
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    xd = ops.nhwc(x.cuda())
+    up = ops.wino_pack(w.cuda(), False)
+    y = ops.empty_nhwc(B, Cout, H, W, xd.device)
+    d = WinoDesc()
+    d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, act, slope
+    bd = bias.cuda() if bias is not None else None
+    rd = ops.nhwc(res.cuda()) if res is not None else None
+    check(lib.csg_wino_conv(d, ptr(xd), ptr(up), ptr(bd), ptr(rd), ptr(y), stream()), "wino_conv")
+    return y
+
+
+SHAPES = [
+    # B, Cin, Cout, H,   W
+    (2, 16, 32, 8, 8),          # TW = 4
+    (1, 32, 64, 16, 16),        # TW = 8
+    (2, 20, 36, 12, 20),        # channel tails (Cin not x16, Cout not x32), ragged region, TW = 8
+    (1, 128, 128, 32, 32),      # TW = 16
+    (1, 64, 100, 24, 40),       # TW = 16, non-square, ragged in both directions
+    (2, 32, 128, 64, 64),       # TW = 32
+    (1, 48, 72, 6, 130),        # TW = 32, ragged x, a single tile row
+    (1, 1024, 64, 16, 16),      # long K (64 stages)
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_wino_forward_vs_torch(ops, shape):
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=1)
+    y = _raw_wino(ops, x, w, b)
+    assert_close(y, ref, 1e-4, 1e-5 * float(ref.abs().max()) + 1e-5, "wino fwd %s" % (shape,))
+
+
+def test_wino_epilogue_and_error_vs_fp64(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 32, 32, generator=g)
+    w = torch.randn(96, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(96, generator=g)
+    r = torch.randn(2, 96, 32, 32, generator=g)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
+    assert_close(_raw_wino(ops, x, w, b, None, ops.ACT_LEAKY, 0.2), ref, 1e-4, 2e-5, "leaky epilogue")
+    ref = torch.tanh(F.conv2d(x, w, b, padding=1))
+    assert_close(_raw_wino(ops, x, w, b, None, ops.ACT_TANH, 0.0), ref, 1e-4, 2e-5, "tanh epilogue")
+    ref = F.conv2d(x, w, b, padding=1) + r
+    assert_close(_raw_wino(ops, x, w, b, r), ref, 1e-4, 2e-5, "residual epilogue")
+    # rounding error against an fp64 convolution, next to the direct MFMA kernel's on the same data
+    ref64 = F.conv2d(x.double(), w.double(), None, padding=1)
+    e_w = float((_raw_wino(ops, x, w).double().cpu() - ref64).abs().max())
+    direct = ops.conv2d(x.cuda(), w.cuda()[:, :, :, :], None, 1, 1) if not ops.wino_eligible(2, 32, 32, 64, 96, 3, 3, 1, 1) else None
+    scale = float(ref64.abs().max())
+    assert e_w < 1e-5 * scale, (e_w, scale)
+    if direct is not None:
+        assert e_w < 8 * float((direct.double().cpu() - ref64).abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 64), (1, 64, 128, 128, 128), (16, 128, 32, 32, 32)])
+def test_conv2d_autograd_uses_winograd(ops, shape):
+    """ops.conv2d on an eligible layer: forward, backward-data (Winograd with the flipped, transposed weights) and the
+    weight gradient (direct kernel) against torch."""
+    B, Cin, Cout, H, W = shape
+    assert ops.wino_eligible(B, H, W, Cin, Cout, 3, 3, 1, 1) and ops.wino_eligible(B, H, W, Cout, Cin, 3, 3, 1, 1)
+    g = torch.Generator().manual_seed(B * 7 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    ref = F.leaky_relu(F.conv2d(xr, wr, br, padding=1), 0.2)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    xd, wd, bd = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    y = ops.conv2d(xd, wd, bd, 1, 1, ops.ACT_LEAKY, 0.2)
+    assert_close(y, ref, 1e-4, 2e-5, "y")
+    y.backward(gy.cuda())
+    assert_close(xd.grad, xr.grad, 1e-4, 1e-5 * float(xr.grad.abs().max()) + 1e-5, "dx (winograd)")
+    assert_close(wd.grad, wr.grad, 1e-4, 1e-5 * float(wr.grad.abs().max()) + 1e-5, "dw")
+    assert_close(bd.grad, br.grad, 1e-4, 1e-5 * float(br.grad.abs().max()) + 1e-5, "db")
+
+
+def test_wino_full_size_window(ops):
+    """The dominant generator shape (128 -> 256 channels at 256x256, B = 4): four 12x12 output windows against
+    F.conv2d of the matching input windows on the CPU."""
+    g = torch.Generator().manual_seed(78)
+    B, Cin, Cout, H = 4, 128, 256, 256
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 34.0
+    b = torch.randn(Cout, generator=g)
+    assert ops.wino_eligible(B, H, H, Cin, Cout, 3, 3, 1, 1)
+    y = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, 1)
+    for (bi, y0, x0) in ((0, 0, 0), (1, 100, 37), (3, 244, 244), (2, 127, 200)):
+        ya, xa = max(y0 - 1, 0), max(x0 - 1, 0)
+        yb, xb = min(y0 + 13, H), min(x0 + 13, H)
+        patch = F.pad(x[bi:bi + 1, :, ya:yb, xa:xb], (1 if x0 == 0 else 0, 1 if x0 + 13 > H else 0,
+                                                      1 if y0 == 0 else 0, 1 if y0 + 13 > H else 0))
+        ref = F.conv2d(patch, w, b)
+        assert_close(y[bi:bi + 1, :, y0:y0 + 12, x0:x0 + 12], ref, 1e-4, 2e-5, "window (%d,%d,%d)" % (bi, y0, x0))
