@@ -48,6 +48,7 @@ enum KernelId {
   K_SPECTRAL_BWD,
   K_WINO_CONV,
   K_WINO_PACK,
+  K_WINO_WGRAD,
   K_COUNT
 };
 

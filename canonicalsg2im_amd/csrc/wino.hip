@@ -28,6 +28,9 @@
 //   * Epilogue: each wave reduces its row over nu (M A), the four rows meet in LDS (A^T .), 16-byte stores.
 #include <stddef.h>
 
+#include <type_traits>
+
+#include "csg_buffer.h"
 #include "csg_common.h"
 
 using namespace csg;
@@ -106,13 +109,43 @@ __global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, 
 }
 
 // ------------------------------------------------------------------------------------ convolution
+// smallest row stride >= C*PS (even) for which the 32 lanes of a ds_read_b64 group — tile (tx, tyl), word offset
+// PS*tx + 2*RS*tyl — fall on 32 different bank pairs (bank = word address mod 64)
+constexpr int wn_row_stride(int TW) {
+  const int C = 2 * TW + 2;
+  for (int pad = 0; pad < 256; pad += 2) {
+    const int RS = C * WN_PS + pad;
+    unsigned long long used = 0;
+    bool ok = true;
+    for (int j = 0; j < 32 && ok; ++j) {
+      const int wa = (WN_PS * (j % TW) + 2 * RS * (j / TW)) & 63;
+      const unsigned long long m = (1ull << wa) | (1ull << ((wa + 1) & 63));
+      if (used & m) ok = false;
+      used |= m;
+    }
+    if (ok) return RS;
+  }
+  return C * WN_PS;
+}
+
+// Every VALU instruction of the single wave per SIMD takes issue time away from the fp32 MFMAs (measured: 57 % matrix
+// pipe busy with 2 VALU per MFMA in the loop, profiles/r02_pmc_wino.md), so the loop body carries none that is not
+// arithmetic of the transform: the tile geometry is a template parameter (LDS offsets become instruction immediates),
+// the per-stage advance of the global loads rides in the SCALAR offset of the buffer instructions, and the stage loop
+// is unrolled by two so that the LDS buffer is a compile-time constant.
+template <int TW>
 __global__ __launch_bounds__(256, 1) void k_wino_conv(WinoParams p, const float* __restrict__ x,
                                                        const float4* __restrict__ up, const float* __restrict__ bias,
                                                        const float* __restrict__ res, float* __restrict__ y) {
+  constexpr int TH = 64 / TW;
+  constexpr int R = 2 * TH + 2, C = 2 * TW + 2;
+  constexpr int RS = wn_row_stride(TW);
+  constexpr int BUFW = R * RS + 16;              // words per input buffer (+ a 16-word dump slot)
+  constexpr int HALF = (C / 2) * WN_PS;          // odd columns live HALF words after the even ones
+  constexpr int NLD = (R * C * 4 + 255) / 256;   // float4 global loads per thread and stage
+  constexpr int RPG = 32 / TW;                   // tile rows per tile group
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int R = 2 * p.TH + 2, C = 2 * p.TW + 2;
-  const int bufw = R * p.RS;                     // words per input buffer
 
   // ---- block -> (image, region, channel block); channel blocks of one region are adjacent (same XCD: input reuse)
   int bid = wn_xcd_remap(blockIdx.x, gridDim.x);
@@ -122,80 +155,72 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv(WinoParams p, const float*
   bid /= p.tbx;
   const int by = bid % p.tby;
   const int img = bid / p.tby;
-  const int X0 = bx * 2 * p.TW, Y0 = by * 2 * p.TH;          // first output pixel of the region
+  const int X0 = bx * 2 * TW, Y0 = by * 2 * TH;              // first output pixel of the region
 
-  // ---- staging plan of this thread (k-invariant): global offset (floats, channel 0) and LDS word offset
-  int goff[WN_MAXLD], loff[WN_MAXLD];
-  const int nld = R * C * 4;
+  // ---- staging plan of this thread (k-invariant): byte offset of channel 0 in x (CSG_OOB_OFF: zero padding or no
+  // work) and LDS word offset (threads beyond the region write a dump slot at the end of the buffer).  All loads go
+  // through buffer descriptors: no branch, and the channel advance of a stage is the instruction's scalar offset.
+  // Channels past Cin inside the last stage are NOT masked: they hold finite activations (or zeros past the end of
+  // the tensor) and meet zero weights in the packed operand.
+  const csg_i32x4 rsX = csg_make_srd(x, (long long)p.B * p.H * p.W * p.x_cs * 4);
+  const csg_i32x4 rsU = csg_make_srd(up, (long long)16 * p.NT32 * p.Q8 * 64 * 16);
+  unsigned goff[NLD];
+  int loff[NLD];
 #pragma unroll
-  for (int i = 0; i < WN_MAXLD; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int e = tid + 256 * i;
-    goff[i] = -1;
-    loff[i] = -1;
-    if (e < nld) {
+    goff[i] = CSG_OOB_OFF;
+    loff[i] = BUFW - 16 + (tid & 3) * 4;
+    if (e < R * C * 4) {
       const int pix = e >> 2, c4 = e & 3;
       const int row = pix / C, col = pix - row * C;
       const int iy = Y0 + row - 1, ix = X0 + col - 1;
-      loff[i] = row * p.RS + ((col & 1) * (C >> 1) + (col >> 1)) * WN_PS + c4 * 4;
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) goff[i] = ((img * p.H + iy) * p.W + ix) * p.x_cs + c4 * 4;
+      loff[i] = row * RS + ((col & 1) * (C >> 1) + (col >> 1)) * WN_PS + c4 * 4;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+        goff[i] = (unsigned)(((img * p.H + iy) * p.W + ix) * p.x_cs + c4 * 4) * 4u;
     }
   }
-  float4 st[WN_MAXLD];
-  auto load_stage = [&](int s) {
-    const int kb = s * WN_BK;
+  csg_f32x4 st[NLD];
+  auto load_stage = [&](int s) {                 // s past the end: finite garbage or zeros, never consumed
 #pragma unroll
-    for (int i = 0; i < WN_MAXLD; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      // Cin % 4 == 0: a float4 never straddles the channel end
-      if (goff[i] >= 0 && kb + (((tid + 256 * i) & 3) << 2) < p.Cin) v = *(const float4*)(x + (int64_t)goff[i] + kb);
-      st[i] = v;
-    }
+    for (int i = 0; i < NLD; ++i) st[i] = csg_buf_load_x4(rsX, (int)goff[i], s * (WN_BK * 4), 0);
   };
-  auto store_stage = [&](int buf) {
-    float* base = smem + buf * bufw;
+  auto store_stage = [&](float* base) {
 #pragma unroll
-    for (int i = 0; i < WN_MAXLD; ++i) {
-      if (loff[i] >= 0) {
-        *(float2*)(base + loff[i]) = make_float2(st[i].x, st[i].y);
-        *(float2*)(base + loff[i] + 2) = make_float2(st[i].z, st[i].w);
-      }
+    for (int i = 0; i < NLD; ++i) {
+      float* dst = base + loff[i];
+      *(float2*)(dst) = make_float2(st[i].x, st[i].y);
+      *(float2*)(dst + 2) = make_float2(st[i].z, st[i].w);
     }
   };
 
   // ---- this lane's tile inside each of the two tile groups, and the two input rows its wave combines
   const int j = lane & 31, h = lane >> 5;
-  const int tx = j % p.TW, tyl = j / p.TW;
-  const int rows_per_group = 32 / p.TW;
+  const int tx = j % TW, tyl = j / TW;
   // row xi of B^T d:  xi=0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
   const int ia = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
   const int ib = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
   const float sgn = wave == 1 ? 1.0f : -1.0f;
-  int aoff[2][2];                                // [group][row a/b]: word offset of column 0 (even half), channel pair h
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int ty = mt * rows_per_group + tyl;
-    aoff[mt][0] = (2 * ty + ia) * p.RS + tx * WN_PS + 2 * h;
-    aoff[mt][1] = (2 * ty + ib) * p.RS + tx * WN_PS + 2 * h;
-  }
-  const int half = (C >> 1) * WN_PS;             // odd columns live `half` words after the even ones
+  // word offsets of (row a / row b, column 0, channel pair h) for tile group 0; group 1 is 2*RPG rows further down
+  const float* pa0 = smem + (2 * tyl + ia) * RS + tx * WN_PS + 2 * h;
+  const float* pb0 = smem + (2 * tyl + ib) * RS + tx * WN_PS + 2 * h;
 
-  // ---- packed weights of this wave: [xi = wave][nu][nt32][q][lane]
-  int uoff[4][2];
-  bool uok[2];
+  // ---- packed weights of this wave: [xi = wave][nu][nt32][q][lane], byte offsets; q rides in the scalar offset
+  unsigned uoff[4][2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int nt32 = nb * 2 + nt;
-    uok[nt] = nt32 < p.NT32;
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu) uoff[nu][nt] = (((wave * 4 + nu) * p.NT32 + (uok[nt] ? nt32 : 0)) * p.Q8) * 64 + lane;
+    for (int nu = 0; nu < 4; ++nu)
+      uoff[nu][nt] = nt32 < p.NT32 ? (unsigned)((((wave * 4 + nu) * p.NT32 + nt32) * p.Q8) * 64 + lane) * 16u : CSG_OOB_OFF;
   }
-  float4 ua[4][2], ub[4][2];
-  auto load_u = [&](float4 (&u)[4][2], int q) {
+  csg_f32x4 ua[4][2], ub[4][2];
+  auto load_u = [&](csg_f32x4 (&u)[4][2], int q) {
+    const int qq = min(q, p.Q8 - 1);             // the prefetch past the end re-reads the last block (scalar op)
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        u[nu][nt] = (uok[nt] && q < p.Q8) ? up[uoff[nu][nt] + q * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int nt = 0; nt < 2; ++nt) u[nu][nt] = csg_buf_load_x4(rsU, (int)uoff[nu][nt], qq * 1024, 0);
   };
 
   f32x16 acc[4][2][2];
@@ -208,56 +233,123 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv(WinoParams p, const float*
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nu][mt][nt][e] = 0.f;
 
-  // one k-oct (8 channels) of one stage: 16 ds_read_b64 + 16 VALU per tile group, then 32 MFMAs per group
-  auto compute_oct = [&](const float* buf, int o, const float4 (&u)[4][2]) {
+  // One "group" = one k-oct (8 channels) of one tile group: 16 ds_read_b64 -> 32 VALU (B^T d B) -> 32 MFMAs.
+  // The loop below is software-pipelined by hand over groups: while the MFMAs of group g run, the LDS reads of
+  // group g+1 are already issued and its transform is slotted between the last MFMAs (sched_group_barrier), so the
+  // single wave per SIMD keeps the matrix pipe fed.
+  struct RawG {
+    float2 a[2][4], b[2][4];                     // [channel pair][column] of input rows ia / ib
+  };
+  auto read_group = [&](int bufsel, int o, int mt, RawG& r) {     // every offset below is an immediate
+    const float* pa = pa0 + bufsel * BUFW + mt * (2 * RPG * RS) + 8 * o;
+    const float* pb = pb0 + bufsel * BUFW + mt * (2 * RPG * RS) + 8 * o;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float2 v[4][2];                            // [nu][channel pair]
+    for (int cp = 0; cp < 2; ++cp)
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp) {
-        const float* pa = buf + aoff[mt][0] + 8 * o + 4 * cp;
-        const float* pb = buf + aoff[mt][1] + 8 * o + 4 * cp;
-        float2 r[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {            // column c of the 4x4 patch: even/odd halves, then + c>>1 pixels
-          const int co = (c & 1) * half + (c >> 1) * WN_PS;
-          const float2 da = *(const float2*)(pa + co), db = *(const float2*)(pb + co);
-          r[c] = make_float2(da.x + sgn * db.x, da.y + sgn * db.y);
-        }
-        v[0][cp] = make_float2(r[0].x - r[2].x, r[0].y - r[2].y);
-        v[1][cp] = make_float2(r[1].x + r[2].x, r[1].y + r[2].y);
-        v[2][cp] = make_float2(r[2].x - r[1].x, r[2].y - r[1].y);
-        v[3][cp] = make_float2(r[1].x - r[3].x, r[1].y - r[3].y);
+      for (int c = 0; c < 4; ++c) {              // column c of the 4x4 patch: even/odd halves, then + c>>1 pixels
+        const int co = (c & 1) * HALF + (c >> 1) * WN_PS + 4 * cp;
+        r.a[cp][c] = *(const float2*)(pa + co);
+        r.b[cp][c] = *(const float2*)(pb + co);
       }
+  };
+  auto transform = [&](const RawG& r, float2 (&v)[4][2]) {
 #pragma unroll
-      for (int nu = 0; nu < 4; ++nu)
+    for (int cp = 0; cp < 2; ++cp) {
+      float2 q[4];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          // weights as the first operand: D[i = channel][j = tile] -> a lane holds one tile and runs of 4 channels
-          acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].x, v[nu][0].x, acc[nu][mt][nt], 0, 0, 0);
-          acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].y, v[nu][0].y, acc[nu][mt][nt], 0, 0, 0);
-          acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].z, v[nu][1].x, acc[nu][mt][nt], 0, 0, 0);
-          acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].w, v[nu][1].y, acc[nu][mt][nt], 0, 0, 0);
-        }
+      for (int c = 0; c < 4; ++c) q[c] = make_float2(r.a[cp][c].x + sgn * r.b[cp][c].x, r.a[cp][c].y + sgn * r.b[cp][c].y);
+      v[0][cp] = make_float2(q[0].x - q[2].x, q[0].y - q[2].y);
+      v[1][cp] = make_float2(q[1].x + q[2].x, q[1].y + q[2].y);
+      v[2][cp] = make_float2(q[2].x - q[1].x, q[2].y - q[1].y);
+      v[3][cp] = make_float2(q[1].x - q[3].x, q[1].y - q[3].y);
     }
+  };
+  auto mfma_group = [&](int mt, const csg_f32x4 (&u)[4][2], const float2 (&v)[4][2]) {
+    // k-step outermost: consecutive MFMAs go to 8 different accumulators
+    // weights as the first operand: D[i = channel][j = tile] -> a lane holds one tile and runs of 4 channels
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].x, v[nu][0].x, acc[nu][mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].y, v[nu][0].y, acc[nu][mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].z, v[nu][1].x, acc[nu][mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].w, v[nu][1].y, acc[nu][mt][nt], 0, 0, 0);
+  };
+  // issue order of one pipeline step: the 16 LDS reads, 16 MFMAs back to back, then MFMA / 2 VALU alternating
+#define WN_STEP_SCHED()                                   \
+  __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);     \
+  __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);     \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);    \
+  }
+
+  // one stage = 16 channels out of buffer `bufsel` (compile-time), entered with v0 = transform of (s, oct 0, group 0)
+  RawG raw;
+  float2 v0[4][2], v1[4][2];
+  auto stage = [&](int s, auto bufsel_tag) {
+    constexpr int bufsel = decltype(bufsel_tag)::value;
+    load_stage(s + 1);
+    load_u(ub, 2 * s + 1);
+    __builtin_amdgcn_sched_barrier(0);           // the global loads of the next stage lead the trip
+
+    read_group(bufsel, 0, 1, raw);
+    mfma_group(0, ua, v0);
+    transform(raw, v1);
+    WN_STEP_SCHED();
+    __builtin_amdgcn_sched_barrier(0);
+
+    read_group(bufsel, 1, 0, raw);
+    mfma_group(1, ua, v1);
+    transform(raw, v0);
+    WN_STEP_SCHED();
+    __builtin_amdgcn_sched_barrier(0);
+
+    load_u(ua, 2 * s + 2);
+    read_group(bufsel, 1, 1, raw);
+    mfma_group(0, ub, v0);
+    transform(raw, v1);
+    __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+    WN_STEP_SCHED();
+    __builtin_amdgcn_sched_barrier(0);
+
+    store_stage(smem + (bufsel ^ 1) * BUFW);     // the buffer every wave finished reading one trip ago
+    __syncthreads();
+    read_group(bufsel ^ 1, 0, 0, raw);           // first group of the next stage, under the last MFMAs of this one
+    mfma_group(1, ub, v1);
+    transform(raw, v0);
+    WN_STEP_SCHED();
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   // ---- K loop
   load_stage(0);
   load_u(ua, 0);
-  store_stage(0);
+  store_stage(smem);
   __syncthreads();
-  for (int s = 0; s < p.nstage; ++s) {
-    const float* buf = smem + (s & 1) * bufw;
-    const bool more = s + 1 < p.nstage;
-    if (more) load_stage(s + 1);
-    load_u(ub, 2 * s + 1);
-    compute_oct(buf, 0, ua);
-    if (more) load_u(ua, 2 * s + 2);
-    compute_oct(buf, 1, ub);
-    if (more) store_stage((s + 1) & 1);
-    __syncthreads();
+  read_group(0, 0, 0, raw);
+  transform(raw, v0);
+  int s = 0;
+  for (; s + 1 < p.nstage; s += 2) {
+    stage(s, std::integral_constant<int, 0>());
+    stage(s + 1, std::integral_constant<int, 1>());
   }
+  if (s < p.nstage) stage(s, std::integral_constant<int, 0>());
+  __syncthreads();                               // every wave is done reading before the epilogue reuses the LDS
+  const int rows_per_group = RPG;
 
   // ---- epilogue: M A per wave (row xi), A^T . across the four waves through LDS, one channel group at a time
   //   R[0] = M0 + M1 + M2,  R[1] = M1 - M2 - M3;   Y[0][b] = R0b + R1b + R2b,  Y[1][b] = R1b - R2b - R3b
@@ -287,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv(WinoParams p, const float*
       const int tile = item >> 3, cq = item & 7;
       const int n = nb * 64 + nt * 32 + cq * 4;
       const int mt = tile >> 5, jj = tile & 31;
-      const int ttx = jj % p.TW, tty = mt * rows_per_group + jj / p.TW;
+      const int ttx = jj % TW, tty = mt * rows_per_group + jj / TW;
       const int oy = Y0 + 2 * tty, ox = X0 + 2 * ttx;
       if (n < p.Cout && oy < p.H && ox < p.W) {
         float4 rr[4][2];
@@ -331,25 +423,6 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv(WinoParams p, const float*
 }
 
 // ------------------------------------------------------------------------------------ host side
-static int wn_row_stride(int TW) {
-  // smallest row stride >= C*PS (even) for which the 32 lanes of a ds_read_b64 group — tile (tx, tyl), word offset
-  // PS*tx + 2*RS*tyl — fall on 32 different bank pairs (bank = word address mod 64)
-  const int C = 2 * TW + 2;
-  for (int pad = 0; pad < 256; pad += 2) {
-    const int RS = C * WN_PS + pad;
-    unsigned long long used = 0;
-    bool ok = true;
-    for (int j = 0; j < 32 && ok; ++j) {
-      const int wa = (WN_PS * (j % TW) + 2 * RS * (j / TW)) & 63;
-      const unsigned long long m = (1ull << wa) | (1ull << ((wa + 1) & 63));
-      if (used & m) ok = false;
-      used |= m;
-    }
-    if (ok) return RS;
-  }
-  return C * WN_PS;
-}
-
 static int wn_plan(const csg_wino_desc* d, WinoParams& p, size_t& shm, const char* who) {
   CSG_REQUIRE(d != nullptr, CSG_E_BADSHAPE, "%s: null descriptor", who);
   CSG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, CSG_E_BADSHAPE, "%s: non-positive dimension", who);
@@ -358,8 +431,10 @@ static int wn_plan(const csg_wino_desc* d, WinoParams& p, size_t& shm, const cha
   CSG_REQUIRE(d->Cin % 4 == 0 && d->x_cs % 4 == 0 && d->x_cs >= d->Cin && d->Cout % 4 == 0 && d->y_cs % 4 == 0 &&
                   d->y_cs >= d->Cout,
               CSG_E_UNSUPPORTED, "%s: channel counts and strides must be multiples of 4", who);
-  CSG_REQUIRE((int64_t)d->B * d->H * d->W * (int64_t)(d->x_cs > d->y_cs ? d->x_cs : d->y_cs) < (1ll << 31), CSG_E_UNSUPPORTED,
-              "%s: tensor too large for 32-bit offsets", who);
+  CSG_REQUIRE((int64_t)d->B * d->H * d->W * (int64_t)(d->x_cs > d->y_cs ? d->x_cs : d->y_cs) * 4 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
+              "%s: tensor too large for 32-bit byte offsets", who);
+  CSG_REQUIRE((int64_t)16 * ((d->Cout + 31) / 32) * ((d->Cin + 7) / 8) * 1024 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
+              "%s: packed weights too large for 32-bit byte offsets", who);
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_cs = d->x_cs; p.Cout = d->Cout; p.y_cs = d->y_cs;
   p.TW = d->W >= 64 ? 32 : (d->W >= 32 ? 16 : (d->W >= 16 ? 8 : 4));
   p.TH = 64 / p.TW;
@@ -367,14 +442,14 @@ static int wn_plan(const csg_wino_desc* d, WinoParams& p, size_t& shm, const cha
   p.tby = (d->H / 2 + p.TH - 1) / p.TH;
   p.nblocks = (d->Cout + 63) / 64;
   p.RS = wn_row_stride(p.TW);
+  CSG_REQUIRE(d->Cin % 16 == 0, CSG_E_UNSUPPORTED, "%s: Cin must be a multiple of 16 (one LDS stage)", who);
   p.NT32 = (d->Cout + 31) / 32;
   p.Q8 = (d->Cin + 7) / 8;
   p.act = d->act; p.slope = d->slope;
   p.nstage = (d->Cin + WN_BK - 1) / WN_BK;
-  const size_t in_bytes = (size_t)2 * (2 * p.TH + 2) * p.RS * 4;
+  const size_t in_bytes = (size_t)2 * ((2 * p.TH + 2) * p.RS + 16) * 4;        // + the dump slots of idle staging lanes
   const size_t ep_bytes = (size_t)4 * 2 * 64 * WN_RSE * 4;
   shm = in_bytes > ep_bytes ? in_bytes : ep_bytes;
-  CSG_REQUIRE((2 * p.TH + 2) * (2 * p.TW + 2) * 4 <= WN_MAXLD * 256, CSG_E_UNSUPPORTED, "%s: staging plan too large", who);
   return CSG_OK;
 }
 
@@ -413,8 +488,12 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wino_conv, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    const void* fns[4] = {(const void*)k_wino_conv<32>, (const void*)k_wino_conv<16>, (const void*)k_wino_conv<8>,
+                          (const void*)k_wino_conv<4>};
+    for (const void* fn : fns) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }
     attr_set[dev] = true;
   }
   CSG_REQUIRE(shm <= 96 * 1024, CSG_E_UNSUPPORTED, "csg_wino_conv: %zu bytes of LDS", shm);
@@ -423,8 +502,311 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
   CSG_REQUIRE(grid < (1ll << 31), CSG_E_UNSUPPORTED, "csg_wino_conv: grid too large");
   // algorithmic FLOPs of the DIRECT convolution this replaces (2 * M * 9*Cin * Cout): what FlopCounterMode counts
   ProfScope ps(K_WINO_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
-  hipLaunchKernelGGL(k_wino_conv, dim3((unsigned)grid), dim3(256), shm, s, p, x, (const float4*)packed, bias, residual, y);
+  const float4* up = (const float4*)packed;
+  if (p.TW == 32)
+    hipLaunchKernelGGL(k_wino_conv<32>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+  else if (p.TW == 16)
+    hipLaunchKernelGGL(k_wino_conv<16>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+  else if (p.TW == 8)
+    hipLaunchKernelGGL(k_wino_conv<8>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+  else
+    hipLaunchKernelGGL(k_wino_conv<4>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
   return check_launch("csg_wino_conv");
+}
+
+}  // extern "C"
+
+// ====================================================================================== weight gradient
+// dW (3x3) of a 3x3 / stride 1 / pad 1 convolution by Winograd F(3x3, 2x2): per 2x2 tile of dY and the 4x4 input
+// patch around it,
+//     dW += A^T [ (G dY_t G^T) (.) (B^T X_t B) ] A            16 multiplications instead of 36
+// with A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]], G = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]] and
+// B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,-1,0,1]].  The sum over tiles is taken INSIDE the brackets: 16 GEMMs
+//     Acc_p[cout][cin] = sum_tiles E_p[tile][cout] * V_p[tile][cin]
+// whose reduction index is the tile.  A block owns 64 cout x 64 cin x 16 positions over a slice of the tiles; wave w
+// owns row xi = w.  Both operands are formed in registers from plain coalesced global loads (32 consecutive channels
+// per half-wave; the two half-waves work on two consecutive tiles = the k-pair of v_mfma_f32_32x32x2_f32): no LDS and
+// no barrier in the main loop.  Slabs per tile slice + the ordered reduction of igemm.hip (k_wgrad_reduce) give a
+// bit-reproducible result; the bias gradient rides along in wave 1, which loads all four pixels of every dY tile.
+struct WinoWgParams {
+  int B, H, W, Cin, x_cs, Cout, y_cs;
+  int TXn, TYn, ntiles;
+  int cblocks, kblocks;
+  int nsplit, tps;               // tiles per split (even)
+};
+
+#define WG_EPS 33                // words per row of the epilogue exchange buffer
+
+__global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const float* __restrict__ x,
+                                                        const float* __restrict__ dy, float* __restrict__ slabs,
+                                                        float* __restrict__ dbslabs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  int bid = wn_xcd_remap(blockIdx.x, gridDim.x);
+  // all (cout block, cin block) pairs of one tile slice are adjacent: the slice's dY and X stay in that XCD's L2
+  const int kb = bid % p.kblocks;
+  bid /= p.kblocks;
+  const int cb = bid % p.cblocks;
+  const int sp = bid / p.cblocks;
+  const int t0 = sp * p.tps, t1 = min(p.ntiles, t0 + p.tps);
+
+  // rows of the dY tile / of the input patch this wave combines
+  //   e = G dY:  xi=0: dY0;  1: (dY0+dY1)/2;  2: (dY0-dY1)/2;  3: dY1
+  //   r = B^T X: xi=0: X0-X2;  1: X1+X2;  2: X2-X1;  3: X3-X1
+  const bool need0 = wave != 3, need1 = wave != 0;
+  const float ea = wave == 0 ? 1.f : (wave == 3 ? 0.f : 0.5f);
+  const float eb = wave == 0 ? 0.f : (wave == 3 ? 1.f : (wave == 1 ? 0.5f : -0.5f));
+  const int ia = wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? 2 : 3));
+  const int ib = wave == 0 ? 2 : (wave == 1 ? 2 : 1);
+  const float sgn = wave == 1 ? 1.0f : -1.0f;
+
+  int co[2], ci[2];
+  bool cok[2], kok[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    co[m] = cb * 64 + m * 32 + c;
+    cok[m] = co[m] < p.Cout;
+    ci[m] = kb * 64 + m * 32 + c;
+    kok[m] = ci[m] < p.Cin;
+  }
+  const bool do_db = dbslabs != nullptr && kb == 0 && wave == 1;
+  float dbacc[2] = {0.f, 0.f};
+
+  // position of the next tile this lane loads: tile t0 + h, then steps of 2
+  int tl = t0 + h;
+  int tx = tl % p.TXn, trow = tl / p.TXn;
+  int ty = trow % p.TYn, img = trow / p.TYn;
+  auto advance = [&]() {
+    tl += 2;
+    tx += 2;
+    if (tx >= p.TXn) {
+      tx -= p.TXn;
+      ty += 1;
+      if (ty >= p.TYn) {
+        ty = 0;
+        img += 1;
+      }
+    }
+  };
+
+  struct Raw {
+    float dy[2][2][2];   // [cout group][row][col]
+    float xr[2][2][4];   // [cin group][row a/b][col]
+  };
+  const csg_i32x4 rsX = csg_make_srd(x, (long long)p.B * p.H * p.W * p.x_cs * 4);
+  const csg_i32x4 rsY = csg_make_srd(dy, (long long)p.B * p.H * p.W * p.y_cs * 4);
+  auto load_pair = [&](Raw& r) {                 // branch-free: absent elements get an out-of-range offset -> 0
+    const bool ok = tl < t1;
+    const int y0 = 2 * ty, x0 = 2 * tx;
+    const int pix0 = (img * p.H + y0) * p.W + x0;                  // first pixel of the dY tile
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx) {
+          const bool v = ok & cok[m] & (i == 0 ? need0 : need1);
+          const unsigned off = (unsigned)((pix0 + i * p.W + jx) * p.y_cs + co[m]) * 4u;
+          r.dy[m][i][jx] = csg_buf_load_x1(rsY, (int)(v ? off : CSG_OOB_OFF), 0, 0);
+        }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int dyr = -1 + (rr == 0 ? ia : ib);
+        const int iy = y0 + dyr;
+        const bool rowok = ok & kok[m] & (iy >= 0) & (iy < p.H);
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+          const int ix = x0 - 1 + jx;
+          const bool v = rowok & (ix >= 0) & (ix < p.W);
+          const unsigned off = (unsigned)((pix0 + dyr * p.W + jx - 1) * p.x_cs + ci[m]) * 4u;
+          r.xr[m][rr][jx] = csg_buf_load_x1(rsX, (int)(v ? off : CSG_OOB_OFF), 0, 0);
+        }
+      }
+    }
+    advance();
+  };
+
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nu][mt][nt][e] = 0.f;
+
+  auto compute_pair = [&](const Raw& r) {
+    float E[4][2], V[4][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float e0 = ea * r.dy[m][0][0] + eb * r.dy[m][1][0];
+      const float e1 = ea * r.dy[m][0][1] + eb * r.dy[m][1][1];
+      E[0][m] = e0;
+      E[1][m] = 0.5f * (e0 + e1);
+      E[2][m] = 0.5f * (e0 - e1);
+      E[3][m] = e1;
+      if (do_db) dbacc[m] += (r.dy[m][0][0] + r.dy[m][0][1]) + (r.dy[m][1][0] + r.dy[m][1][1]);
+      float q[4];
+#pragma unroll
+      for (int jx = 0; jx < 4; ++jx) q[jx] = r.xr[m][0][jx] + sgn * r.xr[m][1][jx];
+      V[0][m] = q[0] - q[2];
+      V[1][m] = q[1] + q[2];
+      V[2][m] = q[2] - q[1];
+      V[3][m] = q[3] - q[1];
+    }
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(E[nu][mt], V[nu][nt], acc[nu][mt][nt], 0, 0, 0);
+  };
+
+  // ---- main loop over tile pairs, raw loads one pair ahead (two named register sets)
+  const int npairs = (t1 - t0 + 1) / 2;
+  Raw ra, rb;
+  if (npairs > 0) load_pair(ra);
+  int kp = 0;
+  for (; kp + 1 < npairs; kp += 2) {
+    load_pair(rb);
+    compute_pair(ra);
+    if (kp + 2 < npairs) load_pair(ra);
+    compute_pair(rb);
+  }
+  if (kp < npairs) compute_pair(ra);
+
+  // ---- epilogue: R_xi[b] = sum_nu Acc[xi][nu] A^T[b][nu] per wave; dW[a][b] = sum_xi A^T[a][xi] R_xi[b] through LDS,
+  //      one 32x32 (cout, cin) quadrant at a time; slab layout [split][Cout][tap = 3a+b][Cin]
+  float* slab = slabs + (int64_t)sp * p.Cout * 9 * p.Cin;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float a0 = acc[0][mt][nt][e], a1 = acc[1][mt][nt][e], a2 = acc[2][mt][nt][e], a3 = acc[3][mt][nt][e];
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * h;             // cout row inside the quadrant
+        smem[((wave * 3 + 0) * 32 + i) * WG_EPS + c] = a0 + a1 + a2;
+        smem[((wave * 3 + 1) * 32 + i) * WG_EPS + c] = a1 - a2;
+        smem[((wave * 3 + 2) * 32 + i) * WG_EPS + c] = a1 + a2 + a3;
+      }
+      __syncthreads();
+      const int kcol = tid & 31;
+      const int cin_g = kb * 64 + nt * 32 + kcol;
+#pragma unroll
+      for (int rep = 0; rep < 4; ++rep) {
+        const int i = (tid >> 5) + 8 * rep;
+        const int cout_g = cb * 64 + mt * 32 + i;
+        if (cout_g < p.Cout && cin_g < p.Cin) {
+          float R[4][3];
+#pragma unroll
+          for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) R[xi][b] = smem[((xi * 3 + b) * 32 + i) * WG_EPS + kcol];
+          float* dst = slab + (int64_t)cout_g * 9 * p.Cin + cin_g;
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            dst[(0 * 3 + b) * p.Cin] = R[0][b] + R[1][b] + R[2][b];
+            dst[(1 * 3 + b) * p.Cin] = R[1][b] - R[2][b];
+            dst[(2 * 3 + b) * p.Cin] = R[1][b] + R[2][b] + R[3][b];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  if (do_db) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float tot = dbacc[m] + __shfl_xor(dbacc[m], 32, 64);
+      if (h == 0 && cok[m]) dbslabs[(int64_t)sp * p.Cout + co[m]] = tot;
+    }
+  }
+}
+
+__global__ void k_wino_slab_reduce(const float* __restrict__ ws, int64_t n, int nsplit, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = ws[i];
+  for (int s = 1; s < nsplit; ++s) a += ws[(int64_t)s * n + i];
+  out[i] = a;
+}
+
+static int wn_wg_plan(const csg_wino_desc* d, WinoWgParams& p, const char* who) {
+  CSG_REQUIRE(d != nullptr, CSG_E_BADSHAPE, "%s: null descriptor", who);
+  CSG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, CSG_E_BADSHAPE, "%s: non-positive dimension", who);
+  CSG_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0 && d->W >= 4, CSG_E_UNSUPPORTED, "%s: H=%d, W=%d must be even", who, d->H, d->W);
+  CSG_REQUIRE(d->x_cs >= d->Cin && d->y_cs >= d->Cout, CSG_E_BADSHAPE, "%s: channel strides", who);
+  CSG_REQUIRE((int64_t)d->B * d->H * d->W * (int64_t)(d->x_cs > d->y_cs ? d->x_cs : d->y_cs) * 4 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
+              "%s: tensor too large for 32-bit byte offsets", who);
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_cs = d->x_cs; p.Cout = d->Cout; p.y_cs = d->y_cs;
+  p.TXn = d->W / 2;
+  p.TYn = d->H / 2;
+  const int64_t nt = (int64_t)d->B * p.TXn * p.TYn;
+  CSG_REQUIRE(nt < (1ll << 30), CSG_E_UNSUPPORTED, "%s: too many tiles", who);
+  p.ntiles = (int)nt;
+  p.cblocks = (d->Cout + 63) / 64;
+  p.kblocks = (d->Cin + 63) / 64;
+  // one block per CU is resident: aim at ~2 waves of blocks, at least 64 tile pairs per block, at most 512 slabs
+  const int tiles2d = p.cblocks * p.kblocks;
+  int ns = (512 + tiles2d - 1) / tiles2d;
+  const int max_ns = (int)((nt + 127) / 128);
+  if (ns > max_ns) ns = max_ns;
+  if (ns > 512) ns = 512;
+  if (ns < 1) ns = 1;
+  int tps = (int)((nt + ns - 1) / ns);
+  tps += tps & 1;
+  p.tps = tps;
+  p.nsplit = (int)((nt + tps - 1) / tps);
+  return CSG_OK;
+}
+
+extern "C" {
+
+int64_t csg_wino_bwd_weight_workspace(const csg_wino_desc* d) {
+  WinoWgParams p;
+  if (wn_wg_plan(d, p, "csg_wino_bwd_weight_workspace")) return -1;
+  return (int64_t)p.nsplit * d->Cout * (9 * (int64_t)d->Cin + 1) * 4;
+}
+
+int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy, float* dw, float* db, float* workspace,
+                        int64_t workspace_bytes, void* stream) {
+  WinoWgParams p;
+  int rc = wn_wg_plan(d, p, "csg_wino_bwd_weight");
+  if (rc) return rc;
+  const int64_t wsize = (int64_t)d->Cout * 9 * d->Cin;
+  const int64_t need = (int64_t)p.nsplit * (wsize + d->Cout) * 4;
+  CSG_REQUIRE(workspace != nullptr && workspace_bytes >= need, CSG_E_WORKSPACE, "csg_wino_bwd_weight: workspace %ld < %ld bytes",
+              (long)workspace_bytes, (long)need);
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t shm = (size_t)4 * 3 * 32 * WG_EPS * 4;
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_wino_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino_bwd_weight: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    attr_set[dev] = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* dbslabs = db != nullptr ? workspace + (int64_t)p.nsplit * wsize : nullptr;
+  {
+    ProfScope ps(K_WINO_WGRAD, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
+    hipLaunchKernelGGL(k_wino_wgrad, dim3((unsigned)(p.cblocks * p.kblocks * p.nsplit)), dim3(256), shm, s, p, x, dy, workspace,
+                       dbslabs);
+    rc = check_launch("csg_wino_bwd_weight");
+    if (rc) return rc;
+  }
+  {
+    ProfScope ps(K_WGRAD_REDUCE, (double)(p.nsplit + 1) * wsize * 4, s);
+    hipLaunchKernelGGL(k_wino_slab_reduce, dim3((unsigned)cdiv(wsize, 256)), dim3(256), 0, s, workspace, wsize, p.nsplit, dw);
+    if (db != nullptr)
+      hipLaunchKernelGGL(k_wino_slab_reduce, dim3((unsigned)cdiv(d->Cout, 256)), dim3(256), 0, s, dbslabs, (int64_t)d->Cout,
+                         p.nsplit, db);
+    rc = check_launch("csg_wino_bwd_weight(reduce)");
+  }
+  return rc;
 }
 
 }  // extern "C"

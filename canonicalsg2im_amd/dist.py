@@ -47,12 +47,21 @@ def all_reduce_stats(sums):
 
 
 class GradBuckets:
-    """Flat fp32 buckets over the parameters that actually receive gradients.
+    """Gradient exchange of one optimiser's parameters: persistent flat fp32 buckets, `.grad` kept as VIEWS into
+    them, one all-reduce per bucket launched asynchronously from a post-accumulate hook as soon as the bucket's last
+    gradient of the current backward has landed — the collectives of the early (deep) layers' buckets travel over
+    xGMI while the rest of the backward is still computing.
 
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large messages beat many small ones,
-    so buckets are ~64 MB (the generator's 375 MB of gradients travel in 6 collectives).  Parameters
-    without a gradient (the never-used `repr_net` / `image_encoder` of G and D — SURVEY.md §9
-    item 11) are skipped at sync time instead of tripping a DDP 'unused parameter' error."""
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large messages beat many small ones, so buckets are
+    ~64 MB (the generator's 375 MB of gradients travel in 6 collectives).  Buckets are filled in reverse registration
+    order, which is the order gradients become ready.  Which parameters take part is discovered at the first
+    synchronisation: those that received a gradient — the never-used `repr_net` / `image_encoder` of G and D
+     stay out instead of tripping a DDP 'unused parameter' error.  In steady state nothing is
+    allocated: a hook copies the fresh gradient into its slot (the only extra pass over the gradients — there is no
+    `torch.cat`, no copy back) and re-points `.grad` at the slot, which is what the optimiser then reads.
+
+    Usage per backward:  begin(); loss.backward(); [independent work]; finish()  — or all_reduce_mean() for both.
+    On a single rank every method returns immediately and nothing is registered."""
 
     def __init__(self, params, bucket_bytes=64 << 20):
         seen, self.params = set(), []
@@ -61,68 +70,108 @@ class GradBuckets:
                 seen.add(id(p))
                 self.params.append(p)
         self.bucket_bytes = bucket_bytes
+        self.flats, self.members, self.slot = [], [], {}        # per bucket: flat tensor, [params]; param id -> (bucket, view)
+        self.built = False
+        self._active = False
+        self._pending, self._fired, self._works, self._next = [], set(), [], 0
+        self.allocations = 0                                    # flat buffers ever allocated (tests: steady state adds none)
 
-    def _buckets(self, tensors):
-        cur, size = [], 0
-        for t in tensors:
-            n = t.numel() * t.element_size()
+    # ---- construction (first synchronisation)
+    def _build(self):
+        live = [p for p in self.params if p.grad is not None]
+        cur, size, groups = [], 0, []
+        for p in reversed(live):                                 # reverse registration order ~ order of readiness
+            n = p.numel() * 4
             if cur and size + n > self.bucket_bytes:
-                yield cur
+                groups.append(cur)
                 cur, size = [], 0
-            cur.append(t)
+            cur.append(p)
             size += n
         if cur:
-            yield cur
+            groups.append(cur)
+        for b, group in enumerate(groups):
+            flat = torch.zeros(sum(p.numel() for p in group), device=group[0].device, dtype=torch.float32)
+            self.allocations += 1
+            off = 0
+            for p in group:
+                view = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+                self.slot[id(p)] = (b, view)
+                p.register_post_accumulate_grad_hook(self._hook)
+            self.flats.append(flat)
+            self.members.append(group)
+        self.built = True
+
+    def _launch_ready(self, force=False):
+        """Launch, in bucket order (identical on every rank), the all-reduces of the buckets that are complete."""
+        while self._next < len(self.flats) and (force or self._pending[self._next] == 0):
+            b = self._next
+            if self._pending[b]:                                 # parameters that got no gradient this time contribute 0
+                for p in self.members[b]:
+                    if id(p) not in self._fired:
+                        self.slot[id(p)][1].zero_()
+            self._works.append(dist.all_reduce(self.flats[b], op=_avg_op(), async_op=True))
+            self._next += 1
+
+    def _hook(self, p):
+        if not self._active:
+            return
+        b, view = self.slot[id(p)]
+        if p.grad is not view:
+            view.copy_(p.grad)
+            p.grad = view
+        if id(p) not in self._fired:
+            self._fired.add(id(p))
+            self._pending[b] -= 1
+        self._launch_ready()
+
+    # ---- per-backward protocol
+    def begin(self):
+        """Call right before `backward()` (after zero_grad): arms the hooks for this backward."""
+        if world_size() == 1 or not self.built:
+            return
+        self._pending = [len(g) for g in self.members]
+        self._fired, self._works, self._next = set(), [], 0
+        self._active = True
+
+    def flush(self):
+        """After `backward()`: launch whatever has not been launched yet; the collectives keep running."""
+        if world_size() == 1:
+            return
+        if not self.built:
+            self._build()
+            self.begin()
+            for group in self.members:                           # first time: gradients are ordinary tensors
+                for p in group:
+                    self._hook(p)
+        self._launch_ready(force=True)
+        self._active = False
+
+    def finish(self):
+        """Wait for the collectives; gradients are then the mean over ranks.  Returns the bytes exchanged."""
+        if world_size() == 1:
+            return 0
+        self.flush()
+        for w in self._works:
+            w.wait()
+        if not _has_avg():
+            n = world_size()
+            for flat in self.flats:
+                flat.div_(n)
+        self._works = []
+        return sum(f.numel() * 4 for f in self.flats)
 
     def all_reduce_mean(self):
-        """grad <- mean over ranks, in place.  Every rank must hold gradients for the same
-        parameters (true here: replicas run the same graph)."""
-        n = world_size()
-        if n == 1:
-            return 0
-        grads = [p.grad for p in self.params if p.grad is not None]
-        nbytes = 0
-        for bucket in self._buckets(grads):
-            flat = torch.cat([g.reshape(-1) for g in bucket])
-            dist.all_reduce(flat)
-            flat.div_(n)
-            off = 0
-            for g in bucket:
-                k = g.numel()
-                g.copy_(flat[off:off + k].view_as(g))
-                off += k
-            nbytes += flat.numel() * 4
-        return nbytes
+        """grad <- mean over ranks (begin() may or may not have been called before the backward)."""
+        return self.finish()
 
 
-    # ---- split form: start the collectives now, finish them later (overlap with independent work)
-    def all_reduce_start(self):
-        """Flatten the gradients into buckets and launch one ASYNC all-reduce per bucket.  Returns the
-        pending list for `all_reduce_finish` (None on a single rank)."""
-        if world_size() == 1:
-            return None
-        pending = []
-        grads = [p.grad for p in self.params if p.grad is not None]
-        for bucket in self._buckets(grads):
-            flat = torch.cat([g.reshape(-1) for g in bucket])
-            pending.append((flat, bucket, dist.all_reduce(flat, async_op=True)))
-        return pending
+def _has_avg():
+    return dist.get_backend() == "nccl"            # RCCL implements ncclAvg; gloo has no averaging reduction
 
-    def all_reduce_finish(self, pending):
-        """Wait for the collectives of `all_reduce_start`, average, and scatter back into the .grad tensors."""
-        if not pending:
-            return 0
-        n, nbytes = world_size(), 0
-        for flat, bucket, work in pending:
-            work.wait()
-            flat.div_(n)
-            off = 0
-            for g in bucket:
-                k = g.numel()
-                g.copy_(flat[off:off + k].view_as(g))
-                off += k
-            nbytes += flat.numel() * 4
-        return nbytes
+
+def _avg_op():
+    return dist.ReduceOp.AVG if _has_avg() else dist.ReduceOp.SUM
 
 
 def broadcast_module(module, src=0):

@@ -111,11 +111,12 @@ def _conv_launch(d, x, w, bias, res, y, what):
 # ---- Winograd F(2x2,3x3) path (csrc/wino.hip): 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip
 WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "16384"))     # B*H*W below which the direct kernel stays
 WINO_ENABLED = os.environ.get("CSG_WINOGRAD", "1") != "0"
+WINO_WGRAD = os.environ.get("CSG_WINOGRAD_WGRAD", "1") != "0"
 
 
 def wino_eligible(B, H, W, Cin, Cout, KH, KW, stride, pad):
     return (WINO_ENABLED and KH == 3 and KW == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 and W >= 8
-            and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 16 and Cout >= 32 and B * H * W >= WINO_MIN_PIXELS)
+            and Cin % 16 == 0 and Cout % 4 == 0 and Cout >= 32 and B * H * W >= WINO_MIN_PIXELS)
 
 
 def wino_pack(weight, backward_data, sigma=None):
@@ -205,7 +206,21 @@ class _Conv2d(torch.autograd.Function):
             for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
                 _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and WINO_WGRAD and wino_eligible(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
+            # Winograd F(3x3,2x2) weight gradient (csrc/wino.hip), same output layout as the direct kernel
+            d = WinoDesc()
+            d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, IH, IW, Cin, Cin, Cout, Cout, ACT_NONE, 0.0
+            nbytes = lib.csg_wino_bwd_weight_workspace(d)
+            if nbytes < 0:
+                raise RuntimeError("wino_bwd_weight_workspace: " + _lib.last_error())
+            ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
+            dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
+            if want_db:
+                db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
+            check(lib.csg_wino_bwd_weight(d, ptr(x), ptr(dpre), ptr(dwp), ptr(db), ptr(ws), nbytes, stream()),
+                  "wino_bwd_weight")
+            dw = dwp.permute(0, 3, 1, 2)
+        elif ctx.needs_input_grad[1]:
             d, _, _ = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad)
             nbytes = lib.csg_conv_bwd_weight_workspace(d)
             if nbytes < 0:

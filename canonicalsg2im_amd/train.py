@@ -90,6 +90,7 @@ class Trainer:
         log_prob = calc_log_p(get_conv_converse(self.model), self.non_meta_relations, conv_counts)
         loss_conv = torch.mean(r * log_prob)
         self.optimizer_converse.zero_grad(set_to_none=True)
+        self.converse_buckets.begin()
         loss_conv.backward()
         self.converse_buckets.all_reduce_mean()
         self.optimizer_converse.step()
@@ -107,12 +108,16 @@ class Trainer:
         G = self.gans_model(batch, model_out, mode="compute_generator_loss")
         G = {k: (v if k == "bbox_pred_all" else v.mean()) for k, v in G.items()}
         self.optimizer.zero_grad(set_to_none=True)
+        self.g_buckets.begin()
         G["total_loss"].backward()
-        # N > 1: the generator's gradient all-reduce (~375 MB) runs on RCCL's stream while the discriminator
-        # losses below are computed — they read neither the generator's parameters nor its gradients
-        # (imgs_pred is detached), so applying the generator's Adam step after them changes nothing.
-        g_pending = self.g_buckets.all_reduce_start()
-        if g_pending is None:
+        # N > 1: each 64 MB bucket of the generator's gradients (~375 MB in all) is all-reduced on RCCL's stream as
+        # soon as the backward has filled it, and the tail keeps travelling while the discriminator losses below are
+        # computed — they read neither the generator's parameters nor its gradients (imgs_pred is detached), so
+        # applying the generator's Adam step after them changes nothing.
+        g_pending = csg_dist.world_size() > 1
+        if g_pending:
+            self.g_buckets.flush()
+        else:
             self.optimizer.step()
         self._d_requires_grad(True)
         if opt.learned_converse:
@@ -122,22 +127,33 @@ class Trainer:
         if not opt.skip_generation and opt.freeze_options != "generation":
             D = self.gans_model(batch, model_out, mode="compute_discriminator_loss")
             D = {k: v.mean() for k, v in D.items()}
+            # the three discriminators' backward passes are independent: every all-reduce is in flight (asynchronous)
+            # before the first optimiser step waits for its own
             self.discriminator.optimizer_d_img.zero_grad(set_to_none=True)
+            self.d_buckets.begin()
             D["total_img_loss"].backward()
-            self.d_buckets.all_reduce_mean()
-            self.discriminator.optimizer_d_img.step()
+            self.d_buckets.flush()
             if not opt.use_img_disc:                                    # train.py:478-480
                 self.discriminator.optimizer_d_obj.zero_grad(set_to_none=True)
+                self.dobj_buckets.begin()
                 D["total_obj_loss"].backward()
-                self.dobj_buckets.all_reduce_mean()
-                self.discriminator.optimizer_d_obj.step()
-            if opt.mask_size > 0 and "total_mask_loss" in D:             # train.py:482-485
+                self.dobj_buckets.flush()
+            do_mask = opt.mask_size > 0 and "total_mask_loss" in D       # train.py:482-485
+            if do_mask:
                 self.discriminator.optimizer_d_mask.zero_grad(set_to_none=True)
+                self.dmask_buckets.begin()
                 D["total_mask_loss"].backward()
-                self.dmask_buckets.all_reduce_mean()
+                self.dmask_buckets.flush()
+            self.d_buckets.finish()
+            self.discriminator.optimizer_d_img.step()
+            if not opt.use_img_disc:
+                self.dobj_buckets.finish()
+                self.discriminator.optimizer_d_obj.step()
+            if do_mask:
+                self.dmask_buckets.finish()
                 self.discriminator.optimizer_d_mask.step()
-        if g_pending is not None:
-            self.g_buckets.all_reduce_finish(g_pending)
+        if g_pending:
+            self.g_buckets.finish()
             self.optimizer.step()
         if not opt.use_img_disc:
             self.discriminator.obj_discriminator.release_index()        # the prefetched object list dies with its batch

@@ -189,6 +189,12 @@ int csg_wino_pack_weights(const float* w, int64_t Cout, int64_t Cin, int32_t bac
                           float* packed, void* stream);
 int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, const float* bias,
                   const float* residual, float* y, void* stream);
+/* Weight gradient of the same layers by Winograd F(3x3,2x2): dw [Cout][3][3][Cin] (the layout of
+ * csg_conv_bwd_weight), db (Cout) or NULL; x (B,H,W,Cin) the layer's input, dy (B,H,W,Cout) the gradient of its
+ * pre-activation output.  Deterministic: per-slice slabs in `workspace` + an ordered reduction.              */
+int64_t csg_wino_bwd_weight_workspace(const csg_wino_desc* d);
+int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy, float* dw, float* db, float* workspace,
+                        int64_t workspace_bytes, void* stream);
 
 /* dpre = dy * act'(.) evaluated from the OUTPUT y (leaky: y>0 ? 1 : slope; tanh: 1-y^2)          */
 int csg_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float slope, float* dpre, void* stream);

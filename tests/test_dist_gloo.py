@@ -34,20 +34,43 @@ def _worker(rank, world, port, out):
     full = make_batch(vocab, BatchConfig(4, 8, 2, 4, "random"), seed=3)
     mine = shard_batch(full, rank, world)
     x = mine[2].reshape(mine[2].shape[0], -1)[:, :6]    # boxes as features
+    buckets = D.GradBuckets(list(net.parameters()) + list(unused.parameters()), bucket_bytes=256)
+    # first backward: buckets do not exist yet — they are built at the first synchronisation from the parameters
+    # that received a gradient (the unused module stays out)
+    buckets.begin()
     loss = net(x).pow(2).mean()
     loss.backward()
-    buckets = D.GradBuckets(list(net.parameters()) + list(unused.parameters()), bucket_bytes=256)
-    before = [p.grad.clone() for p in net.parameters()]
+    local = [p.grad.clone() for p in net.parameters()]
     nbytes = buckets.all_reduce_mean()
-    # the split (asynchronous) form must give the same averages
+    assert buckets.built and len(buckets.flats) >= 2 and nbytes == sum(p.numel() for p in net.parameters()) * 4
+    assert all(id(p) not in buckets.slot for p in unused.parameters())
     averaged = [p.grad.clone() for p in net.parameters()]
-    for p, g in zip(net.parameters(), before):
-        p.grad.copy_(g)
-    pending = buckets.all_reduce_start()
-    assert pending is not None and len(pending) >= 2          # 256-byte buckets: several collectives in flight
-    assert buckets.all_reduce_finish(pending) == nbytes
+    allocs = buckets.allocations
+    # steady state: hooks copy each gradient into its slot during the backward and launch the bucket's all-reduce when
+    # its last gradient lands; `.grad` IS the slot afterwards; nothing new is allocated; same averages
+    for p in net.parameters():
+        p.grad = None
+    buckets.begin()
+    net(x).pow(2).mean().backward()
+    launched_in_backward = len(buckets._works)
+    buckets.flush()
+    assert launched_in_backward == len(buckets.flats)         # every bucket was complete before flush()
+    assert buckets.finish() == nbytes and buckets.allocations == allocs
     for p, g in zip(net.parameters(), averaged):
         assert torch.equal(p.grad, g)
+        assert p.grad.data_ptr() == buckets.slot[id(p)][1].data_ptr()
+    # a backward in which one parameter gets no gradient: its slot contributes zeros, the others still average
+    for p in net.parameters():
+        p.grad = None
+    buckets.begin()
+    (net[0](x).pow(2).mean()).backward()                      # only the first Linear
+    buckets.finish()
+    assert net[2].weight.grad is None and net[0].weight.grad is not None
+    for p, g in zip(net.parameters(), local):                 # restore the first result for the checks below
+        p.grad = None
+    buckets.begin()
+    net(x).pow(2).mean().backward()
+    buckets.finish()
     # SyncBN message
     xs = torch.randn(2, 5, 4, 4, generator=torch.Generator().manual_seed(7 + rank)) * (1 + rank) + rank
     C = 5

@@ -18,6 +18,12 @@ SHAPES = [(16, 128, 256, 256), (16, 128, 128, 256), (16, 64, 64, 256), (16, 128,
           (16, 256, 128, 256)]
 
 
+ONLY = [int(a) for a in sys.argv[1:] if a.isdigit()]
+if ONLY:
+    SHAPES = [SHAPES[i] for i in ONLY]
+FWD_ONLY = "--fwd" in sys.argv
+
+
 def bench(fn, n=10):
     fn()
     torch.cuda.synchronize()
@@ -41,6 +47,26 @@ for (B, Cin, Cout, H) in SHAPES:
         with torch.no_grad():
             ms = bench(lambda: ops.conv2d(x, w, b, 1, 1))
         out[mode] = ms
-    print("Cin %4d Cout %4d %3dx%-3d  wino %7.3f ms %6.1f TF | direct %7.3f ms %6.1f TF | x%.2f" %
+    if FWD_ONLY:
+        print("Cin %4d Cout %4d %3dx%-3d  fwd: wino %7.3f ms %6.1f TF | direct %7.3f ms %6.1f TF" %
+              (Cin, Cout, H, H, out["wino"], flop / out["wino"] / 1e9, out["direct"], flop / out["direct"] / 1e9), flush=True)
+        continue
+    # weight gradient: time backward with only the weight requiring grad
+    wg = {}
+    for mode in ("wino", "direct"):
+        ops.WINO_ENABLED = True
+        ops.WINO_WGRAD = mode == "wino"
+        wr = w.clone().requires_grad_(True)
+        y = ops.conv2d(x, wr, None, 1, 1)
+        gy = torch.randn_like(y)
+
+        def run():
+            wr.grad = None
+            y.backward(gy, retain_graph=True)
+        wg[mode] = bench(run, 5)
+    ops.WINO_WGRAD = True
+    print("Cin %4d Cout %4d %3dx%-3d  fwd: wino %7.3f ms %6.1f TF | direct %7.3f ms %6.1f TF | x%.2f   wgrad: wino %7.3f ms "
+          "%6.1f TF | direct %7.3f ms %6.1f TF | x%.2f" %
           (Cin, Cout, H, H, out["wino"], flop / out["wino"] / 1e9, out["direct"], flop / out["direct"] / 1e9,
-           out["direct"] / out["wino"]), flush=True)
+           out["direct"] / out["wino"], wg["wino"], flop / wg["wino"] / 1e9, wg["direct"], flop / wg["direct"] / 1e9,
+           wg["direct"] / wg["wino"]), flush=True)
