@@ -530,102 +530,99 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
 // bit-reproducible result; the bias gradient rides along in wave 1, which loads all four pixels of every dY tile.
 struct WinoWgParams {
   int B, H, W, Cin, x_cs, Cout, y_cs;
-  int TXn, TYn, ntiles;
+  int RXn, RYn, nregions;        // stage regions per tile row / column of an image, in all
   int cblocks, kblocks;
-  int nsplit, tps;               // tiles per split (even)
+  int nsplit, rps;               // regions per split
 };
 
 #define WG_EPS 33                // words per row of the epilogue exchange buffer
 
+// Stage = TSX x TSY = 16 tiles (8 k-pairs of v_mfma_f32_32x32x2_f32) of one image: its (2TSY+2) x (2TSX+2) input
+// patch and 2TSY x 2TSX dY pixels, 64 channels each, are staged in LDS by 16-byte global loads (13 per thread and
+// stage; the first version fetched every operand with its own dword load — 24 VMEM instructions per 16 MFMAs, and one
+// VMEM issue costs the lone wave of a SIMD ~40 matrix-pipe cycles).  Operands are then read with ds_read_b32 (32
+// consecutive channels per half-wave: conflict-free), transformed in registers (G dY G^T without its 1/2 factors,
+// which are folded into the epilogue; B^T X B) and fed to 16 MFMAs per k-pair.  Two LDS buffers, global loads of stage
+// s+1 issued before the MFMAs of stage s, one barrier per stage.  Regions tile the image exactly (host-checked), so
+// only the one-pixel halo needs masking: per-thread flags x uniform edge conditions, one v_cndmask per load; the
+// region's position rides in the scalar offset of the buffer loads.
+template <int TSX>
 __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const float* __restrict__ x,
                                                         const float* __restrict__ dy, float* __restrict__ slabs,
                                                         float* __restrict__ dbslabs) {
+  constexpr int TSY = 16 / TSX;
+  constexpr int XR = 2 * TSY + 2, XC = 2 * TSX + 2, YR = 2 * TSY, YC = 2 * TSX;
+  constexpr int NLX = (XR * XC * 16 + 255) / 256, NLY = (YR * YC * 16) / 256;
+  static_assert((YR * YC * 16) % 256 == 0, "dY staging divides evenly");
+  constexpr int XW = NLX * 256 * 4, YW = YR * YC * 64, BUFW = XW + YW;     // words; the X area is padded to whole DMAs
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   int bid = wn_xcd_remap(blockIdx.x, gridDim.x);
-  // all (cout block, cin block) pairs of one tile slice are adjacent: the slice's dY and X stay in that XCD's L2
+  // all (cout block, cin block) pairs of one slice are adjacent: the slice's dY and X stay in that XCD's L2
   const int kb = bid % p.kblocks;
   bid /= p.kblocks;
   const int cb = bid % p.cblocks;
   const int sp = bid / p.cblocks;
-  const int t0 = sp * p.tps, t1 = min(p.ntiles, t0 + p.tps);
+  const int r0 = sp * p.rps, r1 = min(p.nregions, r0 + p.rps);
 
-  // rows of the dY tile / of the input patch this wave combines
-  //   e = G dY:  xi=0: dY0;  1: (dY0+dY1)/2;  2: (dY0-dY1)/2;  3: dY1
-  //   r = B^T X: xi=0: X0-X2;  1: X1+X2;  2: X2-X1;  3: X3-X1
-  const bool need0 = wave != 3, need1 = wave != 0;
-  const float ea = wave == 0 ? 1.f : (wave == 3 ? 0.f : 0.5f);
-  const float eb = wave == 0 ? 0.f : (wave == 3 ? 1.f : (wave == 1 ? 0.5f : -0.5f));
+  // rows of the dY tile / of the input patch this wave combines (unscaled: the 1/2 of G are applied in the epilogue)
+  //   e = G dY:  xi=0: dY0;  1: dY0+dY1;  2: dY0-dY1;  3: dY1          r = B^T X: xi=0: X0-X2; 1: X1+X2; 2: X2-X1; 3: X3-X1
   const int ia = wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? 2 : 3));
   const int ib = wave == 0 ? 2 : (wave == 1 ? 2 : 1);
   const float sgn = wave == 1 ? 1.0f : -1.0f;
+  const float ea = wave == 3 ? 0.f : 1.f;
+  const float eb = wave == 0 ? 0.f : (wave == 2 ? -1.f : 1.f);
 
-  int co[2], ci[2];
-  bool cok[2], kok[2];
+  // ---- staging plan (k-invariant).  Staging is LDS-DMA (buffer_load_dwordx4 ... lds): element e = tid + 256 i of
+  // the linear [pixel][64 channels] image lands at LDS byte 16 e — exactly the wave-uniform base + 16 * lane the
+  // instruction writes — so the stage costs no VGPRs and no ds_write; out-of-range lanes (halo outside the image,
+  // channel tail, padding of the last DMA) are written as zeros.  Relative byte offsets inside the region (the X
+  // descriptor sits one row + one pixel before the tensor, so halo offsets are non-negative) and halo flags:
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(x - (int64_t)(p.W + 1) * p.x_cs), 0, (int)(((long long)p.B * p.H * p.W + p.W + 1) * p.x_cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY =
+      __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long long)p.B * p.H * p.W * p.y_cs * 4), 0x00020000);
+  unsigned xoff[NLX], yoff[NLY];
+  int xflag[NLX];                                // flag bits: 1 first row, 2 last row, 4 first col, 8 last col
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    co[m] = cb * 64 + m * 32 + c;
-    cok[m] = co[m] < p.Cout;
-    ci[m] = kb * 64 + m * 32 + c;
-    kok[m] = ci[m] < p.Cin;
+  for (int i = 0; i < NLX; ++i) {
+    const int e = tid + 256 * i;
+    const int pix = e >> 4, c4 = e & 15;
+    const int row = pix / XC, col = pix - row * XC;
+    const int ch = kb * 64 + c4 * 4;
+    const bool ok = (e < XR * XC * 16) & (ch < p.Cin);
+    xoff[i] = ok ? (unsigned)((row * p.W + col) * p.x_cs + ch) * 4u : CSG_OOB_OFF;
+    xflag[i] = (row == 0 ? 1 : 0) | (row == XR - 1 ? 2 : 0) | (col == 0 ? 4 : 0) | (col == XC - 1 ? 8 : 0);
   }
+#pragma unroll
+  for (int i = 0; i < NLY; ++i) {
+    const int e = tid + 256 * i;
+    const int pix = e >> 4, c4 = e & 15;
+    const int row = pix / YC, col = pix - row * YC;
+    const int ch = cb * 64 + c4 * 4;
+    yoff[i] = ch < p.Cout ? (unsigned)((row * p.W + col) * p.y_cs + ch) * 4u : CSG_OOB_OFF;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto dma_stage = [&](int r, int bufsel) {      // region r -> (image, region row, region column); r >= r1: not consumed
+    const int rr = min(r, p.nregions - 1);
+    const int rx = rr % p.RXn, t = rr / p.RXn;
+    const int ry = t % p.RYn, img = t / p.RYn;
+    const int y0 = ry * 2 * TSY, x0 = rx * 2 * TSX;
+    const int edge = (y0 == 0 ? 1 : 0) | (y0 + 2 * TSY == p.H ? 2 : 0) | (x0 == 0 ? 4 : 0) | (x0 + 2 * TSX == p.W ? 8 : 0);
+    const int pix0 = (img * p.H + y0) * p.W + x0;
+    float* base = smem + bufsel * BUFW + wave * 256;       // this wave's 64 x 16 bytes of every 256-lane DMA row
+#pragma unroll
+    for (int i = 0; i < NLX; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(base + i * 1024), 16,
+                                               (int)((xflag[i] & edge) ? CSG_OOB_OFF : xoff[i]), pix0 * p.x_cs * 4, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NLY; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_ptr)(base + XW + i * 1024), 16, (int)yoff[i], pix0 * p.y_cs * 4, 0, 0);
+  };
+
   const bool do_db = dbslabs != nullptr && kb == 0 && wave == 1;
   float dbacc[2] = {0.f, 0.f};
-
-  // position of the next tile this lane loads: tile t0 + h, then steps of 2
-  int tl = t0 + h;
-  int tx = tl % p.TXn, trow = tl / p.TXn;
-  int ty = trow % p.TYn, img = trow / p.TYn;
-  auto advance = [&]() {
-    tl += 2;
-    tx += 2;
-    if (tx >= p.TXn) {
-      tx -= p.TXn;
-      ty += 1;
-      if (ty >= p.TYn) {
-        ty = 0;
-        img += 1;
-      }
-    }
-  };
-
-  struct Raw {
-    float dy[2][2][2];   // [cout group][row][col]
-    float xr[2][2][4];   // [cin group][row a/b][col]
-  };
-  const csg_i32x4 rsX = csg_make_srd(x, (long long)p.B * p.H * p.W * p.x_cs * 4);
-  const csg_i32x4 rsY = csg_make_srd(dy, (long long)p.B * p.H * p.W * p.y_cs * 4);
-  auto load_pair = [&](Raw& r) {                 // branch-free: absent elements get an out-of-range offset -> 0
-    const bool ok = tl < t1;
-    const int y0 = 2 * ty, x0 = 2 * tx;
-    const int pix0 = (img * p.H + y0) * p.W + x0;                  // first pixel of the dY tile
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jx = 0; jx < 2; ++jx) {
-          const bool v = ok & cok[m] & (i == 0 ? need0 : need1);
-          const unsigned off = (unsigned)((pix0 + i * p.W + jx) * p.y_cs + co[m]) * 4u;
-          r.dy[m][i][jx] = csg_buf_load_x1(rsY, (int)(v ? off : CSG_OOB_OFF), 0, 0);
-        }
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const int dyr = -1 + (rr == 0 ? ia : ib);
-        const int iy = y0 + dyr;
-        const bool rowok = ok & kok[m] & (iy >= 0) & (iy < p.H);
-#pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-          const int ix = x0 - 1 + jx;
-          const bool v = rowok & (ix >= 0) & (ix < p.W);
-          const unsigned off = (unsigned)((pix0 + dyr * p.W + jx - 1) * p.x_cs + ci[m]) * 4u;
-          r.xr[m][rr][jx] = csg_buf_load_x1(rsX, (int)(v ? off : CSG_OOB_OFF), 0, 0);
-        }
-      }
-    }
-    advance();
-  };
 
   f32x16 acc[4][2][2];
 #pragma unroll
@@ -637,6 +634,29 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nu][mt][nt][e] = 0.f;
 
+  struct Raw {
+    float dy[2][2][2];   // [cout group][row][col]
+    float xr[2][2][4];   // [cin group][row a/b][col]
+  };
+  // tile t = 2*kp + h of the stage: (tsx, tsy) = (t % TSX, t / TSX); every offset is an immediate once kp is unrolled
+  const float* lx = smem + h * (2 * 64) + c;     // h = 1: the next tile, two pixels to the right (TSX is even)
+  auto read_pair = [&](int bufsel, int kp, Raw& r) {
+    const int t = 2 * kp, tsx = t % TSX, tsy = t / TSX;
+    const float* bx = lx + bufsel * BUFW;
+    const float* by = bx + XW;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx) r.dy[m][i][jx] = by[((2 * tsy + i) * YC + 2 * tsx + jx) * 64 + m * 32];
+#pragma unroll
+      for (int jx = 0; jx < 4; ++jx) {
+        r.xr[m][0][jx] = bx[((2 * tsy + ia) * XC + 2 * tsx + jx) * 64 + m * 32];
+        r.xr[m][1][jx] = bx[((2 * tsy + ib) * XC + 2 * tsx + jx) * 64 + m * 32];
+      }
+    }
+  };
   auto compute_pair = [&](const Raw& r) {
     float E[4][2], V[4][2];
 #pragma unroll
@@ -644,8 +664,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
       const float e0 = ea * r.dy[m][0][0] + eb * r.dy[m][1][0];
       const float e1 = ea * r.dy[m][0][1] + eb * r.dy[m][1][1];
       E[0][m] = e0;
-      E[1][m] = 0.5f * (e0 + e1);
-      E[2][m] = 0.5f * (e0 - e1);
+      E[1][m] = e0 + e1;
+      E[2][m] = e0 - e1;
       E[3][m] = e1;
       if (do_db) dbacc[m] += (r.dy[m][0][0] + r.dy[m][0][1]) + (r.dy[m][1][0] + r.dy[m][1][1]);
       float q[4];
@@ -665,21 +685,46 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
           acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(E[nu][mt], V[nu][nt], acc[nu][mt][nt], 0, 0, 0);
   };
 
-  // ---- main loop over tile pairs, raw loads one pair ahead (two named register sets)
-  const int npairs = (t1 - t0 + 1) / 2;
+  // one stage out of buffer `bufsel` (compile-time): reads of pair kp+1 are issued before the MFMAs of pair kp
   Raw ra, rb;
-  if (npairs > 0) load_pair(ra);
-  int kp = 0;
-  for (; kp + 1 < npairs; kp += 2) {
-    load_pair(rb);
-    compute_pair(ra);
-    if (kp + 2 < npairs) load_pair(ra);
+  auto stage = [&](int r, auto bufsel_tag) {
+    constexpr int bufsel = decltype(bufsel_tag)::value;
+    dma_stage(r + 1, bufsel ^ 1);                // the buffer every wave finished reading before the last barrier
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kp = 0; kp < 8; kp += 2) {
+      read_pair(bufsel, kp + 1, rb);
+      compute_pair(ra);
+      __builtin_amdgcn_sched_barrier(0);         // keeps the LDS reads one pair ahead, not eight (registers)
+      if (kp + 2 < 8) {
+        read_pair(bufsel, kp + 2, ra);
+        compute_pair(rb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                             // (its fence waits for this wave's DMAs: vmcnt(0))
+    read_pair(bufsel ^ 1, 0, ra);                // first pair of the next stage under the last MFMAs of this one
     compute_pair(rb);
-  }
-  if (kp < npairs) compute_pair(ra);
+    __builtin_amdgcn_sched_barrier(0);
+  };
 
-  // ---- epilogue: R_xi[b] = sum_nu Acc[xi][nu] A^T[b][nu] per wave; dW[a][b] = sum_xi A^T[a][xi] R_xi[b] through LDS,
+  if (r0 < r1) {
+    dma_stage(r0, 0);
+    __syncthreads();
+    read_pair(0, 0, ra);
+    int r = r0;
+    for (; r + 1 < r1; r += 2) {
+      stage(r, std::integral_constant<int, 0>());
+      stage(r + 1, std::integral_constant<int, 1>());
+    }
+    if (r < r1) stage(r, std::integral_constant<int, 0>());
+  }
+  __syncthreads();
+
+  // ---- epilogue: with g = (1, 1/2, 1/2, 1) the true accumulators are g_xi g_nu Acc'.  Per wave
+  //      R_xi[b] = g_xi sum_nu g_nu Acc'[xi][nu] A^T[b][nu];  dW[a][b] = sum_xi A^T[a][xi] R_xi[b] through LDS,
   //      one 32x32 (cout, cin) quadrant at a time; slab layout [split][Cout][tap = 3a+b][Cin]
+  const float gx = (wave == 1 || wave == 2) ? 0.5f : 1.0f;
   float* slab = slabs + (int64_t)sp * p.Cout * 9 * p.Cin;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -687,11 +732,11 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float a0 = acc[0][mt][nt][e], a1 = acc[1][mt][nt][e], a2 = acc[2][mt][nt][e], a3 = acc[3][mt][nt][e];
+        const float a0 = acc[0][mt][nt][e], a1 = 0.5f * acc[1][mt][nt][e], a2 = 0.5f * acc[2][mt][nt][e], a3 = acc[3][mt][nt][e];
         const int i = (e & 3) + 8 * (e >> 2) + 4 * h;             // cout row inside the quadrant
-        smem[((wave * 3 + 0) * 32 + i) * WG_EPS + c] = a0 + a1 + a2;
-        smem[((wave * 3 + 1) * 32 + i) * WG_EPS + c] = a1 - a2;
-        smem[((wave * 3 + 2) * 32 + i) * WG_EPS + c] = a1 + a2 + a3;
+        smem[((wave * 3 + 0) * 32 + i) * WG_EPS + c] = gx * (a0 + a1 + a2);
+        smem[((wave * 3 + 1) * 32 + i) * WG_EPS + c] = gx * (a1 - a2);
+        smem[((wave * 3 + 2) * 32 + i) * WG_EPS + c] = gx * (a1 + a2 + a3);
       }
       __syncthreads();
       const int kcol = tid & 31;
@@ -721,7 +766,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const float tot = dbacc[m] + __shfl_xor(dbacc[m], 32, 64);
-      if (h == 0 && cok[m]) dbslabs[(int64_t)sp * p.Cout + co[m]] = tot;
+      const int co = cb * 64 + m * 32 + c;
+      if (h == 0 && co < p.Cout) dbslabs[(int64_t)sp * p.Cout + co] = tot;
     }
   }
 }
@@ -734,32 +780,36 @@ __global__ void k_wino_slab_reduce(const float* __restrict__ ws, int64_t n, int 
   out[i] = a;
 }
 
+static int wn_wg_tsx(int W) { return W >= 32 ? 16 : (W >= 16 ? 8 : 4); }
+
 static int wn_wg_plan(const csg_wino_desc* d, WinoWgParams& p, const char* who) {
   CSG_REQUIRE(d != nullptr, CSG_E_BADSHAPE, "%s: null descriptor", who);
   CSG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, CSG_E_BADSHAPE, "%s: non-positive dimension", who);
-  CSG_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0 && d->W >= 4, CSG_E_UNSUPPORTED, "%s: H=%d, W=%d must be even", who, d->H, d->W);
-  CSG_REQUIRE(d->x_cs >= d->Cin && d->y_cs >= d->Cout, CSG_E_BADSHAPE, "%s: channel strides", who);
-  CSG_REQUIRE((int64_t)d->B * d->H * d->W * (int64_t)(d->x_cs > d->y_cs ? d->x_cs : d->y_cs) * 4 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
-              "%s: tensor too large for 32-bit byte offsets", who);
+  const int tsx = wn_wg_tsx(d->W), tsy = 16 / tsx;
+  CSG_REQUIRE(d->W >= 8 && d->W % (2 * tsx) == 0 && d->H % (2 * tsy) == 0, CSG_E_UNSUPPORTED,
+              "%s: H=%d, W=%d must be multiples of the %dx%d-tile stage", who, d->H, d->W, tsx, tsy);
+  CSG_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0 && d->x_cs % 4 == 0 && d->y_cs % 4 == 0 && d->x_cs >= d->Cin &&
+                  d->y_cs >= d->Cout,
+              CSG_E_UNSUPPORTED, "%s: channel counts and strides must be multiples of 4", who);
+  CSG_REQUIRE(((int64_t)d->B * d->H * d->W + d->W + 1) * (int64_t)(d->x_cs > d->y_cs ? d->x_cs : d->y_cs) * 4 < CSG_MAX_RECORDS,
+              CSG_E_UNSUPPORTED, "%s: tensor too large for 32-bit byte offsets", who);
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_cs = d->x_cs; p.Cout = d->Cout; p.y_cs = d->y_cs;
-  p.TXn = d->W / 2;
-  p.TYn = d->H / 2;
-  const int64_t nt = (int64_t)d->B * p.TXn * p.TYn;
-  CSG_REQUIRE(nt < (1ll << 30), CSG_E_UNSUPPORTED, "%s: too many tiles", who);
-  p.ntiles = (int)nt;
+  p.RXn = d->W / (2 * tsx);
+  p.RYn = d->H / (2 * tsy);
+  const int64_t nr = (int64_t)d->B * p.RXn * p.RYn;
+  CSG_REQUIRE(nr < (1ll << 30), CSG_E_UNSUPPORTED, "%s: too many regions", who);
+  p.nregions = (int)nr;
   p.cblocks = (d->Cout + 63) / 64;
   p.kblocks = (d->Cin + 63) / 64;
-  // one block per CU is resident: aim at ~2 waves of blocks, at least 64 tile pairs per block, at most 512 slabs
+  // one block per CU is resident: aim at ~2 waves of blocks, at least 8 stages per block, at most 512 slabs
   const int tiles2d = p.cblocks * p.kblocks;
   int ns = (512 + tiles2d - 1) / tiles2d;
-  const int max_ns = (int)((nt + 127) / 128);
+  const int max_ns = (int)((nr + 7) / 8);
   if (ns > max_ns) ns = max_ns;
   if (ns > 512) ns = 512;
   if (ns < 1) ns = 1;
-  int tps = (int)((nt + ns - 1) / ns);
-  tps += tps & 1;
-  p.tps = tps;
-  p.nsplit = (int)((nt + tps - 1) / tps);
+  p.rps = (int)((nr + ns - 1) / ns);
+  p.nsplit = (int)((nr + p.rps - 1) / p.rps);
   return CSG_OK;
 }
 
@@ -783,18 +833,32 @@ int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy,
   static bool attr_set[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const size_t shm = (size_t)4 * 3 * 32 * WG_EPS * 4;
+  const int tsx = wn_wg_tsx(d->W), tsy = 16 / tsx;
+  // per buffer: the X patch padded to whole 256-lane DMAs + the dY pixels, 64 channels x 4 bytes each
+  const size_t x_f4 = (size_t)(((2 * tsy + 2) * (2 * tsx + 2) * 16 + 255) / 256) * 256;
+  const size_t stage_bytes = 2 * (x_f4 * 16 + (size_t)(2 * tsy) * (2 * tsx) * 64 * 4);
+  const size_t ep_bytes = (size_t)4 * 3 * 32 * WG_EPS * 4;
+  const size_t shm = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wino_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino_bwd_weight: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    const void* fns[3] = {(const void*)k_wino_wgrad<16>, (const void*)k_wino_wgrad<8>, (const void*)k_wino_wgrad<4>};
+    for (const void* fn : fns) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino_bwd_weight: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }
     attr_set[dev] = true;
   }
+  CSG_REQUIRE(shm <= 128 * 1024, CSG_E_UNSUPPORTED, "csg_wino_bwd_weight: %zu bytes of LDS", shm);
   hipStream_t s = (hipStream_t)stream;
   float* dbslabs = db != nullptr ? workspace + (int64_t)p.nsplit * wsize : nullptr;
   {
     ProfScope ps(K_WINO_WGRAD, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
-    hipLaunchKernelGGL(k_wino_wgrad, dim3((unsigned)(p.cblocks * p.kblocks * p.nsplit)), dim3(256), shm, s, p, x, dy, workspace,
-                       dbslabs);
+    const dim3 grid((unsigned)(p.cblocks * p.kblocks * p.nsplit));
+    if (tsx == 16)
+      hipLaunchKernelGGL(k_wino_wgrad<16>, grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+    else if (tsx == 8)
+      hipLaunchKernelGGL(k_wino_wgrad<8>, grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+    else
+      hipLaunchKernelGGL(k_wino_wgrad<4>, grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
     rc = check_launch("csg_wino_bwd_weight");
     if (rc) return rc;
   }

@@ -206,13 +206,14 @@ class _Conv2d(torch.autograd.Function):
             for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
                 _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        wino_wg = -1
         if ctx.needs_input_grad[1] and WINO_WGRAD and wino_eligible(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
-            # Winograd F(3x3,2x2) weight gradient (csrc/wino.hip), same output layout as the direct kernel
             d = WinoDesc()
             d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, IH, IW, Cin, Cin, Cout, Cout, ACT_NONE, 0.0
-            nbytes = lib.csg_wino_bwd_weight_workspace(d)
-            if nbytes < 0:
-                raise RuntimeError("wino_bwd_weight_workspace: " + _lib.last_error())
+            wino_wg = lib.csg_wino_bwd_weight_workspace(d)      # < 0: the 16-tile stages do not tile this image exactly
+        if wino_wg >= 0:
+            # Winograd F(3x3,2x2) weight gradient (csrc/wino.hip), same output layout as the direct kernel
+            nbytes = wino_wg
             ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
             dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
             if want_db:

@@ -109,11 +109,33 @@ def test_conv2d_autograd_uses_winograd(ops, shape):
     assert_close(bd.grad, br.grad, 1e-4, 1e-5 * float(br.grad.abs().max()) + 1e-5, "db")
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 32, 8, 8), (1, 20, 36, 12, 20), (3, 64, 100, 24, 40), (2, 96, 64, 64, 64),
-                                   (1, 128, 256, 128, 128), (5, 32, 128, 6, 130)])
+def test_wino_weight_gradient_rejects_images_its_stages_do_not_tile(ops):
+    """The F(3x3,2x2) kernel stages 16 tiles (16x1, 8x2 or 4x4) at a time and wants them to tile the image exactly;
+    other sizes are refused by the C ABI (the autograd op then keeps the direct kernel)."""
+    from canonicalsg2im_amd._lib import WinoDesc, lib
+    for (H, W, ok) in ((12, 20, False), (24, 40, False), (6, 130, False), (8, 8, True), (4, 16, True), (2, 64, True)):
+        d = WinoDesc()
+        d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = 1, H, W, 16, 16, 32, 32, 0, 0.0
+        assert (lib.csg_wino_bwd_weight_workspace(d) >= 0) == ok, (H, W)
+    x = torch.randn(20, 16, 24, 40, device="cuda", requires_grad=True)       # eligible forward, ragged for the wgrad
+    w = (torch.randn(32, 16, 3, 3, device="cuda") / 12.0).requires_grad_(True)
+    assert ops.wino_eligible(20, 24, 40, 16, 32, 3, 3, 1, 1)
+    y = ops.conv2d(x, w, None, 1, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr, wr = x.detach().cpu().requires_grad_(True), w.detach().cpu().requires_grad_(True)
+    ref = F.conv2d(xr, wr, padding=1)
+    ref.backward(gy.cpu())
+    assert_close(y, ref, 1e-4, 2e-5, "y")
+    assert_close(w.grad, wr.grad, 1e-4, 1e-5 * float(wr.grad.abs().max()), "dw (direct kernel fallback)")
+    assert_close(x.grad, xr.grad, 1e-4, 1e-5 * float(xr.grad.abs().max()), "dx")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32, 8, 8), (1, 20, 36, 16, 16), (3, 64, 100, 24, 32), (2, 96, 64, 64, 64),
+                                   (1, 128, 256, 128, 128), (5, 32, 128, 6, 128), (3, 36, 68, 10, 64)])
 def test_wino_weight_gradient_vs_torch(ops, shape):
     """csg_wino_bwd_weight (F(3x3,2x2)) through the C ABI: dW in the direct kernel's [Cout][3][3][Cin] layout and the
-    bias gradient, channel tails, odd tile counts (ragged last tile pair), several tile slices."""
+    bias gradient; channel tails, every stage geometry (4x4, 8x2, 16x1 tiles), odd region counts, several slices."""
     from canonicalsg2im_amd._lib import WinoDesc, check, lib, ptr, stream
     B, Cin, Cout, H, W = shape
     g = torch.Generator().manual_seed(sum(shape) + 1)
