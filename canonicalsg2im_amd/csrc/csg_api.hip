@@ -33,7 +33,7 @@ struct Rec {
   double work;
   hipEvent_t e0, e1;
 };
-static int g_prof = 0;   // 0 off, 1 every kernel, 2 only the dominant one (k_igemm_fwd<128>)
+static int g_prof = 0;   // 0 off, 1 every kernel, 2 only the dominant convolution kernels (k_wino_conv, k_igemm_fwd<128>)
 static std::mutex g_mu;
 static std::vector<Rec> g_pending;
 static std::vector<hipEvent_t> g_free;
@@ -42,7 +42,7 @@ static double g_work[K_COUNT];
 static int64_t g_n[K_COUNT];
 static Rec g_cur;
 
-bool prof_on(int kid) { return g_prof == 1 || (g_prof == 2 && kid == K_IGEMM_FWD); }
+bool prof_on(int kid) { return g_prof == 1 || (g_prof == 2 && (kid == K_IGEMM_FWD || kid == K_WINO_CONV)); }
 
 static hipEvent_t get_event() {
   if (!g_free.empty()) {

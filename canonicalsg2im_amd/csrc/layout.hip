@@ -170,6 +170,21 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
           axis_taps(ty, bx[o * 4 + 1], bx[o * 4 + 3], M, iy0, wy, wy1);
           act = (wy != 0.0f) || (wy1 != 0.0f);
         }
+        // dense scenes (config C5: 128 objects per image): also drop the objects whose x support misses this block's
+        // pixel chunk.  The bilinear weight vanishes outside  x0 - w/(2n) < t < x0 + w (1 + 1/(2n))  (n source
+        // pixels); the test keeps one output pixel of slack on each side, and a skipped object would have added
+        // exact zeros, so the sum — and its order among the remaining objects — is unchanged.
+        if (act) {
+          const float bx0 = bx[o * 4 + 0], bw = bx[o * 4 + 2];
+          const float n = masks == nullptr ? 8.0f : (float)M;
+          const float lo = fminf(bx0 - bw / (2.0f * n), bx0 + bw * (1.0f + 1.0f / (2.0f * n)));
+          const float hi = fmaxf(bx0 - bw / (2.0f * n), bx0 + bw * (1.0f + 1.0f / (2.0f * n)));
+          const int xs0 = min((int)(((int64_t)x0 * W) / OW), W - 1);
+          const int xs1 = min((int)(((int64_t)(x0 + npx - 1) * W) / OW), W - 1);
+          const float step = W > 1 ? 1.0f / (float)(W - 1) : 1.0f;
+          // (NaN boxes fail neither comparison: they stay active, as in the reference)
+          if (lin01(xs1, W) + step < lo || lin01(xs0, W) - step > hi) act = false;
+        }
       }
       unsigned long long m = __ballot(act);
       int slot = __popcll(m & ((1ull << tid) - 1ull));

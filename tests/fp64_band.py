@@ -85,3 +85,70 @@ class Band:
         assert self.rows, tag + ": nothing compared"
         assert not self.bad, "%s: %d of %d gradient tensors outside the fp32 noise band\n%s" % (
             tag, len(self.bad), len(self.rows), "\n".join(self.bad[:25]))
+
+
+# ---------------------------------------------------------------------------------------------- one training step
+def grad_rows(named_params, state32, state64, skip=("repr_net", "image_encoder")):
+    """[(name, hip grad, fp32 oracle grad, fp64 oracle grad)] for every parameter all three sides hold a gradient for."""
+    rows = []
+    for k, p in named_params:
+        if any(s in k for s in skip) or state32 is None or k not in state32:
+            continue
+        o, o64 = state32[k], state64[k]
+        if p.grad is None or not torch.is_tensor(o) or o.grad is None or o64.grad is None:
+            continue
+        rows.append((k, p.grad, o.grad, o64.grad))
+    return rows
+
+
+def step_against_oracles(tr, batch, oracle_mod, train_mod):
+    """Run ONE `Trainer.step` on the HIP path and the same step on the oracle in fp32 and in fp64 (same weights).
+
+    Generator / graph-encoder gradients: the three evaluations see identical inputs.  Discriminator gradients: the
+    discriminator update sees the GENERATED image, |img| ~ 0.05 at initialisation, so the 1e-5 absolute fp32 noise of
+    a 60-convolution generator is 1e-4..1e-3 relative and the discriminators' gradients are linear in their input.
+    To test the discriminators' own arithmetic at the contract's level they are fed the same image on every side:
+    the oracle's discriminator losses are evaluated (fp32 and fp64) on the image the HIP generator produced, after the
+    two spectral-norm iterations of the generator-loss passes, exactly as in the step."""
+    opt = tr.opt
+    ts = train_mod.oracle_state_from(tr, oracle_mod)
+    ts64 = trainstate_to64(ts, oracle_mod)
+    tsd = train_mod.oracle_state_from(tr, oracle_mod)
+    tsd64 = trainstate_to64(tsd, oracle_mod)
+    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    torch.cuda.synchronize()
+    Go, Do, img_o = oracle_mod.train_step(ts, batch)
+    _, _, img64 = oracle_mod.train_step(ts64, batch_to64(batch))
+    if not opt.skip_generation:
+        for state, cast in ((tsd, lambda t: t), (tsd64, lambda t: t.double())):
+            mo = tuple(None if t is None else cast(t.detach().cpu().float()) for t in tr.last_model_out)
+            b = batch if state is tsd else batch_to64(batch)
+            with torch.no_grad():
+                oracle_mod.generator_losses(opt, state.d, b, mo, dobj_state=state.dobj, dmask_state=state.dmask)
+            Dl = oracle_mod.discriminator_losses(opt, state.d, b, mo, dobj_state=state.dobj, dmask_state=state.dmask)
+            Dl["total_img_loss"].backward()
+            if state.dobj is not None:
+                Dl["total_obj_loss"].backward()
+            if "total_mask_loss" in Dl:
+                Dl["total_mask_loss"].backward()
+    rows = {"SG": grad_rows(tr.model.sg_to_layout.module.named_parameters(), ts.sg, ts64.sg) if hasattr(tr.model, "sg_to_layout") else []}
+    if not opt.skip_generation:
+        rows["G"] = grad_rows(tr.model.layout_to_image_model.module.named_parameters(), ts.g, ts64.g)
+        rows["D"] = grad_rows(tr.discriminator.img_discriminator.named_parameters(), tsd.d, tsd64.d)
+        if tsd.dobj is not None:
+            rows["Dobj"] = grad_rows(tr.discriminator.obj_discriminator.named_parameters(), tsd.dobj, tsd64.dobj)
+        if tsd.dmask is not None:
+            rows["Dmask"] = grad_rows(tr.discriminator.mask_discriminator.named_parameters(), tsd.dmask, tsd64.dmask)
+    return {"G": G, "D": D, "Go": Go, "Do": Do, "img_o": img_o, "img64": img64, "ts": ts, "ts64": ts64, "rows": rows}
+
+
+def band_of(res, tr, tag, dump=None, **kw):
+    band = Band(**kw)
+    if res["img_o"] is not None:
+        band.add("imgs_pred (judged by rtol 1e-4 elsewhere)", tr.last_model_out[0], res["img_o"], res["img64"])
+        band.bad = []
+    for group, rows in res["rows"].items():
+        for k, mine, want, want64 in rows:
+            band.add("%s %s" % (group, k), mine, want, want64)
+    band.check(tag, dump=dump)
+    return band

@@ -15,7 +15,7 @@ import pytest
 import torch
 
 from conftest import ROOT, assert_close
-from fp64_band import Band, batch_to64, state_to64, trainstate_to64
+from fp64_band import Band, band_of, grad_rows, state_to64, step_against_oracles
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -33,19 +33,6 @@ def scaled_close(mine, want, msg, rel_atol=1e-5, floor=1e-7):
     assert_close(mine, want, RTOL, rel_atol * float(want.abs().max()) + floor, msg)
 
 
-def _grad_table(named_params, state32, state64, skip=("repr_net", "image_encoder")):
-    """[(name, hip grad, fp32 oracle grad, fp64 oracle grad)] for every parameter all sides hold a gradient for."""
-    rows = []
-    for k, p in named_params:
-        if any(s in k for s in skip) or k not in state32:
-            continue
-        o, o64 = state32[k], state64[k]
-        if p.grad is None or not torch.is_tensor(o) or o.grad is None or o64.grad is None:
-            continue
-        rows.append((k, p.grad, o.grad, o64.grad))
-    return rows
-
-
 def _run_step(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed):
     import oracle
     from canonicalsg2im_amd import train as T
@@ -55,17 +42,12 @@ def _run_step(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed):
     assert opt.ngf == 64 and opt.ndf == 64 and opt.gconv_hidden_dim == 512 and opt.gconv_dim == 128
     torch.manual_seed(seed)
     tr = T.Trainer(opt, cuda)
-    ts = T.oracle_state_from(tr, oracle)
-    ts64 = trainstate_to64(ts, oracle)
     batch = make_batch(vocab, batch_cfg, seed=batch_seed)
-    G, D = tr.step([None if t is None else t.cuda() for t in batch])
-    torch.cuda.synchronize()
-    Go, Do, img_o = oracle.train_step(ts, batch)
-    oracle.train_step(ts64, batch_to64(batch))
-    return tr, ts, ts64, G, D, Go, Do, img_o
+    return tr, step_against_oracles(tr, batch, oracle, T)
 
 
-def _check_step(tr, ts, ts64, G, D, Go, Do, img_o, tag):
+def _check_step(tr, res, tag):
+    G, D, Go, Do, img_o = res["G"], res["D"], res["Go"], res["Do"], res["img_o"]
     assert set(G) == set(Go) and set(D) == set(Do)
     for k in Go:
         if k == "bbox_pred_all":
@@ -77,10 +59,8 @@ def _check_step(tr, ts, ts64, G, D, Go, Do, img_o, tag):
     # tanh image, |img| <= 1: absolute 1e-4 of the output scale on top of rtol
     assert_close(tr.last_model_out[0], img_o, RTOL, 1e-4, tag + " imgs_pred")
 
-    g_rows = _grad_table(tr.model.layout_to_image_model.module.named_parameters(), ts.g, ts64.g)
-    sg_rows = _grad_table(tr.model.sg_to_layout.module.named_parameters(), ts.sg, ts64.sg)
-    d_rows = _grad_table(tr.discriminator.img_discriminator.named_parameters(), ts.d, ts64.d)
-    o_rows = _grad_table(tr.discriminator.obj_discriminator.named_parameters(), ts.dobj, ts64.dobj) if ts.dobj else []
+    rows = res["rows"]
+    g_rows, sg_rows, d_rows = rows["G"], rows["SG"], rows["D"]
     # the generator alone has 7 blocks x (3 convs + 3 SPADE norms x 3 convs): every one of them is compared
     assert len(g_rows) >= 130 and len(d_rows) >= 17 and len(sg_rows) >= 25, (len(g_rows), len(d_rows), len(sg_rows))
     must = ["head_0.conv_0.weight_orig", "G_middle_1.norm_1.mlp_gamma.weight", "up_0.conv_s.weight_orig",
@@ -96,29 +76,25 @@ def _check_step(tr, ts, ts64, G, D, Go, Do, img_o, tag):
     # the graph encoder's objective (smooth-L1 on the boxes) is smooth: its gradients meet the plain contract
     for k, mine, want, _ in sg_rows:
         scaled_close(mine, want, "%s SG d%s" % (tag, k))
-    band = Band()
-    for group, rows in (("G", g_rows), ("SG", sg_rows), ("D", d_rows), ("Dobj", o_rows)):
-        for k, mine, want, want64 in rows:
-            band.add("%s %s" % (group, k), mine, want, want64)
-    band.check(tag, dump=os.path.join(ROOT, "gpurun_out", "r02_band_%s.txt" % tag))
+    band_of(res, tr, tag, dump=os.path.join(ROOT, "gpurun_out", "r02_band_%s.txt" % tag))
 
 
 def test_c3_full_width_step_vs_oracle(cuda):
     """BASELINE config C3's per-image workload: COCO vocabulary, 256x256, 1-30 objects, default recipe
     (image + object-crop discriminators), batch 2."""
     from canonicalsg2im_amd.synth import BatchConfig
-    out = _run_step(cuda, "coco", ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "2"],
-                    BatchConfig(2, 256, 1, 30, "random"), seed=0, batch_seed=3)
-    _check_step(*out, tag="C3")
+    tr, res = _run_step(cuda, "coco", ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "2"],
+                        BatchConfig(2, 256, 1, 30, "random"), seed=0, batch_seed=3)
+    _check_step(tr, res, tag="C3")
 
 
 def test_c4_full_width_step_vs_oracle(cuda):
     """BASELINE config C4's per-image workload: Visual-Genome vocabulary (179 classes, 46 predicates),
     256x256, 3-30 objects, default recipe, batch 2."""
     from canonicalsg2im_amd.synth import BatchConfig
-    out = _run_step(cuda, "vg", ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "2"],
-                    BatchConfig(2, 256, 3, 30, "random"), seed=1, batch_seed=4)
-    _check_step(*out, tag="C4")
+    tr, res = _run_step(cuda, "vg", ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "2"],
+                        BatchConfig(2, 256, 3, 30, "random"), seed=1, batch_seed=4)
+    _check_step(tr, res, tag="C4")
 
 
 def _clevr_scene(rng, sizes, vocab):
@@ -184,7 +160,7 @@ def test_c5_sg2layout_default_width_vs_oracle(cuda):
     ((ov64 * wv.double()).sum() + (bp64 * wb.double()).sum()).backward()
     scaled_close(obj_vecs, ov, "C5 obj_vecs")
     scaled_close(boxes_pred, bp, "C5 boxes_pred")
-    rows = _grad_table(model.named_parameters(), state, state64, skip=())
+    rows = grad_rows(model.named_parameters(), state, state64, skip=())
     assert len(rows) >= 25
     assert any(r[0] == "trans_candidates_weights" for r in rows)
     # 5 layers of ReLU MLPs over 16 000 triplets: ReLU gates flip here too (hub objects average ~250 messages whose

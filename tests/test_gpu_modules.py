@@ -6,6 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import assert_close, load_golden, state_from_shapes
+from fp64_band import Band, step_against_oracles
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -97,9 +98,11 @@ def _trainer_from_golden(cuda):
 def test_full_train_step_vs_reference(cuda):
     """scripts/train.py:353-393 on the HIP modules against the step replayed with the reference's
     own modules: image, loss dicts, gradients, spectral-norm / BatchNorm state, post-step weights."""
+    import oracle
     from canonicalsg2im_amd import train as T
     meta, a, opt, tr, batch = _trainer_from_golden(cuda)
-    G, D = tr.step(batch)
+    res = step_against_oracles(tr, [None if t is None else t.cpu() for t in batch], oracle, T)
+    G, D = res["G"], res["D"]
     for k in ("bbox_pred_all", "bbox_pred", "GAN_Img", "GAN_Feat", "total_loss"):
         assert_close(G[k].reshape(a["G:" + k].shape), a["G:" + k], RTOL, 1e-5, "G " + k)
     for k in ("D_img_fake", "D_img_real", "total_img_loss"):
@@ -108,18 +111,27 @@ def test_full_train_step_vs_reference(cuda):
     gnamed = dict(tr.model.layout_to_image_model.module.named_parameters())
     sgnamed = dict(tr.model.sg_to_layout.module.named_parameters())
     dnamed = dict(tr.discriminator.img_discriminator.named_parameters())
-    n = 0
+    # Gradients: against the fp64 evaluation of the oracle, the HIP path must be as accurate as the REFERENCE'S OWN fp32
+    # numbers in the fixture are (tests/fp64_band.py: GAN gradients are piecewise constant in the activations, so no
+    # fp32 implementation reproduces another to 1e-4 — the reference's fixture itself sits 1e-4..1e-2 from fp64)
+    band, n = Band(), 0
+    ts64 = res["ts64"]
     for k, v in a.items():
         if k.startswith("ggrad:"):
-            assert_close(gnamed[k[6:]].grad, v, 1e-3, 1e-6, k)
+            band.add("G " + k[6:], gnamed[k[6:]].grad, v, ts64.g[k[6:]].grad)
             n += 1
         elif k.startswith("sggrad:") and sgnamed[k[7:]].grad is not None:
-            assert_close(sgnamed[k[7:]].grad, v, 1e-3, 1e-6, k)
+            band.add("SG " + k[7:], sgnamed[k[7:]].grad, v, ts64.sg[k[7:]].grad)
             n += 1
         elif k.startswith("dgrad:"):
+            # the reference's discriminator gradients were taken on the reference's own generated image, which
+            # differs from ours by fp32 noise: sanity only; the strict check is the teacher-forced one below
             assert_close(dnamed[k[6:]].grad, v, 1e-3, 1e-6, k)
             n += 1
+    for k, mine, want, want64 in res["rows"]["D"]:
+        band.add("D " + k, mine, want, want64)
     assert n > 30
+    band.check("train_step fixture")
     lr = opt.learning_rate
 
     def check_param(name, mine, want, gkey):          # see tests/test_oracle_golden.py for the rationale
@@ -160,8 +172,10 @@ def test_default_step_with_object_discriminator_vs_reference(cuda):
     _load(tr.model.layout_to_image_model.module, state_from_shapes(sh["g"], 22, requires_grad=False), strict=False)
     _load(tr.discriminator.img_discriminator, state_from_shapes(sh["d"], 23, requires_grad=False), strict=False)
     _load(tr.discriminator.obj_discriminator, state_from_shapes(sh["dobj"], 24, requires_grad=False))
+    import oracle
     batch = [a["imgs"], a["objs"], a["boxes"], a["triplets"], None, a["tt"], None, None]
-    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    res = step_against_oracles(tr, batch, oracle, T)
+    G, D = res["G"], res["D"]
     for k in ("bbox_pred", "GAN_Img", "GAN_Feat", "GAN_Obj", "GAN_Ac", "total_loss"):
         assert_close(G[k].reshape(a["G:" + k].shape), a["G:" + k], RTOL, 1e-5, "G " + k)
     for k in ("D_img_fake", "D_img_real", "total_img_loss", "D_img_wrong", "D_obj", "D_ac_real", "D_ac_fake",
@@ -172,17 +186,22 @@ def test_default_step_with_object_discriminator_vs_reference(cuda):
     dsd = tr.discriminator.img_discriminator.state_dict()
     gnamed = dict(tr.model.layout_to_image_model.module.named_parameters())
     n = 0
+    band = Band()
     for k, v in a.items():
         if k.startswith("ograd:"):
-            assert_close(onamed[k[6:]].grad, v, 1e-3, 2e-6, k)
+            assert_close(onamed[k[6:]].grad, v, 1e-3, 2e-6, k)       # reference's own image: sanity (see above)
             n += 1
         elif k.startswith("ggrad:"):
-            assert_close(gnamed[k[6:]].grad, v, 1e-3, 1e-6, k)
+            band.add("G " + k[6:], gnamed[k[6:]].grad, v, res["ts64"].g[k[6:]].grad)
         elif k.startswith("d_after:"):
             assert_close(dsd[k[8:]], v, 1e-3, 2e-6, k)
         elif k.startswith("o_after:") and ("running_" in k or "num_batches" in k):
             assert_close(osd[k[8:]], v, 1e-3, 2e-6, k)
+    for group in ("D", "Dobj"):
+        for k, mine, want, want64 in res["rows"][group]:
+            band.add("%s %s" % (group, k), mine, want, want64)
     assert n >= 12
+    band.check("train_step_objdisc fixture")
 
 
 def test_step_with_masks_vs_reference(cuda):
@@ -203,8 +222,10 @@ def test_step_with_masks_vs_reference(cuda):
     _load(tr.discriminator.obj_discriminator, state_from_shapes(sh["dobj"], 44, requires_grad=False))
     _load(tr.discriminator.mask_discriminator, state_from_shapes(sh["dmask"], 45, requires_grad=False))
     sgm.mask_noise = a["mask_noise"].cuda()
+    import oracle
     batch = [a["imgs"], a["objs"], a["boxes"], a["triplets"], None, a["tt"], a["masks"], None]
-    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    res = step_against_oracles(tr, batch, oracle, T)
+    G, D = res["G"], res["D"]
     assert {k[2:] for k in a if k.startswith("G:")} == set(G.keys())
     assert {k[2:] for k in a if k.startswith("D:")} == set(D.keys())
     for k in G:
@@ -215,20 +236,26 @@ def test_step_with_masks_vs_reference(cuda):
     sgnamed = dict(sgm.named_parameters())
     sgsd = sgm.state_dict()
     n = 0
+    band = Band()
     for k, v in a.items():
         if k.startswith("mgrad:"):
+            # mask discriminator: its input is the PREDICTED masks (reference's own vs ours): sanity; strict check below
             assert_close(mnamed[k[6:]].grad, v, 1e-3, 1e-6 + 1e-3 * float(v.abs().max()), k)
             n += 1
         elif k.startswith("sggrad:"):
             if float(v.abs().max()) < 1e-6:      # conv bias in front of a BatchNorm: analytically zero, rounding noise
                 assert float(sgnamed[k[7:]].grad.abs().max()) < 1e-6, k
             else:
-                assert_close(sgnamed[k[7:]].grad, v, 1e-3, 1e-7 + 1e-3 * float(v.abs().max()), k)
+                band.add("SG " + k[7:], sgnamed[k[7:]].grad, v, res["ts64"].sg[k[7:]].grad)
             n += 1
         elif k.startswith("sg_after:"):
             assert_close(sgsd[k[9:]], v, 1e-3, 2e-6, k)
             n += 1
+    for group in ("D", "Dobj", "Dmask"):
+        for k, mine, want, want64 in res["rows"][group]:
+            band.add("%s %s" % (group, k), mine, want, want64)
     assert n > 15
+    band.check("train_step_masks fixture")
 
 
 def test_generated_image_vs_reference(cuda):
