@@ -530,7 +530,7 @@ def generator_losses(opt, d_state, batch, model_out, training=True, dobj_state=N
         G["bbox_pred"] = G["bbox_pred_all"].mean()
         if masks is not None:                                                                 # :88-92
             M = masks.shape[-1]
-            bce = F.binary_cross_entropy(masks_pred.view(-1, M, M), masks.view(-1, M, M).float(),
+            bce = F.binary_cross_entropy(masks_pred.view(-1, M, M), masks.view(-1, M, M).to(masks_pred.dtype),
                                          reduction="none").mean(dim=(1, 2))
             G["masks_pred"] = (bce[mask.bool().nonzero()[:, 0]] * opt.mask_pred_loss_weight).mean()
     if not opt.skip_generation:

@@ -109,3 +109,105 @@ def test_bench_contract_with_two_ranks():
     assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert d["losses_finite"] and d["value"] > 0 and "cpu_baseline" not in d
     assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 / 1000.0)) / d["value"] < 0.02
+
+
+# ------------------------------------------------------------------ SyncBN backward and the converse all-gather
+def _syncbn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from canonicalsg2im_amd import dist as D, ops
+    D.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(500 + rank)
+    C = 12
+    x = (torch.randn(2, C, 6, 5, generator=g) * (1.5 + rank) + 0.3 * rank).cuda().requires_grad_(True)
+    gb = (torch.randn(2, 2 * C, 6, 5, generator=g) * 0.4).cuda().requires_grad_(True)
+    w = torch.randn(2, C, 6, 5, generator=g).cuda()
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    y = ops.norm_act(x, gb, rm, rv, instance=False, training=True, slope=0.2, sync=True)
+    (y * w).sum().backward()
+    out[rank] = {k: v.detach().cpu() for k, v in dict(x=x, gb=gb, w=w, y=y, dx=x.grad, dgb=gb.grad, rm=rm, rv=rv).items()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_syncbn_forward_and_backward_over_two_ranks_vs_oracle():
+    """The SPADE norm under data parallelism (ops._NormAct with an initialised process group): forward statistics AND
+    the backward's (sum dn, sum dn*xhat) are all-reduced in fp64, N-replica formula clamp(var, eps)^-1/2
+    (sync_batchnorm/batchnorm.py:74-93, 128-145).  Two ranks with different shards against the oracle's multi-replica
+    evaluation differentiated by autograd: outputs, dx, d(gamma||beta), running statistics."""
+    import torch.nn.functional as F
+    import oracle
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_syncbn_worker, args=(world, port, out), nprocs=world, join=True)
+    r = [out[0], out[1]]
+    C = 12
+    xs = [r[i]["x"].clone().requires_grad_(True) for i in range(2)]
+    gbs = [r[i]["gb"].clone().requires_grad_(True) for i in range(2)]
+    rm, rv = torch.zeros(C), torch.ones(C)
+    ys = oracle.syncbn_multi_replica(xs, rm, rv)
+    loss = 0
+    outs = []
+    for i in range(2):
+        yi = F.leaky_relu(ys[i] * (1 + gbs[i][:, :C]) + gbs[i][:, C:], 0.2)
+        outs.append(yi)
+        loss = loss + (yi * r[i]["w"]).sum()
+    loss.backward()
+    for i in range(2):
+        assert torch.allclose(r[i]["y"], outs[i].detach(), rtol=1e-4, atol=1e-5), "y rank %d" % i
+        assert torch.allclose(r[i]["dx"], xs[i].grad, rtol=1e-4, atol=1e-5), "dx rank %d" % i
+        assert torch.allclose(r[i]["dgb"], gbs[i].grad, rtol=1e-4, atol=1e-5), "dgb rank %d" % i
+        assert torch.allclose(r[i]["rm"], rm, rtol=1e-4, atol=1e-6) and torch.allclose(r[i]["rv"], rv, rtol=1e-4, atol=1e-6)
+    assert torch.equal(r[0]["rm"], r[1]["rm"]) and torch.equal(r[0]["rv"], r[1]["rv"])
+
+
+def _converse_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from canonicalsg2im_amd import dist as D
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import make_vocab
+    D.init_from_env(backend="gloo")
+    vocab = make_vocab("tiny")
+    opt = T.make_opt(vocab, ARGV + ["--learned_converse", "1", "--skip_generation", "1"])
+    torch.manual_seed(77 + rank)
+    tr = T.Trainer(opt, torch.device("cuda:0"))           # broadcast makes the replicas identical
+    g = torch.Generator().manual_seed(9)
+    r_full = torch.rand(4, generator=g) * 3
+    cc_full = torch.randint(0, 3, (4, 8, 9), generator=g).float()
+    sl = slice(2 * rank, 2 * rank + 2)
+    w = tr.model.sg_to_layout.module.converse_candidates_weights
+    w0 = w.detach().clone()
+    tr._converse_step(r_full[sl].cuda(), cc_full[sl].cuda())
+    out[rank] = {"grad": w.grad.detach().cpu().clone(), "w0": w0.cpu(), "w1": w.detach().cpu().clone()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_converse_reinforce_reward_is_normalised_over_the_global_batch():
+    """--learned_converse: the per-sample reward is normalised with the mean / std of the GLOBAL batch (all-gather of
+    bbox_pred_all, scripts/train.py:371-381) and the gradient averaged over ranks: equal to the single-process update
+    on the whole batch."""
+    from canonicalsg2im_amd.scripts.graphs_utils import calc_log_p
+    from canonicalsg2im_amd.sg2im.model import get_conv_converse
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_converse_worker, args=(world, port, out), nprocs=world, join=True)
+    assert torch.equal(out[0]["grad"], out[1]["grad"]) and torch.equal(out[0]["w1"], out[1]["w1"])
+    g = torch.Generator().manual_seed(9)
+    r_full = torch.rand(4, generator=g) * 3
+    cc_full = torch.randint(0, 3, (4, 8, 9), generator=g).float()
+    w = out[0]["w0"].clone().requires_grad_(True)
+    eps = float(torch.finfo(torch.float32).eps)
+    r = (r_full - r_full.mean()) / (r_full.std() + eps)
+    non_meta = list(range(2, 8))
+    log_prob = calc_log_p(get_conv_converse({"sg_to_layout.module.converse_candidates_weights": w}), non_meta, cc_full)
+    torch.mean(r * log_prob).backward()
+    assert torch.allclose(out[0]["grad"], w.grad, rtol=1e-4, atol=1e-6)
+    assert not torch.equal(out[0]["w1"], out[0]["w0"])
