@@ -392,7 +392,7 @@ def mask_discriminator(state, vocab, objs, layout_masks, training=True, prefix="
         O, M = mk.shape[0], mk.shape[1]
         one_hot = torch.zeros((O, ncls), dtype=mk.dtype).scatter_(1, lab.view(-1, 1).long(), 1.0)
         rows.append(torch.cat([one_hot.view(O, -1, 1, 1).expand(-1, -1, M, M), mk.unsqueeze(1)], dim=1))
-    inp = torch.cat(rows, dim=0).float()
+    inp = torch.cat(rows, dim=0).to(state[prefix + "discriminator_0.model0.0.weight"].dtype)     # `.float()` in fp32
     result, i = [], 0
     while (prefix + "discriminator_%d.model0.0.weight" % i) in state:
         result.append(nlayer_discriminator(state, prefix + "discriminator_%d." % i, inp, training))
