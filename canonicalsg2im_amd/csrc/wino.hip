@@ -460,18 +460,19 @@ int64_t csg_wino_pack_bytes(int64_t N, int64_t K) {
   return (int64_t)16 * cdiv(N, 32) * cdiv(K, 8) * 64 * 16;
 }
 
-int csg_wino_pack_weights(const float* w, int64_t Cout, int64_t Cin, int32_t backward_data, const float* sigma,
-                          float* packed, void* stream) {
+int csg_wino_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int64_t Cout, int64_t Cin,
+                          int32_t backward_data, const float* sigma, float* packed, void* stream) {
   CSG_REQUIRE(w != nullptr && packed != nullptr && Cout > 0 && Cin > 0, CSG_E_BADSHAPE, "csg_wino_pack_weights: bad arguments");
   CSG_REQUIRE(((uintptr_t)packed % 16) == 0, CSG_E_UNSUPPORTED, "csg_wino_pack_weights: packed must be 16-byte aligned");
-  // w is (Cout, Cin, 3, 3) contiguous.  forward: n = cout, k = cin;  backward-data: n = cin, k = cout, taps flipped
+  // w is the (Cout, Cin, 3, 3) weight with element strides (s_o, s_i, s_h, s_w) — contiguous or channels-last.
+  // forward: n = cout, k = cin;  backward-data: n = cin, k = cout, taps flipped
   const int64_t N = backward_data ? Cin : Cout, K = backward_data ? Cout : Cin;
-  const int64_t s_n = backward_data ? 9 : Cin * 9, s_k = backward_data ? Cin * 9 : 9;
+  const int64_t s_n = backward_data ? s_i : s_o, s_k = backward_data ? s_o : s_i;
   const int NT32 = (int)cdiv(N, 32), Q8 = (int)cdiv(K, 8);
   const int64_t total = (int64_t)16 * NT32 * Q8 * 64;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(K_WINO_PACK, (double)Cout * Cin * 9 * 4 + (double)total * 16, s);
-  hipLaunchKernelGGL(k_wino_pack, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, s_n, s_k, (int64_t)3, (int64_t)1,
+  hipLaunchKernelGGL(k_wino_pack, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
                      backward_data ? 1 : 0, (int)N, (int)K, sigma, NT32, Q8, (float4*)packed);
   return check_launch("csg_wino_pack_weights");
 }

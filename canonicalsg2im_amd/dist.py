@@ -94,7 +94,10 @@ class GradBuckets:
             self.allocations += 1
             off = 0
             for p in group:
-                view = flat[off:off + p.numel()].view(p.shape)
+                view = flat[off:off + p.numel()]
+                # the slot mirrors the parameter's own (dense) memory layout — conv weights are channels-last — so that
+                # the fused optimiser walks parameter, gradient and moments in the same element order
+                view = view.view(p.shape) if p.is_contiguous() else view.as_strided(p.shape, p.stride())
                 off += p.numel()
                 self.slot[id(p)] = (b, view)
                 p.register_post_accumulate_grad_hook(self._hook)

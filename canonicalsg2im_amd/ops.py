@@ -121,13 +121,14 @@ def wino_eligible(B, H, W, Cin, Cout, KH, KW, stride, pad):
 
 def wino_pack(weight, backward_data, sigma=None):
     """Transformed weights U = G g G^T of a (Cout,Cin,3,3) weight in the MFMA operand order of k_wino_conv."""
-    w = _f32(weight.detach()).contiguous()
+    w = _f32(weight.detach())                    # any strides: contiguous and channels-last parameters alike
     Cout, Cin = w.shape[0], w.shape[1]
     N, K = (Cin, Cout) if backward_data else (Cout, Cin)
     nbytes = lib.csg_wino_pack_bytes(N, K)
     packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-    check(lib.csg_wino_pack_weights(ptr(w), Cout, Cin, 1 if backward_data else 0, ptr(sigma), ptr(packed), stream()),
-          "wino_pack_weights")
+    st = w.stride()
+    check(lib.csg_wino_pack_weights(ptr(w), st[0], st[1], st[2], st[3], Cout, Cin, 1 if backward_data else 0, ptr(sigma),
+                                    ptr(packed), stream()), "wino_pack_weights")
     return packed
 
 
@@ -159,7 +160,8 @@ class _Conv2d(torch.autograd.Function):
             _wino_launch(x, up, bias.detach() if bias is not None else None, res, y, B, IH, IW, Cin, Cout, act, slope,
                          "wino_conv_fwd")
         else:
-            wp = packs[0] if packs is not None else weight.detach().permute(0, 2, 3, 1).contiguous()   # [Cout][KH][KW][Cin]
+            # [Cout][KH][KW][Cin]: free for channels-last parameters (sg2im.layers.Conv2d keeps them that way)
+            wp = packs[0] if packs is not None else weight.detach().permute(0, 2, 3, 1).contiguous()
             d, OH, OW = _desc_forward(B, IH, IW, Cin, Cout, KH, KW, stride, pad, act, slope)
             y = empty_nhwc(B, Cout, OH, OW, x.device)
             _conv_launch(d, x, wp, bias.detach() if bias is not None else None, res, y, "conv_fwd")

@@ -27,6 +27,10 @@ class Conv2d(nn.Conv2d):
         k, s, p = self.kernel_size, self.stride, self.padding
         if k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or self.dilation != (1, 1) or self.groups != 1:
             raise NotImplementedError("Conv2d: only square, undilated, ungrouped convolutions are on the hot path")
+        # channels-last parameter memory == the kernels' [Cout][KH][KW][Cin] operand AND the weight-gradient kernels'
+        # output: no repack in the forward, and autograd adopts dW as .grad without a layout copy (same values, same
+        # state_dict; `spectral_norm` puts its `weight_orig` back to row-major, the order of its u / v vectors)
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
     def forward(self, x, residual=None):
         return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.act, self.slope, residual)

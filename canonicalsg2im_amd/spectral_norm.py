@@ -25,6 +25,8 @@ class HipSpectralNorm(SpectralNorm):
 
 
 def spectral_norm(module, name='weight', n_power_iterations=1, eps=1e-12, dim=None):
+    w = getattr(module, name)
+    w.data = w.data.contiguous()                 # rows of W.view(Cout, -1) in the reference's (Cin, KH, KW) order
     module = _torch_spectral_norm(module, name, n_power_iterations, eps, dim)
     for hook in module._forward_pre_hooks.values():
         if isinstance(hook, SpectralNorm) and hook.name == name:

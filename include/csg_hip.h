@@ -173,7 +173,8 @@ int csg_conv_bwd_weight(const csg_conv_desc* d, const float* x, const float* dy,
  * and (cin,cout) pair, fp32 throughout.  x (B,H,W,Cin) NHWC with channel stride x_cs, y likewise with y_cs;
  * H, W even; channel counts multiples of 4.  y = act(conv + bias) [+ residual] exactly as csg_conv_fwd.
  * `packed`: the transformed weights U = G g G^T in MFMA operand order, csg_wino_pack_bytes(N, K) bytes, produced by
- * csg_wino_pack_weights from the (Cout,Cin,3,3) contiguous weight: backward_data = 0 -> operand of the forward
+ * csg_wino_pack_weights from the (Cout,Cin,3,3) weight with element strides (s_o,s_i,s_h,s_w) — contiguous or
+ * channels-last parameters alike: backward_data = 0 -> operand of the forward
  * (N = Cout, K = Cin); 1 -> operand of dX = conv(dY, flipped W^T) (N = Cin, K = Cout: call csg_wino_conv with
  * Cin := Cout, Cout := Cin).  `sigma` (device scalar or NULL) divides every weight first — W / sigma of spectral
  * normalisation — so a spectrally normalised layer needs no materialised W_eff.                            */
@@ -185,8 +186,8 @@ typedef struct csg_wino_desc {
   float slope;
 } csg_wino_desc;
 int64_t csg_wino_pack_bytes(int64_t N, int64_t K);
-int csg_wino_pack_weights(const float* w, int64_t Cout, int64_t Cin, int32_t backward_data, const float* sigma,
-                          float* packed, void* stream);
+int csg_wino_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int64_t Cout, int64_t Cin,
+                          int32_t backward_data, const float* sigma, float* packed, void* stream);
 int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, const float* bias,
                   const float* residual, float* y, void* stream);
 /* Weight gradient of the same layers by Winograd F(3x3,2x2): dw [Cout][3][3][Cin] (the layout of
