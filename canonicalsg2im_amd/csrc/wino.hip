@@ -27,6 +27,7 @@
 //     before the MFMAs of stage s and written to LDS after them: one barrier per 8192 matrix-pipe cycles.
 //   * Epilogue: each wave reduces its row over nu (M A), the four rows meet in LDS (A^T .), 16-byte stores.
 #include <stddef.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -52,6 +53,7 @@ struct WinoParams {
   int act;
   float slope;
   int nstage;          // ceil(Cin / 16)
+  int variant;         // 1: 64 tiles per block (k_wino_conv), 2: 32 tiles per block, two blocks per CU (k_wino_conv2)
 };
 
 __device__ __forceinline__ int wn_xcd_remap(int bid, int nblk) {
@@ -422,6 +424,219 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv(WinoParams p, const float*
   }
 }
 
+// ------------------------------------------------------------------------------------ convolution, 2 blocks per CU
+// Same algorithm with HALF the tile set per block: 32 tiles (TW x TH) x 64 output channels, accumulators 4 nu x 2
+// channel groups = 128 registers, so TWO blocks are resident per CU (two waves per SIMD).  A lone wave pays for every
+// VMEM / LDS / VALU issue and for its prologue and epilogue with idle matrix-pipe time (k_wino_conv: 55 % busy); here
+// the partner wave's MFMAs run underneath, and one block's epilogue under the other block's main loop.  To fit 256
+// registers the weights are single-buffered: the eight operands of one channel group are reloaded (for the next
+// k-oct) right after their last MFMA, while the other group's 16 MFMAs run.
+template <int TW>
+__global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float* __restrict__ x,
+                                                        const float4* __restrict__ up, const float* __restrict__ bias,
+                                                        const float* __restrict__ res, float* __restrict__ y) {
+  constexpr int TH = 32 / TW;
+  constexpr int R = 2 * TH + 2, C = 2 * TW + 2;
+  constexpr int RS = wn_row_stride(TW);
+  constexpr int BUFW = R * RS + 16;
+  constexpr int HALF = (C / 2) * WN_PS;
+  constexpr int NLD = (R * C * 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  int bid = wn_xcd_remap(blockIdx.x, gridDim.x);
+  const int nb = bid % p.nblocks;
+  bid /= p.nblocks;
+  const int bx = bid % p.tbx;
+  bid /= p.tbx;
+  const int by = bid % p.tby;
+  const int img = bid / p.tby;
+  const int X0 = bx * 2 * TW, Y0 = by * 2 * TH;
+
+  const csg_i32x4 rsX = csg_make_srd(x, (long long)p.B * p.H * p.W * p.x_cs * 4);
+  const csg_i32x4 rsU = csg_make_srd(up, (long long)16 * p.NT32 * p.Q8 * 64 * 16);
+  unsigned goff[NLD];
+  int loff[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + 256 * i;
+    goff[i] = CSG_OOB_OFF;
+    loff[i] = BUFW - 16 + (tid & 3) * 4;
+    if (e < R * C * 4) {
+      const int pix = e >> 2, c4 = e & 3;
+      const int row = pix / C, col = pix - row * C;
+      const int iy = Y0 + row - 1, ix = X0 + col - 1;
+      loff[i] = row * RS + ((col & 1) * (C >> 1) + (col >> 1)) * WN_PS + c4 * 4;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+        goff[i] = (unsigned)(((img * p.H + iy) * p.W + ix) * p.x_cs + c4 * 4) * 4u;
+    }
+  }
+  csg_f32x4 st[NLD];
+  auto load_stage = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) st[i] = csg_buf_load_x4(rsX, (int)goff[i], s * (WN_BK * 4), 0);
+  };
+  auto store_stage = [&](float* base) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      float* dst = base + loff[i];
+      *(float2*)(dst) = make_float2(st[i].x, st[i].y);
+      *(float2*)(dst + 2) = make_float2(st[i].z, st[i].w);
+    }
+  };
+
+  const int j = lane & 31, h = lane >> 5;
+  const int tx = j % TW, tyl = j / TW;
+  const int ia = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+  const int ib = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+  const float sgn = wave == 1 ? 1.0f : -1.0f;
+  const float* pa0 = smem + (2 * tyl + ia) * RS + tx * WN_PS + 2 * h;
+  const float* pb0 = smem + (2 * tyl + ib) * RS + tx * WN_PS + 2 * h;
+
+  unsigned uoff[4][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int nt32 = nb * 2 + nt;
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+      uoff[nu][nt] = nt32 < p.NT32 ? (unsigned)((((wave * 4 + nu) * p.NT32 + nt32) * p.Q8) * 64 + lane) * 16u : CSG_OOB_OFF;
+  }
+  csg_f32x4 u[4][2];
+  auto load_u_half = [&](int nt, int q) {        // operands of channel group nt for k-oct q (clamped: see k_wino_conv)
+    const int qq = min(q, p.Q8 - 1);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) u[nu][nt] = csg_buf_load_x4(rsU, (int)uoff[nu][nt], qq * 1024, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nu][nt][e] = 0.f;
+
+  float2 v[4][2];
+  auto prepare = [&](int bufsel, int o) {        // 16 ds_read_b64 + 32 VALU: V = B^T d B of this lane's tile, k-oct o
+    const float* pa = pa0 + bufsel * BUFW + 8 * o;
+    const float* pb = pb0 + bufsel * BUFW + 8 * o;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      float2 q[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int co = (c & 1) * HALF + (c >> 1) * WN_PS + 4 * cp;
+        const float2 da = *(const float2*)(pa + co), db = *(const float2*)(pb + co);
+        q[c] = make_float2(da.x + sgn * db.x, da.y + sgn * db.y);
+      }
+      v[0][cp] = make_float2(q[0].x - q[2].x, q[0].y - q[2].y);
+      v[1][cp] = make_float2(q[1].x + q[2].x, q[1].y + q[2].y);
+      v[2][cp] = make_float2(q[2].x - q[1].x, q[2].y - q[1].y);
+      v[3][cp] = make_float2(q[1].x - q[3].x, q[1].y - q[3].y);
+    }
+  };
+  auto mfma_half = [&](int nt) {                 // 16 MFMAs: k-step outermost, 4 accumulators in rotation
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].x, v[nu][0].x, acc[nu][nt], 0, 0, 0);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].y, v[nu][0].y, acc[nu][nt], 0, 0, 0);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].z, v[nu][1].x, acc[nu][nt], 0, 0, 0);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nu][nt].w, v[nu][1].y, acc[nu][nt], 0, 0, 0);
+  };
+  auto stage = [&](int s, auto bufsel_tag) {
+    constexpr int bufsel = decltype(bufsel_tag)::value;
+    load_stage(s + 1);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      prepare(bufsel, o);
+      mfma_half(0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_u_half(0, 2 * s + o + 1);
+      mfma_half(1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_u_half(1, 2 * s + o + 1);
+    }
+    store_stage(smem + (bufsel ^ 1) * BUFW);
+    __syncthreads();
+  };
+
+  load_stage(0);
+  load_u_half(0, 0);
+  load_u_half(1, 0);
+  store_stage(smem);
+  __syncthreads();
+  int s = 0;
+  for (; s + 1 < p.nstage; s += 2) {
+    stage(s, std::integral_constant<int, 0>());
+    stage(s + 1, std::integral_constant<int, 1>());
+  }
+  if (s < p.nstage) stage(s, std::integral_constant<int, 0>());
+
+  // ---- epilogue (as k_wino_conv, 32 tiles): R[0] = M0+M1+M2, R[1] = M1-M2-M3 per wave, A^T . through LDS
+  float* rbuf = smem;                            // [xi][b][32 tiles][WN_RSE]
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float r0[4], r1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float m0 = acc[0][nt][4 * g + e], m1 = acc[1][nt][4 * g + e], m2 = acc[2][nt][4 * g + e], m3 = acc[3][nt][4 * g + e];
+        r0[e] = m0 + m1 + m2;
+        r1[e] = m1 - m2 - m3;
+      }
+      const int ch = 8 * g + 4 * h;
+      *(float4*)(rbuf + ((wave * 2 + 0) * 32 + j) * WN_RSE + ch) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+      *(float4*)(rbuf + ((wave * 2 + 1) * 32 + j) * WN_RSE + ch) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+    }
+    __syncthreads();
+    {
+      const int tile = tid >> 3, cq = tid & 7;   // 32 tiles x 8 channel quads: one item per thread
+      const int n = nb * 64 + nt * 32 + cq * 4;
+      const int ttx = tile % TW, tty = tile / TW;
+      const int oy = Y0 + 2 * tty, ox = X0 + 2 * ttx;
+      if (n < p.Cout && oy < p.H && ox < p.W) {
+        float4 rr[4][2];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) rr[xi][b] = *(const float4*)(rbuf + ((xi * 2 + b) * 32 + tile) * WN_RSE + cq * 4);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias != nullptr) bv = *(const float4*)(bias + n);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            float vv[4];
+            const float4 q0 = rr[0][b], q1 = rr[1][b], q2 = rr[2][b], q3 = rr[3][b];
+            if (a == 0) {
+              vv[0] = q0.x + q1.x + q2.x; vv[1] = q0.y + q1.y + q2.y; vv[2] = q0.z + q1.z + q2.z; vv[3] = q0.w + q1.w + q2.w;
+            } else {
+              vv[0] = q1.x - q2.x - q3.x; vv[1] = q1.y - q2.y - q3.y; vv[2] = q1.z - q2.z - q3.z; vv[3] = q1.w - q2.w - q3.w;
+            }
+            vv[0] += bv.x; vv[1] += bv.y; vv[2] += bv.z; vv[3] += bv.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (p.act == CSG_ACT_LEAKY)
+                vv[e] = vv[e] > 0.f ? vv[e] : vv[e] * p.slope;
+              else if (p.act == CSG_ACT_TANH)
+                vv[e] = tanhf(vv[e]);
+            }
+            const int64_t pix = ((int64_t)img * p.H + (oy + a)) * p.W + (ox + b);
+            if (res != nullptr) {
+              const float4 rv = *(const float4*)(res + pix * p.y_cs + n);
+              vv[0] += rv.x; vv[1] += rv.y; vv[2] += rv.z; vv[3] += rv.w;
+            }
+            *(float4*)(y + pix * p.y_cs + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+          }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------ host side
 static int wn_plan(const csg_wino_desc* d, WinoParams& p, size_t& shm, const char* who) {
   CSG_REQUIRE(d != nullptr, CSG_E_BADSHAPE, "%s: null descriptor", who);
@@ -436,8 +651,15 @@ static int wn_plan(const csg_wino_desc* d, WinoParams& p, size_t& shm, const cha
   CSG_REQUIRE((int64_t)16 * ((d->Cout + 31) / 32) * ((d->Cin + 7) / 8) * 1024 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
               "%s: packed weights too large for 32-bit byte offsets", who);
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_cs = d->x_cs; p.Cout = d->Cout; p.y_cs = d->y_cs;
-  p.TW = d->W >= 64 ? 32 : (d->W >= 32 ? 16 : (d->W >= 16 ? 8 : 4));
-  p.TH = 64 / p.TW;
+  static const int variant = getenv("CSG_WINO_VARIANT") ? atoi(getenv("CSG_WINO_VARIANT")) : 2;
+  p.variant = variant;
+  if (variant == 2) {            // 32 tiles per block, two blocks per CU
+    p.TW = d->W >= 32 ? 16 : (d->W >= 16 ? 8 : 4);
+    p.TH = 32 / p.TW;
+  } else {                       // 64 tiles per block, one block per CU
+    p.TW = d->W >= 64 ? 32 : (d->W >= 32 ? 16 : (d->W >= 16 ? 8 : 4));
+    p.TH = 64 / p.TW;
+  }
   p.tbx = (d->W / 2 + p.TW - 1) / p.TW;
   p.tby = (d->H / 2 + p.TH - 1) / p.TH;
   p.nblocks = (d->Cout + 63) / 64;
@@ -448,7 +670,7 @@ static int wn_plan(const csg_wino_desc* d, WinoParams& p, size_t& shm, const cha
   p.act = d->act; p.slope = d->slope;
   p.nstage = (d->Cin + WN_BK - 1) / WN_BK;
   const size_t in_bytes = (size_t)2 * ((2 * p.TH + 2) * p.RS + 16) * 4;        // + the dump slots of idle staging lanes
-  const size_t ep_bytes = (size_t)4 * 2 * 64 * WN_RSE * 4;
+  const size_t ep_bytes = (size_t)4 * 2 * (p.variant == 2 ? 32 : 64) * WN_RSE * 4;
   shm = in_bytes > ep_bytes ? in_bytes : ep_bytes;
   return CSG_OK;
 }
@@ -489,8 +711,9 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    const void* fns[4] = {(const void*)k_wino_conv<32>, (const void*)k_wino_conv<16>, (const void*)k_wino_conv<8>,
-                          (const void*)k_wino_conv<4>};
+    const void* fns[7] = {(const void*)k_wino_conv<32>, (const void*)k_wino_conv<16>, (const void*)k_wino_conv<8>,
+                          (const void*)k_wino_conv<4>, (const void*)k_wino_conv2<16>, (const void*)k_wino_conv2<8>,
+                          (const void*)k_wino_conv2<4>};
     for (const void* fn : fns) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
@@ -504,6 +727,15 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
   // algorithmic FLOPs of the DIRECT convolution this replaces (2 * M * 9*Cin * Cout): what FlopCounterMode counts
   ProfScope ps(K_WINO_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
   const float4* up = (const float4*)packed;
+  if (p.variant == 2) {
+    if (p.TW == 16)
+      hipLaunchKernelGGL(k_wino_conv2<16>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+    else if (p.TW == 8)
+      hipLaunchKernelGGL(k_wino_conv2<8>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+    else
+      hipLaunchKernelGGL(k_wino_conv2<4>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+    return check_launch("csg_wino_conv");
+  }
   if (p.TW == 32)
     hipLaunchKernelGGL(k_wino_conv<32>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
   else if (p.TW == 16)
