@@ -766,6 +766,7 @@ struct WinoWgParams {
   int RXn, RYn, nregions;        // stage regions per tile row / column of an image, in all
   int cblocks, kblocks;
   int nsplit, rps;               // regions per split
+  int nt;                        // input-channel groups of 32 per block (2: one block per CU, 1: two)
 };
 
 #define WG_EPS 33                // words per row of the epilogue exchange buffer
@@ -779,13 +780,14 @@ struct WinoWgParams {
 // s+1 issued before the MFMAs of stage s, one barrier per stage.  Regions tile the image exactly (host-checked), so
 // only the one-pixel halo needs masking: per-thread flags x uniform edge conditions, one v_cndmask per load; the
 // region's position rides in the scalar offset of the buffer loads.
-template <int TSX>
-__global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const float* __restrict__ x,
+template <int TSX, int NT>
+__global__ __launch_bounds__(256, NT == 2 ? 1 : 2) void k_wino_wgrad(WinoWgParams p, const float* __restrict__ x,
                                                         const float* __restrict__ dy, float* __restrict__ slabs,
                                                         float* __restrict__ dbslabs) {
   constexpr int TSY = 16 / TSX;
   constexpr int XR = 2 * TSY + 2, XC = 2 * TSX + 2, YR = 2 * TSY, YC = 2 * TSX;
-  constexpr int NLX = (XR * XC * 16 + 255) / 256, NLY = (YR * YC * 16) / 256;
+  constexpr int XCH = 32 * NT, XF4 = XCH / 4;    // input channels per block and pixel, as floats / as 16-byte pieces
+  constexpr int NLX = (XR * XC * XF4 + 255) / 256, NLY = (YR * YC * 16) / 256;
   static_assert((YR * YC * 16) % 256 == 0, "dY staging divides evenly");
   constexpr int XW = NLX * 256 * 4, YW = YR * YC * 64, BUFW = XW + YW;     // words; the X area is padded to whole DMAs
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
   const int c = lane & 31, h = lane >> 5;
   int bid = wn_xcd_remap(blockIdx.x, gridDim.x);
   // all (cout block, cin block) pairs of one slice are adjacent: the slice's dY and X stay in that XCD's L2
-  const int kb = bid % p.kblocks;
+  const int kb = bid % p.kblocks;                // input-channel block of XCH channels
   bid /= p.kblocks;
   const int cb = bid % p.cblocks;
   const int sp = bid / p.cblocks;
@@ -821,10 +823,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
 #pragma unroll
   for (int i = 0; i < NLX; ++i) {
     const int e = tid + 256 * i;
-    const int pix = e >> 4, c4 = e & 15;
+    const int pix = e / XF4, c4 = e - pix * XF4;
     const int row = pix / XC, col = pix - row * XC;
-    const int ch = kb * 64 + c4 * 4;
-    const bool ok = (e < XR * XC * 16) & (ch < p.Cin);
+    const int ch = kb * XCH + c4 * 4;
+    const bool ok = (e < XR * XC * XF4) & (ch < p.Cin);
     xoff[i] = ok ? (unsigned)((row * p.W + col) * p.x_cs + ch) * 4u : CSG_OOB_OFF;
     xflag[i] = (row == 0 ? 1 : 0) | (row == XR - 1 ? 2 : 0) | (col == 0 ? 4 : 0) | (col == XC - 1 ? 8 : 0);
   }
@@ -857,41 +859,44 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
   const bool do_db = dbslabs != nullptr && kb == 0 && wave == 1;
   float dbacc[2] = {0.f, 0.f};
 
-  f32x16 acc[4][2][2];
+  f32x16 acc[4][2][NT];
 #pragma unroll
   for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nu][mt][nt][e] = 0.f;
 
   struct Raw {
-    float dy[2][2][2];   // [cout group][row][col]
-    float xr[2][2][4];   // [cin group][row a/b][col]
+    float dy[2][2][2];    // [cout group][row][col]
+    float xr[NT][2][4];   // [cin group][row a/b][col]
   };
   // tile t = 2*kp + h of the stage: (tsx, tsy) = (t % TSX, t / TSX); every offset is an immediate once kp is unrolled
-  const float* lx = smem + h * (2 * 64) + c;     // h = 1: the next tile, two pixels to the right (TSX is even)
+  // h = 1: the next tile, two pixels to the right (TSX is even)
+  const float* lxx = smem + h * (2 * XCH) + c;
+  const float* lxy = smem + XW + h * (2 * 64) + c;
   auto read_pair = [&](int bufsel, int kp, Raw& r) {
     const int t = 2 * kp, tsx = t % TSX, tsy = t / TSX;
-    const float* bx = lx + bufsel * BUFW;
-    const float* by = bx + XW;
+    const float* bx = lxx + bufsel * BUFW;
+    const float* by = lxy + bufsel * BUFW;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jx = 0; jx < 2; ++jx) r.dy[m][i][jx] = by[((2 * tsy + i) * YC + 2 * tsx + jx) * 64 + m * 32];
 #pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
       for (int jx = 0; jx < 4; ++jx) {
-        r.xr[m][0][jx] = bx[((2 * tsy + ia) * XC + 2 * tsx + jx) * 64 + m * 32];
-        r.xr[m][1][jx] = bx[((2 * tsy + ib) * XC + 2 * tsx + jx) * 64 + m * 32];
+        r.xr[m][0][jx] = bx[((2 * tsy + ia) * XC + 2 * tsx + jx) * XCH + m * 32];
+        r.xr[m][1][jx] = bx[((2 * tsy + ib) * XC + 2 * tsx + jx) * XCH + m * 32];
       }
-    }
   };
   auto compute_pair = [&](const Raw& r) {
-    float E[4][2], V[4][2];
+    float E[4][2], V[4][NT];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const float e0 = ea * r.dy[m][0][0] + eb * r.dy[m][1][0];
@@ -901,6 +906,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
       E[2][m] = e0 - e1;
       E[3][m] = e1;
       if (do_db) dbacc[m] += (r.dy[m][0][0] + r.dy[m][0][1]) + (r.dy[m][1][0] + r.dy[m][1][1]);
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
       float q[4];
 #pragma unroll
       for (int jx = 0; jx < 4; ++jx) q[jx] = r.xr[m][0][jx] + sgn * r.xr[m][1][jx];
@@ -914,7 +922,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
           acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(E[nu][mt], V[nu][nt], acc[nu][mt][nt], 0, 0, 0);
   };
 
@@ -962,7 +970,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float a0 = acc[0][mt][nt][e], a1 = 0.5f * acc[1][mt][nt][e], a2 = 0.5f * acc[2][mt][nt][e], a3 = acc[3][mt][nt][e];
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WinoWgParams p, const flo
       }
       __syncthreads();
       const int kcol = tid & 31;
-      const int cin_g = kb * 64 + nt * 32 + kcol;
+      const int cin_g = kb * XCH + nt * 32 + kcol;
 #pragma unroll
       for (int rep = 0; rep < 4; ++rep) {
         const int i = (tid >> 5) + 8 * rep;
@@ -1032,11 +1040,13 @@ static int wn_wg_plan(const csg_wino_desc* d, WinoWgParams& p, const char* who) 
   const int64_t nr = (int64_t)d->B * p.RXn * p.RYn;
   CSG_REQUIRE(nr < (1ll << 30), CSG_E_UNSUPPORTED, "%s: too many regions", who);
   p.nregions = (int)nr;
+  static const int variant = getenv("CSG_WINO_WGRAD_VARIANT") ? atoi(getenv("CSG_WINO_WGRAD_VARIANT")) : 2;
+  p.nt = variant == 2 ? 1 : 2;                   // 32 (two blocks per CU) or 64 input channels per block
   p.cblocks = (d->Cout + 63) / 64;
-  p.kblocks = (d->Cin + 63) / 64;
-  // one block per CU is resident: aim at ~2 waves of blocks, at least 8 stages per block, at most 512 slabs
+  p.kblocks = (d->Cin + 32 * p.nt - 1) / (32 * p.nt);
+  // 1 or 2 blocks per CU are resident: aim at ~2 waves of blocks, at least 8 stages per block, at most 512 slabs
   const int tiles2d = p.cblocks * p.kblocks;
-  int ns = (512 + tiles2d - 1) / tiles2d;
+  int ns = (512 * (3 - p.nt) + tiles2d - 1) / tiles2d;
   const int max_ns = (int)((nr + 7) / 8);
   if (ns > max_ns) ns = max_ns;
   if (ns > 512) ns = 512;
@@ -1067,13 +1077,14 @@ int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy,
   int dev = 0;
   (void)hipGetDevice(&dev);
   const int tsx = wn_wg_tsx(d->W), tsy = 16 / tsx;
-  // per buffer: the X patch padded to whole 256-lane DMAs + the dY pixels, 64 channels x 4 bytes each
-  const size_t x_f4 = (size_t)(((2 * tsy + 2) * (2 * tsx + 2) * 16 + 255) / 256) * 256;
+  // per buffer: the X patch (32*nt channels) padded to whole 256-lane DMAs + the dY pixels (64 channels)
+  const size_t x_f4 = (size_t)(((2 * tsy + 2) * (2 * tsx + 2) * 8 * p.nt + 255) / 256) * 256;
   const size_t stage_bytes = 2 * (x_f4 * 16 + (size_t)(2 * tsy) * (2 * tsx) * 64 * 4);
   const size_t ep_bytes = (size_t)4 * 3 * 32 * WG_EPS * 4;
   const size_t shm = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    const void* fns[3] = {(const void*)k_wino_wgrad<16>, (const void*)k_wino_wgrad<8>, (const void*)k_wino_wgrad<4>};
+    const void* fns[6] = {(const void*)k_wino_wgrad<16, 2>, (const void*)k_wino_wgrad<8, 2>, (const void*)k_wino_wgrad<4, 2>,
+                          (const void*)k_wino_wgrad<16, 1>, (const void*)k_wino_wgrad<8, 1>, (const void*)k_wino_wgrad<4, 1>};
     for (const void* fn : fns) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino_bwd_weight: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
@@ -1086,12 +1097,21 @@ int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy,
   {
     ProfScope ps(K_WINO_WGRAD, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
     const dim3 grid((unsigned)(p.cblocks * p.kblocks * p.nsplit));
-    if (tsx == 16)
-      hipLaunchKernelGGL(k_wino_wgrad<16>, grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
-    else if (tsx == 8)
-      hipLaunchKernelGGL(k_wino_wgrad<8>, grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
-    else
-      hipLaunchKernelGGL(k_wino_wgrad<4>, grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+    if (p.nt == 2) {
+      if (tsx == 16)
+        hipLaunchKernelGGL((k_wino_wgrad<16, 2>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+      else if (tsx == 8)
+        hipLaunchKernelGGL((k_wino_wgrad<8, 2>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+      else
+        hipLaunchKernelGGL((k_wino_wgrad<4, 2>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+    } else {
+      if (tsx == 16)
+        hipLaunchKernelGGL((k_wino_wgrad<16, 1>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+      else if (tsx == 8)
+        hipLaunchKernelGGL((k_wino_wgrad<8, 1>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+      else
+        hipLaunchKernelGGL((k_wino_wgrad<4, 1>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+    }
     rc = check_launch("csg_wino_bwd_weight");
     if (rc) return rc;
   }
