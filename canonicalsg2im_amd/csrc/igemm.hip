@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "csg_common.h"
+#include "csg_reduce.h"
 
 using namespace csg;
 
@@ -682,20 +683,6 @@ __global__ __launch_bounds__(256, 2) void k_igemm_wgrad(IgemmParams p, const flo
   }
 }
 
-__global__ void k_wgrad_reduce(const float* __restrict__ ws, int64_t n4, int nsplit, float* __restrict__ dw) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  float4 a = ((const float4*)ws)[i];
-  for (int s = 1; s < nsplit; ++s) {
-    float4 b = ((const float4*)ws)[(int64_t)s * n4 + i];
-    a.x += b.x;
-    a.y += b.y;
-    a.z += b.z;
-    a.w += b.w;
-  }
-  ((float4*)dw)[i] = a;
-}
-
 // ------------------------------------------------------------------------------- host side
 static int validate(const csg_conv_desc* d, const char* who) {
   CSG_REQUIRE(d != nullptr, CSG_E_BADSHAPE, "%s: null descriptor", who);
@@ -907,12 +894,8 @@ int csg_conv_bwd_weight(const csg_conv_desc* d, const float* x, const float* dy,
   if (nsplit > 1) {
     const int64_t n4 = (int64_t)d->Cout * p.wrow / 4;
     ProfScope ps(K_WGRAD_REDUCE, (double)(nsplit + 1) * n4 * 16, s);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, s, workspace, n4, nsplit, dw);
-    if (db != nullptr) {
-      const int64_t b4 = d->Cout / 4;
-      hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv(b4, 256)), dim3(256), 0, s,
-                         workspace + (int64_t)nsplit * d->Cout * p.wrow, b4, nsplit, db);
-    }
+    launch_slab_reduce(workspace, n4 * 4, dw, workspace + (int64_t)nsplit * d->Cout * p.wrow, db != nullptr ? d->Cout : 0,
+                       db, nsplit, s);
     rc = check_launch("csg_conv_bwd_weight(reduce)");
   }
   return rc;

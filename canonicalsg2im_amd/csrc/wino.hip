@@ -33,6 +33,7 @@
 
 #include "csg_buffer.h"
 #include "csg_common.h"
+#include "csg_reduce.h"
 
 using namespace csg;
 
@@ -68,46 +69,60 @@ __device__ __forceinline__ int wn_xcd_remap(int bid, int nblk) {
 // strides (s_n, s_k, s_h, s_w) so that the same kernel packs the forward operand (n = cout, k = cin) and the
 // backward-data operand (n = cin, k = cout, taps flipped).  `sigma` (nullable) divides every weight first
 // (W / sigma of spectral normalisation, rounded as the reference rounds it).
+// One block packs 32 n x 32 k (all 9 taps, all 16 positions): the taps are staged in LDS with the loads running
+// along whichever of n / k is the contiguous axis of the parameter (each weight is read from memory once), a thread
+// then forms G g G^T for its (n, 4 k) and writes its 16 float4 — 1 KB contiguous per wave and position.
+#define WP_LD 33
 __global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, int64_t s_n, int64_t s_k, int64_t s_h,
                                                     int64_t s_w, int flip, int N, int K, const float* __restrict__ sigma,
                                                     int NT32, int Q8, float4* __restrict__ up) {
-  const int64_t total = (int64_t)16 * NT32 * Q8 * 64;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int lane = (int)(idx & 63);
-  int64_t rest = idx >> 6;
-  const int q = (int)(rest % Q8);
-  rest /= Q8;
-  const int nt = (int)(rest % NT32);
-  const int p = (int)(rest / NT32);
-  const int xi = p >> 2, nu = p & 3;
-  const int n = nt * 32 + (lane & 31), h = lane >> 5;
+  __shared__ float g[9][32][WP_LD];
+  const int tid = threadIdx.x;
+  const int qb = blockIdx.x, nt = blockIdx.y;         // k range [32 qb, 32 qb + 32), n range [32 nt, 32 nt + 32)
+  const bool k_fast = s_k <= s_n;
   const float sg = sigma != nullptr ? sigma[0] : 1.0f;
-  // rows of G: (1,0,0), (1/2,1/2,1/2), (1/2,-1/2,1/2), (0,0,1)
-  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-  float out[4];
+  for (int e = tid; e < 9 * 1024; e += 256) {
+    const int t = e >> 10, r = e & 1023;
+    const int nl = k_fast ? (r >> 5) : (r & 31), kl = k_fast ? (r & 31) : (r >> 5);
+    const int n = nt * 32 + nl, k = qb * 32 + kl;
+    const int a = t / 3, b = t - 3 * a;
+    const int aa = flip ? 2 - a : a, bb = flip ? 2 - b : b;
+    float v = 0.f;
+    if (n < N && k < K) {
+      v = w[(int64_t)n * s_n + (int64_t)k * s_k + aa * s_h + bb * s_w];
+      if (sigma != nullptr) v = v / sg;
+    }
+    g[t][nl][kl] = v;
+  }
+  __syncthreads();
+  const int lane = tid & 63, ql = tid >> 6;            // 4 q per block, one per wave
+  const int q = qb * 4 + ql;
+  if (q >= Q8) return;
+  const int nl = lane & 31, h = lane >> 5;
+  float u[16][4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int k = 8 * q + (e >> 1) * 4 + 2 * h + (e & 1);
-    float u = 0.f;
-    if (n < N && k < K) {
-      const float* g = w + (int64_t)n * s_n + (int64_t)k * s_k;
+    const int kl = 8 * ql + (e >> 1) * 4 + 2 * h + (e & 1);
+    float t[4][3];                                     // t = G g  (rows of G: (1,0,0), (1/2,1/2,1/2), (1/2,-1/2,1/2), (0,0,1))
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        float t = 0.f;                              // t = sum_b g[a][b] * G[nu][b]
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const int aa = flip ? 2 - a : a, bb = flip ? 2 - b : b;
-          float gv = g[aa * s_h + bb * s_w];
-          if (sigma != nullptr) gv = gv / sg;
-          t += gv * G[nu][b];
-        }
-        u += G[xi][a] * t;
-      }
+    for (int b = 0; b < 3; ++b) {
+      const float g0 = g[b][nl][kl], g1 = g[3 + b][nl][kl], g2 = g[6 + b][nl][kl];
+      t[0][b] = g0;
+      t[1][b] = 0.5f * g0 + 0.5f * g1 + 0.5f * g2;
+      t[2][b] = 0.5f * g0 - 0.5f * g1 + 0.5f * g2;
+      t[3][b] = g2;
     }
-    out[e] = u;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      u[xi * 4 + 0][e] = t[xi][0];
+      u[xi * 4 + 1][e] = 0.5f * t[xi][0] + 0.5f * t[xi][1] + 0.5f * t[xi][2];
+      u[xi * 4 + 2][e] = 0.5f * t[xi][0] - 0.5f * t[xi][1] + 0.5f * t[xi][2];
+      u[xi * 4 + 3][e] = t[xi][2];
+    }
   }
-  up[idx] = make_float4(out[0], out[1], out[2], out[3]);
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+    up[(((int64_t)p * NT32 + nt) * Q8 + q) * 64 + lane] = make_float4(u[p][0], u[p][1], u[p][2], u[p][3]);
 }
 
 // ------------------------------------------------------------------------------------ convolution
@@ -694,7 +709,7 @@ int csg_wino_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h,
   const int64_t total = (int64_t)16 * NT32 * Q8 * 64;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(K_WINO_PACK, (double)Cout * Cin * 9 * 4 + (double)total * 16, s);
-  hipLaunchKernelGGL(k_wino_pack, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
+  hipLaunchKernelGGL(k_wino_pack, dim3((unsigned)cdiv(Q8, 4), (unsigned)NT32), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
                      backward_data ? 1 : 0, (int)N, (int)K, sigma, NT32, Q8, (float4*)packed);
   return check_launch("csg_wino_pack_weights");
 }
@@ -1013,14 +1028,6 @@ __global__ __launch_bounds__(256, NT == 2 ? 1 : 2) void k_wino_wgrad(WinoWgParam
   }
 }
 
-__global__ void k_wino_slab_reduce(const float* __restrict__ ws, int64_t n, int nsplit, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float a = ws[i];
-  for (int s = 1; s < nsplit; ++s) a += ws[(int64_t)s * n + i];
-  out[i] = a;
-}
-
 static int wn_wg_tsx(int W) { return W >= 32 ? 16 : (W >= 16 ? 8 : 4); }
 
 static int wn_wg_plan(const csg_wino_desc* d, WinoWgParams& p, const char* who) {
@@ -1094,6 +1101,10 @@ int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy,
   CSG_REQUIRE(shm <= 128 * 1024, CSG_E_UNSUPPORTED, "csg_wino_bwd_weight: %zu bytes of LDS", shm);
   hipStream_t s = (hipStream_t)stream;
   float* dbslabs = db != nullptr ? workspace + (int64_t)p.nsplit * wsize : nullptr;
+  if (p.nsplit == 1) {          // a single slice: the block results ARE the gradient
+    workspace = dw;
+    dbslabs = db;
+  }
   {
     ProfScope ps(K_WINO_WGRAD, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
     const dim3 grid((unsigned)(p.cblocks * p.kblocks * p.nsplit));
@@ -1115,12 +1126,9 @@ int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy,
     rc = check_launch("csg_wino_bwd_weight");
     if (rc) return rc;
   }
-  {
+  if (p.nsplit > 1) {
     ProfScope ps(K_WGRAD_REDUCE, (double)(p.nsplit + 1) * wsize * 4, s);
-    hipLaunchKernelGGL(k_wino_slab_reduce, dim3((unsigned)cdiv(wsize, 256)), dim3(256), 0, s, workspace, wsize, p.nsplit, dw);
-    if (db != nullptr)
-      hipLaunchKernelGGL(k_wino_slab_reduce, dim3((unsigned)cdiv(d->Cout, 256)), dim3(256), 0, s, dbslabs, (int64_t)d->Cout,
-                         p.nsplit, db);
+    launch_slab_reduce(workspace, wsize, dw, dbslabs, db != nullptr ? d->Cout : 0, db, p.nsplit, s);
     rc = check_launch("csg_wino_bwd_weight(reduce)");
   }
   return rc;

@@ -109,7 +109,7 @@ def _conv_launch(d, x, w, bias, res, y, what):
 
 
 # ---- Winograd F(2x2,3x3) path (csrc/wino.hip): 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip
-WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "16384"))     # B*H*W below which the direct kernel stays
+WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "4096"))     # B*H*W below which the direct kernel stays
 WINO_ENABLED = os.environ.get("CSG_WINOGRAD", "1") != "0"
 WINO_WGRAD = os.environ.get("CSG_WINOGRAD_WGRAD", "1") != "0"
 
