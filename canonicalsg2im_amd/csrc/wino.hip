@@ -55,6 +55,8 @@ struct WinoParams {
   float slope;
   int nstage;          // ceil(Cin / 16)
   int variant;         // 1: 64 tiles per block (k_wino_conv), 2: 32 tiles per block, two blocks per CU (k_wino_conv2)
+  int ksplit, sps;     // k_wino_conv2: input-channel stages cut into ksplit ranges of sps stages, one output slab each
+  long long slab;      // floats per slab (B*H*W*y_cs)
 };
 
 __device__ __forceinline__ int wn_xcd_remap(int bid, int nblk) {
@@ -460,6 +462,8 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   int bid = wn_xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid % p.ksplit;              // splits of one tile are neighbours: they share the input in L2
+  bid /= p.ksplit;
   const int nb = bid % p.nblocks;
   bid /= p.nblocks;
   const int bx = bid % p.tbx;
@@ -577,17 +581,19 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float
     __syncthreads();
   };
 
-  load_stage(0);
-  load_u_half(0, 0);
-  load_u_half(1, 0);
+  const int s_begin = split * p.sps, s_end = min(p.nstage, s_begin + p.sps);
+  y += (long long)split * p.slab;
+  load_stage(s_begin);
+  load_u_half(0, 2 * s_begin);
+  load_u_half(1, 2 * s_begin);
   store_stage(smem);
   __syncthreads();
-  int s = 0;
-  for (; s + 1 < p.nstage; s += 2) {
+  int s = s_begin;
+  for (; s + 1 < s_end; s += 2) {
     stage(s, std::integral_constant<int, 0>());
     stage(s + 1, std::integral_constant<int, 1>());
   }
-  if (s < p.nstage) stage(s, std::integral_constant<int, 0>());
+  if (s < s_end) stage(s, std::integral_constant<int, 0>());
 
   // ---- epilogue (as k_wino_conv, 32 tiles): R[0] = M0+M1+M2, R[1] = M1-M2-M3 per wave, A^T . through LDS
   float* rbuf = smem;                            // [xi][b][32 tiles][WN_RSE]
@@ -684,6 +690,9 @@ static int wn_plan(const csg_wino_desc* d, WinoParams& p, size_t& shm, const cha
   p.Q8 = (d->Cin + 7) / 8;
   p.act = d->act; p.slope = d->slope;
   p.nstage = (d->Cin + WN_BK - 1) / WN_BK;
+  p.ksplit = 1;
+  p.sps = p.nstage;
+  p.slab = (long long)d->B * d->H * d->W * d->y_cs;
   const size_t in_bytes = (size_t)2 * ((2 * p.TH + 2) * p.RS + 16) * 4;        // + the dump slots of idle staging lanes
   const size_t ep_bytes = (size_t)4 * 2 * (p.variant == 2 ? 32 : 64) * WN_RSE * 4;
   shm = in_bytes > ep_bytes ? in_bytes : ep_bytes;
@@ -714,12 +723,44 @@ int csg_wino_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h,
   return check_launch("csg_wino_pack_weights");
 }
 
+// Split over the input channels when the tile grid alone cannot fill the chip (backward-data of the gamma/beta
+// convolutions: 128 output channels, 2048 input channels): only without an epilogue (bias / activation / residual)
+// and with a dense output, the slabs are summed in a fixed order by k_slab_reduce.
+static void wn_split_plan(WinoParams& p, bool plain) {
+  if (p.variant != 2 || !plain || p.y_cs != p.Cout) return;
+  const int64_t blocks = (int64_t)p.B * p.tby * p.tbx * p.nblocks;
+  if (blocks >= 384 || p.nstage < 16) return;
+  int ks = (int)((512 + blocks - 1) / blocks);
+  if (ks > p.nstage / 8) ks = p.nstage / 8;
+  if (ks < 2) return;
+  p.sps = (p.nstage + ks - 1) / ks;
+  p.ksplit = (p.nstage + p.sps - 1) / p.sps;
+}
+
+int64_t csg_wino_conv_workspace(const csg_wino_desc* d) {
+  WinoParams p;
+  size_t shm = 0;
+  if (wn_plan(d, p, shm, "csg_wino_conv_workspace")) return -1;
+  wn_split_plan(p, d->act == CSG_ACT_NONE);
+  return p.ksplit > 1 ? (int64_t)p.ksplit * p.slab * 4 : 0;
+}
+
 int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, const float* bias, const float* residual,
-                  float* y, void* stream) {
+                  float* y, float* workspace, int64_t workspace_bytes, void* stream) {
   WinoParams p;
   size_t shm = 0;
   int rc = wn_plan(d, p, shm, "csg_wino_conv");
   if (rc) return rc;
+  wn_split_plan(p, d->act == CSG_ACT_NONE && bias == nullptr && residual == nullptr);
+  if (p.ksplit > 1 && (workspace == nullptr || workspace_bytes < (int64_t)p.ksplit * p.slab * 4)) {   // no slabs: unsplit
+    p.ksplit = 1;
+    p.sps = p.nstage;
+  }
+  float* const y_final = y;
+  if (p.ksplit > 1) {
+    CSG_REQUIRE(((uintptr_t)workspace % 16) == 0, CSG_E_UNSUPPORTED, "csg_wino_conv: workspace must be 16-byte aligned");
+    y = workspace;
+  }
   CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 16) == 0, CSG_E_UNSUPPORTED,
               "csg_wino_conv: pointers must be 16-byte aligned");
   static bool attr_set[16] = {};
@@ -737,7 +778,7 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
   }
   CSG_REQUIRE(shm <= 96 * 1024, CSG_E_UNSUPPORTED, "csg_wino_conv: %zu bytes of LDS", shm);
   hipStream_t s = (hipStream_t)stream;
-  const int64_t grid = (int64_t)p.B * p.tby * p.tbx * p.nblocks;
+  const int64_t grid = (int64_t)p.B * p.tby * p.tbx * p.nblocks * p.ksplit;
   CSG_REQUIRE(grid < (1ll << 31), CSG_E_UNSUPPORTED, "csg_wino_conv: grid too large");
   // algorithmic FLOPs of the DIRECT convolution this replaces (2 * M * 9*Cin * Cout): what FlopCounterMode counts
   ProfScope ps(K_WINO_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
@@ -749,7 +790,12 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
       hipLaunchKernelGGL(k_wino_conv2<8>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
     else
       hipLaunchKernelGGL(k_wino_conv2<4>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
-    return check_launch("csg_wino_conv");
+    rc = check_launch("csg_wino_conv");
+    if (rc == CSG_OK && p.ksplit > 1) {
+      launch_slab_reduce(workspace, p.slab, y_final, nullptr, 0, nullptr, p.ksplit, s);
+      rc = check_launch("csg_wino_conv(slab sum)");
+    }
+    return rc;
   }
   if (p.TW == 32)
     hipLaunchKernelGGL(k_wino_conv<32>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);

@@ -135,7 +135,12 @@ def wino_pack(weight, backward_data, sigma=None):
 def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what):
     d = WinoDesc()
     d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, act, slope
-    check(lib.csg_wino_conv(d, ptr(x), ptr(packed), ptr(bias), ptr(res), ptr(y), stream()), what)
+    ws, nws = None, 0
+    if bias is None and res is None and act == ACT_NONE:
+        nws = lib.csg_wino_conv_workspace(d)
+        if nws > 0:
+            ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32)
+    check(lib.csg_wino_conv(d, ptr(x), ptr(packed), ptr(bias), ptr(res), ptr(y), ptr(ws), nws, stream()), what)
 
 
 class _Conv2d(torch.autograd.Function):

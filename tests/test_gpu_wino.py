@@ -31,7 +31,7 @@ def _raw_wino(ops, x, w, bias=None, res=None, act=0, slope=0.0):
     d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, act, slope
     bd = bias.cuda() if bias is not None else None
     rd = ops.nhwc(res.cuda()) if res is not None else None
-    check(lib.csg_wino_conv(d, ptr(xd), ptr(up), ptr(bd), ptr(rd), ptr(y), stream()), "wino_conv")
+    check(lib.csg_wino_conv(d, ptr(xd), ptr(up), ptr(bd), ptr(rd), ptr(y), None, 0, stream()), "wino_conv")
     return y
 
 
@@ -46,6 +46,40 @@ SHAPES = [
     (1, 48, 72, 6, 130),        # TW = 32, ragged x, a single tile row
     (1, 1024, 64, 16, 16),      # long K (64 stages)
 ]
+
+
+@pytest.mark.parametrize("shape", [(2, 2048, 128, 16, 16), (1, 1168, 64, 32, 16), (1, 272, 32, 8, 8)])
+def test_wino_split_over_input_channels(ops, shape):
+    """Few tiles, few output channels, many input channels (backward-data of the gamma/beta convolutions): the launch
+    is split over the input channels into slabs and summed in a fixed order — same result as the unsplit launch up to
+    the association of the sum, bit-identical from run to run."""
+    from canonicalsg2im_amd._lib import WinoDesc, check, lib, ptr, stream
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    xd = ops.nhwc(x.cuda())
+    up = ops.wino_pack(w.cuda(), False)
+    d = WinoDesc()
+    d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, 0, 0.0
+    nws = lib.csg_wino_conv_workspace(d)
+    assert nws > 0 and nws % (B * H * W * Cout * 4) == 0 and nws // (B * H * W * Cout * 4) >= 2
+    ws = torch.empty(nws // 4, device="cuda")
+    outs = []
+    for _ in range(2):
+        ws.fill_(float("nan"))
+        y = ops.empty_nhwc(B, Cout, H, W, xd.device)
+        check(lib.csg_wino_conv(d, ptr(xd), ptr(up), None, None, ptr(y), ptr(ws), nws, stream()), "wino_conv")
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    y0 = _raw_wino(ops, x, w)                                   # no workspace: unsplit
+    scale = float(ref.abs().max())
+    assert_close(outs[0], ref.float(), 1e-4, 1e-5 * scale + 1e-5, "wino split %s" % (shape,))
+    assert_close(outs[0], y0, 1e-4, 1e-5 * scale + 1e-5, "wino split vs unsplit %s" % (shape,))
+    # with an epilogue the plan never splits
+    d.act = 1
+    assert lib.csg_wino_conv_workspace(d) == 0
 
 
 @pytest.mark.parametrize("shape", SHAPES)
