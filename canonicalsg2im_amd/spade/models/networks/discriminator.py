@@ -1,5 +1,8 @@
 """Multiscale PatchGAN discriminator (reference: spade/models/networks/discriminator.py:66-206)."""
+import os
+
 import numpy as np
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -62,6 +65,17 @@ class NLayerDiscriminator(BaseNetwork):
         return results[1:] if not self.opt.no_ganFeat_loss else results[-1]
 
 
+SCALE_STREAMS = os.environ.get("CSG_D_SCALE_STREAMS", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 class MultiscaleDiscriminator(BaseNetwork):
     def __init__(self, opt):
         super().__init__()
@@ -94,13 +108,35 @@ class MultiscaleDiscriminator(BaseNetwork):
         grad_channels = None
         if want_img != want_seg and S % 4 == 0:
             grad_channels = (S, x.size(1)) if want_img else (0, S)
+        scales = [D for name, D in self.named_children() if name.startswith('discriminator')]
+        if len(scales) > 1 and SCALE_STREAMS and x.is_cuda:
+            return self._forward_concurrent(scales, x, S, grad_channels)
         result = []
-        for name, D in self.named_children():
-            if name.startswith('discriminator'):
-                out = D(x, seg_first=S, grad_channels=grad_channels)
-                result.append(out if not self.opt.no_ganFeat_loss else [out])
-                x = self.downsample(x)
+        for D in scales:
+            out = D(x, seg_first=S, grad_channels=grad_channels)
+            result.append(out if not self.opt.no_ganFeat_loss else [out])
+            x = self.downsample(x)
         return result
+
+    def _forward_concurrent(self, scales, x, S, grad_channels):
+        """Scale 0 on the caller's stream, the lower-resolution scales (grids that cannot fill the chip) on a side
+        stream, joined by events at both ends; autograd replays each scale's backward on the stream of its forward."""
+        main = torch.cuda.current_stream(x.device)
+        side = _side_stream(x.device)
+        side.wait_stream(main)
+        x.record_stream(side)
+        lower = []
+        with torch.cuda.stream(side):
+            xs = x
+            for D in scales[1:]:
+                xs = self.downsample(xs)
+                lower.append(D(xs, seg_first=S, grad_channels=grad_channels))
+        first = scales[0](x, seg_first=S, grad_channels=grad_channels)
+        main.wait_stream(side)
+        for out in lower:
+            for t in (out if isinstance(out, (list, tuple)) else [out]):
+                t.record_stream(main)
+        return [out if not self.opt.no_ganFeat_loss else [out] for out in [first] + lower]
 
 
 class AcDiscriminator(nn.Module):
