@@ -53,6 +53,7 @@ struct WinoParams {
   int NT32, Q8;        // extents of the packed weights
   int act;
   float slope;
+  float gate_slope;    // epilogue gate: y *= (gate > 0 ? 1 : gate_slope)
   int nstage;          // ceil(Cin / 16)
   int variant;         // 1: 64 tiles per block (k_wino_conv), 2: 32 tiles per block, two blocks per CU (k_wino_conv2)
   int ksplit, sps;     // k_wino_conv2: input-channel stages cut into ksplit ranges of sps stages, one output slab each
@@ -155,7 +156,8 @@ constexpr int wn_row_stride(int TW) {
 template <int TW>
 __global__ __launch_bounds__(256, 1) void k_wino_conv(WinoParams p, const float* __restrict__ x,
                                                        const float4* __restrict__ up, const float* __restrict__ bias,
-                                                       const float* __restrict__ res, float* __restrict__ y) {
+                                                       const float* __restrict__ res, const float* __restrict__ gate,
+                                                       float* __restrict__ y) {
   constexpr int TH = 64 / TW;
   constexpr int R = 2 * TH + 2, C = 2 * TW + 2;
   constexpr int RS = wn_row_stride(TW);
@@ -433,6 +435,11 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv(WinoParams p, const float*
               const float4 rv = *(const float4*)(res + pix * p.y_cs + n);
               v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
             }
+            if (gate != nullptr) {
+              const float4 gv = *(const float4*)(gate + pix * p.y_cs + n);
+              v[0] *= gv.x > 0.f ? 1.f : p.gate_slope; v[1] *= gv.y > 0.f ? 1.f : p.gate_slope;
+              v[2] *= gv.z > 0.f ? 1.f : p.gate_slope; v[3] *= gv.w > 0.f ? 1.f : p.gate_slope;
+            }
             *(float4*)(y + pix * p.y_cs + n) = make_float4(v[0], v[1], v[2], v[3]);
           }
       }
@@ -451,7 +458,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv(WinoParams p, const float*
 template <int TW>
 __global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float* __restrict__ x,
                                                         const float4* __restrict__ up, const float* __restrict__ bias,
-                                                        const float* __restrict__ res, float* __restrict__ y) {
+                                                        const float* __restrict__ res, const float* __restrict__ gate,
+                                                        float* __restrict__ y) {
   constexpr int TH = 32 / TW;
   constexpr int R = 2 * TH + 2, C = 2 * TW + 2;
   constexpr int RS = wn_row_stride(TW);
@@ -650,6 +658,11 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float
               const float4 rv = *(const float4*)(res + pix * p.y_cs + n);
               vv[0] += rv.x; vv[1] += rv.y; vv[2] += rv.z; vv[3] += rv.w;
             }
+            if (gate != nullptr) {
+              const float4 gv = *(const float4*)(gate + pix * p.y_cs + n);
+              vv[0] *= gv.x > 0.f ? 1.f : p.gate_slope; vv[1] *= gv.y > 0.f ? 1.f : p.gate_slope;
+              vv[2] *= gv.z > 0.f ? 1.f : p.gate_slope; vv[3] *= gv.w > 0.f ? 1.f : p.gate_slope;
+            }
             *(float4*)(y + pix * p.y_cs + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
           }
       }
@@ -746,12 +759,14 @@ int64_t csg_wino_conv_workspace(const csg_wino_desc* d) {
 }
 
 int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, const float* bias, const float* residual,
-                  float* y, float* workspace, int64_t workspace_bytes, void* stream) {
+                  const float* gate, float gate_slope, float* y, float* workspace, int64_t workspace_bytes, void* stream) {
   WinoParams p;
   size_t shm = 0;
   int rc = wn_plan(d, p, shm, "csg_wino_conv");
   if (rc) return rc;
-  wn_split_plan(p, d->act == CSG_ACT_NONE && bias == nullptr && residual == nullptr);
+  wn_split_plan(p, d->act == CSG_ACT_NONE && bias == nullptr && residual == nullptr && gate == nullptr);
+  p.gate_slope = gate_slope;
+  CSG_REQUIRE(gate == nullptr || ((uintptr_t)gate % 16) == 0, CSG_E_UNSUPPORTED, "csg_wino_conv: gate must be 16-byte aligned");
   if (p.ksplit > 1 && (workspace == nullptr || workspace_bytes < (int64_t)p.ksplit * p.slab * 4)) {   // no slabs: unsplit
     p.ksplit = 1;
     p.sps = p.nstage;
@@ -785,11 +800,11 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
   const float4* up = (const float4*)packed;
   if (p.variant == 2) {
     if (p.TW == 16)
-      hipLaunchKernelGGL(k_wino_conv2<16>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+      hipLaunchKernelGGL(k_wino_conv2<16>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
     else if (p.TW == 8)
-      hipLaunchKernelGGL(k_wino_conv2<8>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+      hipLaunchKernelGGL(k_wino_conv2<8>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
     else
-      hipLaunchKernelGGL(k_wino_conv2<4>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+      hipLaunchKernelGGL(k_wino_conv2<4>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
     rc = check_launch("csg_wino_conv");
     if (rc == CSG_OK && p.ksplit > 1) {
       launch_slab_reduce(workspace, p.slab, y_final, nullptr, 0, nullptr, p.ksplit, s);
@@ -798,13 +813,13 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
     return rc;
   }
   if (p.TW == 32)
-    hipLaunchKernelGGL(k_wino_conv<32>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+    hipLaunchKernelGGL(k_wino_conv<32>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
   else if (p.TW == 16)
-    hipLaunchKernelGGL(k_wino_conv<16>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+    hipLaunchKernelGGL(k_wino_conv<16>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
   else if (p.TW == 8)
-    hipLaunchKernelGGL(k_wino_conv<8>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+    hipLaunchKernelGGL(k_wino_conv<8>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
   else
-    hipLaunchKernelGGL(k_wino_conv<4>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, y);
+    hipLaunchKernelGGL(k_wino_conv<4>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
   return check_launch("csg_wino_conv");
 }
 

@@ -132,7 +132,9 @@ def wino_pack(weight, backward_data, sigma=None):
     return packed
 
 
-def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what):
+def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what, gate=None, gate_slope=0.0):
+    """Returns True when `gate` was folded into the launch (a launch split over the input channels has no epilogue:
+    the caller applies the gate in a separate pass then)."""
     d = WinoDesc()
     d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, act, slope
     ws, nws = None, 0
@@ -140,7 +142,10 @@ def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what):
         nws = lib.csg_wino_conv_workspace(d)
         if nws > 0:
             ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32)
-    check(lib.csg_wino_conv(d, ptr(x), ptr(packed), ptr(bias), ptr(res), ptr(y), ptr(ws), nws, stream()), what)
+            gate = None
+    check(lib.csg_wino_conv(d, ptr(x), ptr(packed), ptr(bias), ptr(res), ptr(gate), gate_slope, ptr(y), ptr(ws), nws,
+                            stream()), what)
+    return gate is not None
 
 
 class _Conv2d(torch.autograd.Function):
@@ -148,7 +153,12 @@ class _Conv2d(torch.autograd.Function):
     include/csg_hip.h (K8/K11)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, pad, act, slope, packs=None, dx_range=None):
+    def forward(ctx, x, weight, bias, residual, stride, pad, act, slope, packs=None, dx_range=None, in_act=None,
+                grad_is_pre=False):
+        """`in_act=(act, slope)`: x is the output of that activation and THIS call is its only consumer — the
+        backward returns dx already multiplied by act'(x), i.e. the gradient of the producer's pre-activation (folded
+        into the Winograd backward-data epilogue).  `grad_is_pre=True` is the producer's half of the pair: its incoming
+        gradient needs no activation derivative any more."""
         x = nhwc(_f32(x))
         B, Cin, IH, IW = x.shape
         Cout, Cin_w, KH, KW = weight.shape
@@ -156,7 +166,7 @@ class _Conv2d(torch.autograd.Function):
             Cin_w = packs[0].shape[3]              # packed weights carry their own channel padding
         if Cin_w != Cin:
             raise RuntimeError("conv2d: weight expects %d input channels, x has %d" % (Cin_w, Cin))
-        ctx.packs, ctx.dx_range = packs, dx_range
+        ctx.packs, ctx.dx_range, ctx.in_act, ctx.grad_is_pre = packs, dx_range, in_act, grad_is_pre
         res = nhwc(residual) if residual is not None else None
         if dx_range is None and wino_eligible(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
             OH, OW = IH, IW
@@ -180,7 +190,8 @@ class _Conv2d(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW, act, slope = ctx.geom
         dy = nhwc(dy)
-        if act != ACT_NONE:
+        gated = ctx.in_act is None
+        if act != ACT_NONE and not ctx.grad_is_pre:
             dpre = torch.empty_like(dy)
             check(lib.csg_act_bwd(ptr(dy), ptr(y), dy.numel(), act, slope, ptr(dpre), stream()), "act_bwd")
         else:
@@ -205,13 +216,17 @@ class _Conv2d(torch.autograd.Function):
             # dX = conv3x3(dY, flipped W^T): the same Winograd kernel with the roles of the channel counts swapped
             ut = ctx.packs[3] if (ctx.packs is not None and len(ctx.packs) > 3) else wino_pack(weight, True)
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
-            _wino_launch(dpre, ut, None, None, dx, B, IH, IW, Cout, Cin, ACT_NONE, 0.0, "wino_conv_bwd_data")
+            gated = _wino_launch(dpre, ut, None, None, dx, B, IH, IW, Cout, Cin, ACT_NONE, 0.0, "wino_conv_bwd_data",
+                                 gate=x if ctx.in_act is not None else None,
+                                 gate_slope=ctx.in_act[1] if ctx.in_act is not None else 0.0) or ctx.in_act is None
         elif ctx.needs_input_grad[0]:
             wt = ctx.packs[1] if ctx.packs is not None else \
                 weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
             for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
                 _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
+        if dx is not None and not gated:              # the producer's activation derivative as a separate pass
+            check(lib.csg_act_bwd(ptr(dx), ptr(x), dx.numel(), ctx.in_act[0], ctx.in_act[1], ptr(dx), stream()), "act_bwd")
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         wino_wg = -1
         if ctx.needs_input_grad[1] and WINO_WGRAD and wino_eligible(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
@@ -248,7 +263,7 @@ class _Conv2d(torch.autograd.Function):
             check(lib.csg_colsum(ptr(dpre), rows, Cout, Cout, ptr(db), ptr(part), nch, stream()), "colsum")
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy                            # the residual is added AFTER the activation (igemm.hip epilogue)
-        return dx, dw, db, dres, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
 def pack_conv_weight(weight):
@@ -265,7 +280,7 @@ def pack_conv_weight(weight):
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, residual=None, packs=None,
-           dx_range=None):
+           dx_range=None, in_act=None, grad_is_pre=False):
     """Channel counts that are not multiples of 4 (conv_img: 3 outputs, the PatchGAN head: 1) are
     zero-padded to 16-byte pixel rows; the result is a channel-slice view of the padded output."""
     Cout, Cin = weight.shape[0], weight.shape[1]
@@ -287,7 +302,12 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, r
         residual = F.pad(residual, (0, 0, 0, 0, 0, po)) if residual is not None else None
     if dx_range is not None and (dx_range[0] % 4 or dx_range[1] % 4 or pc):
         raise RuntimeError("conv2d: dx_range must be 4-aligned channel bounds of an unpadded input")
-    y = _Conv2d.apply(x, weight, bias, residual, int(stride), int(padding), int(act), float(slope), packs, dx_range)
+    if in_act is not None and (pc or dx_range is not None or in_act[0] != ACT_LEAKY):
+        raise RuntimeError("conv2d: in_act needs an unpadded input, no dx_range and a (Leaky)ReLU producer")
+    if grad_is_pre and po:
+        raise RuntimeError("conv2d: grad_is_pre needs an unpadded output")
+    y = _Conv2d.apply(x, weight, bias, residual, int(stride), int(padding), int(act), float(slope), packs, dx_range,
+                      in_act, bool(grad_is_pre))
     return y[:, :Cout] if po else y
 
 

@@ -89,8 +89,12 @@ class SPADE(nn.Module):
             seg = segmap.at(x.size(2))
         else:
             seg = segmap if segmap.shape[2:] == x.shape[2:] else F.interpolate(segmap, size=x.shape[2:], mode='nearest')
-        actv = self.mlp_shared(seg)
+        # actv = ReLU(mlp_shared(seg)) has ONE consumer, the gamma||beta convolution: the ReLU derivative is folded into
+        # that convolution's backward-data epilogue (in_act), and mlp_shared's backward receives the gradient of its
+        # pre-activation directly (grad_is_pre) — no separate pass over the 128-channel maps
+        sh = self.mlp_shared[0]
+        actv = ops.conv2d(seg, sh.weight, sh.bias, 1, sh.padding[0], sh.act, sh.slope, grad_is_pre=True)
         w = torch.cat([self.mlp_gamma.weight, self.mlp_beta.weight], dim=0)
         b = torch.cat([self.mlp_gamma.bias, self.mlp_beta.bias], dim=0)
-        gb = ops.conv2d(actv, w, b, 1, self.pw)                     # (B, 2C, h, w): gamma || beta
+        gb = ops.conv2d(actv, w, b, 1, self.pw, in_act=(sh.act, sh.slope))      # (B, 2C, h, w): gamma || beta
         return self.param_free_norm(x, gb=gb, fused_slope=fused_slope)

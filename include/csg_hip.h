@@ -191,10 +191,15 @@ int csg_wino_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h,
 /* `workspace` (csg_wino_conv_workspace(d) bytes, may be 0 / NULL): slabs of a split over the input channels, used
  * when the tile grid alone cannot fill the chip and the call has no epilogue (bias, residual, activation) — the
  * backward-data pass of the 128 -> 2048 gamma/beta convolutions; summed in a fixed order (bit-reproducible).
- * Without (enough) workspace the launch runs unsplit.                                                            */
+ * Without (enough) workspace the launch runs unsplit.
+ * `gate` (nullable, the layout of y): y *= (gate > 0 ? 1 : gate_slope) as the last step — the derivative of the
+ * (Leaky)ReLU that PRODUCED this convolution's input, folded into the backward-data pass of the SPADE gamma/beta
+ * convolutions (their input `actv` = ReLU(mlp_shared(seg)), normalization.py:96-100, has no other consumer), which
+ * replaces a separate pass over the 128-channel maps.  A gated call is never split.                              */
 int64_t csg_wino_conv_workspace(const csg_wino_desc* d);
 int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, const float* bias,
-                  const float* residual, float* y, float* workspace, int64_t workspace_bytes, void* stream);
+                  const float* residual, const float* gate, float gate_slope, float* y, float* workspace,
+                  int64_t workspace_bytes, void* stream);
 /* Weight gradient of the same layers by Winograd F(3x3,2x2): dw [Cout][3][3][Cin] (the layout of
  * csg_conv_bwd_weight), db (Cout) or NULL; x (B,H,W,Cin) the layer's input, dy (B,H,W,Cout) the gradient of its
  * pre-activation output.  Deterministic: per-slice slabs in `workspace` + an ordered reduction.              */

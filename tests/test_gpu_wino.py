@@ -31,7 +31,7 @@ def _raw_wino(ops, x, w, bias=None, res=None, act=0, slope=0.0):
     d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, act, slope
     bd = bias.cuda() if bias is not None else None
     rd = ops.nhwc(res.cuda()) if res is not None else None
-    check(lib.csg_wino_conv(d, ptr(xd), ptr(up), ptr(bd), ptr(rd), ptr(y), None, 0, stream()), "wino_conv")
+    check(lib.csg_wino_conv(d, ptr(xd), ptr(up), ptr(bd), ptr(rd), None, 0.0, ptr(y), None, 0, stream()), "wino_conv")
     return y
 
 
@@ -70,7 +70,7 @@ def test_wino_split_over_input_channels(ops, shape):
     for _ in range(2):
         ws.fill_(float("nan"))
         y = ops.empty_nhwc(B, Cout, H, W, xd.device)
-        check(lib.csg_wino_conv(d, ptr(xd), ptr(up), None, None, ptr(y), ptr(ws), nws, stream()), "wino_conv")
+        check(lib.csg_wino_conv(d, ptr(xd), ptr(up), None, None, None, 0.0, ptr(y), ptr(ws), nws, stream()), "wino_conv")
         outs.append(y)
     assert torch.equal(outs[0], outs[1])
     y0 = _raw_wino(ops, x, w)                                   # no workspace: unsplit
@@ -211,3 +211,32 @@ def test_wino_full_size_window(ops):
                                                       1 if y0 == 0 else 0, 1 if y0 + 13 > H else 0))
         ref = F.conv2d(patch, w, b)
         assert_close(y[bi:bi + 1, :, y0:y0 + 12, x0:x0 + 12], ref, 1e-4, 2e-5, "window (%d,%d,%d)" % (bi, y0, x0))
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 128, 256, 64, 64),     # Winograd, gate folded into the backward-data epilogue
+                                   (1, 32, 128, 2048, 16, 16),    # backward-data split over 2048 channels: separate gate pass
+                                   (2, 32, 128, 64, 8, 8)])       # direct kernels
+def test_producer_activation_folded_into_consumer_backward(ops, shape):
+    """SPADE's actv = ReLU(conv(seg)) -> conv(actv): the pair (grad_is_pre, in_act) gives the gradients of the plain
+    composition."""
+    B, C0, C1, C2, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    seg = torch.randn(B, C0, H, W, generator=g)
+    w1 = torch.randn(C1, C0, 3, 3, generator=g) / (3.0 * C0 ** 0.5)
+    b1 = torch.randn(C1, generator=g) * 0.1
+    w2 = torch.randn(C2, C1, 3, 3, generator=g) / (3.0 * C1 ** 0.5)
+    gy = torch.randn(B, C2, H, W, generator=g)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (seg, w1, b1, w2)]
+    dev = [t.clone().cuda().requires_grad_(True) for t in (seg, w1, b1, w2)]
+    actv = ops.conv2d(dev[0], dev[1], dev[2], 1, 1, ops.ACT_LEAKY, 0.0, grad_is_pre=True)
+    y = ops.conv2d(actv, dev[3], None, 1, 1, in_act=(ops.ACT_LEAKY, 0.0))
+    got = torch.autograd.grad(y, dev, ops.nhwc(gy.cuda()))
+    # the reference uses the device's gates: a pre-activation within rounding of zero may land on either side
+    pre = F.conv2d(ref_in[0], ref_in[1], ref_in[2], padding=1)
+    gates = (actv.detach().cpu() > 0).double()
+    assert float(((pre.detach() > 0).double() - gates).abs().mean()) < 1e-4
+    out = F.conv2d(pre * gates, ref_in[3], None, padding=1)
+    ref = torch.autograd.grad(out, ref_in, gy.double())
+    for name, a, b in zip(("dseg", "dw1", "db1", "dw2"), got, ref):
+        scale = float(b.abs().max())
+        assert_close(a, b.float(), 2e-4, 2e-4 * scale, "%s %s" % (name, shape))

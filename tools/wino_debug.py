@@ -11,7 +11,7 @@ def raw(x, up, Cout):
     y = ops.empty_nhwc(B, Cout, H, W, xd.device)
     d = WinoDesc()
     d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, 0, 0.0
-    check(lib.csg_wino_conv(d, ptr(xd), ptr(up), None, None, ptr(y), None, 0, stream()), "wino")
+    check(lib.csg_wino_conv(d, ptr(xd), ptr(up), None, None, None, 0.0, ptr(y), None, 0, stream()), "wino")
     torch.cuda.synchronize()
     return y.cpu()
 
