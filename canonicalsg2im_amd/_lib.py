@@ -37,6 +37,12 @@ class WinoDesc(ctypes.Structure):
                 ("y_cs", c_i32), ("act", c_i32), ("slope", c_f32)]
 
 
+class FewDesc(ctypes.Structure):
+    """Mirror of `csg_few_desc` (include/csg_hip.h)."""
+    _fields_ = [("B", c_i32), ("IH", c_i32), ("IW", c_i32), ("Cin", c_i32), ("x_cs", c_i32), ("KH", c_i32), ("KW", c_i32),
+                ("pad", c_i32), ("cout_real", c_i32), ("act", c_i32), ("slope", c_f32)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/csg_hip.h
 SIGNATURES = {
     "csg_version": (c_i32, []),
@@ -71,6 +77,12 @@ SIGNATURES = {
     "csg_conv_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_wino_pack_bytes": (c_i64, [c_i64, c_i64]),
     "csg_wino_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
+    "csg_conv_few_supported": (c_i32, [ctypes.POINTER(FewDesc)]),
+    "csg_conv_few_fwd_workspace": (c_i64, [ctypes.POINTER(FewDesc)]),
+    "csg_conv_few_fwd": (c_i32, [ctypes.POINTER(FewDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_conv_few_bwd_data": (c_i32, [ctypes.POINTER(FewDesc), c_p, c_p, c_p, c_p]),
+    "csg_conv_few_bwd_weight_workspace": (c_i64, [ctypes.POINTER(FewDesc)]),
+    "csg_conv_few_bwd_weight": (c_i32, [ctypes.POINTER(FewDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_wino_conv_workspace": (c_i64, [ctypes.POINTER(WinoDesc)]),
     "csg_wino_conv": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_i64, c_p]),
     "csg_wino_bwd_weight_workspace": (c_i64, [ctypes.POINTER(WinoDesc)]),

@@ -92,7 +92,8 @@ static const char* kNames[K_COUNT] = {
     "norm_bwd_reduce", "norm_bwd_dx",    "upsample2x_fwd",   "upsample2x_bwd",  "avgpool3s2_fwd",    "avgpool3s2_bwd", "crop_fwd", "crop_bwd",
     "maxpool2_fwd",   "maxpool2_bwd",   "l1_mean_fwd",      "l1_mean_bwd",
     "canon_build",    "canon_emit",     "spectral_norm_fwd", "spectral_norm_bwd",
-    "wino_conv",      "wino_pack",      "wino_wgrad"};
+    "wino_conv",      "wino_pack",      "wino_wgrad",
+    "few_fwd",        "few_bwd_data",   "few_bwd_weight"};
 
 }  // namespace csg
 

@@ -49,6 +49,9 @@ enum KernelId {
   K_WINO_CONV,
   K_WINO_PACK,
   K_WINO_WGRAD,
+  K_FEW_FWD,
+  K_FEW_BWD_DATA,
+  K_FEW_BWD_WEIGHT,
   K_COUNT
 };
 

@@ -15,7 +15,7 @@ from . import _lib
 from . import dist as csg_dist
 import os
 
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, WinoDesc, check, lib, ptr, stream
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, WinoDesc, check, lib, ptr, stream
 
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
@@ -109,6 +109,7 @@ def _conv_launch(d, x, w, bias, res, y, what):
 
 
 # ---- Winograd F(2x2,3x3) path (csrc/wino.hip): 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip
+FEW_ENABLED = os.environ.get("CSG_FEW_OUTPUT_KERNELS", "1") != "0"   # csrc/fewn.hip for convolutions with <= 4 outputs
 WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "4096"))     # B*H*W below which the direct kernel stays
 WINO_ENABLED = os.environ.get("CSG_WINOGRAD", "1") != "0"
 WINO_WGRAD = os.environ.get("CSG_WINOGRAD_WGRAD", "1") != "0"
@@ -148,13 +149,23 @@ def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what, 
     return gate is not None
 
 
+def _few_desc(B, IH, IW, Cin, KH, KW, stride, pad, cout_real, act, slope):
+    """Descriptor of csrc/fewn.hip if this convolution is one it serves (<= 4 outputs, stride 1, 3x3 or 4x4), else None."""
+    if not FEW_ENABLED or cout_real is None or stride != 1 or KH != KW:
+        return None
+    d = FewDesc()
+    d.B, d.IH, d.IW, d.Cin, d.x_cs, d.KH, d.KW, d.pad, d.cout_real, d.act, d.slope = \
+        B, IH, IW, Cin, Cin, KH, KW, pad, cout_real, act, slope
+    return d if lib.csg_conv_few_supported(d) == 1 else None
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv2d(x, w) + b) [+ residual] — reference nn.Conv2d call sites listed in
     include/csg_hip.h (K8/K11)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, stride, pad, act, slope, packs=None, dx_range=None, in_act=None,
-                grad_is_pre=False):
+                grad_is_pre=False, cout_real=None):
         """`in_act=(act, slope)`: x is the output of that activation and THIS call is its only consumer — the
         backward returns dx already multiplied by act'(x), i.e. the gradient of the producer's pre-activation (folded
         into the Winograd backward-data epilogue).  `grad_is_pre=True` is the producer's half of the pair: its incoming
@@ -168,7 +179,18 @@ class _Conv2d(torch.autograd.Function):
             raise RuntimeError("conv2d: weight expects %d input channels, x has %d" % (Cin_w, Cin))
         ctx.packs, ctx.dx_range, ctx.in_act, ctx.grad_is_pre = packs, dx_range, in_act, grad_is_pre
         res = nhwc(residual) if residual is not None else None
-        if dx_range is None and wino_eligible(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
+        ctx.few = None
+        if Cout == 4 and res is None and dx_range is None and packs is None and in_act is None:
+            ctx.few = _few_desc(B, IH, IW, Cin, KH, KW, stride, pad, cout_real, act, slope)
+        if ctx.few is not None:
+            OH, OW = IH + 2 * pad - KH + 1, IW + 2 * pad - KW + 1
+            y = empty_nhwc(B, Cout, OH, OW, x.device)
+            wp = weight.detach().permute(0, 2, 3, 1).contiguous()
+            nws = lib.csg_conv_few_fwd_workspace(ctx.few)
+            ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32) if nws > 0 else None
+            check(lib.csg_conv_few_fwd(ctx.few, ptr(x), ptr(wp), ptr(bias.detach() if bias is not None else None), ptr(y),
+                                       ptr(ws), nws, stream()), "conv_few_fwd")
+        elif dx_range is None and wino_eligible(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
             OH, OW = IH, IW
             y = empty_nhwc(B, Cout, OH, OW, x.device)
             up = packs[2] if (packs is not None and len(packs) > 2) else wino_pack(weight, False)
@@ -197,6 +219,26 @@ class _Conv2d(torch.autograd.Function):
         else:
             dpre = dy
         dx = dw = db = dres = None
+        if ctx.few is not None:
+            if ctx.needs_input_grad[0] and Cin >= 256:
+                wp = weight.detach().permute(0, 2, 3, 1).contiguous()
+                dx = empty_nhwc(B, Cin, IH, IW, dy.device)
+                check(lib.csg_conv_few_bwd_data(ctx.few, ptr(dpre), ptr(wp), ptr(dx), stream()), "conv_few_bwd_data")
+            elif ctx.needs_input_grad[0]:
+                # few input channels as well (conv_img: 64): a (pixels x 36) x (36 x 64) product, fine on the matrix cores
+                wt = weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]
+                dx = empty_nhwc(B, Cin, IH, IW, dy.device)
+                for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
+                    _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                nbytes = lib.csg_conv_few_bwd_weight_workspace(ctx.few)
+                ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
+                dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
+                db = torch.empty(Cout, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+                check(lib.csg_conv_few_bwd_weight(ctx.few, ptr(x), ptr(dpre), ptr(dwp), ptr(db), ptr(ws), nbytes, stream()),
+                      "conv_few_bwd_weight")
+                dw = dwp.permute(0, 3, 1, 2)
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0] and ctx.dx_range is not None:
             # only input channels [lo, hi) are wanted by the consumer of dx (the discriminator's packed
             # [layout | img | pad] input: the image part in the generator pass, the layout part in the
@@ -263,7 +305,7 @@ class _Conv2d(torch.autograd.Function):
             check(lib.csg_colsum(ptr(dpre), rows, Cout, Cout, ptr(db), ptr(part), nch, stream()), "colsum")
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy                            # the residual is added AFTER the activation (igemm.hip epilogue)
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 def pack_conv_weight(weight):
@@ -307,7 +349,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, r
     if grad_is_pre and po:
         raise RuntimeError("conv2d: grad_is_pre needs an unpadded output")
     y = _Conv2d.apply(x, weight, bias, residual, int(stride), int(padding), int(act), float(slope), packs, dx_range,
-                      in_act, bool(grad_is_pre))
+                      in_act, bool(grad_is_pre), Cout if Cout + po == 4 else None)
     return y[:, :Cout] if po else y
 
 

@@ -207,6 +207,31 @@ int64_t csg_wino_bwd_weight_workspace(const csg_wino_desc* d);
 int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy, float* dw, float* db, float* workspace,
                         int64_t workspace_bytes, void* stream);
 
+/* ---- K8n: stride-1 convolutions with at most four output channels (csrc/fewn.hip) --------------------------------
+ * `conv_img` (generator.py:46,120-121: 64 -> 3, 3x3, pad 1, tanh behind it) and the PatchGAN prediction heads
+ * (discriminator.py:185-187: 512 -> 1, 4x4, pad 2): a 32-wide MFMA tile wastes 29 (31) of its columns on them; these
+ * are VALU kernels that move the many-channel side once.  Output channels are padded to 4 (y, dy: (B,OH,OW,4); w, dw:
+ * [4][KH][KW][Cin] with rows >= cout_real zero; bias, db: 4 floats); KH = KW in {3, 4}; Cin in {32, 64, ..., 1024};
+ * KH*KW*cout_real <= 36.  The weight gradient is bit-reproducible (per-block slabs + ordered sum).               */
+typedef struct csg_few_desc {
+  int32_t B, IH, IW;
+  int32_t Cin, x_cs;
+  int32_t KH, KW, pad;
+  int32_t cout_real;
+  int32_t act;
+  float slope;
+} csg_few_desc;
+int csg_conv_few_supported(const csg_few_desc* d);      /* 1 / 0 */
+/* forward `workspace` (csg_conv_few_fwd_workspace bytes, may be 0): slabs of a split over the input channels for maps
+ * with few pixels and many channels (the heads); summed in a fixed order.  Without it the launch runs unsplit.    */
+int64_t csg_conv_few_fwd_workspace(const csg_few_desc* d);
+int csg_conv_few_fwd(const csg_few_desc* d, const float* x, const float* w, const float* bias, float* y, float* workspace,
+                     int64_t workspace_bytes, void* stream);
+int csg_conv_few_bwd_data(const csg_few_desc* d, const float* dy, const float* w, float* dx, void* stream);
+int64_t csg_conv_few_bwd_weight_workspace(const csg_few_desc* d);
+int csg_conv_few_bwd_weight(const csg_few_desc* d, const float* x, const float* dy, float* dw, float* db,
+                            float* workspace, int64_t workspace_bytes, void* stream);
+
 /* dpre = dy * act'(.) evaluated from the OUTPUT y (leaky: y>0 ? 1 : slope; tanh: 1-y^2)          */
 int csg_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float slope, float* dpre, void* stream);
 /* out[c] = sum_rows x[r, c] over (rows, C) with row stride x_cs — bias gradients; partial (nchunk,2C) fp64 */

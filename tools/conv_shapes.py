@@ -31,7 +31,7 @@ def shapes(H, S=32, ngf=64, ndf=64):
         out.append((name + ".conv_1", fmid, fout, r, 3, 1, 1, 1))
         if fin != fout:
             out.append((name + ".conv_s", fin, fout, r, 1, 1, 0, 1))
-    out.append(("conv_img", nf, 4, H, 3, 1, 1, 1))
+    out.append(("conv_img", nf, 3, H, 3, 1, 1, 1))
     for sc, h in (("D0", H), ("D1", (H - 1) // 2 + 1)):
         c_in = (S + 3 + 3) // 4 * 4
         out.append((sc + ".model0", c_in, ndf, h, 4, 2, 2, 4))
@@ -41,7 +41,7 @@ def shapes(H, S=32, ngf=64, ndf=64):
         out.append((sc + ".model2", 2 * ndf, 4 * ndf, h2, 4, 2, 2, 4))
         h3 = h2 // 2 + 1
         out.append((sc + ".model3", 4 * ndf, 8 * ndf, h3, 4, 1, 2, 4))
-        out.append((sc + ".model4", 8 * ndf, 4, h3 + 1, 4, 1, 2, 4))
+        out.append((sc + ".model4", 8 * ndf, 1, h3 + 1, 4, 1, 2, 4))
     return out
 
 
