@@ -56,18 +56,21 @@ def _act(y, act):
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_forward_backward(ops, case):
     B, Cin, Cout, H, W, K, s, p, act, has_bias, has_res = case
-    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    g = torch.Generator().manual_seed(1000 + CONV_CASES.index(case))     # (hash() of a tuple with strings changes per process)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
     b = torch.randn(Cout, generator=g) if has_bias else None
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     br = b.clone().requires_grad_(True) if has_bias else None
-    y_ref = _act(F.conv2d(xr, wr, br, stride=s, padding=p), act)
+    pre_ref = F.conv2d(xr, wr, br, stride=s, padding=p)
+    y_ref = _act(pre_ref, act)
     res = torch.randn(y_ref.shape, generator=g) if has_res else None
     rr = res.clone().requires_grad_(True) if has_res else None
     if has_res:
         y_ref = y_ref + rr
     gy = torch.randn(y_ref.shape, generator=g)
+    if act in ("relu", "lrelu"):          # a pre-activation within rounding of the kink may land on either side of it
+        gy = gy * (pre_ref.detach().abs() > 1e-5).float()
     y_ref.backward(gy)
 
     xd, wd = dev(x, True), dev(w, True)
