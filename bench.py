@@ -244,7 +244,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if args.config == "C3" and H == 256 and args.batch == 16 and not args.use_img_disc and not args.vgg_loss:
-                key = "k_wino_conv<32>" if dom == "wino_conv" else "k_igemm_fwd<128>"
+                key = "k_wino_conv2<16>" if dom == "wino_conv" else "k_igemm_fwd<128>"      # the launches on maps >= 32 wide
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -297,11 +297,12 @@ def main():
         out["hbm_kernels"] = hbm
         out["hbm_kernels_note"] = ("algorithmic bytes / HIP-event time; launches that move a few MB (the graph kernels on "
                                    "COCO-sized graphs: ~30 triplets per image) are launch-latency bound — their rates on "
-                                   "dense graphs are in profiles/r01j_bench_C5_dense_graphs.json")
+                                   "dense graphs are in profiles/r02f_bench_C5_dense_graphs.json")
         out["kernels"] = kern
         out["kernels_note"] = ("per-kernel table, roofline_wgrad and hbm_kernels: %d untimed steps after the timed region "
-                               "with a HIP event pair on every launch; `roofline`: events on k_igemm_fwd<128> only, "
-                               "inside the timed region" % prof_all_steps)
+                               "with a HIP event pair on every launch (summed durations exceed the step where the two "
+                               "PatchGAN scales overlap on their streams); `roofline`: events on the k_wino_conv and "
+                               "k_igemm_fwd<128> launches only, inside the timed region" % prof_all_steps)
     if gen_ms is not None:
         # algorithmic work of SPADEGenerator fwd+bwd per image (FlopCounterMode; S = 32 or 128)
         S = len(vocab["attributes"]) * 32
