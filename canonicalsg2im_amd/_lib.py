@@ -107,7 +107,8 @@ SIGNATURES = {
     "csg_l1_mean_fwd": (c_i32, [c_p, c_p, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_l1_mean_bwd": (c_i32, [c_p, c_p, c_p, c_i64, c_p, c_p]),
     "csg_spectral_norm_workspace": (c_i64, [c_i64, c_i64]),
-    "csg_spectral_norm_fwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f32, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_spectral_norm_fwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f32, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64,
+                                      c_p]),
     "csg_spectral_norm_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                                       c_p, c_p, c_i64, c_p]),
     "csg_canon_workspace": (c_i64, [c_i64]),

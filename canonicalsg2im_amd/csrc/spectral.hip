@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_sn_rowdot(const float* __restrict__ w, 
 __global__ __launch_bounds__(256) void k_sn_scale(const float* __restrict__ w, const float* __restrict__ s, int Cout,
                                                    float eps, int iterate, float* __restrict__ u,
                                                    float* __restrict__ u_used, float* __restrict__ sigma, int64_t n4,
-                                                   float* __restrict__ w_eff) {
+                                                   float* __restrict__ w_eff, int Cin, int khw) {
   __shared__ double sm[16];
   float nrm = 1.f;
   if (iterate) {
@@ -134,9 +134,23 @@ __global__ __launch_bounds__(256) void k_sn_scale(const float* __restrict__ w, c
   }
   const float sg = (float)block_sum(dot, sm);
   if (blockIdx.x == 0 && threadIdx.x == 0) sigma[0] = sg;
+  if (Cin == 0) {                        // W_eff in the memory order of W
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+      const float4 a = ld4(w + e * 4);
+      *(float4*)(w_eff + e * 4) = make_float4(a.x / sg, a.y / sg, a.z / sg, a.w / sg);     // `weight / sigma`
+    }
+    return;
+  }
+  // W is (Cout, Cin, KH, KW) row-major; W_eff is written in channels-last memory [Cout][KH][KW][Cin] — the
+  // convolution kernels' forward operand — one float4 of input channels per thread (the reads gather 4 floats khw apart)
+  const int q = Cin >> 2;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
-    const float4 a = ld4(w + e * 4);
-    *(float4*)(w_eff + e * 4) = make_float4(a.x / sg, a.y / sg, a.z / sg, a.w / sg);     // `weight / sigma`
+    const int c4 = (int)(e % q);
+    const int64_t r = e / q;             // (co, tap)
+    const int t = (int)(r % khw);
+    const int64_t co = r / khw;
+    const float* src = w + (co * Cin + c4 * 4) * khw + t;
+    *(float4*)(w_eff + e * 4) = make_float4(src[0] / sg, src[khw] / sg, src[2 * khw] / sg, src[3 * khw] / sg);
   }
 }
 
@@ -213,8 +227,10 @@ int64_t csg_spectral_norm_workspace(int64_t Cout, int64_t K) {
 }
 
 int csg_spectral_norm_fwd(const float* w, float* u, float* v, int64_t Cout, int64_t K, int iterate, float eps,
-                          float* w_eff, float* sigma, float* u_used, float* v_used, void* workspace,
+                          float* w_eff, int64_t cl_Cin, float* sigma, float* u_used, float* v_used, void* workspace,
                           int64_t workspace_bytes, void* stream) {
+  CSG_REQUIRE(cl_Cin == 0 || (cl_Cin % 4 == 0 && K % cl_Cin == 0), CSG_E_BADSHAPE,
+              "csg_spectral_norm_fwd: channels-last output needs Cin %% 4 == 0 dividing K");
   CSG_REQUIRE(Cout > 0 && K > 0 && K % 4 == 0, CSG_E_BADSHAPE,
               "csg_spectral_norm_fwd: bad shape Cout=%ld K=%ld (K must be a multiple of 4)", (long)Cout, (long)K);
   CSG_REQUIRE(workspace && workspace_bytes >= csg_spectral_norm_workspace(Cout, K), CSG_E_BADSHAPE,
@@ -237,7 +253,7 @@ int csg_spectral_norm_fwd(const float* w, float* u, float* v, int64_t Cout, int6
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_sn_scale, dim3((unsigned)grid), dim3(256), 0, s, w, sv, (int)Cout, eps, iterate, u, u_used, sigma,
-                     n4, w_eff);
+                     n4, w_eff, (int)cl_Cin, cl_Cin ? (int)(K / cl_Cin) : 1);
   return check_launch("csg_spectral_norm_fwd");
 }
 

@@ -6,15 +6,15 @@ activations are logical (B,C,H,W) tensors whose MEMORY is NHWC (channel stride 1
 with `empty_nhwc` / `nhwc`.  Nothing here runs on CPU tensors.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_optimizer_step_post_hook
 
 from . import _lib
 from . import dist as csg_dist
-import os
-
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, WinoDesc, check, lib, ptr, stream
 
 __all__ = [
@@ -147,6 +147,24 @@ def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what, 
     check(lib.csg_wino_conv(d, ptr(x), ptr(packed), ptr(bias), ptr(res), ptr(gate), gate_slope, ptr(y), ptr(ws), nws,
                             stream()), what)
     return gate is not None
+
+
+# Caches derived from trainable weights are keyed on (weight_epoch(), tensor._version): the fused multi-tensor Adam updates
+# parameters WITHOUT bumping `_version` (checked on torch 2.10), so every optimiser step — of any optimiser, the
+# reference trainer's own included — advances a global counter through torch's optimiser post-step hook; in-place edits
+# outside an optimiser (load_state_dict, copy_) still show in `_version`.
+_WEIGHT_EPOCH = [0]
+
+
+def _bump_weight_epoch(*_args, **_kwargs):
+    _WEIGHT_EPOCH[0] += 1
+
+
+_register_optimizer_step_post_hook(_bump_weight_epoch)
+
+
+def weight_epoch():
+    return _WEIGHT_EPOCH[0]
 
 
 def _few_desc(B, IH, IW, Cin, KH, KW, stride, pad, cout_real, act, slope):
@@ -379,10 +397,12 @@ class _SpectralWeight(torch.autograd.Function):
             raise RuntimeError("spectral_weight: weight (%d x %d) needs K %% 4 == 0" % (Cout, K))
         dev = w.device
         ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
-        w_eff = torch.empty_like(w)
+        # 4-D weights come out in channels-last memory: the convolution kernels' forward operand, no repack per call
+        cl = w.shape[1] if (w.dim() == 4 and w.shape[1] % 4 == 0) else 0
+        w_eff = torch.empty_like(w, memory_format=torch.channels_last) if cl else torch.empty_like(w)
         small = torch.empty(1 + Cout + K, device=dev, dtype=torch.float32)      # sigma | u_used | v_used
         sigma, u_used, v_used = small[:1], small[1:1 + Cout], small[1 + Cout:]
-        check(lib.csg_spectral_norm_fwd(ptr(w), ptr(u), ptr(v), Cout, K, 1 if iterate else 0, eps, ptr(w_eff),
+        check(lib.csg_spectral_norm_fwd(ptr(w), ptr(u), ptr(v), Cout, K, 1 if iterate else 0, eps, ptr(w_eff), cl,
                                         ptr(sigma), ptr(u_used), ptr(v_used), ptr(ws), nbytes, stream()),
               "spectral_norm_fwd")
         ctx.save_for_backward(w, small)                 # u, v are buffers (no grad): updated in place by the kernel

@@ -54,10 +54,16 @@ class NLayerDiscriminator(BaseNetwork):
                 conv = sub[0]
                 w = conv.weight
                 pad = x.size(1) - w.size(1)
-                parts = [w[:, 3:3 + seg_first], w[:, :3]]
-                if pad:
-                    parts.append(w.new_zeros(w.size(0), pad, w.size(2), w.size(3)))
-                x = ops.conv2d(x, torch.cat(parts, dim=1), conv.bias, conv.stride[0], conv.padding[0], conv.act,
+                # the permuted, padded weight is the same for every pass between two optimiser steps (and, with the
+                # parameters frozen during the generator's passes, a constant there): built once per weight version
+                key = (ops.weight_epoch(), w._version, w.data_ptr(), w.requires_grad and torch.is_grad_enabled(), seg_first, pad)
+                if getattr(self, "_w0_key", None) != key:
+                    parts = [w[:, 3:3 + seg_first], w[:, :3]]
+                    if pad:
+                        parts.append(w.new_zeros(w.size(0), pad, w.size(2), w.size(3)))
+                    self._w0 = torch.cat(parts, dim=1).contiguous(memory_format=torch.channels_last)
+                    self._w0_key = key
+                x = ops.conv2d(x, self._w0, conv.bias, conv.stride[0], conv.padding[0], conv.act,
                                conv.slope, dx_range=grad_channels)
             else:
                 x = sub(x)

@@ -331,8 +331,10 @@ int csg_canon_emit(const int64_t* objs0, const int64_t* n_objs, int64_t B, int64
  * along (Cout, Cin, KH, KW) — rows must be dense, e.g. contiguous or the [Cout][KH][KW][Cin] layout of
  * csg_conv_bwd_weight.  One workspace size serves both calls. */
 int64_t csg_spectral_norm_workspace(int64_t Cout, int64_t K);
+/* cl_Cin = 0: W_eff in W's memory order; cl_Cin = Cin (a multiple of 4): W is (Cout,Cin,KH,KW) row-major and W_eff is
+ * written in channels-last memory [Cout][KH][KW][Cin], the convolution kernels' forward operand (no repack).      */
 int csg_spectral_norm_fwd(const float* w, float* u, float* v, int64_t Cout, int64_t K, int iterate, float eps,
-                          float* w_eff, float* sigma, float* u_used, float* v_used, void* workspace,
+                          float* w_eff, int64_t cl_Cin, float* sigma, float* u_used, float* v_used, void* workspace,
                           int64_t workspace_bytes, void* stream);
 int csg_spectral_norm_bwd(const float* dweff, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW, int64_t s0,
                           int64_t s1, int64_t s2, int64_t s3, const float* w, const float* u_used,

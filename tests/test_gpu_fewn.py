@@ -60,7 +60,7 @@ def test_few_output_conv_vs_torch(ops, case):
             ops.FEW_ENABLED = True
         outs[few] = (y.detach(), got)
         tag = "%s few=%s" % (case, few)
-        assert_close(y, ref.float(), 1e-4, 1e-5 * float(ref.abs().max()) + 1e-6, "y " + tag)
+        assert_close(y, ref.float(), 1e-4, 1e-5 * float(ref.detach().abs().max()) + 1e-6, "y " + tag)
         for name, a, r in zip(("dx", "dw", "db"), got, ref_g):
             assert_close(a, r.float(), 1e-4, 2e-5 * float(r.abs().max()) + 1e-6, name + " " + tag)
     # bit-reproducible weight gradient
