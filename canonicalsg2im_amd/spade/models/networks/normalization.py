@@ -63,6 +63,48 @@ def get_nonspade_norm_layer(opt, norm_type='instance'):
     return wrap
 
 
+class _JoinedPair(torch.autograd.Function):
+    """`joined` IS the memory of the two parameters `a` (first half along dim 0) and `b` (second half): the forward
+    hands it out as one tensor without a copy, the backward hands the halves of its gradient to the parameters."""
+
+    @staticmethod
+    def forward(ctx, a, b, joined):
+        ctx.n = a.shape[0]
+        return joined.view_as(joined)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.n], g[ctx.n:], None
+
+
+def _join_storage(pa, pb):
+    """Make the parameters `pa`, `pb` (same shape) the two halves of ONE allocation and return it ((2n, ...), in the
+    parameters' memory format).  `.data` is re-pointed, the Parameter objects (optimiser state, state_dict keys) stay;
+    called again only when something (`module.to`, a fresh load) has separated them."""
+    cl = pa.dim() == 4
+    joined = torch.empty((2 * pa.shape[0],) + tuple(pa.shape[1:]), device=pa.device, dtype=pa.dtype)
+    if cl:
+        joined = joined.contiguous(memory_format=torch.channels_last)
+    n = pa.shape[0]
+    with torch.no_grad():
+        joined[:n].copy_(pa)
+        joined[n:].copy_(pb)
+    pa.data = joined[:n]
+    pb.data = joined[n:]
+    return joined
+
+
+def _joined(mod, name, pa, pb):
+    j = getattr(mod, name, None)
+    n = pa.shape[0]
+    if (j is None or j.device != pa.device or pa.data_ptr() != j.data_ptr() or
+            pb.data_ptr() != j.data_ptr() + n * j.stride(0) * j.element_size() or pa.stride() != j.stride()
+            or pb.stride() != j.stride()):
+        j = _join_storage(pa, pb)
+        object.__setattr__(mod, name, j)               # a plain attribute: not a buffer, not in the state_dict
+    return _JoinedPair.apply(pa, pb, j)
+
+
 class SPADE(nn.Module):
     def __init__(self, config_text, norm_nc, label_nc):
         super().__init__()
@@ -94,7 +136,9 @@ class SPADE(nn.Module):
         # pre-activation directly (grad_is_pre) — no separate pass over the 128-channel maps
         sh = self.mlp_shared[0]
         actv = ops.conv2d(seg, sh.weight, sh.bias, 1, sh.padding[0], sh.act, sh.slope, grad_is_pre=True)
-        w = torch.cat([self.mlp_gamma.weight, self.mlp_beta.weight], dim=0)
-        b = torch.cat([self.mlp_gamma.bias, self.mlp_beta.bias], dim=0)
+        # gamma and beta convolutions share their input: ONE convolution with 2C outputs, whose weight is the two
+        # parameters laid out back to back in one allocation (no torch.cat per call)
+        w = _joined(self, "_joined_w", self.mlp_gamma.weight, self.mlp_beta.weight)
+        b = _joined(self, "_joined_b", self.mlp_gamma.bias, self.mlp_beta.bias)
         gb = ops.conv2d(actv, w, b, 1, self.pw, in_act=(sh.act, sh.slope))      # (B, 2C, h, w): gamma || beta
         return self.param_free_norm(x, gb=gb, fused_slope=fused_slope)
