@@ -45,7 +45,20 @@ __global__ __launch_bounds__(256) void k_norm_stats_partial(const float* __restr
     d4 s = d4zero(), ss = d4zero();
     if (rr < R) {
       const float* xp = x + ((int64_t)g * P) * x_cs + (qb + q) * 4;
-      for (int64_t p = p0 + rr; p < p1; p += R) {
+      // four loads in flight per thread (one per iteration leaves HBM a third busy); same order of additions
+      int64_t p = p0 + rr;
+      for (; p + 3 * R < p1; p += 4 * R) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld4(xp + (p + u * R) * x_cs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double a = v[u].x, b = v[u].y, c = v[u].z, d = v[u].w;
+          s.x += a; s.y += b; s.z += c; s.w += d;
+          ss.x += a * a; ss.y += b * b; ss.z += c * c; ss.w += d * d;
+        }
+      }
+      for (; p < p1; p += R) {
         const float4 v = ld4(xp + p * x_cs);
         const double a = v.x, b = v.y, c = v.z, d = v.w;
         s.x += a; s.y += b; s.z += c; s.w += d;
@@ -130,6 +143,7 @@ __global__ __launch_bounds__(256) void k_norm_apply_fwd(const float* __restrict_
                                                          const float* __restrict__ gb, float slope, int64_t P, int C,
                                                          int64_t n4, float* __restrict__ y) {
   const int Q = C >> 2;
+#pragma unroll 2
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pix = e / Q;
     const int q = (int)(e - pix * Q);
@@ -170,6 +184,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const float* __restrict
     if (rr < R) {
       const int co = (qb + q) * 4;
       const float4 m = ld4(mean + (int64_t)g * C + co), r = ld4(invstd + (int64_t)g * C + co);
+#pragma unroll 2
       for (int64_t p = p0 + rr; p < p1; p += R) {
         const int64_t pix = (int64_t)g * P + p;
         const float4 xv = ld4(x + pix * C + co);
@@ -218,6 +233,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_dx(const float* __restrict__ d
                                                       const double* __restrict__ dsums, double inv_count, int64_t P,
                                                       int C, int64_t n4, float* __restrict__ dx) {
   const int Q = C >> 2;
+#pragma unroll 2
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pix = e / Q;
     const int q = (int)(e - pix * Q);
