@@ -142,15 +142,27 @@ __global__ __launch_bounds__(256) void k_sn_scale(const float* __restrict__ w, c
     return;
   }
   // W is (Cout, Cin, KH, KW) row-major; W_eff is written in channels-last memory [Cout][KH][KW][Cin] — the
-  // convolution kernels' forward operand — one float4 of input channels per thread (the reads gather 4 floats khw apart)
-  const int q = Cin >> 2;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
-    const int c4 = (int)(e % q);
-    const int64_t r = e / q;             // (co, tap)
-    const int t = (int)(r % khw);
-    const int64_t co = r / khw;
-    const float* src = w + (co * Cin + c4 * 4) * khw + t;
-    *(float4*)(w_eff + e * 4) = make_float4(src[0] / sg, src[khw] / sg, src[2 * khw] / sg, src[3 * khw] / sg);
+  // convolution kernels' forward operand.  One block per output channel: its row is read as it lies, transposed
+  // (cin, tap) -> (tap, cin) through LDS and written as it will lie (both sides coalesced).
+  extern __shared__ __attribute__((aligned(16))) float row[];          // [khw][Cin + 4]
+  const int K = Cin * khw, LD = Cin + 4;
+  for (int co = blockIdx.x; co < Cout; co += gridDim.x) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < (K >> 2); e += 256) {
+      const float4 a = ld4(w + (int64_t)co * K + e * 4);
+      const float v[4] = {a.x / sg, a.y / sg, a.z / sg, a.w / sg};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * e + j, ci = k / khw, t = k - ci * khw;
+        row[t * LD + ci] = v[j];
+      }
+    }
+    __syncthreads();
+    const int q = Cin >> 2;
+    for (int e = threadIdx.x; e < (K >> 2); e += 256) {
+      const int t = e / q, c4 = e - t * q;
+      *(float4*)(w_eff + (int64_t)co * K + e * 4) = *(const float4*)(row + t * LD + c4 * 4);
+    }
   }
 }
 
@@ -252,7 +264,15 @@ int csg_spectral_norm_fwd(const float* w, float* u, float* v, int64_t Cout, int6
   int64_t grid = cdiv(n4, 256 * 4);
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_sn_scale, dim3((unsigned)grid), dim3(256), 0, s, w, sv, (int)Cout, eps, iterate, u, u_used, sigma,
+  size_t shm = 0;
+  if (cl_Cin) {
+    const int khw = (int)(K / cl_Cin);
+    shm = (size_t)khw * (cl_Cin + 4) * sizeof(float);
+    CSG_REQUIRE(shm <= 64 * 1024, CSG_E_UNSUPPORTED, "csg_spectral_norm_fwd: a %ld-element row does not fit the transpose buffer",
+                (long)K);
+    grid = Cout < 2048 ? Cout : 2048;
+  }
+  hipLaunchKernelGGL(k_sn_scale, dim3((unsigned)grid), dim3(256), shm, s, w, sv, (int)Cout, eps, iterate, u, u_used, sigma,
                      n4, w_eff, (int)cl_Cin, cl_Cin ? (int)(K / cl_Cin) : 1);
   return check_launch("csg_spectral_norm_fwd");
 }

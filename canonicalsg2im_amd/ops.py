@@ -398,7 +398,8 @@ class _SpectralWeight(torch.autograd.Function):
         dev = w.device
         ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
         # 4-D weights come out in channels-last memory: the convolution kernels' forward operand, no repack per call
-        cl = w.shape[1] if (w.dim() == 4 and w.shape[1] % 4 == 0) else 0
+        cl = w.shape[1] if (w.dim() == 4 and w.shape[1] % 4 == 0 and w.shape[2] * w.shape[3] > 1
+                           and w.shape[2] * w.shape[3] * (w.shape[1] + 4) * 4 <= 65536) else 0
         w_eff = torch.empty_like(w, memory_format=torch.channels_last) if cl else torch.empty_like(w)
         small = torch.empty(1 + Cout + K, device=dev, dtype=torch.float32)      # sigma | u_used | v_used
         sigma, u_used, v_used = small[:1], small[1:1 + Cout], small[1 + Cout:]
