@@ -115,7 +115,8 @@ __device__ __forceinline__ void mask_weight_grad(const float* __restrict__ mk, i
   dwdiy = (m[1][0] - m[0][0]) * (1.f - rx) + (m[1][1] - m[0][1]) * rx;
 }
 
-#define LAY_OB 32    // objects per LDS batch
+#define LAY_OB 32    // active objects staged in LDS at a time
+#define LAY_CULL 256 // objects culled and compacted per pass (one per thread)
 #define LAY_PXC 256  // max pixels per block chunk
 #define LAY_EPT 8    // float4 elements per thread
 
@@ -127,11 +128,11 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_wx = sm;                       // [LAY_OB][pxc]
   float* s_vec = sm + LAY_OB * pxc;       // [LAY_OB][S]
-  float* s_wy = s_vec + LAY_OB * S;       // [LAY_OB]
-  int* s_act = (int*)(s_wy + LAY_OB);     // [LAY_OB] object index of each active slot
-  int* s_n = s_act + LAY_OB;              // [1]
-  float* s_wy1 = (float*)(s_n + 4);       // [LAY_OB] mask path: weight of the upper row tap
-  int* s_iy0 = (int*)(s_wy1 + LAY_OB);    // [LAY_OB] mask path: lower row tap index
+  float* s_wy = s_vec + LAY_OB * S;       // [LAY_CULL] row weight of each active slot
+  float* s_wy1 = s_wy + LAY_CULL;         // [LAY_CULL] mask path: weight of the upper row tap
+  int* s_iy0 = (int*)(s_wy1 + LAY_CULL);  // [LAY_CULL] mask path: lower row tap index
+  int* s_act = s_iy0 + LAY_CULL;          // [LAY_CULL] object index of each active slot
+  int* s_cnt = s_act + LAY_CULL;          // [4] active objects per wave
 
   const int tid = threadIdx.x;
   const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * pxc;
@@ -161,28 +162,31 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
   const uint8_t* vb = valid + (int64_t)b * O;
   const float* vv = vecs + (int64_t)b * O * S;
 
-  for (int ob = 0; ob < O; ob += LAY_OB) {
+  // Culling: ONE pass over up to 256 objects (a thread each, all four waves), compacted in index order — the order
+  // of the reference's sum.  Dense scenes then stage their ~10 surviving objects in one batch instead of walking four
+  // 32-object batches with three barriers and two dependent global-load latencies each.
+  for (int ob = 0; ob < O; ob += LAY_CULL) {
     __syncthreads();
-    if (tid < 64) {  // wave 0: row coverage + ordered compaction of the active objects
-      int o = ob + tid;
-      float wy = 0.f;
+    {
+      const int o = ob + tid;
+      float wy = 0.f, wy1 = 0.f;
       bool act = false;
-      float wy1 = 0.f;
       int iy0 = 0;
-      if (tid < LAY_OB && o < O && vb[o]) {
+      if (o < O && vb[o]) {
+        const float4 bq = *(const float4*)(bx + o * 4);
         if (masks == nullptr) {
-          wy = coverage(ty, bx[o * 4 + 1], bx[o * 4 + 3]);
+          wy = coverage(ty, bq.y, bq.w);
           act = (wy != 0.0f);
         } else {
-          axis_taps(ty, bx[o * 4 + 1], bx[o * 4 + 3], M, iy0, wy, wy1);
+          axis_taps(ty, bq.y, bq.w, M, iy0, wy, wy1);
           act = (wy != 0.0f) || (wy1 != 0.0f);
         }
-        // dense scenes (config C5: 128 objects per image): also drop the objects whose x support misses this block's
-        // pixel chunk.  The bilinear weight vanishes outside  x0 - w/(2n) < t < x0 + w (1 + 1/(2n))  (n source
-        // pixels); the test keeps one output pixel of slack on each side, and a skipped object would have added
-        // exact zeros, so the sum — and its order among the remaining objects — is unchanged.
+        // also drop the objects whose x support misses this block's pixel chunk.  The bilinear weight vanishes outside
+        // x0 - w/(2n) < t < x0 + w (1 + 1/(2n))  (n source pixels); the test keeps one output pixel of slack on each
+        // side, and a skipped object would have added exact zeros, so the sum — and its order among the remaining
+        // objects — is unchanged.
         if (act) {
-          const float bx0 = bx[o * 4 + 0], bw = bx[o * 4 + 2];
+          const float bx0 = bq.x, bw = bq.z;
           const float n = masks == nullptr ? 8.0f : (float)M;
           const float lo = fminf(bx0 - bw / (2.0f * n), bx0 + bw * (1.0f + 1.0f / (2.0f * n)));
           const float hi = fmaxf(bx0 - bw / (2.0f * n), bx0 + bw * (1.0f + 1.0f / (2.0f * n)));
@@ -193,65 +197,72 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
           if (lin01(xs1, W) + step < lo || lin01(xs0, W) - step > hi) act = false;
         }
       }
-      unsigned long long m = __ballot(act);
-      int slot = __popcll(m & ((1ull << tid) - 1ull));
+      const unsigned long long m = __ballot(act);
+      const int lane = tid & 63, wv = tid >> 6;
+      if (lane == 0) s_cnt[wv] = __popcll(m);
+      __syncthreads();
+      int base = 0;
+      for (int w = 0; w < wv; ++w) base += s_cnt[w];
+      const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
       if (act) {
         s_wy[slot] = wy;
         s_wy1[slot] = wy1;
         s_iy0[slot] = iy0;
         s_act[slot] = o;
       }
-      if (tid == 0) *s_n = __popcll(m);
     }
     __syncthreads();
-    const int nact = *s_n;
-    if (nact == 0) continue;
-    for (int i = tid; i < nact * npx; i += 256) {
-      int a = i / npx, xl = i - a * npx;
-      int o = s_act[a];
-      int xsrc = min((int)(((int64_t)(x0 + xl) * W) / OW), W - 1);
-      if (masks == nullptr)
-        s_wx[a * pxc + xl] = coverage(lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]);
-      else  // full 2-D weight of this pixel; the row factor below is 1
-        s_wx[a * pxc + xl] = mask_weight(masks + ((int64_t)b * O + o) * M * M, M, s_iy0[a], s_wy[a], s_wy1[a],
-                                         lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]);
-    }
-    for (int i = tid; i < nact * S; i += 256) {
-      int a = i / S, d = i - a * S;
-      s_vec[a * S + d] = vv[(int64_t)s_act[a] * S + d];
-    }
-    __syncthreads();
-    if (blocked) {
-      const int px0 = (tid / qpp) * LAY_EPT, q4 = (tid % qpp) * 4;
-      if (px0 < npx) {
-        for (int a = 0; a < nact; ++a) {
-          const float wy = masks == nullptr ? s_wy[a] : 1.0f;
-          const float4 v = *(const float4*)&s_vec[a * S + q4];
-          const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
-          const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const int ntot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    for (int a0 = 0; a0 < ntot; a0 += LAY_OB) {
+    const int nact = min(LAY_OB, ntot - a0);
+    if (a0 > 0) __syncthreads();                 // the previous group's s_wx / s_vec are still being read
+      for (int i = tid; i < nact * npx; i += 256) {
+        const int a = i / npx, xl = i - a * npx;
+        const int o = s_act[a0 + a];
+        const int xsrc = min((int)(((int64_t)(x0 + xl) * W) / OW), W - 1);
+        if (masks == nullptr)
+          s_wx[a * pxc + xl] = coverage(lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]);
+        else  // full 2-D weight of this pixel; the row factor below is 1
+          s_wx[a * pxc + xl] = mask_weight(masks + ((int64_t)b * O + o) * M * M, M, s_iy0[a0 + a], s_wy[a0 + a],
+                                           s_wy1[a0 + a], lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]);
+      }
+      for (int i = tid; i < nact * (S >> 2); i += 256) {
+        const int a = i / (S >> 2), d4 = i - a * (S >> 2);
+        *(float4*)&s_vec[a * S + d4 * 4] = *(const float4*)&vv[(int64_t)s_act[a0 + a] * S + d4 * 4];
+      }
+      __syncthreads();
+      if (blocked) {
+        const int px0 = (tid / qpp) * LAY_EPT, q4 = (tid % qpp) * 4;
+        if (px0 < npx) {
+          for (int a = 0; a < nact; ++a) {
+            const float wy = masks == nullptr ? s_wy[a0 + a] : 1.0f;
+            const float4 v = *(const float4*)&s_vec[a * S + q4];
+            const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
+            const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-          for (int i = 0; i < LAY_EPT; ++i) {
-            const float w = wy * wv[i];
+            for (int i = 0; i < LAY_EPT; ++i) {
+              const float w = wy * wv[i];
+              acc[i].x += v.x * w;
+              acc[i].y += v.y * w;
+              acc[i].z += v.z * w;
+              acc[i].w += v.w * w;
+            }
+          }
+        }
+        continue;
+      }
+      for (int a = 0; a < nact; ++a) {
+        const float wy = masks == nullptr ? s_wy[a0 + a] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < LAY_EPT; ++i) {
+          if (tid + 256 * i < nel) {
+            float w = wy * s_wx[a * pxc + ex[i]];
+            float4 v = *(const float4*)&s_vec[a * S + eq[i] * 4];
             acc[i].x += v.x * w;
             acc[i].y += v.y * w;
             acc[i].z += v.z * w;
             acc[i].w += v.w * w;
           }
-        }
-      }
-      continue;
-    }
-    for (int a = 0; a < nact; ++a) {
-      const float wy = masks == nullptr ? s_wy[a] : 1.0f;
-#pragma unroll
-      for (int i = 0; i < LAY_EPT; ++i) {
-        if (tid + 256 * i < nel) {
-          float w = wy * s_wx[a * pxc + ex[i]];
-          float4 v = *(const float4*)&s_vec[a * S + eq[i] * 4];
-          acc[i].x += v.x * w;
-          acc[i].y += v.y * w;
-          acc[i].z += v.z * w;
-          acc[i].w += v.w * w;
         }
       }
     }
@@ -260,6 +271,124 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
 #pragma unroll
   for (int i = 0; i < LAY_EPT; ++i) {
     if (blocked ? ex[i] < npx : tid + 256 * i < nel) *(float4*)&orow[(int64_t)ex[i] * out_cs + eq[i] * 4] = acc[i];
+  }
+}
+
+// The same sum for boxes_to_layout (no masks) with S/4 dividing 256, ROWS output rows per block: the x coverage and
+// the object vectors do not depend on the row, so they are staged once for ROWS rows (dense scenes spend their time
+// culling and staging, not accumulating).  A thread owns one channel quad of eight consecutive pixels in each row.  An
+// object that covers only some of the ROWS rows adds exact zeros to the others: the per-pixel sum and its order are
+// those of k_layout_fwd.
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict__ vecs, const float* __restrict__ boxes,
+                                                          const uint8_t* __restrict__ valid, int O, int S, int H, int W,
+                                                          int OH, int OW, int pxc, float* __restrict__ out, int out_cs,
+                                                          int out_off) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_wx = sm;                         // [LAY_OB][pxc]
+  float* s_vec = sm + LAY_OB * pxc;         // [LAY_OB][S]
+  float* s_wy = s_vec + LAY_OB * S;         // [LAY_CULL][ROWS]
+  int* s_act = (int*)(s_wy + LAY_CULL * ROWS);  // [LAY_CULL]
+  int* s_cnt = s_act + LAY_CULL;            // [4]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, y0 = blockIdx.y * ROWS, x0 = blockIdx.x * pxc;
+  const int npx = min(pxc, OW - x0);
+  const int qpp = S >> 2;
+  const int px0 = (tid / qpp) * LAY_EPT, q4 = (tid % qpp) * 4;
+  float ty[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) ty[r] = lin01(min((int)(((int64_t)min(y0 + r, OH - 1) * H) / OH), H - 1), H);
+  float4 acc[ROWS][LAY_EPT];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int i = 0; i < LAY_EPT; ++i) acc[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* bx = boxes + (int64_t)b * O * 4;
+  const uint8_t* vb = valid + (int64_t)b * O;
+  const float* vv = vecs + (int64_t)b * O * S;
+  const int xs0 = min((int)(((int64_t)x0 * W) / OW), W - 1);
+  const int xs1 = min((int)(((int64_t)(x0 + npx - 1) * W) / OW), W - 1);
+  const float step = W > 1 ? 1.0f / (float)(W - 1) : 1.0f;
+  const float tx_lo = lin01(xs0, W) - step, tx_hi = lin01(xs1, W) + step;
+
+  for (int ob = 0; ob < O; ob += LAY_CULL) {
+    __syncthreads();
+    {
+      const int o = ob + tid;
+      float wy[ROWS];
+      bool act = false;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) wy[r] = 0.f;
+      if (o < O && vb[o]) {
+        const float4 bq = *(const float4*)(bx + o * 4);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          wy[r] = (y0 + r < OH) ? coverage(ty[r], bq.y, bq.w) : 0.f;
+          act = act || (wy[r] != 0.0f);
+        }
+        if (act) {                          // x support vs this block's pixel chunk (see k_layout_fwd)
+          const float lo = fminf(bq.x - bq.z / 16.0f, bq.x + bq.z * (1.0f + 1.0f / 16.0f));
+          const float hi = fmaxf(bq.x - bq.z / 16.0f, bq.x + bq.z * (1.0f + 1.0f / 16.0f));
+          if (tx_hi < lo || tx_lo > hi) act = false;
+        }
+      }
+      const unsigned long long m = __ballot(act);
+      const int lane = tid & 63, wv = tid >> 6;
+      if (lane == 0) s_cnt[wv] = __popcll(m);
+      __syncthreads();
+      int base = 0;
+      for (int w = 0; w < wv; ++w) base += s_cnt[w];
+      const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (act) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) s_wy[slot * ROWS + r] = wy[r];
+        s_act[slot] = o;
+      }
+    }
+    __syncthreads();
+    const int ntot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    for (int a0 = 0; a0 < ntot; a0 += LAY_OB) {
+      const int nact = min(LAY_OB, ntot - a0);
+      if (a0 > 0) __syncthreads();
+      for (int i = tid; i < nact * npx; i += 256) {
+        const int a = i / npx, xl = i - a * npx;
+        const int o = s_act[a0 + a];
+        const int xsrc = min((int)(((int64_t)(x0 + xl) * W) / OW), W - 1);
+        s_wx[a * pxc + xl] = coverage(lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]);
+      }
+      for (int i = tid; i < nact * qpp; i += 256) {
+        const int a = i / qpp, d4 = i - a * qpp;
+        *(float4*)&s_vec[a * S + d4 * 4] = *(const float4*)&vv[(int64_t)s_act[a0 + a] * S + d4 * 4];
+      }
+      __syncthreads();
+      if (px0 < npx) {
+        for (int a = 0; a < nact; ++a) {
+          const float4 v = *(const float4*)&s_vec[a * S + q4];
+          const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
+          const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            const float wy = s_wy[(a0 + a) * ROWS + r];
+#pragma unroll
+            for (int i = 0; i < LAY_EPT; ++i) {
+              const float w = wy * wv[i];
+              acc[r][i].x += v.x * w;
+              acc[r][i].y += v.y * w;
+              acc[r][i].z += v.z * w;
+              acc[r][i].w += v.w * w;
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    if (y0 + r >= OH) break;
+    float* orow = out + ((int64_t)(b * OH + y0 + r) * OW + x0) * out_cs + out_off;
+#pragma unroll
+    for (int i = 0; i < LAY_EPT; ++i)
+      if (px0 + i < npx) *(float4*)&orow[(int64_t)(px0 + i) * out_cs + q4] = acc[r][i];
   }
 }
 
@@ -548,8 +677,17 @@ int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, 
   if (pxc > LAY_PXC) pxc = LAY_PXC;
   if (pxc > OW) pxc = (int)OW;
   CSG_REQUIRE(pxc >= 1, CSG_E_UNSUPPORTED, "csg_layout_fwd: S too large for one chunk");
-  size_t shm = (size_t)(LAY_OB * pxc + LAY_OB * S + LAY_OB) * 4 + (LAY_OB + 4) * 4 + 2 * LAY_OB * 4;
+  size_t shm = (size_t)(LAY_OB * pxc + LAY_OB * S) * 4 + (size_t)4 * LAY_CULL * 4 + 16;
   ProfScope p(K_LAYOUT_FWD, (double)B * OH * OW * S * 4, s);  // algorithmic bytes: the output, once
+  if (masks == nullptr && (256 % qpp) == 0 && (pxc % LAY_EPT) == 0 && OH >= 32) {
+    // boxes_to_layout on maps from 32 rows up: four rows per block share the staged x coverage and object vectors
+    constexpr int ROWS = 4;
+    const size_t shm4 = (size_t)(LAY_OB * pxc + LAY_OB * S) * 4 + (size_t)LAY_CULL * ROWS * 4 + (size_t)LAY_CULL * 4 + 16;
+    dim3 grid4((unsigned)cdiv(OW, pxc), (unsigned)cdiv(OH, ROWS), (unsigned)B);
+    hipLaunchKernelGGL(k_layout_fwd_rows<ROWS>, grid4, dim3(256), shm4, s, vecs, boxes, valid, (int)O, (int)S, (int)H, (int)W,
+                       (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off);
+    return check_launch("csg_layout_fwd");
+  }
   dim3 grid((unsigned)cdiv(OW, pxc), (unsigned)OH, (unsigned)B);
   hipLaunchKernelGGL(k_layout_fwd, grid, dim3(256), shm, s, vecs, boxes, valid, masks, (int)M, (int)O, (int)S, (int)H,
                      (int)W, (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off);
