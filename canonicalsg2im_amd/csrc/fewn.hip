@@ -107,7 +107,15 @@ __global__ void k_few_finish(FewParams p, const float4* __restrict__ slabs, int 
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= npix) return;
   float4 a = slabs[o];
-  for (int s = 1; s < ksplit; ++s) {
+  int s = 1;
+  for (; s + 4 <= ksplit; s += 4) {            // four loads in flight, added in slab order
+    float4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = slabs[(int64_t)(s + u) * npix + o];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w; }
+  }
+  for (; s < ksplit; ++s) {
     const float4 v = slabs[(int64_t)s * npix + o];
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
   }

@@ -412,8 +412,17 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(IgemmParams p, const fl
     const int n = (int)(e - (long long)m * q) * 4;
     const float* src = ws + (long long)m * d.Cout + n;
     float4 a = *(const float4*)src;
-    for (int s = 1; s < p.ksplit; ++s) {
-      const float4 t = *(const float4*)(src + (long long)s * p.M * d.Cout);
+    const long long slab = (long long)p.M * d.Cout;
+    int s = 1;
+    for (; s + 4 <= p.ksplit; s += 4) {          // four loads in flight, added in slab order
+      float4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *(const float4*)(src + (s + u) * slab);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w; }
+    }
+    for (; s < p.ksplit; ++s) {
+      const float4 t = *(const float4*)(src + s * slab);
       a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
     }
     long long pix = m;
