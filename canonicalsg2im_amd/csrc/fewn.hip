@@ -49,14 +49,22 @@ __global__ __launch_bounds__(256) void k_few_fwd(FewParams p, const float* __res
   const int c_begin = split * cps * FW_CK;
   const int c_end = min(p.Cin, c_begin + cps * FW_CK);
   for (int c0 = c_begin; c0 < c_end; c0 += FW_CK) {
-    for (int e = tid; e < PH * PW * (FW_CK / 4); e += 256) {
+    // (19 x 19 or 11 x 35 pixels) x 4 quads <= 7 x 256: every load of a thread is issued before its first LDS store
+    float4 st[7];
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+      const int e = tid + 256 * it;
       const int pix = e >> 2, c4 = e & 3;
       const int r = pix / PW, c = pix - r * PW;
       const int iy = oy0 + r - p.pad, ix = ox0 + c - p.pad;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
-        v = *(const float4*)(x + ((int64_t)(b * p.IH + iy) * p.IW + ix) * p.x_cs + c0 + c4 * 4);
-      *(float4*)(patch + pix * FW_LD + c4 * 4) = v;
+      st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < PH * PW * (FW_CK / 4) && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+        st[it] = *(const float4*)(x + ((int64_t)(b * p.IH + iy) * p.IW + ix) * p.x_cs + c0 + c4 * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+      const int e = tid + 256 * it;
+      if (e < PH * PW * (FW_CK / 4)) *(float4*)(patch + (e >> 2) * FW_LD + (e & 3) * 4) = st[it];
     }
     __syncthreads();
     // one tap at a time: 4 * NR scalar weight quads live at once (fully unrolled, the compiler hoists every weight of
