@@ -212,3 +212,62 @@ def test_dropin_aliases_resolve_the_reference_import_paths(built):
         "print('ALIASES_OK')\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ALIASES_OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_weight_epoch_advances_where_tensor_versions_do_not(built):
+    """Caches derived from trainable weights (the PatchGAN's permuted first-layer weight) are keyed on
+    ops.weight_epoch(): the fused multi-tensor Adam updates parameters without bumping `_version`, so the key must
+    advance on every optimiser step of ANY optimiser (torch's global post-step hook)."""
+    from canonicalsg2im_amd import ops
+    p = torch.nn.Parameter(torch.randn(4, 4))
+    p.grad = torch.randn(4, 4)
+    for kw in ({"fused": True}, {"foreach": True}, {}):
+        opt = torch.optim.Adam([p], lr=1e-3, **kw)
+        e0, v0 = ops.weight_epoch(), p._version
+        before = p.detach().clone()
+        opt.step()
+        assert not torch.equal(before, p.detach())
+        assert ops.weight_epoch() == e0 + 1, kw
+        if kw.get("fused"):
+            assert p._version == v0          # the reason the epoch exists; if torch changes this, the key still works
+    sgd = torch.optim.SGD([p], lr=0.1)
+    e0 = ops.weight_epoch()
+    sgd.step()
+    assert ops.weight_epoch() == e0 + 1
+
+
+def test_spade_gamma_beta_parameters_share_one_allocation(built):
+    """normalization._joined: the two parameters become the halves of one tensor (no torch.cat per call), gradients
+    reach both, an optimiser step shows through the joined tensor, `module.to(...)` separates them and the next call
+    joins them again; state_dict keys and values are untouched."""
+    from canonicalsg2im_amd.spade.models.networks import normalization as N
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.randn(3, 4, 3, 3).contiguous(memory_format=torch.channels_last))
+            self.b = torch.nn.Parameter(torch.randn(3, 4, 3, 3).contiguous(memory_format=torch.channels_last))
+            self.ba = torch.nn.Parameter(torch.randn(3))
+            self.bb = torch.nn.Parameter(torch.randn(3))
+
+    m = M()
+    a0, b0 = m.a.detach().clone(), m.b.detach().clone()
+    opt = torch.optim.Adam(m.parameters(), lr=0.1)
+    w = N._joined(m, "_jw", m.a, m.b)
+    bias = N._joined(m, "_jb", m.ba, m.bb)
+    assert w.shape == (6, 4, 3, 3) and torch.equal(w[:3], a0) and torch.equal(w[3:], b0)
+    assert w.is_contiguous(memory_format=torch.channels_last) and bias.shape == (6,)
+    assert m.a.data_ptr() == w.data_ptr() and m.b.data_ptr() == w.data_ptr() + 3 * w.stride(0) * 4
+    ((w * torch.arange(6.0).view(6, 1, 1, 1)).sum() + (bias * torch.arange(6.0)).sum()).backward()
+    assert m.a.grad.unique().tolist() == [0.0, 1.0, 2.0] and m.b.grad.unique().tolist() == [3.0, 4.0, 5.0]
+    assert m.bb.grad.tolist() == [3.0, 4.0, 5.0]
+    opt.step()
+    w2 = N._joined(m, "_jw", m.a, m.b)
+    assert w2.data_ptr() == w.data_ptr() and not torch.equal(w2[3:], b0) and torch.equal(w2[3:], m.b.detach())
+    assert set(m.state_dict().keys()) == {"a", "b", "ba", "bb"}
+    m2 = M()
+    m2.load_state_dict(m.state_dict())
+    assert torch.equal(m2.b, m.b)
+    m.double()                                            # separates the parameters; the next call re-joins them
+    w3 = N._joined(m, "_jw", m.a, m.b)
+    assert w3.dtype == torch.float64 and m.a.data_ptr() == w3.data_ptr() and torch.equal(w3[3:], m.b.detach())
