@@ -77,6 +77,8 @@ SIGNATURES = {
     "csg_conv_bwd_weight": (c_i32, [ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_wino_pack_bytes": (c_i64, [c_i64, c_i64]),
     "csg_wino_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
+    "csg_conv_fwd_multi_workspace": (c_i64, [ctypes.POINTER(ConvDesc), c_i32]),
+    "csg_conv_fwd_multi": (c_i32, [ctypes.POINTER(ConvDesc), c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_conv_few_supported": (c_i32, [ctypes.POINTER(FewDesc)]),
     "csg_conv_few_fwd_workspace": (c_i64, [ctypes.POINTER(FewDesc)]),
     "csg_conv_few_fwd": (c_i32, [ctypes.POINTER(FewDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),

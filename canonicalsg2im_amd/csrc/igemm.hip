@@ -83,6 +83,15 @@ struct IgemmParams {
   int ksplit, kt_per_split;
   FastDiv div_ow, div_oh;
   unsigned img_bytes;   // bytes of one input image (IHp*IWp*x_cs*4)
+  long long ws_off;     // floats: where this launch's split-K slabs start in the workspace
+};
+
+// Up to four descriptors served by ONE launch (blockIdx.y picks one): the parity classes of a stride-2 transposed
+// convolution (PatchGAN backward-data).  Each class alone is a quarter of the pixels — grids of 35-140 tiles for 512
+// block slots — and used to be its own launch plus its own split-K epilogue.
+#define IG_MAXCLS 4
+struct IgemmMulti {
+  IgemmParams p[IG_MAXCLS];
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -95,9 +104,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // The three tap tables are 48 consecutive ints of the by-value kernel argument.  Lanes 0..47 copy
 // them from the kernarg segment with ONE vector load each (indexing them per lane through scalar
 // registers would cost 48 SGPRs and spill the hot loop's scalars).
-__device__ __forceinline__ void load_taps(int* s_tap, int tid) {
+__device__ __forceinline__ void load_taps(int* s_tap, int tid, int karg_word = 0) {
   const int* ka = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
-  if (tid < 3 * CSG_MAX_TAPS) s_tap[tid] = ka[offsetof(csg_conv_desc, tap_dy) / 4 + tid];
+  if (tid < 3 * CSG_MAX_TAPS) s_tap[tid] = ka[karg_word + offsetof(csg_conv_desc, tap_dy) / 4 + tid];
 }
 
 __device__ __forceinline__ void decompose(const IgemmParams& p, unsigned m, int& b, int& gy, int& gx) {
@@ -109,11 +118,14 @@ __device__ __forceinline__ void decompose(const IgemmParams& p, unsigned m, int&
 }
 
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float* __restrict__ x,
-                                                       const float* __restrict__ w, const float* __restrict__ bias,
-                                                       const float* __restrict__ res, float* __restrict__ y,
-                                                       float* __restrict__ ws) {
+template <int BN, bool MULTI = false>
+__global__ __launch_bounds__(256, 2) void k_igemm_fwd(typename std::conditional<MULTI, IgemmMulti, IgemmParams>::type karg,
+                                                       const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ res,
+                                                       float* __restrict__ y, float* __restrict__ ws) {
+  const IgemmParams& p = *((const IgemmParams*)&karg + (MULTI ? blockIdx.y : 0));
+  if (MULTI && (int)blockIdx.x >= p.mtiles * p.ntiles * p.ksplit) return;
+  ws += p.ws_off;
   constexpr int MI = BN == 32 ? 1 : 2;       // 32x32 tiles per wave along m
   constexpr int NI = BN == 128 ? 2 : 1;      // ... along n
   constexpr int WM = BN == 32 ? 4 : 2;       // waves along m
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
   }
   const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
 
-  load_taps(s_tap, tid);
+  load_taps(s_tap, tid, MULTI ? (int)(blockIdx.y * (sizeof(IgemmParams) / 4)) : 0);
 
   // ---- buffer descriptors (wave-uniform): A based at the image of this tile's first row
   const int m_first = min(mt * IG_BM, p.M - 1);
@@ -401,9 +413,13 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(IgemmParams p, const float
 }
 
 // second pass of a split-K launch: ordered slab sum + the forward epilogue, 4 channels per thread
-__global__ __launch_bounds__(256) void k_splitk_epilogue(IgemmParams p, const float* __restrict__ ws,
-                                                          const float* __restrict__ bias,
+template <bool MULTI = false>
+__global__ __launch_bounds__(256) void k_splitk_epilogue(typename std::conditional<MULTI, IgemmMulti, IgemmParams>::type karg,
+                                                          const float* __restrict__ ws, const float* __restrict__ bias,
                                                           const float* __restrict__ res, float* __restrict__ y) {
+  const IgemmParams& p = *((const IgemmParams*)&karg + (MULTI ? blockIdx.y : 0));
+  if (MULTI && p.ksplit <= 1) return;
+  ws += p.ws_off;
   const csg_conv_desc& d = p.d;
   const int q = d.Cout >> 2;
   const long long n4 = (long long)p.M * q;
@@ -729,6 +745,7 @@ static void fill(IgemmParams& p, const csg_conv_desc* d) {
   p.div_oh = make_fastdiv((unsigned)d->OHg);
   p.img_bytes = (unsigned)((int64_t)d->IHp * d->IWp * d->x_cs * 4);
   p.mtiles = p.ntiles = 0;
+  p.ws_off = 0;
 }
 
 static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
@@ -802,6 +819,56 @@ static int launch_wgrad(IgemmParams& p, const float* x, const float* dy, float* 
 
 static int pick_bi(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
 
+// ---- several descriptors (same weights, input, output tensor and Cout), one launch -------------------------------
+static int multi_plan(const csg_conv_desc* descs, int n, IgemmMulti& mp, int64_t& ws_floats, int& max_blocks,
+                      const char* who) {
+  CSG_REQUIRE(descs != nullptr && n >= 1 && n <= IG_MAXCLS, CSG_E_BADSHAPE, "%s: 1..%d descriptors", who, IG_MAXCLS);
+  int64_t blocks_total = 0;
+  for (int c = 0; c < n; ++c) {
+    int rc = validate(&descs[c], who);
+    if (rc) return rc;
+    CSG_REQUIRE(descs[c].Cout == descs[0].Cout && descs[c].Cin == descs[0].Cin && descs[c].x_cs == descs[0].x_cs &&
+                    descs[c].y_cs == descs[0].y_cs && descs[c].wtaps == descs[0].wtaps && descs[c].B == descs[0].B,
+                CSG_E_BADSHAPE, "%s: the descriptors must share channels, strides, weights and batch", who);
+    fill(mp.p[c], &descs[c]);
+    const int bn = pick_bn(descs[c].Cout);
+    mp.p[c].mtiles = (mp.p[c].M + IG_BM - 1) / IG_BM;
+    mp.p[c].ntiles = (descs[c].Cout + bn - 1) / bn;
+    blocks_total += (int64_t)mp.p[c].mtiles * mp.p[c].ntiles;
+  }
+  for (int c = n; c < IG_MAXCLS; ++c) mp.p[c] = mp.p[0];
+  // one split factor for all classes, chosen for the grid they form TOGETHER
+  ws_floats = 0;
+  max_blocks = 0;
+  for (int c = 0; c < n; ++c) {
+    IgemmParams& p = mp.p[c];
+    const int nkt = (p.Ktot + IG_BK - 1) / IG_BK;
+    int ks = 1;
+    if (blocks_total < 1024 && nkt >= 16 && p.d.Cout % 4 == 0) ks = pick_split((int)blocks_total, nkt, 8, 64);
+    p.kt_per_split = (nkt + ks - 1) / ks;
+    p.ksplit = (nkt + p.kt_per_split - 1) / p.kt_per_split;
+    p.ws_off = ws_floats;
+    if (p.ksplit > 1) ws_floats += (int64_t)p.ksplit * p.M * p.d.Cout;
+    const int blocks = p.mtiles * p.ntiles * p.ksplit;
+    if (blocks > max_blocks) max_blocks = blocks;
+  }
+  return CSG_OK;
+}
+
+template <int BN>
+static int launch_fwd_multi(IgemmMulti& mp, int n, int max_blocks, const float* x, const float* w, const float* bias,
+                            const float* res, float* y, float* ws, hipStream_t s) {
+  static bool attr_set = false;
+  size_t shm = (size_t)(2 * IG_BM * IG_LD + 2 * BN * IG_LD) * 4 + 48 * 4;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_igemm_fwd<BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_igemm_fwd<BN, true>), dim3((unsigned)max_blocks, (unsigned)n), dim3(256), shm, s, mp, x, w, bias, res,
+                     y, ws);
+  return check_launch("csg_conv_fwd_multi");
+}
+
 extern "C" {
 
 int64_t csg_conv_fwd_workspace(const csg_conv_desc* d) {
@@ -844,8 +911,59 @@ int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const f
     const int64_t n4 = (int64_t)p.M * d->Cout / 4;
     int64_t g = cdiv(n4, 256);
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)g), dim3(256), 0, s, p, workspace, bias, residual, y);
+    hipLaunchKernelGGL(k_splitk_epilogue<false>, dim3((unsigned)g), dim3(256), 0, s, p, workspace, bias, residual, y);
     rc = check_launch("csg_conv_fwd(split-K epilogue)");
+  }
+  return rc;
+}
+
+int64_t csg_conv_fwd_multi_workspace(const csg_conv_desc* descs, int32_t n) {
+  IgemmMulti mp;
+  int64_t wsf = 0;
+  int mb = 0;
+  if (multi_plan(descs, n, mp, wsf, mb, "csg_conv_fwd_multi_workspace")) return -1;
+  return wsf * 4;
+}
+
+int csg_conv_fwd_multi(const csg_conv_desc* descs, int32_t n, const float* x, const float* w, const float* bias,
+                       const float* residual, float* y, float* workspace, int64_t workspace_bytes, void* stream) {
+  IgemmMulti mp;
+  int64_t wsf = 0;
+  int mb = 0;
+  int rc = multi_plan(descs, n, mp, wsf, mb, "csg_conv_fwd_multi");
+  if (rc) return rc;
+  CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, CSG_E_UNSUPPORTED,
+              "csg_conv_fwd_multi: x and w must be 16-byte aligned");
+  CSG_REQUIRE(wsf == 0 || (workspace != nullptr && workspace_bytes >= wsf * 4), CSG_E_WORKSPACE,
+              "csg_conv_fwd_multi: needs %lld bytes of workspace", (long long)(wsf * 4));
+  hipStream_t s = (hipStream_t)stream;
+  const int bn = pick_bn(descs[0].Cout);
+  double flops = 0.0;
+  bool any_split = false;
+  int64_t max_n4 = 0;
+  for (int c = 0; c < n; ++c) {
+    flops += 2.0 * mp.p[c].M * (double)mp.p[c].Ktot * descs[c].Cout;
+    any_split = any_split || mp.p[c].ksplit > 1;
+    const int64_t n4 = (int64_t)mp.p[c].M * descs[c].Cout / 4;
+    if (n4 > max_n4) max_n4 = n4;
+  }
+  {
+    ProfScope ps(bn == 128 ? K_IGEMM_FWD : K_IGEMM_FWD64, flops, s);
+    if (bn == 32)
+      rc = launch_fwd_multi<32>(mp, n, mb, x, w, bias, residual, y, workspace, s);
+    else if (bn == 64)
+      rc = launch_fwd_multi<64>(mp, n, mb, x, w, bias, residual, y, workspace, s);
+    else
+      rc = launch_fwd_multi<128>(mp, n, mb, x, w, bias, residual, y, workspace, s);
+    if (rc) return rc;
+  }
+  if (any_split) {
+    ProfScope ps(K_SPLITK_EPI, (double)wsf * 4, s);
+    int64_t g = cdiv(max_n4, 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_splitk_epilogue<true>, dim3((unsigned)g, (unsigned)n), dim3(256), 0, s, mp, workspace, bias, residual,
+                       y);
+    rc = check_launch("csg_conv_fwd_multi(split-K epilogue)");
   }
   return rc;
 }

@@ -108,6 +108,25 @@ def _conv_launch(d, x, w, bias, res, y, what):
     check(lib.csg_conv_fwd(d, ptr(x), ptr(w), ptr(bias), ptr(res), ptr(y), ptr(ws), nbytes, stream()), what)
 
 
+def _conv_launch_classes(descs, x, w, y_ptr, dev, what):
+    """The parity-class descriptors of a strided backward-data pass (same weights, input and output tensor): one
+    launch for all of them (csg_conv_fwd_multi) — each class alone is a quarter of the pixels and cannot fill the chip."""
+    if len(descs) == 1:
+        d = descs[0]
+        nbytes = lib.csg_conv_fwd_workspace(d)
+        if nbytes < 0:
+            raise RuntimeError("conv_fwd_workspace: " + _lib.last_error())
+        ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32) if nbytes > 0 else None
+        check(lib.csg_conv_fwd(d, ptr(x), ptr(w), None, None, y_ptr, ptr(ws), nbytes, stream()), what)
+        return
+    arr = (ConvDesc * len(descs))(*descs)
+    nbytes = lib.csg_conv_fwd_multi_workspace(arr, len(descs))
+    if nbytes < 0:
+        raise RuntimeError("conv_fwd_multi_workspace: " + _lib.last_error())
+    ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32) if nbytes > 0 else None
+    check(lib.csg_conv_fwd_multi(arr, len(descs), ptr(x), ptr(w), None, None, y_ptr, ptr(ws), nbytes, stream()), what)
+
+
 # ---- Winograd F(2x2,3x3) path (csrc/wino.hip): 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip
 FEW_ENABLED = os.environ.get("CSG_FEW_OUTPUT_KERNELS", "1") != "0"   # csrc/fewn.hip for convolutions with <= 4 outputs
 WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "4096"))     # B*H*W below which the direct kernel stays
@@ -264,14 +283,10 @@ class _Conv2d(torch.autograd.Function):
             lo, hi = ctx.dx_range
             wt = weight.detach()[:, lo:hi].permute(1, 2, 3, 0).contiguous()      # [hi-lo][KH][KW][Cout]
             dx = empty_nhwc(B, Cin, IH, IW, dy.device, zero=True)
-            for d in _descs_backward_data(B, IH, IW, hi - lo, Cout, KH, KW, stride, pad, OH, OW):
+            descs = _descs_backward_data(B, IH, IW, hi - lo, Cout, KH, KW, stride, pad, OH, OW)
+            for d in descs:
                 d.y_cs = Cin
-                nbytes = lib.csg_conv_fwd_workspace(d)
-                if nbytes < 0:
-                    raise RuntimeError("conv_fwd_workspace: " + _lib.last_error())
-                ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32) if nbytes > 0 else None
-                check(lib.csg_conv_fwd(d, ptr(dpre), ptr(wt), None, None, ctypes_ptr_off(dx, lo), ptr(ws), nbytes,
-                                       stream()), "conv_bwd_data")
+            _conv_launch_classes(descs, dpre, wt, ctypes_ptr_off(dx, lo), dy.device, "conv_bwd_data")
         elif ctx.needs_input_grad[0] and wino_eligible(B, IH, IW, Cout, Cin, KH, KW, stride, pad):
             # dX = conv3x3(dY, flipped W^T): the same Winograd kernel with the roles of the channel counts swapped
             ut = ctx.packs[3] if (ctx.packs is not None and len(ctx.packs) > 3) else wino_pack(weight, True)
@@ -283,8 +298,8 @@ class _Conv2d(torch.autograd.Function):
             wt = ctx.packs[1] if ctx.packs is not None else \
                 weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
-            for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
-                _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
+            _conv_launch_classes(_descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW), dpre, wt, ptr(dx),
+                                 dy.device, "conv_bwd_data")
         if dx is not None and not gated:              # the producer's activation derivative as a separate pass
             check(lib.csg_act_bwd(ptr(dx), ptr(x), dx.numel(), ctx.in_act[0], ctx.in_act[1], ptr(dx), stream()), "act_bwd")
         want_db = ctx.has_bias and ctx.needs_input_grad[2]

@@ -159,6 +159,12 @@ typedef struct csg_conv_desc {
 int64_t csg_conv_fwd_workspace(const csg_conv_desc* d);
 int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
                  float* y, float* workspace, int64_t workspace_bytes, void* stream);
+/* Up to four descriptors that share weights, input, output tensor, channel counts and batch, served by ONE launch: the
+ * parity classes of a stride-2 transposed convolution (backward-data of the PatchGAN's 4x4/2 layers,
+ * discriminator.py:175-183).  Each class alone fills a fraction of the chip.  Workspace as csg_conv_fwd's.        */
+int64_t csg_conv_fwd_multi_workspace(const csg_conv_desc* descs, int32_t n);
+int csg_conv_fwd_multi(const csg_conv_desc* descs, int32_t n, const float* x, const float* w, const float* bias,
+                       const float* residual, float* y, float* workspace, int64_t workspace_bytes, void* stream);
 /* dw[n][tap][c] = sum_m dy[m][n] * x[src(m,tap)][c]; `d` is the FORWARD descriptor (y_cs = floats per
  * pixel of dy).  Deterministic split-K: partial slabs in `workspace`, then an ordered reduction.
  * db (Cout floats, may be NULL) receives the bias gradient sum_m dy[m][n], accumulated from the dY
