@@ -66,8 +66,9 @@ SIGNATURES = {
                                     c_p, c_p, c_p, c_p]),
     "csg_layout_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64,
                                c_i64, c_p]),
+    "csg_layout_bwd_workspace": (c_i64, [c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32]),
     "csg_layout_bwd": (c_i32, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
-                               c_i64, c_p, c_i32, c_p, c_p, c_p]),
+                               c_i64, c_p, c_i32, c_p, c_p, c_p, c_i64, c_p]),
     "csg_layout_mass": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_layout_paint": (c_i32, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64,
                                  c_i64, c_p]),

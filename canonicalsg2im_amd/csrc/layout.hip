@@ -392,6 +392,166 @@ __global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict
   }
 }
 
+// ---- backward for boxes_to_layout without box gradients, dense scenes --------------------------------------------
+// k_layout_bwd gives every (object, image) a block that walks the object's own box support: the gradient map is read
+// once per covering object (~7x on config C5).  Here it is read ONCE: pass 1 has the forward's tiling (ROWS rows x one
+// pixel chunk per block, the tile of dout held in registers) and, for each object active in the tile, reduces
+// sum_pixels weight * dout over the tile — partial[b][tile][o][S]; it also records which (tile, object) pairs it wrote.
+// Pass 2 (one block per (object, image)) adds an object's partials in tile order.  Fixed association everywhere:
+// bit-reproducible, no atomics.
+#define LAY_BB 8      // objects reduced per LDS round of pass 1
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_layout_bwd_tiles(const float* __restrict__ dout, int out_cs, int out_off,
+                                                           const float* __restrict__ boxes,
+                                                           const uint8_t* __restrict__ valid, int O, int S, int H, int W,
+                                                           int OH, int OW, int pxc, float* __restrict__ partial,
+                                                           uint8_t* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float4* s_part = (float4*)sm;                       // [LAY_BB][256]
+  float* s_wx = sm + LAY_BB * 256 * 4;                // [LAY_BB][pxc]
+  float* s_wy = s_wx + LAY_BB * pxc;                  // [LAY_CULL][ROWS]
+  int* s_act = (int*)(s_wy + LAY_CULL * ROWS);        // [LAY_CULL]
+  int* s_cnt = s_act + LAY_CULL;                      // [4]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, y0 = blockIdx.y * ROWS, x0 = blockIdx.x * pxc;
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
+  const int npx = min(pxc, OW - x0);
+  const int qpp = S >> 2, planes = 256 / qpp;
+  const int plane = tid / qpp, q = tid % qpp;
+  const int px0 = plane * LAY_EPT, q4 = q * 4;
+  float ty[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) ty[r] = lin01(min((int)(((int64_t)min(y0 + r, OH - 1) * H) / OH), H - 1), H);
+  // this thread's 8 pixels x ROWS rows of dout, one channel quad
+  float4 d[ROWS][LAY_EPT];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int i = 0; i < LAY_EPT; ++i) {
+      d[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y0 + r < OH && px0 + i < npx)
+        d[r][i] = *(const float4*)(dout + ((int64_t)(b * OH + y0 + r) * OW + x0 + px0 + i) * out_cs + out_off + q4);
+    }
+  const float* bx = boxes + (int64_t)b * O * 4;
+  const uint8_t* vb = valid + (int64_t)b * O;
+  uint8_t* fl = flags + ((int64_t)b * ntiles + tile) * O;
+  float* pt = partial + ((int64_t)b * ntiles + tile) * O * S;
+  const int xs0 = min((int)(((int64_t)x0 * W) / OW), W - 1);
+  const int xs1 = min((int)(((int64_t)(x0 + npx - 1) * W) / OW), W - 1);
+  const float step = W > 1 ? 1.0f / (float)(W - 1) : 1.0f;
+  const float tx_lo = lin01(xs0, W) - step, tx_hi = lin01(xs1, W) + step;
+
+  for (int ob = 0; ob < O; ob += LAY_CULL) {
+    __syncthreads();
+    {
+      const int o = ob + tid;
+      float wy[ROWS];
+      bool act = false;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) wy[r] = 0.f;
+      if (o < O && vb[o]) {
+        const float4 bq = *(const float4*)(bx + o * 4);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          wy[r] = (y0 + r < OH) ? coverage(ty[r], bq.y, bq.w) : 0.f;
+          act = act || (wy[r] != 0.0f);
+        }
+        if (act) {                          // the forward's x-support test: a dropped object has zero weight in the tile
+          const float lo = fminf(bq.x - bq.z / 16.0f, bq.x + bq.z * (1.0f + 1.0f / 16.0f));
+          const float hi = fmaxf(bq.x - bq.z / 16.0f, bq.x + bq.z * (1.0f + 1.0f / 16.0f));
+          if (tx_hi < lo || tx_lo > hi) act = false;
+        }
+      }
+      if (o < O) fl[o] = act ? 1 : 0;
+      const unsigned long long m = __ballot(act);
+      const int lane = tid & 63, wv = tid >> 6;
+      if (lane == 0) s_cnt[wv] = __popcll(m);
+      __syncthreads();
+      int base = 0;
+      for (int w = 0; w < wv; ++w) base += s_cnt[w];
+      const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (act) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) s_wy[slot * ROWS + r] = wy[r];
+        s_act[slot] = o;
+      }
+    }
+    __syncthreads();
+    const int ntot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    for (int a0 = 0; a0 < ntot; a0 += LAY_BB) {
+      const int nact = min(LAY_BB, ntot - a0);
+      if (a0 > 0) __syncthreads();
+      for (int i = tid; i < nact * pxc; i += 256) {
+        const int a = i / pxc, xl = i - a * pxc;
+        const int o = s_act[a0 + a];
+        const int xsrc = min((int)(((int64_t)min(x0 + xl, OW - 1) * W) / OW), W - 1);
+        s_wx[a * pxc + xl] = xl < npx ? coverage(lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]) : 0.f;
+      }
+      __syncthreads();
+      for (int a = 0; a < nact; ++a) {
+        const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
+        const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          const float wy = s_wy[(a0 + a) * ROWS + r];
+#pragma unroll
+          for (int i = 0; i < LAY_EPT; ++i) {
+            const float w = wy * wv[i];
+            acc.x += d[r][i].x * w; acc.y += d[r][i].y * w; acc.z += d[r][i].z * w; acc.w += d[r][i].w * w;
+          }
+        }
+        s_part[a * 256 + plane * qpp + q] = acc;
+      }
+      __syncthreads();
+      for (int e = tid; e < nact * qpp; e += 256) {   // sum over the pixel planes in plane order
+        const int a = e / qpp, qq = e - a * qpp;
+        float4 t = s_part[a * 256 + qq];
+        for (int pl = 1; pl < planes; ++pl) {
+          const float4 v = s_part[a * 256 + pl * qpp + qq];
+          t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        *(float4*)(pt + (int64_t)s_act[a0 + a] * S + qq * 4) = t;
+      }
+    }
+  }
+}
+
+// pass 2: dvecs[b][o] = (accumulate ? dvecs : 0) + sum over the tiles that flagged o, in tile order
+__global__ __launch_bounds__(256) void k_layout_bwd_gather(const float* __restrict__ partial,
+                                                            const uint8_t* __restrict__ flags,
+                                                            const uint8_t* __restrict__ valid, int O, int S, int ntiles,
+                                                            float* __restrict__ dvecs, int accumulate) {
+  __shared__ float4 s_red[256];
+  const int tid = threadIdx.x, o = blockIdx.x, b = blockIdx.y;
+  const int qpp = S >> 2, lanes = 256 / qpp;
+  const int q = tid % qpp, tl = tid / qpp;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid[(int64_t)b * O + o]) {
+    for (int t = tl; t < ntiles; t += lanes) {
+      const int64_t bt = (int64_t)b * ntiles + t;
+      if (flags[bt * O + o]) {
+        const float4 v = *(const float4*)(partial + (bt * O + o) * S + q * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+  }
+  s_red[tid] = acc;
+  __syncthreads();
+  if (tl == 0) {
+    for (int l = 1; l < lanes; ++l) {
+      const float4 v = s_red[l * qpp + q];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* dv = dvecs + ((int64_t)b * O + o) * S + q * 4;
+    if (accumulate) {
+      const float4 old = *(const float4*)dv;
+      acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+    }
+    *(float4*)dv = acc;
+  }
+}
+
 // One block per (object, image): reduce dout over the box's support only.  256 threads for small layouts,
 // 1024 for >= 64x64 ones (S/4 lanes per pixel, blockDim/(S/4) pixels in flight, two loads per lane in flight).
 __global__ __launch_bounds__(1024) void k_layout_bwd(const float* __restrict__ dout, int out_cs, int out_off,
@@ -694,9 +854,58 @@ int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, 
   return check_launch("csg_layout_fwd");
 }
 
+// tiled two-pass backward: boxes_to_layout, no box gradients, S/4 dividing 256, maps from 32 rows up
+static bool layout_bwd_tiled(const float* masks, const float* dboxes, int64_t S, int64_t OH, int64_t OW, int64_t O, int& pxc,
+                             int& ntiles) {
+  if (masks != nullptr || dboxes != nullptr || S % 4 != 0 || O <= 0) return false;
+  const int qpp = (int)(S / 4);
+  if (qpp > 256 || (256 % qpp) != 0 || OH < 32) return false;
+  pxc = (LAY_EPT * 256) / qpp;
+  if (pxc > LAY_PXC) pxc = LAY_PXC;
+  if (pxc > OW) pxc = (int)OW;
+  if (pxc % LAY_EPT) return false;
+  ntiles = (int)(cdiv(OW, pxc) * cdiv(OH, 4));
+  return true;
+}
+
+int64_t csg_layout_bwd_workspace(int64_t B, int64_t O, int64_t S, int64_t OH, int64_t OW, int32_t has_masks,
+                                 int32_t box_gradients) {
+  int pxc = 0, ntiles = 0;
+  if (B <= 0 || !layout_bwd_tiled(has_masks ? (const float*)1 : nullptr, box_gradients ? (const float*)1 : nullptr, S, OH,
+                                  OW, O, pxc, ntiles))
+    return 0;
+  const int64_t part = B * ntiles * O * S * 4;
+  const int64_t flags = (B * ntiles * O + 15) / 16 * 16;
+  return part + flags;
+}
+
 int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,
                    const float* masks, int64_t M, int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH,
-                   int64_t OW, float* dvecs, int accumulate, const float* vecs, float* dboxes, void* stream) {
+                   int64_t OW, float* dvecs, int accumulate, const float* vecs, float* dboxes, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  {
+    int pxc = 0, ntiles = 0;
+    if (B > 0 && workspace != nullptr && layout_bwd_tiled(masks, dboxes, S, OH, OW, O, pxc, ntiles) &&
+        workspace_bytes >= csg_layout_bwd_workspace(B, O, S, OH, OW, 0, 0) && B <= 65535 && OH <= 4 * 65535) {
+      CSG_REQUIRE(out_cs % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)workspace % 16) == 0,
+                  CSG_E_UNSUPPORTED, "csg_layout_bwd: out_cs, out_off must be multiples of 4, pointers 16-byte aligned");
+      constexpr int ROWS = 4;
+      hipStream_t s = (hipStream_t)stream;
+      float* partial = (float*)workspace;
+      uint8_t* flags = (uint8_t*)workspace + B * ntiles * O * S * 4;
+      const size_t shm = (size_t)LAY_BB * 256 * 16 + (size_t)LAY_BB * pxc * 4 + (size_t)LAY_CULL * ROWS * 4 +
+                         (size_t)LAY_CULL * 4 + 16;
+      ProfScope p(K_LAYOUT_BWD, (double)B * OH * OW * S * 4, s);
+      dim3 grid((unsigned)cdiv(OW, pxc), (unsigned)cdiv(OH, ROWS), (unsigned)B);
+      hipLaunchKernelGGL(k_layout_bwd_tiles<ROWS>, grid, dim3(256), shm, s, dout, (int)out_cs, (int)out_off, boxes, valid,
+                         (int)O, (int)S, (int)H, (int)W, (int)OH, (int)OW, pxc, partial, flags);
+      int rc = check_launch("csg_layout_bwd(tiles)");
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_layout_bwd_gather, dim3((unsigned)O, (unsigned)B), dim3(256), 0, s, partial, flags, valid, (int)O,
+                         (int)S, ntiles, dvecs, accumulate);
+      return check_launch("csg_layout_bwd(gather)");
+    }
+  }
   CSG_REQUIRE(masks == nullptr || (M >= 1 && M <= 1024), CSG_E_BADSHAPE, "csg_layout_bwd: bad mask size %ld", (long)M);
   CSG_REQUIRE(B > 0 && O >= 0 && S > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, CSG_E_BADSHAPE,
               "csg_layout_bwd: bad shape");

@@ -828,8 +828,10 @@ class _LayoutPyramid(torch.autograd.Function):
             if g is None:
                 continue
             g = nhwc(g)
+            nws = lib.csg_layout_bwd_workspace(B, O, S, h, w, 0 if masks is None else 1, 0 if dboxes is None else 1)
+            ws = torch.empty(nws // 4, device=boxes.device, dtype=torch.float32) if nws > 0 else None
             check(lib.csg_layout_bwd(ptr(g), S, 0, ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, W, h, w,
-                                     ptr(dvecs), 1, ptr(vecs), ptr(dboxes), stream()), "layout_bwd")
+                                     ptr(dvecs), 1, ptr(vecs), ptr(dboxes), ptr(ws), nws, stream()), "layout_bwd")
         return dvecs, dboxes, None, None, None, None, None
 
 
@@ -896,8 +898,10 @@ class _DiscInput(torch.autograd.Function):
             dvecs = torch.empty((B, O, S), device=dbuf.device, dtype=torch.float32)
             if ctx.needs_input_grad[2]:
                 dboxes = torch.empty((B, O, 4), device=dbuf.device, dtype=torch.float32)
+            nws = lib.csg_layout_bwd_workspace(B, O, S, H, H, 0 if masks is None else 1, 0 if dboxes is None else 1)
+            ws = torch.empty(nws // 4, device=dbuf.device, dtype=torch.float32) if nws > 0 else None
             check(lib.csg_layout_bwd(ptr(dbuf), Ct, 0, ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, H, H,
-                                     ptr(dvecs), 0, ptr(vecs), ptr(dboxes), stream()), "layout_bwd")
+                                     ptr(dvecs), 0, ptr(vecs), ptr(dboxes), ptr(ws), nws, stream()), "layout_bwd")
         return dimg, dvecs, dboxes, None, None, None
 
 

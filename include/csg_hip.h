@@ -114,10 +114,17 @@ int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, 
                    int64_t out_cs, int64_t out_off, void* stream);
 /* dvecs (B,O,S) = (accumulate ? dvecs : 0) + sum_{y,x} dout * cov * cov.  With `dboxes` (B,O,4) non-NULL (needs
  * `vecs`) the gradient w.r.t. [x0,y0,w,h] is produced too: the grid of layout.py:98-110 is differentiable in the
- * box, and grid_sample's backward w.r.t. its grid is the bilinear weights' derivative.          */
+ * box, and grid_sample's backward w.r.t. its grid is the bilinear weights' derivative.
+ * `workspace` (csg_layout_bwd_workspace bytes; 0 when the shape is not served): boxes_to_layout without box gradients
+ * on maps from 32 rows up runs as two passes that read dout ONCE — per-tile partial sums for the objects active in the
+ * tile, then an ordered sum per object (bit-reproducible).  Without it, one block per (object, image) walks the
+ * object's own box support (dout is read once per covering object).                                          */
+int64_t csg_layout_bwd_workspace(int64_t B, int64_t O, int64_t S, int64_t OH, int64_t OW, int32_t has_masks,
+                                 int32_t box_gradients);
 int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,
                    const float* masks, int64_t M, int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH,
-                   int64_t OW, float* dvecs, int accumulate, const float* vecs, float* dboxes, void* stream);
+                   int64_t OW, float* dvecs, int accumulate, const float* vecs, float* dboxes, void* workspace,
+                   int64_t workspace_bytes, void* stream);
 /* masks_to_layout(test_mode=True) (layout.py:71-74,135-151): painter's compositing, one object per pixel.
  * csg_layout_mass: mass[b,o] = sum(samples[o]) at full resolution (+inf for invalid objects) — the caller sorts it
  * (ascending, stable) into `order` (B,O) int32, -1 after the last valid object.

@@ -244,8 +244,19 @@ def test_layout_golden(ops):
         dv = torch.empty(1, O, S).cuda()
         gw = a["w_" + tag].permute(0, 2, 3, 1).contiguous().cuda()
         check(lib.csg_layout_bwd(ptr(gw), S, 0, ptr(bd), ptr(valid), None, 0, 1, O, S, H, W, H, W, ptr(dv), 0, None, None,
-                                 stream()))
+                                 None, 0, stream()))                       # one block per object
         assert_close(dv[0], a["gvecs_" + tag], RTOL, 1e-5, "layout dvecs " + tag)
+        nws = lib.csg_layout_bwd_workspace(1, O, S, H, W, 0, 0)            # the two-pass tiled form where it applies
+        if nws > 0:
+            ws = torch.full((nws // 4,), float("nan")).cuda()
+            dv2 = torch.full((1, O, S), float("nan")).cuda()
+            check(lib.csg_layout_bwd(ptr(gw), S, 0, ptr(bd), ptr(valid), None, 0, 1, O, S, H, W, H, W, ptr(dv2), 0, None,
+                                     None, ptr(ws), nws, stream()))
+            assert_close(dv2[0], a["gvecs_" + tag], RTOL, 1e-5, "layout dvecs (tiled) " + tag)
+            dv3 = dv2.clone()
+            check(lib.csg_layout_bwd(ptr(gw), S, 0, ptr(bd), ptr(valid), None, 0, 1, O, S, H, W, H, W, ptr(dv3), 1, None,
+                                     None, ptr(ws), nws, stream()))           # accumulate
+            assert torch.equal(dv3, dv2 + dv2)
 
 
 def test_masks_to_layout_golden(ops):
