@@ -56,6 +56,7 @@ struct WinoParams {
   float gate_slope;    // epilogue gate: y *= (gate > 0 ? 1 : gate_slope)
   int nstage;          // ceil(Cin / 16)
   int variant;         // 1: 64 tiles per block (k_wino_conv), 2: 32 tiles per block, two blocks per CU (k_wino_conv2)
+  int ntb;             // k_wino_conv2: 32-channel groups per block (2, or 1 when Cout <= 32)
   int ksplit, sps;     // k_wino_conv2: input-channel stages cut into ksplit ranges of sps stages, one output slab each
   long long slab;      // floats per slab (B*H*W*y_cs)
 };
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_conv(WinoParams p, const float*
 // the partner wave's MFMAs run underneath, and one block's epilogue under the other block's main loop.  To fit 256
 // registers the weights are single-buffered: the eight operands of one channel group are reloaded (for the next
 // k-oct) right after their last MFMA, while the other group's 16 MFMAs run.
-template <int TW>
+template <int TW, int NTB = 2>     // NTB: 32-channel groups per block (1 for layers with <= 32 output channels)
 __global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float* __restrict__ x,
                                                         const float4* __restrict__ up, const float* __restrict__ bias,
                                                         const float* __restrict__ res, const float* __restrict__ gate,
@@ -525,26 +526,26 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float
   const float* pa0 = smem + (2 * tyl + ia) * RS + tx * WN_PS + 2 * h;
   const float* pb0 = smem + (2 * tyl + ib) * RS + tx * WN_PS + 2 * h;
 
-  unsigned uoff[4][2];
+  unsigned uoff[4][NTB];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int nt32 = nb * 2 + nt;
+  for (int nt = 0; nt < NTB; ++nt) {
+    const int nt32 = nb * NTB + nt;
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
       uoff[nu][nt] = nt32 < p.NT32 ? (unsigned)((((wave * 4 + nu) * p.NT32 + nt32) * p.Q8) * 64 + lane) * 16u : CSG_OOB_OFF;
   }
-  csg_f32x4 u[4][2];
+  csg_f32x4 u[4][NTB];
   auto load_u_half = [&](int nt, int q) {        // operands of channel group nt for k-oct q (clamped: see k_wino_conv)
     const int qq = min(q, p.Q8 - 1);
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) u[nu][nt] = csg_buf_load_x4(rsU, (int)uoff[nu][nt], qq * 1024, 0);
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][NTB];
 #pragma unroll
   for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NTB; ++nt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[nu][nt][e] = 0.f;
 
@@ -586,9 +587,11 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float
       mfma_half(0);
       __builtin_amdgcn_sched_barrier(0);
       load_u_half(0, 2 * s + o + 1);
-      mfma_half(1);
-      __builtin_amdgcn_sched_barrier(0);
-      load_u_half(1, 2 * s + o + 1);
+      if (NTB > 1) {
+        mfma_half(NTB - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u_half(NTB - 1, 2 * s + o + 1);
+      }
     }
     store_stage(smem + (bufsel ^ 1) * BUFW);
     __syncthreads();
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float
   y += (long long)split * p.slab;
   load_stage(s_begin);
   load_u_half(0, 2 * s_begin);
-  load_u_half(1, 2 * s_begin);
+  if (NTB > 1) load_u_half(NTB - 1, 2 * s_begin);
   store_stage(smem);
   __syncthreads();
   int s = s_begin;
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float
   // ---- epilogue (as k_wino_conv, 32 tiles): R[0] = M0+M1+M2, R[1] = M1-M2-M3 per wave, A^T . through LDS
   float* rbuf = smem;                            // [xi][b][32 tiles][WN_RSE]
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < NTB; ++nt) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float r0[4], r1[4];
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_conv2(WinoParams p, const float
     __syncthreads();
     {
       const int tile = tid >> 3, cq = tid & 7;   // 32 tiles x 8 channel quads: one item per thread
-      const int n = nb * 64 + nt * 32 + cq * 4;
+      const int n = nb * (32 * NTB) + nt * 32 + cq * 4;
       const int ttx = tile % TW, tty = tile / TW;
       const int oy = Y0 + 2 * tty, ox = X0 + 2 * ttx;
       if (n < p.Cout && oy < p.H && ox < p.W) {
@@ -701,7 +704,8 @@ static int wn_plan(const csg_wino_desc* d, WinoParams& p, size_t& shm, const cha
   }
   p.tbx = (d->W / 2 + p.TW - 1) / p.TW;
   p.tby = (d->H / 2 + p.TH - 1) / p.TH;
-  p.nblocks = (d->Cout + 63) / 64;
+  p.ntb = (variant == 2 && d->Cout <= 32) ? 1 : 2;     // 32-wide blocks for layers with <= 32 output channels
+  p.nblocks = (d->Cout + 32 * p.ntb - 1) / (32 * p.ntb);
   p.RS = wn_row_stride(p.TW);
   CSG_REQUIRE(d->Cin % 16 == 0, CSG_E_UNSUPPORTED, "%s: Cin must be a multiple of 16 (one LDS stage)", who);
   p.NT32 = (d->Cout + 31) / 32;
@@ -787,9 +791,10 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    const void* fns[7] = {(const void*)k_wino_conv<32>, (const void*)k_wino_conv<16>, (const void*)k_wino_conv<8>,
-                          (const void*)k_wino_conv<4>, (const void*)k_wino_conv2<16>, (const void*)k_wino_conv2<8>,
-                          (const void*)k_wino_conv2<4>};
+    const void* fns[10] = {(const void*)k_wino_conv<32>, (const void*)k_wino_conv<16>, (const void*)k_wino_conv<8>,
+                          (const void*)k_wino_conv<4>, (const void*)k_wino_conv2<16, 2>, (const void*)k_wino_conv2<8, 2>,
+                          (const void*)k_wino_conv2<4, 2>, (const void*)k_wino_conv2<16, 1>, (const void*)k_wino_conv2<8, 1>,
+                          (const void*)k_wino_conv2<4, 1>};
     for (const void* fn : fns) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
@@ -804,12 +809,19 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
   ProfScope ps(K_WINO_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
   const float4* up = (const float4*)packed;
   if (p.variant == 2) {
-    if (p.TW == 16)
-      hipLaunchKernelGGL(k_wino_conv2<16>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+    if (p.ntb == 1) {
+      if (p.TW == 16)
+        hipLaunchKernelGGL((k_wino_conv2<16, 1>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+      else if (p.TW == 8)
+        hipLaunchKernelGGL((k_wino_conv2<8, 1>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+      else
+        hipLaunchKernelGGL((k_wino_conv2<4, 1>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+    } else if (p.TW == 16)
+      hipLaunchKernelGGL((k_wino_conv2<16, 2>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
     else if (p.TW == 8)
-      hipLaunchKernelGGL(k_wino_conv2<8>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+      hipLaunchKernelGGL((k_wino_conv2<8, 2>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
     else
-      hipLaunchKernelGGL(k_wino_conv2<4>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+      hipLaunchKernelGGL((k_wino_conv2<4, 2>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
     rc = check_launch("csg_wino_conv");
     if (rc == CSG_OK && p.ksplit > 1) {
       launch_slab_reduce(workspace, p.slab, y_final, nullptr, 0, nullptr, p.ksplit, s);
