@@ -43,10 +43,13 @@ def _f32(t):
     return t
 
 
+_NORM_BLOCKS = int(os.environ.get("CSG_NORM_BLOCKS", "1024"))
+
+
 def _chunks(P, G=1):
     """Pixel chunks of a two-stage reduction: >= 32 pixels each, up to ~1024 blocks in flight
     (low-resolution layers have few pixels but up to 1024 channels: they need many small chunks)."""
-    c = max(1, min(P // 32, max(1, 1024 // max(G, 1))))
+    c = max(1, min(P // 32, max(1, _NORM_BLOCKS // max(G, 1))))
     return int(c)
 
 
