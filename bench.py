@@ -244,7 +244,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if args.config == "C3" and H == 256 and args.batch == 16 and not args.use_img_disc and not args.vgg_loss:
-                key = "k_wino_conv2<16>" if dom == "wino_conv" else "k_igemm_fwd<128>"      # the launches on maps >= 32 wide
+                key = "k_wino_conv2<16, 2>" if dom == "wino_conv" else "k_igemm_fwd<128>"      # the launches on maps >= 32 wide
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
