@@ -227,11 +227,16 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const float* __restrict
 }
 
 // pass 2: dx = invstd * (dn - mean(dn) - xhat * mean(dn*xhat))
+// With (dy2, gb2) a SECOND SPADE modulation of the same normalised x (a residual block's norm_0 and norm_s: same batch
+// statistics) is folded in: dn = dn_1 + dn_2, `dsums` already holds the sum of both reductions — one pass and one dx
+// instead of two passes and an addition.
 __global__ __launch_bounds__(256) void k_norm_bwd_dx(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gb, float slope,
                                                       const double* __restrict__ dsums, double inv_count, int64_t P,
-                                                      int C, int64_t n4, float* __restrict__ dx) {
+                                                      int C, int64_t n4, float* __restrict__ dx,
+                                                      const float* __restrict__ dy2, const float* __restrict__ gb2,
+                                                      float slope2) {
   const int Q = C >> 2;
 #pragma unroll 2
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
@@ -254,6 +259,16 @@ __global__ __launch_bounds__(256) void k_norm_bwd_dx(const float* __restrict__ d
       dn = make_float4(d.x * (1.f + ga.x), d.y * (1.f + ga.y), d.z * (1.f + ga.z), d.w * (1.f + ga.w));
     } else if (slope != 1.0f) {
       dn.x *= lrelu_g(xh.x, slope); dn.y *= lrelu_g(xh.y, slope); dn.z *= lrelu_g(xh.z, slope); dn.w *= lrelu_g(xh.w, slope);
+    }
+    if (dy2 != nullptr) {                 // second modulation (gb2 is required with it)
+      float4 d2 = ld4(dy2 + e * 4);
+      const float4 ga = ld4(gb2 + pix * 2 * C + co);
+      if (slope2 != 1.0f) {
+        const float4 be = ld4(gb2 + pix * 2 * C + C + co);
+        d2.x *= lrelu_g(xh.x * (1.f + ga.x) + be.x, slope2); d2.y *= lrelu_g(xh.y * (1.f + ga.y) + be.y, slope2);
+        d2.z *= lrelu_g(xh.z * (1.f + ga.z) + be.z, slope2); d2.w *= lrelu_g(xh.w * (1.f + ga.w) + be.w, slope2);
+      }
+      dn.x += d2.x * (1.f + ga.x); dn.y += d2.y * (1.f + ga.y); dn.z += d2.z * (1.f + ga.z); dn.w += d2.w * (1.f + ga.w);
     }
     const double* ds = dsums + g * 2 * C;
     float4 a = make_float4((float)(ds[co] * inv_count), (float)(ds[co + 1] * inv_count), (float)(ds[co + 2] * inv_count),
@@ -434,13 +449,14 @@ int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean
 
 int csg_norm_apply_bwd_dx(const float* dy, const float* x, const float* mean, const float* invstd, const float* gb,
                           float slope, const double* dsums, double count, int64_t G, int64_t P, int64_t C, float* dx,
-                          void* stream) {
+                          const float* dy2, const float* gb2, float slope2, void* stream) {
   CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0 && count > 0, CSG_E_BADSHAPE, "csg_norm_apply_bwd_dx: bad shape");
+  CSG_REQUIRE((dy2 == nullptr) == (gb2 == nullptr), CSG_E_BADSHAPE, "csg_norm_apply_bwd_dx: dy2 and gb2 come together");
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = G * P * C / 4;
-  ProfScope p(K_NORM_BWD_DX, (double)G * P * C * 4 * (gb ? 5 : 3), s);
+  ProfScope p(K_NORM_BWD_DX, (double)G * P * C * 4 * ((gb ? 5 : 3) + (dy2 ? 3 : 0)), s);
   hipLaunchKernelGGL(k_norm_bwd_dx, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, mean, invstd, gb, slope, dsums,
-                     1.0 / count, P, (int)C, n4, dx);
+                     1.0 / count, P, (int)C, n4, dx, dy2, gb2, slope2);
   return check_launch("csg_norm_apply_bwd_dx");
 }
 

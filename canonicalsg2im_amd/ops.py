@@ -19,7 +19,7 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, WinoDesc, ch
 
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
-    "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "l1_mean",
+    "norm_act_pair", "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "l1_mean",
     "pack_conv_weight", "wino_pack", "wino_eligible", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
 
@@ -529,8 +529,74 @@ class _NormAct(torch.autograd.Function):
                 csg_dist.all_reduce_stats(dsums)
             dx = torch.empty_like(x)
             check(lib.csg_norm_apply_bwd_dx(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, ptr(dsums), count,
-                                            G, P, C, ptr(dx), stream()), "norm_bwd_dx")
+                                            G, P, C, ptr(dx), None, None, 1.0, stream()), "norm_bwd_dx")
         return dx, dgb, None, None, None, None, None, None, None, None
+
+
+class _NormActPair(torch.autograd.Function):
+    """Two SPADE modulations of ONE normalised x — norm_0 and norm_s of a residual block with a learned shortcut
+    (reference architecture.py:37-47): in training both param-free BatchNorms see the same batch, so the statistics
+    are computed once (each module's running statistics are updated from them), and the backward makes one pass over x
+    that folds both gradients — instead of two statistics passes, two dx passes and autograd's addition."""
+
+    @staticmethod
+    def forward(ctx, x, gb0, gb1, rm0, rv0, rm1, rv1, slope0, slope1, eps, momentum, sync):
+        x = nhwc(_f32(x))
+        B, C, H, W = x.shape
+        P = B * H * W
+        dev = x.device
+        world = _sync_world() if sync else 1
+        count = float(P * world)
+        mean = torch.empty(C, device=dev, dtype=torch.float32)
+        invstd = torch.empty(C, device=dev, dtype=torch.float32)
+        nch = _chunks(P, 1)
+        part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
+        sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+        check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
+        if world > 1:
+            csg_dist.all_reduce_stats(sums)
+        for rm, rv in ((rm0, rv0), (rm1, rv1)):           # same batch statistics, each module's own running buffers
+            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if world > 1 else 0, ptr(mean), ptr(invstd),
+                                        ptr(rm), ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
+        gb0, gb1 = nhwc(gb0), nhwc(gb1)
+        y0, y1 = torch.empty_like(x), torch.empty_like(x)
+        check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, 1, P, C, ptr(y0), stream()),
+              "norm_apply_fwd")
+        check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gb1), slope1, 1, P, C, ptr(y1), stream()),
+              "norm_apply_fwd")
+        ctx.save_for_backward(x, gb0, gb1, mean, invstd)
+        ctx.cfg = (P, C, slope0, slope1, world, count)
+        return y0, y1
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        x, gb0, gb1, mean, invstd = ctx.saved_tensors
+        P, C, slope0, slope1, world, count = ctx.cfg
+        dy0, dy1 = nhwc(dy0), nhwc(dy1)
+        dev = x.device
+        nch = _chunks(P, 1)
+        part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
+        dsums = torch.empty(2, 2 * C, device=dev, dtype=torch.float64)
+        dgb0, dgb1 = torch.empty_like(gb0), torch.empty_like(gb1)
+        check(lib.csg_norm_apply_bwd_reduce(ptr(dy0), ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, 1, P, C, ptr(dgb0),
+                                            ptr(dsums[0]), ptr(part), nch, stream()), "norm_bwd_reduce")
+        check(lib.csg_norm_apply_bwd_reduce(ptr(dy1), ptr(x), ptr(mean), ptr(invstd), ptr(gb1), slope1, 1, P, C, ptr(dgb1),
+                                            ptr(dsums[1]), ptr(part), nch, stream()), "norm_bwd_reduce")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            both = dsums[0] + dsums[1]                    # the reductions are linear in dn: 4C doubles
+            if world > 1:
+                csg_dist.all_reduce_stats(both)
+            dx = torch.empty_like(x)
+            check(lib.csg_norm_apply_bwd_dx(ptr(dy0), ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, ptr(both), count,
+                                            1, P, C, ptr(dx), ptr(dy1), ptr(gb1), slope1, stream()), "norm_bwd_dx")
+        return dx, dgb0, dgb1, None, None, None, None, None, None, None, None, None
+
+
+def norm_act_pair(x, gb0, gb1, rm0, rv0, rm1, rv1, slope0, slope1, eps=1e-5, momentum=0.1, sync=True):
+    """Training-mode BatchNorm statistics of x, then the SPADE modulations (gb0, slope0) and (gb1, slope1) of it."""
+    return _NormActPair.apply(x, gb0, gb1, rm0, rv0, rm1, rv1, float(slope0), float(slope1), float(eps), float(momentum),
+                              bool(sync))
 
 
 def norm_act(x, gb=None, running_mean=None, running_var=None, instance=False, training=True, slope=1.0, eps=1e-5,

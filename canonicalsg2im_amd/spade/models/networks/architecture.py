@@ -5,7 +5,7 @@ import torch.nn as nn
 from .... import ops
 from ....spectral_norm import spectral_norm
 from ....sg2im.layers import Conv2d
-from .normalization import SPADE
+from .normalization import SPADE, spade_pair
 
 
 class SPADEResnetBlock(nn.Module):
@@ -30,8 +30,13 @@ class SPADEResnetBlock(nn.Module):
 
     def forward(self, x, seg):
         # LeakyReLU(0.2) of `actvn` is fused into the SPADE apply pass; the skip add into conv_1's epilogue
-        x_s = self.shortcut(x, seg)
-        dx = self.conv_0(self.norm_0(x, seg, fused_slope=0.2))
+        if self.learned_shortcut:
+            # norm_s and norm_0 normalise the same x: one statistics pass, one backward pass over x (spade_pair)
+            xs, h = spade_pair(self.norm_s, self.norm_0, x, seg, 1.0, 0.2)
+            x_s = self.conv_s(xs)
+        else:
+            x_s, h = x, self.norm_0(x, seg, fused_slope=0.2)
+        dx = self.conv_0(h)
         return self.conv_1(self.norm_1(dx, seg, fused_slope=0.2), residual=x_s)
 
     def shortcut(self, x, seg):

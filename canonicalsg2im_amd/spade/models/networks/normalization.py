@@ -127,6 +127,10 @@ class SPADE(nn.Module):
         self.mlp_beta = Conv2d(nhidden, norm_nc, kernel_size=ks, padding=self.pw)
 
     def forward(self, x, segmap, fused_slope=1.0):
+        return self.param_free_norm(x, gb=self.modulation(x, segmap), fused_slope=fused_slope)
+
+    def modulation(self, x, segmap):
+        """gamma || beta (B, 2C, h, w) of this SPADE for a feature map shaped like x."""
         if isinstance(segmap, SegPyramid):
             seg = segmap.at(x.size(2))
         else:
@@ -140,5 +144,20 @@ class SPADE(nn.Module):
         # parameters laid out back to back in one allocation (no torch.cat per call)
         w = _joined(self, "_joined_w", self.mlp_gamma.weight, self.mlp_beta.weight)
         b = _joined(self, "_joined_b", self.mlp_gamma.bias, self.mlp_beta.bias)
-        gb = ops.conv2d(actv, w, b, 1, self.pw, in_act=(sh.act, sh.slope))      # (B, 2C, h, w): gamma || beta
-        return self.param_free_norm(x, gb=gb, fused_slope=fused_slope)
+        return ops.conv2d(actv, w, b, 1, self.pw, in_act=(sh.act, sh.slope))    # (B, 2C, h, w): gamma || beta
+
+
+def spade_pair(norm_a, norm_b, x, segmap, slope_a, slope_b):
+    """norm_a(x, seg) and norm_b(x, seg) of the SAME x (a residual block's norm_0 and norm_s).  In training both
+    param-free BatchNorms see the same batch: one statistics pass, and a backward that folds both gradients into one
+    pass over x (ops.norm_act_pair).  Anything else (eval mode: each module has its own running statistics; instance
+    norm; affine norms) takes the two ordinary calls."""
+    pa, pb = norm_a.param_free_norm, norm_b.param_free_norm
+    same = (type(pa) is type(pb) and isinstance(pa, (SynchronizedBatchNorm2d, LocalBatchNorm2d)) and not pa.affine
+            and not pb.affine and pa.training and pb.training and pa.eps == pb.eps and pa.momentum == pb.momentum
+            and getattr(pa, "sync", True) == getattr(pb, "sync", True) and x.dim() == 4)
+    if not same:
+        return norm_a(x, segmap, fused_slope=slope_a), norm_b(x, segmap, fused_slope=slope_b)
+    return ops.norm_act_pair(x, norm_a.modulation(x, segmap), norm_b.modulation(x, segmap), pa.running_mean, pa.running_var,
+                             pb.running_mean, pb.running_var, slope_a, slope_b, pa.eps, pa.momentum,
+                             getattr(pa, "sync", True))
