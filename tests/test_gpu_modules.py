@@ -280,6 +280,40 @@ def test_discriminator_features_eval_vs_reference(cuda):
             assert_close(f, a["dfeat_%d_%d" % (i, j)], RTOL, 1e-5, "dfeat %d %d" % (i, j))
 
 
+def test_discriminator_scale_streams_are_bit_neutral(cuda):
+    """The two PatchGAN scales on two event-joined streams (MultiscaleDiscriminator._forward_concurrent) against the
+    same scales run one after the other on one stream: identical features, identical gradients — training mode, with
+    the spectral-norm power iteration restarted from the same u / v."""
+    from canonicalsg2im_amd.spade.models.networks import discriminator as DM
+    meta, a, opt, tr, batch = _trainer_from_golden(cuda)
+    D = tr.discriminator.img_discriminator
+    D.train()
+    state0 = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    img = batch[0].clone().requires_grad_(True)
+    out = {}
+    for streams in (True, False):
+        D.load_state_dict(state0)
+        for p in D.parameters():
+            p.grad = None
+        img.grad = None
+        DM.SCALE_STREAMS = streams
+        try:
+            feats = D(img, batch[1], batch[2])
+            loss = sum(f.square().mean() for scale in feats for f in scale)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            DM.SCALE_STREAMS = True
+        out[streams] = ([f.detach().clone() for scale in feats for f in scale], img.grad.clone(),
+                        {n: p.grad.clone() for n, p in D.named_parameters() if p.grad is not None})
+    for fa, fb in zip(out[True][0], out[False][0]):
+        assert torch.equal(fa, fb)
+    assert torch.equal(out[True][1], out[False][1])
+    assert out[True][2].keys() == out[False][2].keys() and len(out[True][2]) >= 10
+    for n in out[True][2]:
+        assert torch.equal(out[True][2][n], out[False][2][n]), n
+
+
 def test_two_steps_vs_oracle_128(cuda):
     """A COCO-like batch at 128x128 (BASELINE config C2 shape, narrower nets so the CPU oracle stays
     fast): two consecutive optimisation steps, HIP trainer vs oracle, same initial weights."""
