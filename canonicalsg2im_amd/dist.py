@@ -73,7 +73,7 @@ class GradBuckets:
         self.flats, self.members, self.slot = [], [], {}        # per bucket: flat tensor, [params]; param id -> (bucket, view)
         self.built = False
         self._active = False
-        self._pending, self._fired, self._works, self._next = [], set(), [], 0
+        self._pending, self._fired, self._works, self._next, self._streams = [], set(), [], 0, {}
         self.allocations = 0                                    # flat buffers ever allocated (tests: steady state adds none)
 
     # ---- construction (first synchronisation)
@@ -113,6 +113,13 @@ class GradBuckets:
                 for p in self.members[b]:
                     if id(p) not in self._fired:
                         self.slot[id(p)][1].zero_()
+            if self.flats[b].is_cuda:
+                # gradients may have been written on other streams (the PatchGAN's half-resolution scale runs — and is
+                # back-propagated — on a side stream): the collective is enqueued behind everything those streams hold
+                cur = torch.cuda.current_stream(self.flats[b].device)
+                for st in self._streams.get(b, ()):
+                    if st != cur:
+                        cur.wait_stream(st)
             self._works.append(dist.all_reduce(self.flats[b], op=_avg_op(), async_op=True))
             self._next += 1
 
@@ -123,6 +130,8 @@ class GradBuckets:
         if p.grad is not view:
             view.copy_(p.grad)
             p.grad = view
+        if view.is_cuda:
+            self._streams.setdefault(b, set()).add(torch.cuda.current_stream(view.device))
         if id(p) not in self._fired:
             self._fired.add(id(p))
             self._pending[b] -= 1
@@ -135,6 +144,7 @@ class GradBuckets:
             return
         self._pending = [len(g) for g in self.members]
         self._fired, self._works, self._next = set(), [], 0
+        self._streams = {}
         self._active = True
 
     def flush(self):
