@@ -947,8 +947,11 @@ class _DiscInput(torch.autograd.Function):
         masks, M = _prep_masks(masks)
         B, O, S = vecs.shape
         Ct = (S + 3 + 3) // 4 * 4
-        buf = torch.zeros((B, H, H, Ct), device=vecs.device, dtype=torch.float32)
+        # the layout kernel writes channels [0, S) of every pixel; only the image and the pad channels are filled here
+        buf = torch.empty((B, H, H, Ct), device=vecs.device, dtype=torch.float32)
         buf[..., S:S + 3] = img.permute(0, 2, 3, 1)
+        if Ct > S + 3:
+            buf[..., S + 3:] = 0.0
         check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, H, H, ptr(buf), Ct, 0,
                                  stream()), "layout_fwd")
         ctx.save_for_backward(boxes, valid, masks, vecs if ctx.needs_input_grad[2] else None)
