@@ -98,7 +98,7 @@ SIGNATURES = {
     "csg_norm_apply_bwd_reduce": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64,
                                           c_p]),
     "csg_norm_apply_bwd_dx": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_f64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_f32,
-                                      c_p]),
+                                      c_p, c_p, c_p]),
     "csg_upsample2x_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_upsample2x_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_avgpool3s2_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),

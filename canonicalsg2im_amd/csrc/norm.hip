@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256) void k_norm_bwd_dx(const float* __restrict__ d
                                                       const double* __restrict__ dsums, double inv_count, int64_t P,
                                                       int C, int64_t n4, float* __restrict__ dx,
                                                       const float* __restrict__ dy2, const float* __restrict__ gb2,
-                                                      float slope2) {
+                                                      float slope2, const float* __restrict__ dgb,
+                                                      const float* __restrict__ dgb2) {
   const int Q = C >> 2;
 #pragma unroll 2
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
@@ -245,11 +246,16 @@ __global__ __launch_bounds__(256) void k_norm_bwd_dx(const float* __restrict__ d
     const int64_t g = pix / P;
     const int co = q * 4;
     const float4 xv = ld4(x + e * 4);
-    float4 d = ld4(dy + e * 4);
+    float4 d = (gb != nullptr && dgb != nullptr) ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(dy + e * 4);
     const float4 m = ld4(mean + g * C + co), r = ld4(invstd + g * C + co);
     const float4 xh = make_float4((xv.x - m.x) * r.x, (xv.y - m.y) * r.y, (xv.z - m.z) * r.z, (xv.w - m.w) * r.w);
     float4 dn = d;
-    if (gb != nullptr) {
+    if (gb != nullptr && dgb != nullptr) {
+      // pass 1 already wrote d(beta) = dy * activation gate: read it instead of dy and beta (one map less)
+      const float4 ga = ld4(gb + pix * 2 * C + co);
+      d = ld4(dgb + pix * 2 * C + C + co);
+      dn = make_float4(d.x * (1.f + ga.x), d.y * (1.f + ga.y), d.z * (1.f + ga.z), d.w * (1.f + ga.w));
+    } else if (gb != nullptr) {
       const float4 ga = ld4(gb + pix * 2 * C + co);
       if (slope != 1.0f) {
         const float4 be = ld4(gb + pix * 2 * C + C + co);
@@ -261,9 +267,9 @@ __global__ __launch_bounds__(256) void k_norm_bwd_dx(const float* __restrict__ d
       dn.x *= lrelu_g(xh.x, slope); dn.y *= lrelu_g(xh.y, slope); dn.z *= lrelu_g(xh.z, slope); dn.w *= lrelu_g(xh.w, slope);
     }
     if (dy2 != nullptr) {                 // second modulation (gb2 is required with it)
-      float4 d2 = ld4(dy2 + e * 4);
       const float4 ga = ld4(gb2 + pix * 2 * C + co);
-      if (slope2 != 1.0f) {
+      float4 d2 = dgb2 != nullptr ? ld4(dgb2 + pix * 2 * C + C + co) : ld4(dy2 + e * 4);
+      if (slope2 != 1.0f && dgb2 == nullptr) {
         const float4 be = ld4(gb2 + pix * 2 * C + C + co);
         d2.x *= lrelu_g(xh.x * (1.f + ga.x) + be.x, slope2); d2.y *= lrelu_g(xh.y * (1.f + ga.y) + be.y, slope2);
         d2.z *= lrelu_g(xh.z * (1.f + ga.z) + be.z, slope2); d2.w *= lrelu_g(xh.w * (1.f + ga.w) + be.w, slope2);
@@ -449,14 +455,15 @@ int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean
 
 int csg_norm_apply_bwd_dx(const float* dy, const float* x, const float* mean, const float* invstd, const float* gb,
                           float slope, const double* dsums, double count, int64_t G, int64_t P, int64_t C, float* dx,
-                          const float* dy2, const float* gb2, float slope2, void* stream) {
+                          const float* dy2, const float* gb2, float slope2, const float* dgb, const float* dgb2,
+                          void* stream) {
   CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0 && count > 0, CSG_E_BADSHAPE, "csg_norm_apply_bwd_dx: bad shape");
   CSG_REQUIRE((dy2 == nullptr) == (gb2 == nullptr), CSG_E_BADSHAPE, "csg_norm_apply_bwd_dx: dy2 and gb2 come together");
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = G * P * C / 4;
-  ProfScope p(K_NORM_BWD_DX, (double)G * P * C * 4 * ((gb ? 5 : 3) + (dy2 ? 3 : 0)), s);
+  ProfScope p(K_NORM_BWD_DX, (double)G * P * C * 4 * ((gb ? (dgb ? 4 : 5) : 3) + (dy2 ? (dgb2 ? 2 : 3) : 0)), s);
   hipLaunchKernelGGL(k_norm_bwd_dx, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, mean, invstd, gb, slope, dsums,
-                     1.0 / count, P, (int)C, n4, dx, dy2, gb2, slope2);
+                     1.0 / count, P, (int)C, n4, dx, dy2, gb2, slope2, dgb, dgb2);
   return check_launch("csg_norm_apply_bwd_dx");
 }
 

@@ -529,7 +529,7 @@ class _NormAct(torch.autograd.Function):
                 csg_dist.all_reduce_stats(dsums)
             dx = torch.empty_like(x)
             check(lib.csg_norm_apply_bwd_dx(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, ptr(dsums), count,
-                                            G, P, C, ptr(dx), None, None, 1.0, stream()), "norm_bwd_dx")
+                                            G, P, C, ptr(dx), None, None, 1.0, ptr(dgb), None, stream()), "norm_bwd_dx")
         return dx, dgb, None, None, None, None, None, None, None, None
 
 
@@ -589,7 +589,8 @@ class _NormActPair(torch.autograd.Function):
                 csg_dist.all_reduce_stats(both)
             dx = torch.empty_like(x)
             check(lib.csg_norm_apply_bwd_dx(ptr(dy0), ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, ptr(both), count,
-                                            1, P, C, ptr(dx), ptr(dy1), ptr(gb1), slope1, stream()), "norm_bwd_dx")
+                                            1, P, C, ptr(dx), ptr(dy1), ptr(gb1), slope1, ptr(dgb0), ptr(dgb1), stream()),
+                  "norm_bwd_dx")
         return dx, dgb0, dgb1, None, None, None, None, None, None, None, None, None
 
 

@@ -275,10 +275,12 @@ int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean
 /* pass 2: dx = invstd*(dn - dsum0/count - xhat*dsum1/count).  (dy2, gb2, slope2), nullable: a second SPADE modulation
  * of the SAME normalised x (norm_0 and norm_s of a residual block with a learned shortcut, architecture.py:37-47, see
  * the same batch statistics): dn = dn_1 + dn_2 and `dsums` holds the sum of both pass-1 reductions — one pass and one
- * dx instead of two passes and an addition.                                                                     */
+ * dx instead of two passes and an addition.  `dgb` / `dgb2` (nullable): pass 1's output for the same modulation — its
+ * d(beta) half IS dy times the activation gate, so pass 2 reads it instead of dy and beta (one map less, same bits). */
 int csg_norm_apply_bwd_dx(const float* dy, const float* x, const float* mean, const float* invstd, const float* gb,
                           float slope, const double* dsums, double count, int64_t G, int64_t P, int64_t C, float* dx,
-                          const float* dy2, const float* gb2, float slope2, void* stream);
+                          const float* dy2, const float* gb2, float slope2, const float* dgb, const float* dgb2,
+                          void* stream);
 
 /* ---- K7 / pooling ------------------------------------------------------------------------------
  * nearest 2x upsample (generator.py:48,102-121) and its adjoint */
