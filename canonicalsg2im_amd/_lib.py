@@ -94,7 +94,7 @@ SIGNATURES = {
     "csg_colsum": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_norm_stats": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_norm_finalize": (c_i32, [c_p, c_i64, c_i64, c_f64, c_f32, c_i32, c_p, c_p, c_p, c_p, c_f32, c_p]),
-    "csg_norm_apply_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_norm_apply_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_f32, c_p, c_p]),
     "csg_norm_apply_bwd_reduce": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64,
                                           c_p]),
     "csg_norm_apply_bwd_dx": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_f64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_f32,

@@ -138,10 +138,13 @@ __global__ void k_norm_finalize(const double* __restrict__ sums, int G, int C, d
 }
 
 // --------------------------------------------------------------------------------- apply fwd
+// (gb2, slope2, y2), nullable: a second modulation of the same normalised x, written in the same pass (x read once)
 __global__ __launch_bounds__(256) void k_norm_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd,
                                                          const float* __restrict__ gb, float slope, int64_t P, int C,
-                                                         int64_t n4, float* __restrict__ y) {
+                                                         int64_t n4, float* __restrict__ y,
+                                                         const float* __restrict__ gb2, float slope2,
+                                                         float* __restrict__ y2) {
   const int Q = C >> 2;
 #pragma unroll 2
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
@@ -151,6 +154,13 @@ __global__ __launch_bounds__(256) void k_norm_apply_fwd(const float* __restrict_
     float4 v = ld4(x + e * 4);
     const float4 m = ld4(mean + g * C + q * 4), r = ld4(invstd + g * C + q * 4);
     v.x = (v.x - m.x) * r.x; v.y = (v.y - m.y) * r.y; v.z = (v.z - m.z) * r.z; v.w = (v.w - m.w) * r.w;
+    if (y2 != nullptr) {
+      const float4 ga = ld4(gb2 + pix * 2 * C + q * 4), be = ld4(gb2 + pix * 2 * C + C + q * 4);
+      float4 u = make_float4(v.x * (1.f + ga.x) + be.x, v.y * (1.f + ga.y) + be.y, v.z * (1.f + ga.z) + be.z,
+                             v.w * (1.f + ga.w) + be.w);
+      if (slope2 != 1.0f) { u.x = lrelu(u.x, slope2); u.y = lrelu(u.y, slope2); u.z = lrelu(u.z, slope2); u.w = lrelu(u.w, slope2); }
+      st4(y2 + e * 4, u);
+    }
     if (gb != nullptr) {
       const float4 ga = ld4(gb + pix * 2 * C + q * 4), be = ld4(gb + pix * 2 * C + C + q * 4);
       v.x = v.x * (1.f + ga.x) + be.x; v.y = v.y * (1.f + ga.y) + be.y;
@@ -427,12 +437,15 @@ int csg_norm_finalize(const double* sums, int64_t G, int64_t C, double count, fl
 }
 
 int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gb, float slope,
-                       int64_t G, int64_t P, int64_t C, float* y, void* stream) {
+                       int64_t G, int64_t P, int64_t C, float* y, const float* gb2, float slope2, float* y2,
+                       void* stream) {
   CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_norm_apply_fwd: bad shape");
+  CSG_REQUIRE((gb2 == nullptr) == (y2 == nullptr), CSG_E_BADSHAPE, "csg_norm_apply_fwd: gb2 and y2 come together");
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = G * P * C / 4;
-  ProfScope p(K_NORM_APPLY_FWD, (double)G * P * C * 4 * (gb ? 4 : 2), s);
-  hipLaunchKernelGGL(k_norm_apply_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, mean, invstd, gb, slope, P, (int)C, n4, y);
+  ProfScope p(K_NORM_APPLY_FWD, (double)G * P * C * 4 * ((gb ? 4 : 2) + (y2 ? 3 : 0)), s);
+  hipLaunchKernelGGL(k_norm_apply_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, mean, invstd, gb, slope, P, (int)C, n4, y, gb2,
+                     slope2, y2);
   return check_launch("csg_norm_apply_fwd");
 }
 

@@ -503,7 +503,8 @@ class _NormAct(torch.autograd.Function):
             invstd.copy_(torch.rsqrt(running_var + eps))
         gbn = nhwc(gb) if gb is not None else None
         y = torch.empty_like(x)
-        check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gbn), slope, G, P, C, ptr(y), stream()),
+        check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gbn), slope, G, P, C, ptr(y), None, 1.0, None,
+                                     stream()),
               "norm_apply_fwd")
         ctx.save_for_backward(x, gbn, mean, invstd)
         ctx.cfg = (G, P, C, slope, use_batch_stats, world, count)
@@ -560,10 +561,8 @@ class _NormActPair(torch.autograd.Function):
                                         ptr(rm), ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
         gb0, gb1 = nhwc(gb0), nhwc(gb1)
         y0, y1 = torch.empty_like(x), torch.empty_like(x)
-        check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, 1, P, C, ptr(y0), stream()),
-              "norm_apply_fwd")
-        check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gb1), slope1, 1, P, C, ptr(y1), stream()),
-              "norm_apply_fwd")
+        check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, 1, P, C, ptr(y0), ptr(gb1), slope1,
+                                     ptr(y1), stream()), "norm_apply_fwd")
         ctx.save_for_backward(x, gb0, gb1, mean, invstd)
         ctx.cfg = (P, C, slope0, slope1, world, count)
         return y0, y1

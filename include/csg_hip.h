@@ -265,9 +265,11 @@ int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums
  * (batchnorm.py:145, N-replica path).  running_* may be NULL; running_var gets the unbiased var. */
 int csg_norm_finalize(const double* sums, int64_t G, int64_t C, double count, float eps, int32_t mode, float* mean,
                       float* invstd, float* running_mean, float* running_var, float momentum, void* stream);
-/* y = leaky((x-mean)*invstd*(1+gamma)+beta, slope); gb (G*P, 2C) = [gamma | beta] or NULL; slope 1 = no act */
+/* y = leaky((x-mean)*invstd*(1+gamma)+beta, slope); gb (G*P, 2C) = [gamma | beta] or NULL; slope 1 = no act.
+ * (gb2, slope2, y2), nullable: a second modulation of the same normalised x written in the same pass.           */
 int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gb, float slope,
-                       int64_t G, int64_t P, int64_t C, float* y, void* stream);
+                       int64_t G, int64_t P, int64_t C, float* y, const float* gb2, float slope2, float* y2,
+                       void* stream);
 /* pass 1: dgb (if gb) and dsums (G,2C) double = [sum dn | sum dn*xhat]                          */
 int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
                               const float* gb, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
