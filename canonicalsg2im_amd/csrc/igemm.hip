@@ -24,6 +24,7 @@
 // Weight gradient: rows = output channels (A = dY), cols = (tap, input channel) (B = gathered X),
 // reduction over pixels, split across blocks into slabs + ordered reduction as well.
 #include <stddef.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -776,6 +777,8 @@ static void fwd_plan(IgemmParams& p) {
   const int blocks = p.mtiles * p.ntiles;
   int ks = 1;
   if (blocks < 1024 && nkt >= 16 && p.d.Cout % 4 == 0) ks = pick_split(blocks, nkt, 8, 64);
+  static const int force = getenv("CSG_IGEMM_KSPLIT") ? atoi(getenv("CSG_IGEMM_KSPLIT")) : 0;   // experiments only
+  if (force > 0 && p.d.Cout % 4 == 0) ks = force < nkt ? force : nkt;
   p.kt_per_split = (nkt + ks - 1) / ks;
   p.ksplit = (nkt + p.kt_per_split - 1) / p.kt_per_split;
 }
