@@ -85,6 +85,9 @@ struct IgemmParams {
   FastDiv div_ow, div_oh;
   unsigned img_bytes;   // bytes of one input image (IHp*IWp*x_cs*4)
   long long ws_off;     // floats: where this launch's split-K slabs start in the workspace
+  // tail split (ksplit == 1, tail_ks > 1): tiles [0, tail_tile0) run unsplit — whole rounds of the 512 resident
+  // blocks — and only the m-tiles of the last, partly filled round are cut along K into tail_ks slabs
+  int tail_tile0, tail_ks, tail_kt_per, tail_m0;
 };
 
 // Up to four descriptors served by ONE launch (blockIdx.y picks one): the parity classes of a stride-2 transposed
@@ -138,11 +141,29 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(typename std::conditional<
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const csg_conv_desc& d = p.d;
-  int bid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles * p.ksplit);
-  int ks = 0;
-  if (p.ksplit > 1) {
-    ks = bid % p.ksplit;
-    bid /= p.ksplit;
+  int bid, ks = 0;
+  int kt_per = p.kt_per_split;     // k tiles of this block's range
+  bool to_slab = p.ksplit > 1;
+  long long slab_rows = p.M;       // rows per slab and first row held by the slabs
+  int slab_m0 = 0;
+  if (p.tail_ks > 1) {
+    if ((int)blockIdx.x < p.tail_tile0) {
+      bid = xcd_remap(blockIdx.x, p.tail_tile0);
+    } else {
+      const int t = (int)blockIdx.x - p.tail_tile0;
+      ks = t % p.tail_ks;
+      bid = p.tail_tile0 + t / p.tail_ks;
+      kt_per = p.tail_kt_per;
+      to_slab = true;
+      slab_m0 = p.tail_m0;
+      slab_rows = p.M - p.tail_m0;
+    }
+  } else {
+    bid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles * p.ksplit);
+    if (p.ksplit > 1) {
+      ks = bid % p.ksplit;
+      bid /= p.ksplit;
+    }
   }
   const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
 
@@ -177,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(typename std::conditional<
   }
 
   const int nkt_all = (p.Ktot + IG_BK - 1) / IG_BK;
-  const int kt0 = ks * p.kt_per_split;
-  const int kt1 = min(nkt_all, kt0 + p.kt_per_split);
+  const int kt0 = ks * kt_per;
+  const int kt1 = min(nkt_all, kt0 + kt_per);
   // this thread's k position (tap slot, channel) of the tile being loaded, advanced incrementally
   int k_cur = kt0 * IG_BK + kc * 4;
   int slot = k_cur / d.Cin;
@@ -345,8 +366,8 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(typename std::conditional<
   for (int mi = 0; mi < MI; ++mi) {
     const int m = mt * IG_BM + wm * WROWS + mi * 32 + r;
     if (m >= p.M) continue;
-    if (p.ksplit > 1) {  // raw partial sums into this split's slab (Cout % 4 == 0 on this path)
-      float* srow = ws + ((long long)ks * p.M + m) * d.Cout;
+    if (to_slab) {  // raw partial sums into this split's slab (Cout % 4 == 0 on this path)
+      float* srow = ws + ((long long)ks * slab_rows + (m - slab_m0)) * d.Cout;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -423,22 +444,26 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(typename std::condition
   ws += p.ws_off;
   const csg_conv_desc& d = p.d;
   const int q = d.Cout >> 2;
-  const long long n4 = (long long)p.M * q;
+  // tail split: the slabs hold rows [tail_m0, M) only
+  const int m0 = p.tail_ks > 1 ? p.tail_m0 : 0;
+  const int nsl = p.tail_ks > 1 ? p.tail_ks : p.ksplit;
+  const long long n4 = (long long)(p.M - m0) * q;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
-    const unsigned m = (unsigned)(e / q);
-    const int n = (int)(e - (long long)m * q) * 4;
-    const float* src = ws + (long long)m * d.Cout + n;
+    const unsigned ml = (unsigned)(e / q);
+    const unsigned m = ml + (unsigned)m0;
+    const int n = (int)(e - (long long)ml * q) * 4;
+    const float* src = ws + (long long)ml * d.Cout + n;
     float4 a = *(const float4*)src;
-    const long long slab = (long long)p.M * d.Cout;
+    const long long slab = (long long)(p.M - m0) * d.Cout;
     int s = 1;
-    for (; s + 4 <= p.ksplit; s += 4) {          // four loads in flight, added in slab order
+    for (; s + 4 <= nsl; s += 4) {          // four loads in flight, added in slab order
       float4 t[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) t[u] = *(const float4*)(src + (s + u) * slab);
 #pragma unroll
       for (int u = 0; u < 4; ++u) { a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w; }
     }
-    for (; s < p.ksplit; ++s) {
+    for (; s < nsl; ++s) {
       const float4 t = *(const float4*)(src + s * slab);
       a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
     }
@@ -747,6 +772,7 @@ static void fill(IgemmParams& p, const csg_conv_desc* d) {
   p.img_bytes = (unsigned)((int64_t)d->IHp * d->IWp * d->x_cs * 4);
   p.mtiles = p.ntiles = 0;
   p.ws_off = 0;
+  p.tail_tile0 = p.tail_ks = p.tail_kt_per = p.tail_m0 = 0;
 }
 
 static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
@@ -781,6 +807,37 @@ static void fwd_plan(IgemmParams& p) {
   if (force > 0 && p.d.Cout % 4 == 0) ks = force < nkt ? force : nkt;
   p.kt_per_split = (nkt + ks - 1) / ks;
   p.ksplit = (nkt + p.kt_per_split - 1) / p.kt_per_split;
+  // Grids a little above a multiple of the 512 resident blocks (PatchGAN: 580 and 529 tiles): splitting EVERY tile
+  // along K pays slab traffic for all of them.  Instead the whole rounds run unsplit and only the m-tiles of the last,
+  // partly filled round are split, finely enough to fill that round.
+  static const int tail_on = getenv("CSG_IGEMM_TAIL_SPLIT") ? atoi(getenv("CSG_IGEMM_TAIL_SPLIT")) : 1;
+  if (tail_on && force == 0 && blocks > 512 && blocks < 4096 && nkt >= 16 && p.d.Cout % 4 == 0) {
+    const int rounds = blocks / 512;                                  // whole rounds
+    int full_mt = (rounds * 512) / p.ntiles;                          // m-tiles that fit in them
+    const int tail_tiles = (p.mtiles - full_mt) * p.ntiles;
+    if (full_mt > 0 && tail_tiles > 0 && tail_tiles <= 320) {
+      int tks = 512 / tail_tiles;
+      if (tks > nkt / 8) tks = nkt / 8;
+      if (tks >= 2) {
+        p.ksplit = 1;
+        p.kt_per_split = nkt;
+        p.tail_tile0 = full_mt * p.ntiles;
+        p.tail_kt_per = (nkt + tks - 1) / tks;
+        p.tail_ks = (nkt + p.tail_kt_per - 1) / p.tail_kt_per;
+        p.tail_m0 = full_mt * IG_BM;
+        if (p.tail_ks < 2) p.tail_ks = p.tail_tile0 = p.tail_kt_per = p.tail_m0 = 0;
+      }
+    }
+  }
+}
+
+static int64_t fwd_slab_floats(const IgemmParams& p) {
+  if (p.tail_ks > 1) return (int64_t)p.tail_ks * (p.M - p.tail_m0) * p.d.Cout;
+  return p.ksplit > 1 ? (int64_t)p.ksplit * p.M * p.d.Cout : 0;
+}
+static int64_t fwd_grid(const IgemmParams& p) {
+  if (p.tail_ks > 1) return (int64_t)p.tail_tile0 + (int64_t)(p.mtiles * p.ntiles - p.tail_tile0) * p.tail_ks;
+  return (int64_t)p.mtiles * p.ntiles * p.ksplit;
 }
 
 template <int BN>
@@ -792,8 +849,7 @@ static int launch_fwd(IgemmParams& p, const float* x, const float* w, const floa
     (void)hipFuncSetAttribute((const void*)k_igemm_fwd<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_igemm_fwd<BN>, dim3((unsigned)(p.mtiles * p.ntiles * p.ksplit)), dim3(256), shm, s, p, x, w, bias,
-                     res, y, ws);
+  hipLaunchKernelGGL(k_igemm_fwd<BN>, dim3((unsigned)fwd_grid(p)), dim3(256), shm, s, p, x, w, bias, res, y, ws);
   return check_launch("csg_conv_fwd");
 }
 
@@ -879,7 +935,7 @@ int64_t csg_conv_fwd_workspace(const csg_conv_desc* d) {
   IgemmParams p;
   fill(p, d);
   fwd_plan(p);
-  return p.ksplit > 1 ? (int64_t)p.ksplit * p.M * d->Cout * 4 : 0;
+  return fwd_slab_floats(p) * 4;
 }
 
 int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
@@ -891,10 +947,11 @@ int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const f
   IgemmParams p;
   fill(p, d);
   fwd_plan(p);
-  const int64_t need = p.ksplit > 1 ? (int64_t)p.ksplit * p.M * d->Cout * 4 : 0;
+  const int64_t need = fwd_slab_floats(p) * 4;
   if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {  // caller gave no slabs: run unsplit
     p.ksplit = 1;
     p.kt_per_split = (p.Ktot + IG_BK - 1) / IG_BK;
+    p.tail_tile0 = p.tail_ks = p.tail_kt_per = p.tail_m0 = 0;
   }
   hipStream_t s = (hipStream_t)stream;
   const int bn = pick_bn(d->Cout);
@@ -909,9 +966,9 @@ int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const f
       rc = launch_fwd<128>(p, x, w, bias, residual, y, workspace, s);
     if (rc) return rc;
   }
-  if (p.ksplit > 1) {
-    ProfScope ps(K_SPLITK_EPI, (double)(p.ksplit + 1) * p.M * d->Cout * 4, s);
-    const int64_t n4 = (int64_t)p.M * d->Cout / 4;
+  if (p.ksplit > 1 || p.tail_ks > 1) {
+    ProfScope ps(K_SPLITK_EPI, (double)fwd_slab_floats(p) * 4 + (double)(p.M - p.tail_m0) * d->Cout * 4, s);
+    const int64_t n4 = (int64_t)(p.M - p.tail_m0) * d->Cout / 4;
     int64_t g = cdiv(n4, 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_splitk_epilogue<false>, dim3((unsigned)g), dim3(256), 0, s, p, workspace, bias, residual, y);

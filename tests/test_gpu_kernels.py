@@ -40,6 +40,8 @@ CONV_CASES = [
     (1, 128, 72, 24, 24, 3, 1, 1, "relu", True, False),
     (2, 32, 8, 6, 6, 4, 2, 2, "none", True, False),          # stride-2 backward-data parity classes
     (2, 3, 5, 8, 8, 3, 1, 1, "none", True, False),           # channels not multiples of 4 -> padded by the wrapper
+    (4, 64, 32, 130, 130, 3, 1, 1, "lrelu", True, False),    # 529 tiles for 512 block slots: only the last round is split
+    (1, 64, 256, 184, 184, 3, 1, 1, "none", True, True),     # 265 x 2 tiles: tail split with two channel tiles, residual
 ]
 
 
