@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_few_fwd(FewParams p, const float* __res
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      float v = out[n] + (bias != nullptr ? bias[n] : 0.f);
+      float v = out[n] + (bias != nullptr && n < p.nreal ? bias[n] : 0.f);
       if (p.act == CSG_ACT_LEAKY)
         v = v > 0.f ? v : v * p.slope;
       else if (p.act == CSG_ACT_TANH)
@@ -130,7 +130,7 @@ __global__ void k_few_finish(FewParams p, const float4* __restrict__ slabs, int 
   float out[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
-    float v = out[n] + (bias != nullptr ? bias[n] : 0.f);
+    float v = out[n] + (bias != nullptr && n < p.nreal ? bias[n] : 0.f);
     if (p.act == CSG_ACT_LEAKY)
       v = v > 0.f ? v : v * p.slope;
     else if (p.act == CSG_ACT_TANH)

@@ -220,9 +220,14 @@ class _Conv2d(torch.autograd.Function):
         ctx.packs, ctx.dx_range, ctx.in_act, ctx.grad_is_pre = packs, dx_range, in_act, grad_is_pre
         res = nhwc(residual) if residual is not None else None
         ctx.few = None
-        if Cout == 4 and res is None and dx_range is None and packs is None and in_act is None:
+        ctx.cout_w = Cout                       # rows of the weight as given (1..3 when the few-output path takes it raw)
+        if (Cout == 4 or (cout_real is not None and Cout == cout_real and Cout < 4)) and res is None and dx_range is None \
+                and packs is None and in_act is None:
             ctx.few = _few_desc(B, IH, IW, Cin, KH, KW, stride, pad, cout_real, act, slope)
+        if ctx.few is None and Cout % 4:
+            raise RuntimeError("conv2d: an output-channel count that is not a multiple of 4 reached the kernels")
         if ctx.few is not None:
+            Cout = 4                            # the kernels' padded output width
             OH, OW = IH + 2 * pad - KH + 1, IW + 2 * pad - KW + 1
             y = empty_nhwc(B, Cout, OH, OW, x.device)
             wp = weight.detach().permute(0, 2, 3, 1).contiguous()
@@ -266,7 +271,8 @@ class _Conv2d(torch.autograd.Function):
                 check(lib.csg_conv_few_bwd_data(ctx.few, ptr(dpre), ptr(wp), ptr(dx), stream()), "conv_few_bwd_data")
             elif ctx.needs_input_grad[0]:
                 # few input channels as well (conv_img: 64): a (pixels x 36) x (36 x 64) product, fine on the matrix cores
-                wt = weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]
+                w4 = weight.detach() if ctx.cout_w == 4 else F.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, 4 - ctx.cout_w))
+                wt = w4.permute(1, 2, 3, 0).contiguous()                    # [Cin][KH][KW][Cout]
                 dx = empty_nhwc(B, Cin, IH, IW, dy.device)
                 for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
                     _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
@@ -277,7 +283,8 @@ class _Conv2d(torch.autograd.Function):
                 db = torch.empty(Cout, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
                 check(lib.csg_conv_few_bwd_weight(ctx.few, ptr(x), ptr(dpre), ptr(dwp), ptr(db), ptr(ws), nbytes, stream()),
                       "conv_few_bwd_weight")
-                dw = dwp.permute(0, 3, 1, 2)
+                dw = dwp[:ctx.cout_w].permute(0, 3, 1, 2)
+                db = db[:ctx.cout_w] if db is not None else None
             return dx, dw, db, None, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0] and ctx.dx_range is not None:
             # only input channels [lo, hi) are wanted by the consumer of dx (the discriminator's packed
@@ -374,7 +381,13 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, r
             x = F.pad(x, (0, 0, 0, 0, 0, pc))
         if packs is None:
             weight = F.pad(weight, (0, 0, 0, 0, 0, pc))
-    if po:
+    few_raw = False
+    if (po and Cout + po == 4 and not pc and residual is None and packs is None and dx_range is None and in_act is None
+            and x.dim() == 4 and x.is_cuda):
+        # csrc/fewn.hip takes the 1..3 real output channels as they are (no zero-padded copies of weight and bias)
+        few_raw = _few_desc(x.shape[0], x.shape[2], x.shape[3], Cin, weight.shape[2], weight.shape[3], int(stride),
+                            int(padding), Cout, int(act), float(slope)) is not None
+    if po and not few_raw:
         weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, po))
         bias = F.pad(bias, (0, po)) if bias is not None else None
         residual = F.pad(residual, (0, 0, 0, 0, 0, po)) if residual is not None else None

@@ -224,7 +224,8 @@ int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy,
  * `conv_img` (generator.py:46,120-121: 64 -> 3, 3x3, pad 1, tanh behind it) and the PatchGAN prediction heads
  * (discriminator.py:185-187: 512 -> 1, 4x4, pad 2): a 32-wide MFMA tile wastes 29 (31) of its columns on them; these
  * are VALU kernels that move the many-channel side once.  Output channels are padded to 4 (y, dy: (B,OH,OW,4); w, dw:
- * [4][KH][KW][Cin] with rows >= cout_real zero; bias, db: 4 floats); KH = KW in {3, 4}; Cin in {32, 64, ..., 1024};
+ * [4][KH][KW][Cin]; the forward and backward-data passes read only the first cout_real rows of w and entries of bias,
+ * the weight gradient writes all four rows of dw / entries of db, zeros beyond cout_real); KH = KW in {3, 4}; Cin in {32, 64, ..., 1024};
  * KH*KW*cout_real <= 36.  The weight gradient is bit-reproducible (per-block slabs + ordered sum).               */
 typedef struct csg_few_desc {
   int32_t B, IH, IW;
