@@ -39,7 +39,6 @@ def parse():
     p.add_argument("--use_img_disc", type=int, default=0,
                    help="0 = the reference's default COCO/VG recipe (image + object discriminators); 1 = image only")
     p.add_argument("--no_cpu_baseline", action="store_true")
-    p.add_argument("--cpu_image_size", type=int, default=None)
     p.add_argument("--vgg_loss", type=int, default=0,
                    help="1 = keep the VGG perceptual term (reference default; random-feature VGG19 here, the "
                         "pretrained weights cannot be downloaded); 0 = --no_vgg_loss, the configuration "
@@ -52,27 +51,22 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(opt_argv, vocab, cfg, image_size):
-    """The oracle (CPU restatement of the reference path) on ONE image of the same workload."""
+def cpu_baseline(snapshot, batch0, gpu_step0, image_size):
+    """The oracle (CPU restatement of the reference path) on the bench's own per-GPU batch, timed as the CPU baseline —
+    and, because it replays step 0 of the GPU trainer (same initial weights: `snapshot` was taken before that step;
+    same batch), the checker of the benchmarked workload itself: losses and the generated image of the B=16, 256x256,
+    ngf=64 step against the oracle at rtol 1e-4 (`parity_b16`)."""
     import torch
     import oracle
     from canonicalsg2im_amd import train as T
-    from canonicalsg2im_amd.synth import BatchConfig, make_batch
     # torch's CPU convolutions stop scaling (and then regress) well before a 256-thread host is full:
     # 32 threads is what the baseline actually uses and reports
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    argv = [a for a in opt_argv]
-    nimg = 16                                             # the bench's own per-GPU batch: ~20 s of CPU work
-    opt = T.make_opt(vocab, argv + ["--batch_size", str(nimg)])
-    torch.manual_seed(0)
-    tr = T.Trainer(opt, torch.device("cpu"))            # parameter container only; nothing is run on it
-    ts = T.oracle_state_from(tr, oracle)
-    del tr
-    bc = BatchConfig(nimg, image_size, cfg.min_objects, cfg.max_objects, cfg.graph)
-    batch = make_batch(vocab, bc, seed=0)
+    nimg = int(batch0[0].shape[0])
+    ts = T.oracle_state_from(snapshot, oracle)
     t0 = time.time()
-    oracle.train_step(ts, batch)
+    Go, Do, img_o = oracle.train_step(ts, batch0)
     dt = time.time() - t0
     cpu_model = "unknown"
     try:
@@ -82,10 +76,36 @@ def cpu_baseline(opt_argv, vocab, cfg, image_size):
                 break
     except OSError:
         pass
-    return {"value": round(nimg / dt, 4), "unit": "img/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+    base = {"value": round(nimg / dt, 4), "unit": "img/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
             "host_cpus": os.cpu_count(),
-            "sample": "1 full G+D step (oracle.train_step) on a batch of %d images at %dx%d, same widths and graph "
-                      "statistics, torch CPU fp32, %d threads, %.1f s" % (nimg, image_size, image_size, cores, dt)}
+            "sample": "1 full G+D step (oracle.train_step) on the bench's own batch 0 (%d images at %dx%d, same weights "
+                      "as the GPU trainer before its first step), torch CPU fp32, %d threads, %.1f s"
+                      % (nimg, image_size, image_size, cores, dt)}
+    # ---- parity of the benchmarked workload: step 0 of the GPU trainer vs this oracle step
+    RTOL = 1e-4
+    G0, D0, img0 = gpu_step0
+    rows, ok, max_rel = {}, True, 0.0
+    for name, mine, want in [("G." + k, G0[k], Go[k]) for k in sorted(Go) if k != "bbox_pred_all"] + \
+                            [("D." + k, D0[k], Do[k]) for k in sorted(Do)]:
+        a, b = float(mine), float(want.detach().mean())
+        rel = abs(a - b) / max(abs(b), 1e-30)
+        good = abs(a - b) <= RTOL * abs(b) + 1e-6
+        rows[name] = {"hip": a, "oracle": b, "rel": float("%.3g" % rel)}
+        ok, max_rel = ok and good, max(max_rel, rel if abs(b) > 1e-3 else 0.0)
+    keys_ok = (set(G0) == set(Go)) and (set(D0) == set(Do))
+    img_o = img_o.detach()
+    d = (img0.double() - img_o.double()).abs()
+    # tanh image, |img| <= 1: rtol 1e-4 plus 1e-4 of the output scale (the rule of tests/test_gpu_fullwidth.py)
+    img_ok = bool((d <= RTOL * img_o.double().abs() + 1e-4).all())
+    img = {"max_abs_diff": float("%.3g" % d.max()), "rel_l2": float("%.3g" % (d.norm() / img_o.double().norm())),
+           "max_abs": float("%.3g" % img_o.abs().max()), "elements": int(d.numel())}
+    bb = (G0["bbox_pred_all"].double() - Go["bbox_pred_all"].detach().double()).abs()
+    bb_ok = bool((bb <= RTOL * Go["bbox_pred_all"].detach().double().abs() + 1e-5 * float(Go["bbox_pred_all"].abs().max())).all())
+    parity = {"ok": bool(ok and keys_ok and img_ok and bb_ok), "rtol": RTOL, "max_rel": float("%.3g" % max_rel),
+              "losses": rows, "imgs_pred": img, "bbox_pred_all_ok": bb_ok,
+              "note": "step 0 of the GPU trainer (taken before warm-up) vs oracle.train_step on the same weights and batch: "
+                      "every loss at rtol 1e-4 (+1e-6), the whole generated image at rtol 1e-4 + 1e-4 absolute"}
+    return base, parity
 
 
 def main():
@@ -133,6 +153,19 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # parity of the benchmarked workload (N = 1): step 0 on batch 0 is kept (losses + generated image) together with a
+    # CPU snapshot of the weights it started from; the cpu_baseline leg replays exactly that step on the oracle
+    check = world == 1 and not args.no_cpu_baseline
+    snapshot = batch0_cpu = gpu_step0 = None
+    if check:
+        snapshot = T.state_snapshot(trainer)
+        batch0_cpu = make_batch(vocab, bc, seed=0)
+        G0, D0 = trainer.step(batches[0])
+        torch.cuda.synchronize()
+        gpu_step0 = ({k: (v.detach().cpu() if k == "bbox_pred_all" else float(v.detach())) for k, v in G0.items()},
+                     {k: float(v.detach()) for k, v in D0.items()}, trainer.last_model_out[0].detach().float().cpu())
+        del G0, D0
+
     for i in range(args.warmup):
         trainer.step(batches[i % nb])
     sync()
@@ -141,12 +174,14 @@ def main():
         # ~1100 launches of a step would cost ~10 ms/step of queue time and distort `value`
         _lib.prof_reset()
         _lib.prof_enable(2)
+    D.comm_reset()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         G, Dl = trainer.step(batches[i % nb])
     sync()
     elapsed = time.perf_counter() - t0
+    comm = D.comm_report(args.steps) if world > 1 else None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -163,9 +198,11 @@ def main():
         prof_all = _lib.prof_read()
         _lib.prof_enable(0)
     loss_ok = bool(torch.isfinite(G["total_loss"]).item() and torch.isfinite(Dl["total_img_loss"]).item())
+    trainer_buckets = {"g": len(trainer.g_buckets.flats), "d": len(trainer.d_buckets.flats),
+                       "dobj": len(trainer.dobj_buckets.flats) if trainer.dobj_buckets is not None else 0}
 
     # BASELINE.json's second metric: the SPADE generator alone, forward + backward (no optimiser step)
-    gen_ms = None
+    gen_ms = gen_exec_ratio = None
     if H in (64, 128, 256) and args.ngf == 64 and not args.no_gen_metric:
         gen = trainer.model.layout_to_image_model
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -180,6 +217,19 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         gen_ms = e0.elapsed_time(e1) / reps
+        if not args.no_prof:                              # one more pass, untimed, for the executed/algorithmic FLOP ratio
+            _lib.prof_reset()
+            _lib.prof_enable(1)
+            img = gen(batches[0][1], batches[0][2], None, test_mode=False)
+            img.mean().backward()
+            trainer.optimizer.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            pg = _lib.prof_read()
+            _lib.prof_enable(0)
+            alg = sum(pg.get(k, (0.0, 0, 0.0))[2] for k in ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad"))
+            exe = sum(pg.get(k, (0.0, 0, 0.0))[2] * (4.0 / 9.0 if k.startswith("wino") else 1.0)
+                      for k in ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad"))
+            gen_exec_ratio = exe / alg if alg > 0 else None
 
     # the reference's DEFAULT recipe keeps the VGG perceptual term (scripts/args.py:153-154); the headline above is
     # SURVEY.md 8(d)'s --no_vgg_loss configuration.  A short second measurement with the term on (random-feature
@@ -231,6 +281,26 @@ def main():
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         "losses_finite": loss_ok,
     }
+    # Winograd F(2x2,3x3) / F(3x3,2x2) issue 16 multiplications where the direct convolution needs 36: the kernels' `work`
+    # is the ALGORITHMIC FLOP count (2*M*9*Cin*Cout, what FlopCounterMode counts for the layer); the matrix pipe EXECUTES
+    # 4/9 of it.  Every `frac` below is executed FLOPs / time / peak (a hardware utilisation, <= 1 by construction);
+    # the algorithmic rate is reported beside it as `algorithmic` / `algorithmic_over_peak` (it may exceed 1).
+    EXEC = {"wino_conv": 4.0 / 9.0, "wino_wgrad": 4.0 / 9.0}
+    mfma_kernels = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad")
+
+    def mfma_rates(table, names, seconds):
+        """(algorithmic TFLOP/s, executed TFLOP/s) of the launches `names` in a prof table over `seconds`."""
+        alg = sum(table.get(k, (0.0, 0, 0.0))[2] for k in names)
+        exe = sum(table.get(k, (0.0, 0, 0.0))[2] * EXEC.get(k, 1.0) for k in names)
+        return alg / seconds / 1e12, exe / seconds / 1e12
+
+    def roof(alg, exe, **extra):
+        d = {"bound": "mfma", "achieved": round(exe, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(exe / PEAK_FP32_MFMA_TFLOPS, 4), "algorithmic": round(alg, 2),
+             "algorithmic_over_peak": round(alg / PEAK_FP32_MFMA_TFLOPS, 4)}
+        d.update(extra)
+        return d
+
     if prof:
         kern = {}
         for name, (ms, n, work) in prof_all.items():
@@ -249,40 +319,38 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         if n:
-            ach = work / (ms * 1e-3) / 1e12
-            # Winograd F(2x2,3x3) issues 16 multiplications where the direct convolution needs 36: `achieved` counts the
-            # ALGORITHMIC FLOPs (2*M*9*Cin*Cout, what FlopCounterMode counts for the layer), `executed` the MFMA FLOPs
-            # actually issued; `frac` follows the contract (algorithmic / peak, it may exceed 1), `mfma_frac` is the
-            # matrix-pipe utilisation
-            mult = 4.0 / 9.0 if dom == "wino_conv" else 1.0
-            out["roofline"] = {"bound": "mfma",
-                               "kernel": ("k_wino_conv (3x3 convolutions forward + backward-data, Winograd F(2x2,3x3) on fp32 MFMA)"
-                                          if dom == "wino_conv" else "k_igemm_fwd (conv forward + backward-data, all shapes)"),
-                               "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                               "executed": round(ach * mult, 2), "mfma_frac": round(ach * mult / PEAK_FP32_MFMA_TFLOPS, 4),
-                               "traffic": traffic,
-                               "traffic_note": "HBM bytes per launch (read x2-corrected FETCH_SIZE + WRITE_SIZE, two "
-                                               "rocprofv3 --pmc passes of this workload, profiles/pmc_traffic.json)",
-                               "launches": n, "avg_launch_us": round(1000.0 * ms / n, 2),
-                               "algorithmic_gflop_per_launch": round(work / n / 1e9, 3)}
-        # whole step: algorithmic FLOPs of every convolution / linear launch of one step over the step time
-        mfma_kernels = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad")
-        step_flop = sum(prof_all.get(k, (0.0, 0, 0.0))[2] for k in mfma_kernels) / prof_all_steps
-        if step_flop > 0:
-            tf = step_flop / (elapsed / args.steps) / 1e12
-            out["roofline_step"] = {"bound": "mfma", "algorithmic_tflop_per_step": round(step_flop / 1e12, 3),
-                                    "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                                    "note": "sum of 2*M*K*N over every convolution / linear launch of one step (forward, "
-                                            "backward-data, weight gradient) / ms_per_step"}
+            alg, exe = mfma_rates(prof, (dom,), ms * 1e-3)
+            out["roofline"] = roof(
+                alg, exe,
+                kernel=("k_wino_conv2 (3x3 convolutions forward + backward-data, Winograd F(2x2,3x3) on fp32 MFMA, all "
+                        "instantiations)" if dom == "wino_conv" else "k_igemm_fwd (conv forward + backward-data, all shapes)"),
+                achieved_note="EXECUTED MFMA FLOPs (4/9 of the algorithmic 2*M*9*Cin*Cout for Winograd) / HIP-event time "
+                              "of the kernel's launches inside the timed region",
+                traffic=traffic,
+                traffic_note="HBM bytes per launch (read x2-corrected FETCH_SIZE + WRITE_SIZE, two rocprofv3 --pmc passes "
+                             "of this workload, profiles/pmc_traffic.json)",
+                launches=n, avg_launch_us=round(1000.0 * ms / n, 2),
+                algorithmic_gflop_per_launch=round(work / n / 1e9, 3),
+                executed_gflop_per_launch=round(work * EXEC.get(dom, 1.0) / n / 1e9, 3))
+        # whole step: FLOPs of every convolution / linear launch of one step over the step time
+        step_alg, step_exe = mfma_rates(prof_all, mfma_kernels, prof_all_steps * elapsed / args.steps)
+        if step_alg > 0:
+            out["roofline_step"] = roof(
+                step_alg, step_exe,
+                algorithmic_tflop_per_step=round(step_alg * elapsed / args.steps, 3),
+                executed_tflop_per_step=round(step_exe * elapsed / args.steps, 3),
+                note="sum over every convolution / linear launch of one step (forward, backward-data, weight gradient) "
+                     "/ ms_per_step")
         wms = prof_all.get("igemm_wgrad", (0.0, 0, 0.0))[0] + prof_all.get("wino_wgrad", (0.0, 0, 0.0))[0]
-        wwork = prof_all.get("igemm_wgrad", (0.0, 0, 0.0))[2] + prof_all.get("wino_wgrad", (0.0, 0, 0.0))[2]
         if wms > 0:
-            out["roofline_wgrad"] = {"bound": "mfma", "kernels": "k_wino_wgrad (F(3x3,2x2)) + k_igemm_wgrad",
-                                     "achieved": round(wwork / (wms * 1e-3) / 1e12, 2),
-                                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                     "frac": round(wwork / (wms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+            walg, wexe = mfma_rates(prof_all, ("igemm_wgrad", "wino_wgrad"), wms * 1e-3)
+            out["roofline_wgrad"] = roof(walg, wexe, kernels="k_wino_wgrad (F(3x3,2x2)) + k_igemm_wgrad")
+        dms = sum(prof_all.get(k, (0.0, 0, 0.0))[0] for k in ("igemm_fwd", "igemm_fwd64", "igemm_wgrad"))
+        if dms > 0:
+            dalg, dexe = mfma_rates(prof_all, ("igemm_fwd", "igemm_fwd64", "igemm_wgrad"), dms * 1e-3)
+            out["roofline_direct"] = roof(dalg, dexe, kernels="k_igemm_fwd<*> + k_igemm_wgrad<*> (4x4 PatchGAN, 1x1, small "
+                                                               "3x3 convolutions, linears): forward, backward-data, weight gradient",
+                                          ms_per_step=round(dms / prof_all_steps, 3))
         # HBM-bound kernels: algorithmic bytes (K5 messages+indices+output, K6 the layout written
         # once, K9 the activation passes) over their HIP-event time
         hbm = {}
@@ -297,11 +365,11 @@ def main():
         out["hbm_kernels"] = hbm
         out["hbm_kernels_note"] = ("algorithmic bytes / HIP-event time; launches that move a few MB (the graph kernels on "
                                    "COCO-sized graphs: ~30 triplets per image) are launch-latency bound — their rates on "
-                                   "dense graphs are in profiles/r02f_bench_C5_dense_graphs.json")
+                                   "dense graphs are in profiles/*_bench_C5_dense_graphs.json")
         out["kernels"] = kern
-        out["kernels_note"] = ("per-kernel table, roofline_wgrad and hbm_kernels: %d untimed steps after the timed region "
-                               "with a HIP event pair on every launch (summed durations exceed the step where the two "
-                               "PatchGAN scales overlap on their streams); `roofline`: events on the k_wino_conv and "
+        out["kernels_note"] = ("per-kernel table, roofline_wgrad, roofline_direct and hbm_kernels: %d untimed steps after the "
+                               "timed region with a HIP event pair on every launch (summed durations exceed the step where "
+                               "the two PatchGAN scales overlap on their streams); `roofline`: events on the k_wino_conv and "
                                "k_igemm_fwd<128> launches only, inside the timed region" % prof_all_steps)
     if gen_ms is not None:
         # algorithmic work of SPADEGenerator fwd+bwd per image (FlopCounterMode; S = 32 or 128)
@@ -309,18 +377,35 @@ def main():
         gflop = {(256, 32): 870.75, (128, 32): 217.69, (64, 32): 54.42, (256, 128): 3 * 348.37}.get((H, S))
         if gflop:
             tf = gflop * args.batch / gen_ms            # GFLOP/ms == TFLOP/s
-            out["generator_fwd_bwd"] = {"ms": round(gen_ms, 2), "algorithmic_gflop_per_img": gflop,
-                                        "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                                        "note": "SPADEGenerator forward+backward on one %d-image batch, all kernels "
-                                                "(convs, norms, layout, resampling) included" % args.batch}
+            # executed share of those FLOPs: the launch table of one more (untimed) generator pass
+            ratio = gen_exec_ratio if gen_exec_ratio else 1.0
+            out["generator_fwd_bwd"] = roof(
+                tf, tf * ratio, ms=round(gen_ms, 2), algorithmic_gflop_per_img=gflop, executed_over_algorithmic=round(ratio, 4),
+                note="SPADEGenerator forward+backward on one %d-image batch, all kernels (convs, norms, layout, resampling) "
+                     "included in the time; algorithmic FLOPs from BASELINE.md §2, executed share from the kernels' own "
+                     "launch table of one such pass" % args.batch)
+    if comm is not None:
+        # N > 1 audit trail (rank 0's view; every rank exchanges the same messages): what travelled per step and how
+        # long the compute stream sat in GradBuckets.finish() waiting for it
+        comm["grad_buckets"] = {"generator": trainer_buckets["g"], "d_img": trainer_buckets["d"],
+                                "d_obj": trainer_buckets["dobj"]}
+        comm["note"] = ("per-step averages over the timed region on rank 0: gradient all-reduces (one per 64 MB bucket, "
+                        "ReduceOp.AVG on RCCL), SyncBN fp64 (sum, sum^2) all-reduces (one per SPADE norm forward + one "
+                        "per backward), converse all-gathers; grad_copy_bytes = gradients copied into their bucket "
+                        "slots by the post-accumulate hooks; blocked_ms = HIP-event time inside finish() on the "
+                        "compute stream (the exposed part of the exchange)")
+        out["comm"] = comm
     if vgg_variant is not None:
         out["vgg_loss_variant"] = vgg_variant
-    if not args.no_cpu_baseline and world == 1:          # the CPU leg runs at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(opt_argv, vocab, cfg, args.cpu_image_size or H)
+    parity_ok = True
+    if check:                                             # the CPU leg runs at N = 1 only
+        out["cpu_baseline"], out["parity_b16"] = cpu_baseline(snapshot, batch0_cpu, gpu_step0, H)
+        parity_ok = out["parity_b16"]["ok"]
     print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    if not parity_ok:
+        raise SystemExit("bench.py: the benchmarked step does not match the oracle (parity_b16.ok = false)")
 
 
 if __name__ == "__main__":

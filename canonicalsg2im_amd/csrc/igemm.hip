@@ -846,7 +846,8 @@ static int launch_fwd(IgemmParams& p, const float* x, const float* w, const floa
   static bool attr_set = false;
   size_t shm = (size_t)(2 * IG_BM * IG_LD + 2 * BN * IG_LD) * 4 + 48 * 4;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_igemm_fwd<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipError_t e = hipFuncSetAttribute((const void*)k_igemm_fwd<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_conv_fwd: hipFuncSetAttribute(%zu bytes of LDS): %s", shm, hipGetErrorString(e));
     attr_set = true;
   }
   hipLaunchKernelGGL(k_igemm_fwd<BN>, dim3((unsigned)fwd_grid(p)), dim3(256), shm, s, p, x, w, bias, res, y, ws);
@@ -868,7 +869,8 @@ static int launch_wgrad(IgemmParams& p, const float* x, const float* dy, float* 
   static bool attr_set = false;
   size_t shm = (size_t)(2 * 32 * BI + 2 * 32 * WG_LDB) * 4 + 48 * 4;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_igemm_wgrad<BI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipError_t e = hipFuncSetAttribute((const void*)k_igemm_wgrad<BI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_conv_bwd_weight: hipFuncSetAttribute(%zu bytes of LDS): %s", shm, hipGetErrorString(e));
     attr_set = true;
   }
   hipLaunchKernelGGL(k_igemm_wgrad<BI>, dim3((unsigned)(itiles * jtiles * nsplit)), dim3(256), shm, s, p, x, dy, out,
@@ -920,7 +922,8 @@ static int launch_fwd_multi(IgemmMulti& mp, int n, int max_blocks, const float* 
   static bool attr_set = false;
   size_t shm = (size_t)(2 * IG_BM * IG_LD + 2 * BN * IG_LD) * 4 + 48 * 4;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_igemm_fwd<BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipError_t e = hipFuncSetAttribute((const void*)k_igemm_fwd<BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_conv_fwd_multi: hipFuncSetAttribute(%zu bytes of LDS): %s", shm, hipGetErrorString(e));
     attr_set = true;
   }
   hipLaunchKernelGGL((k_igemm_fwd<BN, true>), dim3((unsigned)max_blocks, (unsigned)n), dim3(256), shm, s, mp, x, w, bias, res,
@@ -948,11 +951,9 @@ int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const f
   fill(p, d);
   fwd_plan(p);
   const int64_t need = fwd_slab_floats(p) * 4;
-  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {  // caller gave no slabs: run unsplit
-    p.ksplit = 1;
-    p.kt_per_split = (p.Ktot + IG_BK - 1) / IG_BK;
-    p.tail_tile0 = p.tail_ks = p.tail_kt_per = p.tail_m0 = 0;
-  }
+  CSG_REQUIRE(need == 0 || (workspace != nullptr && workspace_bytes >= need), CSG_E_WORKSPACE,
+              "csg_conv_fwd: needs %lld bytes of workspace (csg_conv_fwd_workspace), got %lld", (long long)need,
+              (long long)workspace_bytes);
   hipStream_t s = (hipStream_t)stream;
   const int bn = pick_bn(d->Cout);
   {

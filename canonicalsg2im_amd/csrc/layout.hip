@@ -489,16 +489,20 @@ __global__ __launch_bounds__(256) void k_layout_bwd_tiles(const float* __restric
       }
       __syncthreads();
       for (int a = 0; a < nact; ++a) {
-        const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
-        const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // planes beyond the chunk (pxc < planes * LAY_EPT on narrow pyramid levels) hold no pixels: they must not read
+        // s_wx past row a (unwritten LDS: 0 * NaN would poison the sum) and contribute an exact zero
+        if (px0 < npx) {
+          const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
+          const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          const float wy = s_wy[(a0 + a) * ROWS + r];
+          for (int r = 0; r < ROWS; ++r) {
+            const float wy = s_wy[(a0 + a) * ROWS + r];
 #pragma unroll
-          for (int i = 0; i < LAY_EPT; ++i) {
-            const float w = wy * wv[i];
-            acc.x += d[r][i].x * w; acc.y += d[r][i].y * w; acc.z += d[r][i].z * w; acc.w += d[r][i].w * w;
+            for (int i = 0; i < LAY_EPT; ++i) {
+              const float w = wy * wv[i];
+              acc.x += d[r][i].x * w; acc.y += d[r][i].y * w; acc.z += d[r][i].z * w; acc.w += d[r][i].w * w;
+            }
           }
         }
         s_part[a * 256 + plane * qpp + q] = acc;

@@ -37,12 +37,43 @@ def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
+# ---- communication audit (bench.py's "comm" object, tests): what was exchanged since the last comm_reset()
+_COMM = {"grad_allreduce_calls": 0, "grad_allreduce_bytes": 0, "syncbn_allreduce_calls": 0, "syncbn_allreduce_bytes": 0,
+         "allgather_calls": 0, "allgather_bytes": 0, "grad_copy_bytes": 0, "wait_events": []}
+
+
+def comm_reset():
+    for k in _COMM:
+        _COMM[k] = [] if k == "wait_events" else 0
+
+
+def comm_note(kind, nbytes):
+    _COMM[kind + "_calls"] += 1
+    _COMM[kind + "_bytes"] += int(nbytes)
+
+
+def comm_report(steps=1):
+    """Per-step averages of the counters since comm_reset(); `blocked_ms` is the HIP-event time the compute stream spent
+    inside GradBuckets.finish() waiting for its collectives (the exposed, non-overlapped part of the gradient exchange)."""
+    out = {"world_size": world_size(), "backend": dist.get_backend() if world_size() > 1 else None}
+    for k, v in _COMM.items():
+        if k != "wait_events":
+            out[k + "_per_step"] = v / max(steps, 1)
+    ms = 0.0
+    for e0, e1 in _COMM["wait_events"]:
+        e1.synchronize()
+        ms += e0.elapsed_time(e1)
+    out["blocked_ms_per_step"] = ms / max(steps, 1)
+    return out
+
+
 def all_reduce_stats(sums):
     """SyncBN exchange (reference sync_batchnorm/batchnorm.py:74-83,105-126): every replica
     contributes its per-channel (sum, sum^2) — one fp64 tensor of 2C values per norm — and gets the
     total back.  One all-reduce replaces the reference's ReduceAddCoalesced + Broadcast pair."""
     if world_size() > 1:
         dist.all_reduce(sums)
+        comm_note("syncbn_allreduce", sums.numel() * sums.element_size())
     return sums
 
 
@@ -56,11 +87,14 @@ class GradBuckets:
     ~64 MB (the generator's 375 MB of gradients travel in 6 collectives).  Buckets are filled in reverse registration
     order, which is the order gradients become ready.  Which parameters take part is discovered at the first
     synchronisation: those that received a gradient — the never-used `repr_net` / `image_encoder` of G and D
-     stay out instead of tripping a DDP 'unused parameter' error.  In steady state nothing is
-    allocated: a hook copies the fresh gradient into its slot (the only extra pass over the gradients — there is no
+     stay out instead of tripping a DDP 'unused parameter' error; a parameter that receives its
+    first gradient on a LATER step (a branch that was inactive before) makes the buckets rebuild at that step's
+    flush() — the set is a function of the model and the step, hence identical on every rank.  In steady state nothing
+    is allocated: a hook copies the fresh gradient into its slot (the only extra pass over the gradients — there is no
     `torch.cat`, no copy back) and re-points `.grad` at the slot, which is what the optimiser then reads.
 
-    Usage per backward:  begin(); loss.backward(); [independent work]; finish()  — or all_reduce_mean() for both.
+    Usage per backward:  begin(); loss.backward(); [independent work]; finish()  — or all_reduce_mean() alone after the
+    backward (the one-shot form: the hooks were not armed, so every gradient is moved into its slot then).
     On a single rank every method returns immediately and nothing is registered."""
 
     def __init__(self, params, bucket_bytes=64 << 20):
@@ -72,12 +106,18 @@ class GradBuckets:
         self.bucket_bytes = bucket_bytes
         self.flats, self.members, self.slot = [], [], {}        # per bucket: flat tensor, [params]; param id -> (bucket, view)
         self.built = False
-        self._active = False
+        self._hooks = []
+        self._state = "idle"                                    # idle -> armed (begin) -> flushed (flush) -> idle (finish)
         self._pending, self._fired, self._works, self._next, self._streams = [], set(), [], 0, {}
         self.allocations = 0                                    # flat buffers ever allocated (tests: steady state adds none)
+        self.rebuilds = 0
+        self._late, self._late_flat = [], None
 
-    # ---- construction (first synchronisation)
+    # ---- construction (first synchronisation, or a parameter's first gradient)
     def _build(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self.flats, self.members, self.slot = [], [], [], {}
         live = [p for p in self.params if p.grad is not None]
         cur, size, groups = [], 0, []
         for p in reversed(live):                                 # reverse registration order ~ order of readiness
@@ -100,7 +140,7 @@ class GradBuckets:
                 view = view.view(p.shape) if p.is_contiguous() else view.as_strided(p.shape, p.stride())
                 off += p.numel()
                 self.slot[id(p)] = (b, view)
-                p.register_post_accumulate_grad_hook(self._hook)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._hook))
             self.flats.append(flat)
             self.members.append(group)
         self.built = True
@@ -121,14 +161,16 @@ class GradBuckets:
                     if st != cur:
                         cur.wait_stream(st)
             self._works.append(dist.all_reduce(self.flats[b], op=_avg_op(), async_op=True))
+            comm_note("grad_allreduce", self.flats[b].numel() * 4)
             self._next += 1
 
     def _hook(self, p):
-        if not self._active:
+        if self._state != "armed":
             return
         b, view = self.slot[id(p)]
         if p.grad is not view:
             view.copy_(p.grad)
+            _COMM["grad_copy_bytes"] += p.grad.numel() * 4
             p.grad = view
         if view.is_cuda:
             self._streams.setdefault(b, set()).add(torch.cuda.current_stream(view.device))
@@ -137,45 +179,86 @@ class GradBuckets:
             self._pending[b] -= 1
         self._launch_ready()
 
+    def _arm(self):
+        self._pending = [len(g) for g in self.members]
+        self._fired, self._works, self._next = set(), [], 0
+        self._streams = {}
+        self._state = "armed"
+
     # ---- per-backward protocol
     def begin(self):
         """Call right before `backward()` (after zero_grad): arms the hooks for this backward."""
         if world_size() == 1 or not self.built:
             return
-        self._pending = [len(g) for g in self.members]
-        self._fired, self._works, self._next = set(), [], 0
-        self._streams = {}
-        self._active = True
+        self._arm()
 
     def flush(self):
         """After `backward()`: launch whatever has not been launched yet; the collectives keep running."""
-        if world_size() == 1:
+        if world_size() == 1 or self._state == "flushed":
             return
-        if not self.built:
-            self._build()
-            self.begin()
-            for group in self.members:                           # first time: gradients are ordinary tensors
+        if not self.built or self._state == "idle":
+            # first synchronisation, or the one-shot form (begin() was not called for this backward, so the hooks did
+            # nothing): every gradient is an ordinary tensor, or a slot view autograd accumulated into
+            if not self.built:
+                self._build()
+            self._arm()
+            for group in self.members:
                 for p in group:
-                    self._hook(p)
+                    if p.grad is not None:
+                        self._hook(p)
         self._launch_ready(force=True)
-        self._active = False
+        # parameters outside the buckets that hold a gradient now (first gradient on a later step): one extra
+        # collective for them this time, and the buckets are rebuilt around the new set at the end of finish()
+        self._late = [p for p in self.params if p.grad is not None and id(p) not in self.slot]
+        if self._late:
+            self._late_flat = torch.cat([p.grad.reshape(-1) for p in self._late])
+            self._works.append(dist.all_reduce(self._late_flat, op=_avg_op(), async_op=True))
+            comm_note("grad_allreduce", self._late_flat.numel() * 4)
+        self._state = "flushed"
 
     def finish(self):
         """Wait for the collectives; gradients are then the mean over ranks.  Returns the bytes exchanged."""
         if world_size() == 1:
             return 0
         self.flush()
+        timed = bool(self.flats) and self.flats[0].is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._works:
             w.wait()
+        if timed:
+            e1.record()
+            _COMM["wait_events"].append((e0, e1))
         if not _has_avg():
             n = world_size()
             for flat in self.flats:
                 flat.div_(n)
+            if self._late:
+                self._late_flat.div_(n)
         self._works = []
-        return sum(f.numel() * 4 for f in self.flats)
+        self._state = "idle"
+        nbytes = sum(f.numel() * 4 for f in self.flats)
+        if self._late:
+            off = 0
+            for p in self._late:
+                p.grad.copy_(self._late_flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            nbytes += off * 4
+            held = {id(p): p.grad.clone() for p in self.params if p.grad is not None}     # out of the old slots
+            self._build()
+            for q in self.params:
+                if id(q) in held:
+                    view = self.slot[id(q)][1]
+                    view.copy_(held[id(q)])
+                    q.grad = view
+            self._late, self._late_flat = [], None
+            self.rebuilds += 1
+        return nbytes
 
     def all_reduce_mean(self):
-        """grad <- mean over ranks (begin() may or may not have been called before the backward)."""
+        """grad <- mean over ranks.  With begin() before the backward the buckets were filled (and partly sent) by the
+        hooks; without it this is the one-shot exchange of whatever gradients the parameters hold now."""
         return self.finish()
 
 
@@ -193,3 +276,5 @@ def broadcast_module(module, src=0):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
+    from . import ops                                  # in-place edit through .data: derived weight caches are stale now
+    ops.invalidate_weight_caches()

@@ -20,7 +20,7 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, WinoDesc, ch
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
     "norm_act_pair", "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "l1_mean",
-    "pack_conv_weight", "wino_pack", "wino_eligible", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
+    "invalidate_weight_caches", "pack_conv_weight", "wino_pack", "wino_eligible", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
 
 
@@ -187,6 +187,14 @@ _register_optimizer_step_post_hook(_bump_weight_epoch)
 
 def weight_epoch():
     return _WEIGHT_EPOCH[0]
+
+
+def invalidate_weight_caches():
+    """Call after editing parameters in place OUTSIDE an optimiser step through `.data` (a broadcast, an EMA swap,
+    weight clipping): such edits bump neither `_version` nor the optimiser hook, so tensors derived from the weights
+    (Winograd operands, the PatchGAN's permuted first-layer weight) would otherwise stay stale until the next step.
+    `dist.broadcast_module` and `Trainer.load_checkpoint` call it."""
+    _bump_weight_epoch()
 
 
 def _few_desc(B, IH, IW, Cin, KH, KW, stride, pad, cout_real, act, slope):

@@ -84,6 +84,7 @@ class Trainer:
         if csg_dist.world_size() > 1:
             parts = [torch.empty_like(r) for _ in range(csg_dist.world_size())]
             torch.distributed.all_gather(parts, r.contiguous())
+            csg_dist.comm_note("allgather", r.numel() * 4 * csg_dist.world_size())
             r_all = torch.cat(parts)
         if r_all.numel() > 1:
             r = (r - r_all.mean()) / (r_all.std() + eps)
@@ -205,6 +206,8 @@ class Trainer:
                 d.optimizer_d_obj.load_state_dict(ckpt['d_obj_optim_state'])
                 if 'd_mask_optim_state' in ckpt:
                     d.optimizer_d_mask.load_state_dict(ckpt['d_mask_optim_state'])
+        from . import ops
+        ops.invalidate_weight_caches()
         c = ckpt.get('counters', {})
         return c.get('t', 0), c.get('epoch', 0)
 
@@ -224,9 +227,29 @@ def obj_disc_state(trainer):
     return dict(trainer.discriminator.obj_discriminator.state_dict())
 
 
+def state_snapshot(trainer):
+    """CPU copies of everything `oracle_state_from` needs (weights, buffers, opt) as plain dicts — taken BEFORE a
+    step so that a checker can replay the same step later (bench.py's `parity_b16`)."""
+    sg, g, d = split_state(trainer)
+    cpu = lambda sd: None if sd is None else {k: v.detach().cpu().clone() for k, v in sd.items()}
+    snap = {"opt": trainer.opt, "sg": cpu(sg), "g": cpu(g), "d": cpu(d), "dobj": None, "vgg": None, "dmask": None,
+            "noise": None}
+    if not trainer.opt.use_img_disc:
+        snap["dobj"] = cpu(obj_disc_state(trainer))
+    if hasattr(trainer.gans_model, "criterionVGG"):
+        snap["vgg"] = cpu(trainer.gans_model.criterionVGG.vgg.state_dict())
+    if not trainer.opt.use_img_disc and trainer.opt.mask_size > 0:
+        snap["dmask"] = cpu(dict(trainer.discriminator.mask_discriminator.state_dict()))
+        noise = trainer.model.sg_to_layout.module.mask_noise
+        snap["noise"] = None if noise is None else noise.detach().cpu().clone()
+    return snap
+
+
 def oracle_state_from(trainer, oracle_mod):
-    """CPU copy of the trainer's weights as an `oracle.TrainState` (used by tests and smoke() only;
-    the oracle module is passed in so that this package never imports it)."""
+    """CPU copy of the trainer's weights (or of a `state_snapshot` of them) as an `oracle.TrainState` (used by tests,
+    smoke() and bench.py's checker leg only; the oracle module is passed in so that this package never imports it)."""
+    snap = trainer if isinstance(trainer, dict) else state_snapshot(trainer)
+
     def leafs(sd, skip=()):
         out = {}
         for k, v in sd.items():
@@ -238,20 +261,14 @@ def oracle_state_from(trainer, oracle_mod):
                 t.requires_grad_(True)
             out[k] = t
         return out
-    sg, g, d = split_state(trainer)
-    sg = leafs(sg)
+    sg = leafs(snap["sg"])
     if "trans_candidates_weights" in sg:
         for k in list(sg):
             if k.endswith("predicates_transitive_weights"):
                 sg[k] = sg["trans_candidates_weights"]
     unused = ("repr_net", "image_encoder")
-    dobj = leafs(obj_disc_state(trainer)) if not trainer.opt.use_img_disc else None
-    vgg = None
-    if hasattr(trainer.gans_model, "criterionVGG"):
-        vgg = {k: v.detach().cpu().clone() for k, v in trainer.gans_model.criterionVGG.vgg.state_dict().items()}
-    dmask = noise = None
-    if not trainer.opt.use_img_disc and trainer.opt.mask_size > 0:
-        dmask = leafs(dict(trainer.discriminator.mask_discriminator.state_dict()))
-        noise = trainer.model.sg_to_layout.module.mask_noise
-        noise = None if noise is None else noise.detach().cpu().clone()
-    return oracle_mod.TrainState(trainer.opt, sg, leafs(g, unused), leafs(d, unused), dobj, vgg, dmask, noise)
+    dobj = leafs(snap["dobj"]) if snap["dobj"] is not None else None
+    vgg = snap["vgg"]
+    dmask = leafs(snap["dmask"]) if snap["dmask"] is not None else None
+    return oracle_mod.TrainState(snap["opt"], sg, leafs(snap["g"], unused), leafs(snap["d"], unused), dobj, vgg, dmask,
+                                 snap["noise"])

@@ -45,8 +45,8 @@ int csg_version(void);
 const char* csg_last_error(void);
 
 /* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline) -------
- * mode 0 = off, 1 = every launch, 2 = only the dominant kernel (k_igemm_fwd<128>): an event pair costs
- * ~9 us of queue time, 10 ms per step when all ~1100 launches carry one, 2 ms in mode 2. */
+ * mode 0 = off, 1 = every launch, 2 = only the dominant convolution kernels (k_wino_conv2<*> and k_igemm_fwd<128>):
+ * an event pair costs ~9 us of queue time, 10 ms per step when all ~1100 launches carry one, 2 ms in mode 2. */
 int csg_prof_enable(int mode);
 int csg_prof_reset(void);
 int csg_prof_num_kernels(void);
@@ -161,8 +161,8 @@ typedef struct csg_conv_desc {
 
 /* y = act(conv(x, w) + bias) [+ residual];  bias and residual may be NULL; residual has y's layout.
  * Layers whose output grid is too small to fill 256 CUs are split along K into `workspace` slabs
- * that an ordered second pass sums (csg_conv_fwd_workspace bytes; with a NULL/short workspace the
- * launch simply runs unsplit). */
+ * that an ordered second pass sums (csg_conv_fwd_workspace bytes; a NULL/short workspace when that is non-zero
+ * is CSG_E_WORKSPACE, as for the multi and weight-gradient entry points). */
 int64_t csg_conv_fwd_workspace(const csg_conv_desc* d);
 int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
                  float* y, float* workspace, int64_t workspace_bytes, void* stream);

@@ -9,7 +9,7 @@ evaluated in fp32 and in fp64 on the CPU differs by up to 9e-3 in relative L2 no
 (profiles/r02_fp64_noise_band.txt) while the losses agree to 1e-7.
 
 The parity statement that CAN be tested is therefore: against the fp64 evaluation of the oracle, the HIP
-path's gradient error is within a small factor of the fp32 reference arithmetic's own error (plus the 1e-4
+path's gradient error is within a small factor (3x) of the fp32 reference arithmetic's own error (plus the 1e-4
 contract where that error is negligible — the graph encoder's gradients, whose objective is smooth)."""
 import torch
 
@@ -50,8 +50,9 @@ def errors(x, ref64):
 class Band:
     """Collects (name, hip-vs-fp64 error, fp32-reference-vs-fp64 error) rows and judges them."""
 
-    def __init__(self, k_l2=5.0, max_cap=0.05, floor=1e-4):
-        """L2 criterion: hip_l2 <= k_l2 * ref_l2 + floor.  The max-norm is only capped (no single entry off by more
+    def __init__(self, k_l2=3.0, max_cap=0.05, floor=1e-4):
+        """L2 criterion: hip_l2 <= k_l2 * ref_l2 + floor (k_l2 = 3: the round-2 tables, profiles/r02_band_C{3,4,5}.txt,
+        hold 0 of 464 tensors beyond 3x and a worst ratio of 2.6 where the reference noise is measurable).  The max-norm is only capped (no single entry off by more
         than 5 % of the tensor's largest): one flipped gate in front of a large activation moves ONE entry of a
         weight gradient by percents of the maximum in either implementation (the fp32 oracle shows 1.4e-1 on
         G_middle_1.conv_0 against its own fp64 evaluation), so a ratio of max-norms says nothing."""
@@ -76,17 +77,17 @@ class Band:
             lines.append("%-64s %10.2e %10.2e %10.2e %10.2e" % r)
         return "\n".join(lines)
 
-    def check(self, tag, dump=None, outlier_share=0.05, outlier_cap=1e-2):
+    def check(self, tag, dump=None, outliers=2, outlier_cap=1e-2, median_cap=1.5):
         """Verdict over all tensors of one step.
 
         A tensor is inside the band if hip_l2 <= k_l2 * ref_l2 + floor.  The noise is made of discrete events — ONE
         flipped gate moves every gradient upstream of it (measured with tools/debug_d_c3.py: a single LeakyReLU flip in
         the 2x512x34x34 map of D0.model3 shifts the gradients of model0..model3 and of the discriminator's embedding by
         3e-4..1e-3 in relative L2 while the fp32 reference, which happened not to flip there, sits at 1e-6) — and which
-        implementation draws the flip is chance.  So a small share of tensors (5 %, at least 2) may leave the band as long
-        as none is off by more than 1e-2 (the fp32 reference itself reaches 9e-3 against fp64), and the typical tensor
-        must be as accurate as the reference's: median of hip_l2 / ref_l2 <= 2 over the tensors whose reference noise
-        is measurable."""
+        implementation draws the flip is chance.  So at most TWO tensors may leave the band (none was outside it in the
+        round-2 runs of C3, C4 and C5) as long as none is off by more than 1e-2 (the fp32 reference itself reaches 9e-3
+        against fp64), and the typical tensor must be as accurate as the reference's: median of hip_l2 / ref_l2 <= 1.5
+        over the tensors whose reference noise is measurable (measured: 0.75 / 1.02 / 0.63)."""
         if dump:
             import os
             os.makedirs(os.path.dirname(dump), exist_ok=True)
@@ -94,12 +95,12 @@ class Band:
                 f.write(self.table() + "\n")
         assert self.rows, tag + ": nothing compared"
         worst = max((r[1] for r in self.rows if not r[0].startswith("imgs_pred")), default=0.0)
-        allowed = max(2, int(outlier_share * len(self.rows)))
+        allowed = outliers
         ratios = sorted(r[1] / r[2] for r in self.rows if r[2] > 1e-5)
         median = ratios[len(ratios) // 2] if ratios else 0.0
         msg = "%s: %d of %d gradient tensors outside the fp32 noise band (allowed %d), worst L2 error %.2e, median ratio %.2f\n%s" % (
             tag, len(self.bad), len(self.rows), allowed, worst, median, "\n".join(self.bad[:25]))
-        assert len(self.bad) <= allowed and worst <= outlier_cap and median <= 2.0, msg
+        assert len(self.bad) <= allowed and worst <= outlier_cap and median <= median_cap, msg
 
 
 # ---------------------------------------------------------------------------------------------- one training step

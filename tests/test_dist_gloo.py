@@ -71,6 +71,46 @@ def _worker(rank, world, port, out):
     buckets.begin()
     net(x).pow(2).mean().backward()
     buckets.finish()
+    # the one-shot form on a later step: all_reduce_mean() WITHOUT begin() — the hooks were not armed, so the fresh
+    # gradients are moved into their slots and exchanged then (they used to be left unreduced, silently)
+    for p in net.parameters():
+        p.grad = None
+    net(x).pow(2).mean().backward()
+    assert all(p.grad.data_ptr() != buckets.slot[id(p)][1].data_ptr() for p in net.parameters())
+    D.comm_reset()
+    assert buckets.all_reduce_mean() == nbytes
+    for p, g in zip(net.parameters(), averaged):
+        assert torch.equal(p.grad, g), "one-shot all_reduce_mean() without begin()"
+        assert p.grad.data_ptr() == buckets.slot[id(p)][1].data_ptr()
+    rep = D.comm_report(steps=1)
+    assert rep["world_size"] == world and rep["backend"] == "gloo"
+    assert rep["grad_allreduce_calls_per_step"] == len(buckets.flats) and rep["grad_allreduce_bytes_per_step"] == nbytes
+    assert rep["grad_copy_bytes_per_step"] == nbytes
+    # a parameter that receives its FIRST gradient on a later step (a branch inactive until now): exchanged by an
+    # extra collective in that step, then the buckets are rebuilt around the new set
+    for p in list(net.parameters()) + list(unused.parameters()):
+        p.grad = None
+    buckets.begin()
+    x4 = x[:, :4]
+    (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
+    lw = unused.weight.grad.clone()
+    buckets.finish()
+    assert buckets.rebuilds == 1 and all(id(p) in buckets.slot for p in unused.parameters())
+    both = [torch.empty_like(lw) for _ in range(world)]
+    dist.all_gather(both, lw)
+    assert torch.allclose(unused.weight.grad, sum(both) / world, rtol=1e-6, atol=1e-8)
+    for p, g in zip(net.parameters(), averaged):
+        assert torch.equal(p.grad, g)
+    assert unused.weight.grad.data_ptr() == buckets.slot[id(unused.weight)][1].data_ptr()
+    late_avg = unused.weight.grad.clone()
+    for p in list(net.parameters()) + list(unused.parameters()):     # and the rebuilt buckets work in steady state
+        p.grad = None
+    buckets.begin()
+    (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
+    buckets.finish()
+    assert torch.allclose(unused.weight.grad, late_avg, rtol=1e-6, atol=1e-8) and buckets.rebuilds == 1
+    for p, g in zip(net.parameters(), averaged):
+        assert torch.equal(p.grad, g)
     # SyncBN message
     xs = torch.randn(2, 5, 4, 4, generator=torch.Generator().manual_seed(7 + rank)) * (1 + rank) + rank
     C = 5

@@ -109,6 +109,18 @@ def test_bench_contract_with_two_ranks():
     assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert d["losses_finite"] and d["value"] > 0 and "cpu_baseline" not in d
     assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 / 1000.0)) / d["value"] < 0.02
+    # the N > 1 line can be audited from its own output: what was exchanged, by which backend, how long it blocked
+    c = d["comm"]
+    assert c["world_size"] == 2 and c["backend"] == "gloo"
+    nb = c["grad_buckets"]
+    assert nb["generator"] >= 1 and nb["d_img"] >= 1 and nb["d_obj"] >= 1
+    assert c["grad_allreduce_calls_per_step"] == nb["generator"] + nb["d_img"] + nb["d_obj"]
+    assert c["grad_allreduce_bytes_per_step"] > 4 * 100000         # > 100 k parameters even at ngf = ndf = 8
+    # 7 SPADE resnet blocks (4 with a learned shortcut: norm_0/norm_s share their statistics) + ... : one all-reduce
+    # per norm in the forward and one in the backward
+    assert c["syncbn_allreduce_calls_per_step"] >= 2 * 14 and c["syncbn_allreduce_bytes_per_step"] > 0
+    assert c["blocked_ms_per_step"] >= 0.0 and c["grad_copy_bytes_per_step"] <= c["grad_allreduce_bytes_per_step"]
+    assert "parity_b16" not in d
 
 
 # ------------------------------------------------------------------ SyncBN backward and the converse all-gather

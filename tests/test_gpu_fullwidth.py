@@ -46,8 +46,7 @@ def _run_step(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed):
     return tr, step_against_oracles(tr, batch, oracle, T)
 
 
-def _check_step(tr, res, tag):
-    G, D, Go, Do, img_o = res["G"], res["D"], res["Go"], res["Do"], res["img_o"]
+def _check_losses_and_image(tr, G, D, Go, Do, img_o, tag):
     assert set(G) == set(Go) and set(D) == set(Do)
     for k in Go:
         if k == "bbox_pred_all":
@@ -58,6 +57,35 @@ def _check_step(tr, res, tag):
         assert_close(D[k].reshape(()), Do[k].reshape(()), RTOL, 1e-6, "%s D %s" % (tag, k))
     # tanh image, |img| <= 1: absolute 1e-4 of the output scale on top of rtol
     assert_close(tr.last_model_out[0], img_o, RTOL, 1e-4, tag + " imgs_pred")
+
+
+def _step_losses_image_only(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed, tag):
+    """One step at the BENCHMARK's batch size: loss dictionaries and the generated image against the fp32 oracle (no
+    fp64 leg — at batch 16 the gradient band would cost minutes of CPU; the per-image networks are the ones the
+    batch-2 tests put through it).  What batch size changes is decided per launch — Winograd tile/slab plans, split-K
+    factors and tail splits, grids above the 512 resident blocks, >1 GB tensors next to the 32-bit offset guards —
+    and every one of those decisions shows in the losses and in the image."""
+    import oracle
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import make_batch, make_vocab
+    vocab = make_vocab(vocab_kind)
+    opt = T.make_opt(vocab, argv)
+    assert opt.ngf == 64 and opt.ndf == 64 and opt.gconv_hidden_dim == 512 and opt.gconv_dim == 128
+    torch.manual_seed(seed)
+    tr = T.Trainer(opt, cuda)
+    ts = T.oracle_state_from(tr, oracle)
+    batch = make_batch(vocab, batch_cfg, seed=batch_seed)
+    G, D = tr.step([None if t is None else t.cuda() for t in batch])
+    torch.cuda.synchronize()
+    Go, Do, img_o = oracle.train_step(ts, batch)
+    _check_losses_and_image(tr, G, D, Go, Do, img_o, tag)
+    del tr
+    torch.cuda.empty_cache()
+
+
+def _check_step(tr, res, tag, sg_band=False):
+    G, D, Go, Do, img_o = res["G"], res["D"], res["Go"], res["Do"], res["img_o"]
+    _check_losses_and_image(tr, G, D, Go, Do, img_o, tag)
 
     rows = res["rows"]
     g_rows, sg_rows, d_rows = rows["G"], rows["SG"], rows["D"]
@@ -73,10 +101,13 @@ def _check_step(tr, res, tag):
              "discriminator_1.model1.0.0.weight_orig", "discriminator_1.model4.0.bias"]
     dhave = {r[0] for r in d_rows}
     assert all(m in dhave for m in dmust), [m for m in dmust if m not in dhave]
-    # the graph encoder's objective (smooth-L1 on the boxes) is smooth: its gradients meet the plain contract
-    for k, mine, want, _ in sg_rows:
-        scaled_close(mine, want, "%s SG d%s" % (tag, k))
-    band_of(res, tr, tag, dump=os.path.join(ROOT, "gpurun_out", "r02_band_%s.txt" % tag))
+    # the graph encoder's objective (smooth-L1 on the boxes) is smooth: its gradients meet the plain contract — except
+    # on dense closure graphs (C5: hub objects average ~250 messages whose ReLU pre-activations sit near zero), where
+    # they are judged by the fp64 band like the GAN gradients (band_of covers every group of rows)
+    if not sg_band:
+        for k, mine, want, _ in sg_rows:
+            scaled_close(mine, want, "%s SG d%s" % (tag, k))
+    band_of(res, tr, tag, dump=os.path.join(ROOT, "gpurun_out", "r03_band_%s.txt" % tag))
 
 
 def test_c3_full_width_step_vs_oracle(cuda):
@@ -95,6 +126,34 @@ def test_c4_full_width_step_vs_oracle(cuda):
     tr, res = _run_step(cuda, "vg", ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "2"],
                         BatchConfig(2, 256, 3, 30, "random"), seed=1, batch_seed=4)
     _check_step(tr, res, tag="C4")
+
+
+def test_c3_batch16_step_vs_oracle(cuda):
+    """BASELINE config C3 exactly as bench.py runs it: COCO vocabulary, 256x256, 1-30 objects, default recipe,
+    batch 16 — the benchmarked workload itself."""
+    from canonicalsg2im_amd.synth import BatchConfig
+    _step_losses_image_only(cuda, "coco", ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "16"],
+                            BatchConfig(16, 256, 1, 30, "random"), seed=0, batch_seed=0, tag="C3/B16")
+
+
+def test_c2_full_width_batch16_step_vs_oracle(cuda):
+    """BASELINE config C2 at full width: COCO vocabulary, 128x128, 3-8 objects, ngf = ndf = 64, batch 16."""
+    from canonicalsg2im_amd.synth import BatchConfig
+    _step_losses_image_only(cuda, "coco", ["--image_size", "128,128", "--no_vgg_loss", "--batch_size", "16"],
+                            BatchConfig(16, 128, 3, 8, "random"), seed=2, batch_seed=5, tag="C2/B16")
+
+
+def test_c5_full_generator_step_vs_oracle(cuda):
+    """BASELINE config C5's whole step: CLEVR vocabulary (4 attributes -> S = 128 layout channels), 64-128 objects per
+    scene with closure graphs (>4 000 triplets per scene), ngf = ndf = 64, 256x256, the README's CLEVR recipe
+    (--use_img_disc 1), batch 2: losses, image, and every gradient of the graph encoder, the generator and both
+    PatchGAN scales inside the fp64 noise band."""
+    from canonicalsg2im_amd.synth import BatchConfig
+    tr, res = _run_step(cuda, "clevr", ["--image_size", "256,256", "--no_vgg_loss", "--use_img_disc", "1",
+                                        "--batch_size", "2"],
+                        BatchConfig(2, 256, 64, 128, "closure"), seed=6, batch_seed=8)
+    assert res["G"]["bbox_pred_all"].numel() == 2 and tr.opt.semantic_nc == 128
+    _check_step(tr, res, tag="C5", sg_band=True)
 
 
 def _clevr_scene(rng, sizes, vocab):
@@ -168,4 +227,4 @@ def test_c5_sg2layout_default_width_vs_oracle(cuda):
     band = Band()
     for k, mine, want, want64 in rows:
         band.add("SG " + k, mine, want, want64)
-    band.check("C5", dump=os.path.join(ROOT, "gpurun_out", "r02_band_C5.txt"))
+    band.check("C5sg", dump=os.path.join(ROOT, "gpurun_out", "r03_band_C5sg.txt"))

@@ -10,6 +10,10 @@ from fp64_band import Band, step_against_oracles
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
+# Second step of a two-step run: Adam's first update is lr * g / (|g| + 1e-8) — where the true gradient is zero (a conv
+# bias in front of a normalisation, padded channels) rounding noise picks the sign, so the two implementations enter
+# step 2 with parameters that differ by up to 2 * lr in those elements; the step-2 losses agree to ~1e-3, not 1e-4
+STEP2 = 2e-3
 
 
 @pytest.fixture(scope="module")
@@ -71,7 +75,7 @@ def test_spade_resblock_vs_reference(cuda):
     sd = blk.state_dict()
     for k, p in blk.named_parameters():
         if ("grad:" + k) in a:
-            assert_close(p.grad, a["grad:" + k], 2e-4, 1e-5, "d" + k)
+            assert_close(p.grad, a["grad:" + k], RTOL, 1e-5 * float(a["grad:" + k].abs().max()) + 1e-6, "d" + k)
     for k, v in a.items():
         if k.startswith("after:"):
             assert_close(sd[k[6:]], v, RTOL, 1e-6, "state " + k[6:])
@@ -332,9 +336,9 @@ def test_two_steps_vs_oracle_128(cuda):
         G, D = tr.step([None if t is None else t.cuda() for t in batch])
         Go, Do, _ = oracle.train_step(ts, batch)
         for k in ("bbox_pred", "GAN_Img", "GAN_Feat", "total_loss"):
-            assert_close(G[k].reshape(()), Go[k].reshape(()), 2e-3 if step else 2e-4, 1e-5, "step %d G %s" % (step, k))
+            assert_close(G[k].reshape(()), Go[k].reshape(()), STEP2 if step else RTOL, 1e-6, "step %d G %s" % (step, k))
         for k in ("D_img_fake", "D_img_real"):
-            assert_close(D[k].reshape(()), Do[k].reshape(()), 2e-3 if step else 2e-4, 1e-5, "step %d D %s" % (step, k))
+            assert_close(D[k].reshape(()), Do[k].reshape(()), STEP2 if step else RTOL, 1e-6, "step %d D %s" % (step, k))
 
 
 def test_vgg_loss_vs_reference(cuda):
@@ -395,9 +399,9 @@ def test_step_with_vgg_loss_vs_oracle(cuda, monkeypatch):
     Go, Do, _ = oracle.train_step(ts, batch)
     assert set(G.keys()) == set(Go.keys()) and "VGG" in G
     for k in ("bbox_pred", "GAN_Img", "GAN_Feat", "VGG", "GAN_Obj", "GAN_Ac", "total_loss"):
-        assert_close(G[k].reshape(()), Go[k].reshape(()), 2e-4, 1e-5, "G %s" % k)
+        assert_close(G[k].reshape(()), Go[k].reshape(()), RTOL, 1e-6, "G %s" % k)
     for k in ("D_img_fake", "D_img_real", "D_obj", "D_ac_real", "D_ac_fake"):
-        assert_close(D[k].reshape(()), Do[k].reshape(()), 2e-4, 1e-5, "D %s" % k)
+        assert_close(D[k].reshape(()), Do[k].reshape(()), RTOL, 1e-6, "D %s" % k)
     # the generator moved the same way: compare a large weight after the Adam step where gradients are significant
     sg, g, d = T.split_state(tr)
     w, wo = g["conv_img.weight"], ts.g["conv_img.weight"]
@@ -430,10 +434,10 @@ def test_ragged_batch_vs_oracle(cuda):
     Go, Do, img_o = oracle.train_step(ts, batch)
     for k in Go:
         if k != "bbox_pred_all":
-            assert_close(G[k].reshape(()), Go[k].reshape(()), 3e-4, 1e-5, "G %s" % k)
-    assert_close(G["bbox_pred_all"], Go["bbox_pred_all"], 3e-4, 1e-6, "bbox_pred_all")
+            assert_close(G[k].reshape(()), Go[k].reshape(()), RTOL, 1e-6, "G %s" % k)
+    assert_close(G["bbox_pred_all"], Go["bbox_pred_all"], RTOL, 1e-6, "bbox_pred_all")
     for k in Do:
-        assert_close(D[k].reshape(()), Do[k].reshape(()), 3e-4, 1e-5, "D %s" % k)
+        assert_close(D[k].reshape(()), Do[k].reshape(()), RTOL, 1e-6, "D %s" % k)
 
 
 def test_graph_only_step_config_c1_vs_oracle(cuda):
@@ -453,8 +457,8 @@ def test_graph_only_step_config_c1_vs_oracle(cuda):
     G, D = tr.step([None if t is None else t.cuda() for t in batch])
     Go, Do, _ = oracle.train_step(ts, batch)
     assert D == {} and Do == {} and set(G) == set(Go) == {"bbox_pred_all", "bbox_pred", "total_loss"}
-    assert_close(G["bbox_pred_all"], Go["bbox_pred_all"], 2e-4, 1e-6, "bbox_pred_all")
-    assert_close(G["total_loss"].reshape(()), Go["total_loss"].reshape(()), 2e-4, 1e-6, "total_loss")
+    assert_close(G["bbox_pred_all"], Go["bbox_pred_all"], RTOL, 1e-6, "bbox_pred_all")
+    assert_close(G["total_loss"].reshape(()), Go["total_loss"].reshape(()), RTOL, 1e-6, "total_loss")
     sg = T.split_state(tr)[0]
     for k in ("box_net.2.weight", "gconvs.4.net2.0.weight", "gconvs.0.net1.0.weight", "attribute_embedding.att_emb_0.weight"):
         assert_close(sg[k], ts.sg[k], 0, 2.2 * opt.learning_rate, k + " after the step")
@@ -482,9 +486,9 @@ def test_other_vocab_steps_vs_oracle(cuda, kind, graph, objs):
     Go, Do, _ = oracle.train_step(ts, batch)
     for k in Go:
         if k != "bbox_pred_all":
-            assert_close(G[k].reshape(()), Go[k].reshape(()), 3e-4, 1e-5, "%s G %s" % (kind, k))
+            assert_close(G[k].reshape(()), Go[k].reshape(()), RTOL, 1e-6, "%s G %s" % (kind, k))
     for k in Do:
-        assert_close(D[k].reshape(()), Do[k].reshape(()), 3e-4, 1e-5, "%s D %s" % (kind, k))
+        assert_close(D[k].reshape(()), Do[k].reshape(()), RTOL, 1e-6, "%s D %s" % (kind, k))
     w, wo = tr.model.sg_to_layout.module.trans_candidates_weights, ts.sg["trans_candidates_weights"]
     assert_close(w, wo, 0, 2.2e-2, "transitive weights after the step (lr 1e-2)")
 
@@ -566,7 +570,10 @@ def test_learned_converse_step_vs_oracle(cuda):
     before = tr.model.sg_to_layout.module.converse_candidates_weights.detach().clone()
     G, D = tr.step([None if t is None else t.cuda() for t in batch])
     Go, Do, _ = oracle.train_step(ts, batch)
-    assert_close(G["loss_conv"], Go["loss_conv"], 2e-3, 1e-5, "loss_conv")
+    # loss_conv = mean(r * log_prob) with r the box losses normalised to zero mean over the batch: a sum of O(1) terms of
+    # both signs that cancels to ~1e-2 of their size, so the terms' 1e-6 relative noise is 1e-4 of the result before the
+    # implementations differ at all; rtol 1e-4 applies to the terms, an absolute 2e-5 (|terms| ~ 1) to their sum
+    assert_close(G["loss_conv"], Go["loss_conv"], RTOL, 2e-5, "loss_conv")
     after = tr.model.sg_to_layout.module.converse_candidates_weights.detach()
     assert not torch.equal(after, before)
     # Adam's first step is lr * sign(g): compare where the gradient is clearly non-zero
