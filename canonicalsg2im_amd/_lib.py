@@ -90,6 +90,11 @@ SIGNATURES = {
     "csg_wino_conv": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_i64, c_p]),
     "csg_wino_bwd_weight_workspace": (c_i64, [ctypes.POINTER(WinoDesc)]),
     "csg_wino_bwd_weight": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_wino4_supported": (c_i32, [ctypes.POINTER(WinoDesc)]),
+    "csg_wino4_pack_bytes": (c_i64, [c_i64, c_i64]),
+    "csg_wino4_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
+    "csg_wino4_conv_workspace": (c_i64, [ctypes.POINTER(WinoDesc)]),
+    "csg_wino4_conv": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_i64, c_p]),
     "csg_act_bwd": (c_i32, [c_p, c_p, c_i64, c_i32, c_f32, c_p, c_p]),
     "csg_colsum": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_norm_stats": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
@@ -171,7 +176,8 @@ def stream():
 
 # ---------------------------------------------------------------- per-kernel timing
 def prof_enable(on=True):
-    """True / 1: time every launch; 2: only the dominant kernel (k_igemm_fwd<128>); False / 0: off."""
+    """True / 1: time every launch; 2: only the dominant convolution kernels (k_wino_conv2, k_igemm_fwd<128>);
+    3: only the streaming (HBM-bound) kernels; False / 0: off."""
     check(lib.csg_prof_enable(int(on)), "prof_enable")
 
 

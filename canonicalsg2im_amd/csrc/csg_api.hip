@@ -33,7 +33,7 @@ struct Rec {
   double work;
   hipEvent_t e0, e1;
 };
-static int g_prof = 0;   // 0 off, 1 every kernel, 2 only the dominant convolution kernels (k_wino_conv, k_igemm_fwd<128>)
+static int g_prof = 0;   // 0 off, 1 every kernel, 2 only the dominant convolution kernels (k_wino_conv, k_igemm_fwd<128>), 3 only the streaming (HBM-bound) kernels
 static std::mutex g_mu;
 static std::vector<Rec> g_pending;
 static std::vector<hipEvent_t> g_free;
@@ -42,7 +42,20 @@ static double g_work[K_COUNT];
 static int64_t g_n[K_COUNT];
 static Rec g_cur;
 
-bool prof_on(int kid) { return g_prof == 1 || (g_prof == 2 && (kid == K_IGEMM_FWD || kid == K_WINO_CONV)); }
+static bool hbm_kernel(int kid) {
+  switch (kid) {
+    case K_GATHER_FWD: case K_GATHER_BWD: case K_SEGAVG_FWD: case K_SEGAVG_BWD: case K_LAYOUT_FWD: case K_LAYOUT_BWD:
+    case K_ACT_BWD: case K_NORM_STATS: case K_NORM_APPLY_FWD: case K_NORM_BWD_REDUCE: case K_NORM_BWD_DX:
+    case K_UPSAMPLE_FWD: case K_UPSAMPLE_BWD: case K_AVGPOOL_FWD: case K_AVGPOOL_BWD:
+      return true;
+    default:
+      return false;
+  }
+}
+
+bool prof_on(int kid) {
+  return g_prof == 1 || (g_prof == 2 && (kid == K_IGEMM_FWD || kid == K_WINO_CONV || kid == K_WINO4_CONV)) || (g_prof == 3 && hbm_kernel(kid));
+}
 
 static hipEvent_t get_event() {
   if (!g_free.empty()) {
@@ -93,7 +106,8 @@ static const char* kNames[K_COUNT] = {
     "maxpool2_fwd",   "maxpool2_bwd",   "l1_mean_fwd",      "l1_mean_bwd",
     "canon_build",    "canon_emit",     "spectral_norm_fwd", "spectral_norm_bwd",
     "wino_conv",      "wino_pack",      "wino_wgrad",
-    "few_fwd",        "few_bwd_data",   "few_bwd_weight"};
+    "few_fwd",        "few_bwd_data",   "few_bwd_weight",
+    "wino4_conv",     "wino4_wgrad"};
 
 }  // namespace csg
 
@@ -104,7 +118,7 @@ const char* csg_last_error(void) { return csg::g_err; }
 
 int csg_prof_enable(int on) {
   csg::resolve();
-  csg::g_prof = on < 0 ? 0 : (on > 2 ? 1 : on);
+  csg::g_prof = on < 0 ? 0 : (on > 3 ? 1 : on);
   return CSG_OK;
 }
 

@@ -52,6 +52,8 @@ enum KernelId {
   K_FEW_FWD,
   K_FEW_BWD_DATA,
   K_FEW_BWD_WEIGHT,
+  K_WINO4_CONV,
+  K_WINO4_WGRAD,
   K_COUNT
 };
 

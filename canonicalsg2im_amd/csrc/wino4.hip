@@ -1,0 +1,517 @@
+// K8w4 — 3x3 / stride 1 / pad 1 convolution by Winograd F(4x4,3x3) on the fp32 matrix cores of gfx950.
+//
+// Same call sites as wino.hip (generator.py:28; architecture.py:29-31; normalization.py:89-94 and their backward-data
+// passes) on maps at least 32 pixels wide: a 4x4 output tile from a 6x6 input tile with 36 multiplications per
+// (cin, cout) pair instead of 144 — 2.25 per output where F(2x2,3x3) needs 4 and the direct sum 9.
+//
+//     U = G g G^T   (6x6 per (cout,cin), packed once per weight version by k_wino4_pack)
+//     V = B^T d B   (6x6 per tile and channel, formed in registers right before the MFMAs)
+//     M_p = sum_cin V_p U_p  for the 36 positions p = (xi, nu)   <- 36 independent GEMMs on v_mfma_f32_32x32x2_f32
+//     Y = A^T M A   (4x4 outputs; bias / activation / residual / gate fused behind it)
+//
+// Interpolation points {0, 1, -1, 1/2, -2, inf}: among the 5-point sets tried on the host (fp32 transforms, fp32
+// k-ordered accumulation, against the fp64 direct sum: tools/wino_error_model.py) this one has the smallest error —
+// 2.2e-6 of the output scale at Cin = 128 and 5.5e-6 at Cin = 1024 (max over the outputs; direct fp32 0.9e-6 / 2.3e-6,
+// F(2x2,3x3) 0.4e-6 / 1.3e-6; the textbook {0, +-1, +-2} reads 6.3e-6 / 1.4e-5).  tests/test_gpu_wino4.py holds the
+// kernel to < 1e-5 of the output scale against fp64.
+//
+// Work decomposition.  A block owns 32 tiles (8 x 4: 32 x 16 output pixels of one image) x 32 output channels x all 36
+// positions with SIX waves: wave w owns row xi = w — six accumulators of 32x32 (96 registers) — and two blocks are
+// resident per CU (three waves per SIMD: the partner waves' MFMAs run under a wave's transform arithmetic).
+//   * B operand (U): as in wino.hip every (position, channel group) is consumed by exactly one wave, so U never goes
+//     through LDS: MFMA operand order [xi][nu][cout/32][cin/8][lane][4], one 16-byte load per four MFMAs, L2 resident.
+//   * A operand (V): the raw input region (18 x 34 pixels x 8 channels per stage) is staged in LDS with the columns
+//     de-interleaved modulo 4 (tile tx reads column 4 tx + c: consecutive tiles are consecutive 32-byte pixels of class
+//     c & 3) and the row groups skewed by two words (word(y, x, ch) = 288 y + 2 (y >> 2) + 8 ((x & 3) * 9 + (x >> 2)) +
+//     ch), which makes every ds_read_b64 of a half-wave (8 x 4 tiles) hit 32 different bank pairs.  Row xi of B^T d is
+//     a combination of five input rows with wave-uniform coefficients (scalar registers); the column transform has
+//     compile-time coefficients.  ~8 VALU per MFMA per wave.
+//   * K loop: 8 channels per LDS stage (24 MFMAs per wave), double-buffered, global loads of stage s+1 issued before
+//     the MFMAs of stage s and written to LDS after them, one barrier per stage.
+//   * Epilogue: each wave reduces its row over nu (M A), the six rows meet in LDS (A^T .) two output columns at a
+//     time, 16-byte stores.
+#include <stddef.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "csg_buffer.h"
+#include "csg_common.h"
+#include "csg_reduce.h"
+
+using namespace csg;
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define W4_TW 8
+#define W4_TH 4
+#define W4_R (4 * W4_TH + 2)      // 18 staged rows
+#define W4_C (4 * W4_TW + 2)      // 34 staged columns
+#define W4_CQ 9                   // columns per class (x & 3): ceil(34 / 4)
+#define W4_PS 8                   // words per staged pixel = channels per stage
+#define W4_RS 288                 // words per staged row: 4 classes x 9 columns x 8 words (a multiple of 16)
+#define W4_BUFW (W4_R * W4_RS + 8 + 16)   // + the skew of the last row group + a dump slot for idle staging lanes
+#define W4_RSE 36                 // words per tile row of the epilogue exchange buffer (32 channels + 4)
+#define W4_NLD 4                  // float4 global loads per thread and stage (18 * 34 * 2 / 384 rounded up)
+#define W4_THREADS 384
+#ifndef W4_COLBAR
+#define W4_COLBAR 1
+#endif
+#ifndef W4_OCC
+#define W4_OCC 3
+#endif
+
+struct Wino4Params {
+  int B, H, W, Cin, x_cs, Cout, y_cs;
+  int tbx, tby;        // block regions per image
+  int nblocks;         // ceil(Cout / 32)
+  int NT32, Q8;        // extents of the packed weights
+  int act;
+  float slope;
+  float gate_slope;
+  int nstage;          // Cin / 8
+  int ksplit, sps;     // input-channel stages cut into ksplit ranges of sps stages, one output slab each
+  long long slab;      // floats per slab (B*H*W*y_cs)
+};
+
+__device__ __forceinline__ int w4_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// B^T of F(4,3) on the points {0, 1, -1, 1/2, -2, inf}; row xi combines input rows rb .. rb+4 (rb = 0 for xi = 0,
+// else 1) with these five coefficients (the sixth entry of every row of B^T is outside that window only as a zero)
+__constant__ float W4_BT5[6][5] = {
+    {1.0f, -1.5f, -2.0f, 1.5f, 1.0f},      // xi = 0: d0 .. d4
+    {-1.0f, 0.5f, 2.5f, 1.0f, 0.0f},       // xi = 1: d1 .. d5
+    {1.0f, -2.5f, 0.5f, 1.0f, 0.0f},
+    {-2.0f, -1.0f, 2.0f, 1.0f, 0.0f},
+    {0.5f, -1.0f, -0.5f, 1.0f, 0.0f},
+    {1.0f, -1.5f, -2.0f, 1.5f, 1.0f},      // xi = 5: d1 .. d5
+};
+
+// ------------------------------------------------------------------------------------ weight packing
+// up[(((xi*6+nu)*NT32 + nt)*Q8 + q)*64 + lane] (float4) = U[xi][nu][n = nt*32 + (lane&31)][k], k = 8q + 2h + {0,1}
+// (.x,.y) and 8q + 4 + 2h + {0,1} (.z,.w), h = lane>>5; zero beyond N / K — the layout of k_wino_pack with 36
+// positions.  G = [[1,0,0],[1/3,1/3,1/3],[-1/3,1/3,-1/3],[-16/15,-8/15,-4/15],[1/15,-2/15,4/15],[0,0,1]].
+#define WP4_LD 33
+__global__ __launch_bounds__(256) void k_wino4_pack(const float* __restrict__ w, int64_t s_n, int64_t s_k, int64_t s_h,
+                                                     int64_t s_w, int flip, int N, int K, const float* __restrict__ sigma,
+                                                     int NT32, int Q8, float4* __restrict__ up) {
+  __shared__ float g[9][32][WP4_LD];
+  const int tid = threadIdx.x;
+  const int qb = blockIdx.x, nt = blockIdx.y;         // k range [32 qb, 32 qb + 32), n range [32 nt, 32 nt + 32)
+  const bool k_fast = s_k <= s_n;
+  const float sg = sigma != nullptr ? sigma[0] : 1.0f;
+  float stage[36];
+#pragma unroll
+  for (int it = 0; it < 36; ++it) {
+    const int t = it >> 2, r = tid + 256 * (it & 3);
+    const int nl = k_fast ? (r >> 5) : (r & 31), kl = k_fast ? (r & 31) : (r >> 5);
+    const int n = nt * 32 + nl, k = qb * 32 + kl;
+    const int a = t / 3, b = t - 3 * a;
+    const int aa = flip ? 2 - a : a, bb = flip ? 2 - b : b;
+    stage[it] = (n < N && k < K) ? w[(int64_t)n * s_n + (int64_t)k * s_k + aa * s_h + bb * s_w] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < 36; ++it) {
+    const int t = it >> 2, r = tid + 256 * (it & 3);
+    const int nl = k_fast ? (r >> 5) : (r & 31), kl = k_fast ? (r & 31) : (r >> 5);
+    g[t][nl][kl] = sigma != nullptr ? stage[it] / sg : stage[it];
+  }
+  __syncthreads();
+  const int lane = tid & 63, ql = tid >> 6;            // 4 q per block, one per wave
+  const int q = qb * 4 + ql;
+  if (q >= Q8) return;
+  const int nl = lane & 31, h = lane >> 5;
+  const float G[6][3] = {{1.0f, 0.0f, 0.0f},
+                         {(float)(1.0 / 3.0), (float)(1.0 / 3.0), (float)(1.0 / 3.0)},
+                         {(float)(-1.0 / 3.0), (float)(1.0 / 3.0), (float)(-1.0 / 3.0)},
+                         {(float)(-16.0 / 15.0), (float)(-8.0 / 15.0), (float)(-4.0 / 15.0)},
+                         {(float)(1.0 / 15.0), (float)(-2.0 / 15.0), (float)(4.0 / 15.0)},
+                         {0.0f, 0.0f, 1.0f}};
+  float t[4][6][3];                                     // [e][xi][b] = (G g)[xi][b]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int kl = 8 * ql + (e >> 1) * 4 + 2 * h + (e & 1);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float g0 = g[b][nl][kl], g1 = g[3 + b][nl][kl], g2 = g[6 + b][nl][kl];
+#pragma unroll
+      for (int xi = 0; xi < 6; ++xi) t[e][xi][b] = G[xi][0] * g0 + G[xi][1] * g1 + G[xi][2] * g2;
+    }
+  }
+#pragma unroll
+  for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) {
+      float u[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] = t[e][xi][0] * G[nu][0] + t[e][xi][1] * G[nu][1] + t[e][xi][2] * G[nu][2];
+      up[(((int64_t)(xi * 6 + nu) * NT32 + nt) * Q8 + q) * 64 + lane] = make_float4(u[0], u[1], u[2], u[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ convolution
+__global__ __launch_bounds__(W4_THREADS, W4_OCC) void k_wino4_conv(Wino4Params p, const float* __restrict__ x,
+                                                               const float4* __restrict__ up,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ res,
+                                                               const float* __restrict__ gate, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // row xi of the transformed domain
+
+  int bid = w4_xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid % p.ksplit;              // splits of one tile are neighbours: they share the input in L2
+  bid /= p.ksplit;
+  const int nb = bid % p.nblocks;                // channel blocks of one region are adjacent (same XCD: input reuse)
+  bid /= p.nblocks;
+  const int bx = bid % p.tbx;
+  bid /= p.tbx;
+  const int by = bid % p.tby;
+  const int img = bid / p.tby;
+  const int X0 = bx * 4 * W4_TW, Y0 = by * 4 * W4_TH;
+
+  const csg_i32x4 rsX = csg_make_srd(x, (long long)p.B * p.H * p.W * p.x_cs * 4);
+  const csg_i32x4 rsU = csg_make_srd(up, (long long)36 * p.NT32 * p.Q8 * 64 * 16);
+
+  // ---- staging plan (k-invariant): element e = tid + 384 i -> (pixel, channel quad) of the 18 x 34 x 8 region
+  unsigned goff[W4_NLD];
+  unsigned loffp[W4_NLD / 2];                    // LDS word offsets / 4, two per register
+#pragma unroll
+  for (int i = 0; i < W4_NLD; ++i) {
+    const int e = tid + W4_THREADS * i;
+    goff[i] = CSG_OOB_OFF;
+    int lo = (W4_BUFW - 16) / 4 + (tid & 3);
+    if (e < W4_R * W4_C * 2) {
+      const int pix = e >> 1, c4 = e & 1;
+      const int row = pix / W4_C, col = pix - row * W4_C;
+      const int iy = Y0 + row - 1, ix = X0 + col - 1;
+      // the two-word skew of the row groups is not a multiple of a float4: it is added back when the offset is unpacked
+      lo = (row * W4_RS + ((col & 3) * W4_CQ + (col >> 2)) * W4_PS + c4 * 4) / 4 + ((row >> 2) << 13);
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+        goff[i] = (unsigned)(((img * p.H + iy) * p.W + ix) * p.x_cs + c4 * 4) * 4u;
+    }
+    if (i & 1)
+      loffp[i >> 1] |= (unsigned)lo << 16;
+    else
+      loffp[i >> 1] = (unsigned)lo;
+  }
+  csg_f32x4 st[W4_NLD];
+  auto load_stage = [&](int s) {                 // s past the end: finite garbage or zeros, never consumed
+#pragma unroll
+    for (int i = 0; i < W4_NLD; ++i) st[i] = csg_buf_load_x4(rsX, (int)goff[i], s * (W4_PS * 4), 0);
+  };
+  auto store_stage = [&](float* base) {
+#pragma unroll
+    for (int i = 0; i < W4_NLD; ++i) {
+      const unsigned lo = (i & 1) ? (loffp[i >> 1] >> 16) : (loffp[i >> 1] & 0xffffu);
+      float* dst = base + (lo & 0x1fffu) * 4 + (lo >> 13) * 2;      // float4 offset + 2 words per row group
+      *(float2*)dst = make_float2(st[i].x, st[i].y);
+      *(float2*)(dst + 2) = make_float2(st[i].z, st[i].w);
+    }
+  };
+
+  // ---- this lane's tile, the five input rows its wave combines and their coefficients (scalar registers)
+  const int j = lane & 31, h = lane >> 5;
+  const int tx = j & (W4_TW - 1), ty = j >> 3;
+  const int rb = wave == 0 ? 0 : 1;
+  const float c0 = W4_BT5[wave][0], c1 = W4_BT5[wave][1], c2 = W4_BT5[wave][2], c3 = W4_BT5[wave][3], c4c = W4_BT5[wave][4];
+  // word offset of (row 4 ty + rb, column 4 tx, channel pair h); rows 4 ty + q with q >= 4 sit in the next row group
+  // (two words of skew): of the five rows rb .. rb+4 only the fourth (q = 3 or 4) has an rb-dependent skew — it gets a
+  // base pointer of its own, every other offset is an instruction immediate
+  const float* p0 = smem + (4 * ty + rb) * W4_RS + 2 * ty + tx * W4_PS + 2 * h;
+  const float* p3 = p0 + 3 * W4_RS + 2 * rb;
+
+  // packed weights of this wave: [xi = wave][nu][nt32][q][lane]; nu and q ride in the SCALAR offset of the load
+  const unsigned uoff = nb < p.NT32 ? (unsigned)((((wave * 6) * p.NT32 + nb) * p.Q8) * 64 + lane) * 16u : CSG_OOB_OFF;
+  const int ustride = p.NT32 * p.Q8 * 1024;      // bytes between positions
+  csg_f32x4 u[6];
+  auto load_u = [&](int nu, int q) {             // operands of position nu for k-oct q (clamped past the end)
+    const int qq = min(q, p.Q8 - 1);
+    u[nu] = csg_buf_load_x4(rsU, (int)uoff, nu * ustride + qq * 1024, 0);
+  };
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
+
+  // Row xi of B^T d for channel pair cp of the staged oct, all six columns: 30 ds_read_b64, 60 VALU
+  float2 t[6];
+  auto rows = [&](int bufsel, int cp) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int co = bufsel * W4_BUFW + ((c & 3) * W4_CQ + (c >> 2)) * W4_PS + 4 * cp;
+      const float2 d0 = *(const float2*)(p0 + co);
+      const float2 d1 = *(const float2*)(p0 + co + W4_RS);
+      const float2 d2 = *(const float2*)(p0 + co + 2 * W4_RS);
+      const float2 d3 = *(const float2*)(p3 + co);
+      const float2 d4 = *(const float2*)(p0 + co + 4 * W4_RS + 2);
+      t[c].x = fmaf(c4c, d4.x, fmaf(c3, d3.x, fmaf(c2, d2.x, fmaf(c1, d1.x, c0 * d0.x))));
+      t[c].y = fmaf(c4c, d4.y, fmaf(c3, d3.y, fmaf(c2, d2.y, fmaf(c1, d1.y, c0 * d0.y))));
+#if W4_COLBAR
+      if (c & 1) __builtin_amdgcn_sched_barrier(0);   // at most two columns of raw reads in flight (registers)
+#endif
+    }
+  };
+  // column nu of (B^T d) B: v = sum_c B^T[nu][c] t[c], formed right before the two MFMAs that consume it
+  auto col = [&](int nu) -> float2 {
+    float2 v;
+#define W4_COL(F)                                                                                     \
+    {                                                                                                 \
+      const float s42 = t[4].F - t[2].F, s31 = t[3].F - t[1].F;                                        \
+      if (nu == 0) v.F = fmaf(1.5f, s31, fmaf(-2.0f, t[2].F, t[0].F + t[4].F));                        \
+      else if (nu == 1) v.F = fmaf(2.5f, t[3].F, fmaf(0.5f, t[2].F, t[4].F - t[1].F));                 \
+      else if (nu == 2) v.F = fmaf(0.5f, t[3].F, fmaf(-2.5f, t[2].F, t[4].F + t[1].F));                \
+      else if (nu == 3) v.F = fmaf(2.0f, s31, s42);                                                   \
+      else if (nu == 4) v.F = fmaf(-0.5f, s31, s42);                                                  \
+      else v.F = fmaf(1.5f, s42, fmaf(-2.0f, t[3].F, t[1].F + t[5].F));                               \
+    }
+    W4_COL(x)
+    W4_COL(y)
+#undef W4_COL
+    return v;
+  };
+  // the two MFMAs of a position are dependent (same accumulator) — free on this pipe: issue interval and dependent
+  // latency of v_mfma_f32_32x32x2_f32 are both 64 cycles
+  auto mfma_cp = [&](auto cp_tag) {
+    constexpr int cp = decltype(cp_tag)::value;
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) {
+      const float2 v = col(nu);
+      acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(cp ? u[nu].z : u[nu].x, v.x, acc[nu], 0, 0, 0);
+      acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(cp ? u[nu].w : u[nu].y, v.y, acc[nu], 0, 0, 0);
+    }
+  };
+  auto stage = [&](int s, auto bufsel_tag) {
+    constexpr int bufsel = decltype(bufsel_tag)::value;
+    rows(bufsel, 0);
+    mfma_cp(std::integral_constant<int, 0>());
+    __builtin_amdgcn_sched_barrier(0);
+    rows(bufsel, 1);
+    load_stage(s + 1);
+    mfma_cp(std::integral_constant<int, 1>());
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) load_u(nu, s + 1);
+    store_stage(smem + (bufsel ^ 1) * W4_BUFW);
+    __syncthreads();
+  };
+
+  const int s_begin = split * p.sps, s_end = min(p.nstage, s_begin + p.sps);
+  y += (long long)split * p.slab;
+  load_stage(s_begin);
+#pragma unroll
+  for (int nu = 0; nu < 6; ++nu) load_u(nu, s_begin);
+  store_stage(smem);
+  __syncthreads();
+  int s = s_begin;
+  for (; s + 1 < s_end; s += 2) {
+    stage(s, std::integral_constant<int, 0>());
+    stage(s + 1, std::integral_constant<int, 1>());
+  }
+  if (s < s_end) stage(s, std::integral_constant<int, 0>());
+
+  // ---- epilogue.  A^T = [[1,1,1,1,1,0],[0,1,-1,1/2,-2,0],[0,1,1,1/4,4,0],[0,1,-1,1/8,-8,1]].
+  // Per wave (row xi): R[b] = sum_nu M[xi][nu] A^T[b][nu]; then Y[a][b] = sum_xi A^T[a][xi] R_xi[b] through LDS, two
+  // output columns b per round: rbuf[xi][b & 1][32 tiles][W4_RSE]
+  float* rbuf = smem;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float r0[4], r1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float m0 = acc[0][4 * g + e], m1 = acc[1][4 * g + e], m2 = acc[2][4 * g + e], m3 = acc[3][4 * g + e],
+                    m4 = acc[4][4 * g + e], m5 = acc[5][4 * g + e];
+        if (round == 0) {
+          r0[e] = ((m0 + m1) + (m2 + m3)) + m4;
+          r1[e] = fmaf(-2.0f, m4, fmaf(0.5f, m3, m1 - m2));
+        } else {
+          r0[e] = fmaf(4.0f, m4, fmaf(0.25f, m3, m1 + m2));
+          r1[e] = fmaf(-8.0f, m4, fmaf(0.125f, m3, m1 - m2)) + m5;
+        }
+      }
+      const int ch = 8 * g + 4 * h;
+      *(float4*)(rbuf + ((wave * 2 + 0) * 32 + j) * W4_RSE + ch) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+      *(float4*)(rbuf + ((wave * 2 + 1) * 32 + j) * W4_RSE + ch) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+    }
+    __syncthreads();
+    for (int item = tid; item < 512; item += W4_THREADS) {      // 32 tiles x 8 channel quads x 2 columns
+      const int cq = item & 7, tile = (item >> 3) & 31, bb = item >> 8;
+      const int n = nb * 32 + cq * 4;
+      const int ttx = tile & (W4_TW - 1), tty = tile >> 3;
+      const int oy = Y0 + 4 * tty, ox = X0 + 4 * ttx + 2 * round + bb;
+      if (n < p.Cout && oy < p.H && ox < p.W) {      // H and W are multiples of 4: a tile is wholly inside or outside
+        float4 rr[6];
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi) rr[xi] = *(const float4*)(rbuf + ((xi * 2 + bb) * 32 + tile) * W4_RSE + cq * 4);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias != nullptr) bv = *(const float4*)(bias + n);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          float vv[4];
+#define W4_ROW(F, I)                                                                                         \
+          if (a == 0) vv[I] = ((rr[0].F + rr[1].F) + (rr[2].F + rr[3].F)) + rr[4].F;                           \
+          else if (a == 1) vv[I] = fmaf(-2.0f, rr[4].F, fmaf(0.5f, rr[3].F, rr[1].F - rr[2].F));              \
+          else if (a == 2) vv[I] = fmaf(4.0f, rr[4].F, fmaf(0.25f, rr[3].F, rr[1].F + rr[2].F));              \
+          else vv[I] = fmaf(-8.0f, rr[4].F, fmaf(0.125f, rr[3].F, rr[1].F - rr[2].F)) + rr[5].F;
+          W4_ROW(x, 0)
+          W4_ROW(y, 1)
+          W4_ROW(z, 2)
+          W4_ROW(w, 3)
+#undef W4_ROW
+          vv[0] += bv.x; vv[1] += bv.y; vv[2] += bv.z; vv[3] += bv.w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (p.act == CSG_ACT_LEAKY)
+              vv[e] = vv[e] > 0.f ? vv[e] : vv[e] * p.slope;
+            else if (p.act == CSG_ACT_TANH)
+              vv[e] = tanhf(vv[e]);
+          }
+          const int64_t pix = ((int64_t)img * p.H + (oy + a)) * p.W + ox;
+          if (res != nullptr) {
+            const float4 rv = *(const float4*)(res + pix * p.y_cs + n);
+            vv[0] += rv.x; vv[1] += rv.y; vv[2] += rv.z; vv[3] += rv.w;
+          }
+          if (gate != nullptr) {
+            const float4 gv = *(const float4*)(gate + pix * p.y_cs + n);
+            vv[0] *= gv.x > 0.f ? 1.f : p.gate_slope; vv[1] *= gv.y > 0.f ? 1.f : p.gate_slope;
+            vv[2] *= gv.z > 0.f ? 1.f : p.gate_slope; vv[3] *= gv.w > 0.f ? 1.f : p.gate_slope;
+          }
+          *(float4*)(y + pix * p.y_cs + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------ host side
+static int w4_plan(const csg_wino_desc* d, Wino4Params& p, size_t& shm, const char* who) {
+  CSG_REQUIRE(d != nullptr, CSG_E_BADSHAPE, "%s: null descriptor", who);
+  CSG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, CSG_E_BADSHAPE, "%s: non-positive dimension", who);
+  CSG_REQUIRE(d->H % 4 == 0 && d->W % 4 == 0 && d->W >= 32 && d->H >= 16, CSG_E_UNSUPPORTED,
+              "%s: F(4x4,3x3) needs H=%d, W=%d multiples of 4, W >= 32, H >= 16", who, d->H, d->W);
+  CSG_REQUIRE(d->Cin % 8 == 0 && d->x_cs % 4 == 0 && d->x_cs >= d->Cin && d->Cout % 4 == 0 && d->y_cs % 4 == 0 &&
+                  d->y_cs >= d->Cout,
+              CSG_E_UNSUPPORTED, "%s: Cin must be a multiple of 8, the other channel counts and strides of 4", who);
+  CSG_REQUIRE((int64_t)d->B * d->H * d->W * (int64_t)(d->x_cs > d->y_cs ? d->x_cs : d->y_cs) * 4 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
+              "%s: tensor too large for 32-bit byte offsets", who);
+  CSG_REQUIRE((int64_t)36 * ((d->Cout + 31) / 32) * ((d->Cin + 7) / 8) * 1024 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
+              "%s: packed weights too large for 32-bit byte offsets", who);
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_cs = d->x_cs; p.Cout = d->Cout; p.y_cs = d->y_cs;
+  p.tbx = (d->W + 4 * W4_TW - 1) / (4 * W4_TW);
+  p.tby = (d->H + 4 * W4_TH - 1) / (4 * W4_TH);
+  p.nblocks = (d->Cout + 31) / 32;
+  p.NT32 = (d->Cout + 31) / 32;
+  p.Q8 = (d->Cin + 7) / 8;
+  p.act = d->act; p.slope = d->slope; p.gate_slope = 0.f;
+  p.nstage = d->Cin / W4_PS;
+  p.ksplit = 1;
+  p.sps = p.nstage;
+  p.slab = (long long)d->B * d->H * d->W * d->y_cs;
+  const size_t in_bytes = (size_t)2 * W4_BUFW * 4;
+  const size_t ep_bytes = (size_t)6 * 2 * 32 * W4_RSE * 4;
+  shm = in_bytes > ep_bytes ? in_bytes : ep_bytes;
+  return CSG_OK;
+}
+
+// Split over the input channels when the tile grid alone cannot fill the chip (see wn_split_plan in wino.hip)
+static void w4_split_plan(Wino4Params& p, bool plain) {
+  if (!plain || p.y_cs != p.Cout) return;
+  const int64_t blocks = (int64_t)p.B * p.tby * p.tbx * p.nblocks;
+  if (blocks >= 384 || p.nstage < 32) return;
+  int ks = (int)((512 + blocks - 1) / blocks);
+  if (ks > p.nstage / 16) ks = p.nstage / 16;
+  if (ks < 2) return;
+  p.sps = (p.nstage + ks - 1) / ks;
+  p.ksplit = (p.nstage + p.sps - 1) / p.sps;
+}
+
+extern "C" {
+
+int32_t csg_wino4_supported(const csg_wino_desc* d) {
+  static const int on = getenv("CSG_WINO4") ? atoi(getenv("CSG_WINO4")) : 1;
+  if (!on || d == nullptr) return 0;
+  return (d->H % 4 == 0 && d->W % 4 == 0 && d->W >= 32 && d->H >= 16 && d->Cin % 8 == 0 && d->Cout % 4 == 0) ? 1 : 0;
+}
+
+int64_t csg_wino4_pack_bytes(int64_t N, int64_t K) {
+  if (N <= 0 || K <= 0) return -1;
+  return (int64_t)36 * cdiv(N, 32) * cdiv(K, 8) * 64 * 16;
+}
+
+int csg_wino4_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int64_t Cout, int64_t Cin,
+                           int32_t backward_data, const float* sigma, float* packed, void* stream) {
+  CSG_REQUIRE(w != nullptr && packed != nullptr && Cout > 0 && Cin > 0, CSG_E_BADSHAPE, "csg_wino4_pack_weights: bad arguments");
+  CSG_REQUIRE(((uintptr_t)packed % 16) == 0, CSG_E_UNSUPPORTED, "csg_wino4_pack_weights: packed must be 16-byte aligned");
+  const int64_t N = backward_data ? Cin : Cout, K = backward_data ? Cout : Cin;
+  const int64_t s_n = backward_data ? s_i : s_o, s_k = backward_data ? s_o : s_i;
+  const int NT32 = (int)cdiv(N, 32), Q8 = (int)cdiv(K, 8);
+  const int64_t total = (int64_t)36 * NT32 * Q8 * 64;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(K_WINO_PACK, (double)Cout * Cin * 9 * 4 + (double)total * 16, s);
+  hipLaunchKernelGGL(k_wino4_pack, dim3((unsigned)cdiv(Q8, 4), (unsigned)NT32), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
+                     backward_data ? 1 : 0, (int)N, (int)K, sigma, NT32, Q8, (float4*)packed);
+  return check_launch("csg_wino4_pack_weights");
+}
+
+int64_t csg_wino4_conv_workspace(const csg_wino_desc* d) {
+  Wino4Params p;
+  size_t shm = 0;
+  if (w4_plan(d, p, shm, "csg_wino4_conv_workspace")) return -1;
+  w4_split_plan(p, d->act == CSG_ACT_NONE);
+  return p.ksplit > 1 ? (int64_t)p.ksplit * p.slab * 4 : 0;
+}
+
+int csg_wino4_conv(const csg_wino_desc* d, const float* x, const float* packed, const float* bias, const float* residual,
+                   const float* gate, float gate_slope, float* y, float* workspace, int64_t workspace_bytes, void* stream) {
+  Wino4Params p;
+  size_t shm = 0;
+  int rc = w4_plan(d, p, shm, "csg_wino4_conv");
+  if (rc) return rc;
+  w4_split_plan(p, d->act == CSG_ACT_NONE && bias == nullptr && residual == nullptr && gate == nullptr);
+  p.gate_slope = gate_slope;
+  CSG_REQUIRE(gate == nullptr || ((uintptr_t)gate % 16) == 0, CSG_E_UNSUPPORTED, "csg_wino4_conv: gate must be 16-byte aligned");
+  if (p.ksplit > 1 && (workspace == nullptr || workspace_bytes < (int64_t)p.ksplit * p.slab * 4)) {   // no slabs: unsplit
+    p.ksplit = 1;
+    p.sps = p.nstage;
+  }
+  float* const y_final = y;
+  if (p.ksplit > 1) {
+    CSG_REQUIRE(((uintptr_t)workspace % 16) == 0, CSG_E_UNSUPPORTED, "csg_wino4_conv: workspace must be 16-byte aligned");
+    y = workspace;
+  }
+  CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 16) == 0, CSG_E_UNSUPPORTED,
+              "csg_wino4_conv: pointers must be 16-byte aligned");
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_wino4_conv, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino4_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    attr_set[dev] = true;
+  }
+  CSG_REQUIRE(shm <= 64 * 1024, CSG_E_UNSUPPORTED, "csg_wino4_conv: %zu bytes of LDS", shm);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t grid = (int64_t)p.B * p.tby * p.tbx * p.nblocks * p.ksplit;
+  CSG_REQUIRE(grid < (1ll << 31), CSG_E_UNSUPPORTED, "csg_wino4_conv: grid too large");
+  // algorithmic FLOPs of the DIRECT convolution this replaces (2 * M * 9*Cin * Cout): what FlopCounterMode counts
+  ProfScope ps(K_WINO4_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
+  hipLaunchKernelGGL(k_wino4_conv, dim3((unsigned)grid), dim3(W4_THREADS), shm, s, p, x, (const float4*)packed, bias, residual,
+                     gate, y);
+  rc = check_launch("csg_wino4_conv");
+  if (rc == CSG_OK && p.ksplit > 1) {
+    launch_slab_reduce(workspace, p.slab, y_final, nullptr, 0, nullptr, p.ksplit, s);
+    rc = check_launch("csg_wino4_conv(slab sum)");
+  }
+  return rc;
+}
+
+}  // extern "C"

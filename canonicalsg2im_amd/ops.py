@@ -20,7 +20,7 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, WinoDesc, ch
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
     "norm_act_pair", "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "l1_mean",
-    "invalidate_weight_caches", "pack_conv_weight", "wino_pack", "wino_eligible", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
+    "invalidate_weight_caches", "pack_conv_weight", "wino_pack", "wino_eligible", "wino_variant", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
 
 
@@ -142,32 +142,45 @@ def wino_eligible(B, H, W, Cin, Cout, KH, KW, stride, pad):
             and Cin % 16 == 0 and Cout % 4 == 0 and Cout >= 32 and B * H * W >= WINO_MIN_PIXELS)
 
 
-def wino_pack(weight, backward_data, sigma=None):
-    """Transformed weights U = G g G^T of a (Cout,Cin,3,3) weight in the MFMA operand order of k_wino_conv."""
+def _wino_desc(B, H, W, Cin, Cout, act=ACT_NONE, slope=0.0):
+    d = WinoDesc()
+    d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, act, slope
+    return d
+
+
+def wino_variant(B, H, W, Cin, Cout):
+    """4: the layer runs Winograd F(4x4,3x3) (csrc/wino4.hip: maps >= 32 wide); 2: F(2x2,3x3) (csrc/wino.hip)."""
+    return 4 if lib.csg_wino4_supported(_wino_desc(B, H, W, Cin, Cout)) == 1 else 2
+
+
+def wino_pack(weight, backward_data, sigma=None, variant=2):
+    """Transformed weights U = G g G^T of a (Cout,Cin,3,3) weight in the MFMA operand order of k_wino_conv
+    (variant 2: 16 positions) or k_wino4_conv (variant 4: 36 positions)."""
     w = _f32(weight.detach())                    # any strides: contiguous and channels-last parameters alike
     Cout, Cin = w.shape[0], w.shape[1]
     N, K = (Cin, Cout) if backward_data else (Cout, Cin)
-    nbytes = lib.csg_wino_pack_bytes(N, K)
+    nbytes = lib.csg_wino4_pack_bytes(N, K) if variant == 4 else lib.csg_wino_pack_bytes(N, K)
     packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
     st = w.stride()
-    check(lib.csg_wino_pack_weights(ptr(w), st[0], st[1], st[2], st[3], Cout, Cin, 1 if backward_data else 0, ptr(sigma),
-                                    ptr(packed), stream()), "wino_pack_weights")
+    fn = lib.csg_wino4_pack_weights if variant == 4 else lib.csg_wino_pack_weights
+    check(fn(ptr(w), st[0], st[1], st[2], st[3], Cout, Cin, 1 if backward_data else 0, ptr(sigma), ptr(packed), stream()),
+          "wino_pack_weights")
     return packed
 
 
-def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what, gate=None, gate_slope=0.0):
+def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what, gate=None, gate_slope=0.0, variant=2):
     """Returns True when `gate` was folded into the launch (a launch split over the input channels has no epilogue:
     the caller applies the gate in a separate pass then)."""
-    d = WinoDesc()
-    d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, act, slope
+    d = _wino_desc(B, H, W, Cin, Cout, act, slope)
+    ws_fn, conv_fn = (lib.csg_wino4_conv_workspace, lib.csg_wino4_conv) if variant == 4 else \
+        (lib.csg_wino_conv_workspace, lib.csg_wino_conv)
     ws, nws = None, 0
     if bias is None and res is None and act == ACT_NONE:
-        nws = lib.csg_wino_conv_workspace(d)
+        nws = ws_fn(d)
         if nws > 0:
             ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32)
             gate = None
-    check(lib.csg_wino_conv(d, ptr(x), ptr(packed), ptr(bias), ptr(res), ptr(gate), gate_slope, ptr(y), ptr(ws), nws,
-                            stream()), what)
+    check(conv_fn(d, ptr(x), ptr(packed), ptr(bias), ptr(res), ptr(gate), gate_slope, ptr(y), ptr(ws), nws, stream()), what)
     return gate is not None
 
 
@@ -246,9 +259,10 @@ class _Conv2d(torch.autograd.Function):
         elif dx_range is None and wino_eligible(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
             OH, OW = IH, IW
             y = empty_nhwc(B, Cout, OH, OW, x.device)
-            up = packs[2] if (packs is not None and len(packs) > 2) else wino_pack(weight, False)
+            var = wino_variant(B, IH, IW, Cin, Cout)
+            up = _frozen_pack(packs, False, var) if (packs is not None and len(packs) > 2) else wino_pack(weight, False, None, var)
             _wino_launch(x, up, bias.detach() if bias is not None else None, res, y, B, IH, IW, Cin, Cout, act, slope,
-                         "wino_conv_fwd")
+                         "wino_conv_fwd", variant=var)
         else:
             # [Cout][KH][KW][Cin]: free for channels-last parameters (sg2im.layers.Conv2d keeps them that way)
             wp = packs[0] if packs is not None else weight.detach().permute(0, 2, 3, 1).contiguous()
@@ -307,11 +321,13 @@ class _Conv2d(torch.autograd.Function):
             _conv_launch_classes(descs, dpre, wt, ctypes_ptr_off(dx, lo), dy.device, "conv_bwd_data")
         elif ctx.needs_input_grad[0] and wino_eligible(B, IH, IW, Cout, Cin, KH, KW, stride, pad):
             # dX = conv3x3(dY, flipped W^T): the same Winograd kernel with the roles of the channel counts swapped
-            ut = ctx.packs[3] if (ctx.packs is not None and len(ctx.packs) > 3) else wino_pack(weight, True)
+            var = wino_variant(B, IH, IW, Cout, Cin)
+            ut = _frozen_pack(ctx.packs, True, var) if (ctx.packs is not None and len(ctx.packs) > 3) else \
+                wino_pack(weight, True, None, var)
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
             gated = _wino_launch(dpre, ut, None, None, dx, B, IH, IW, Cout, Cin, ACT_NONE, 0.0, "wino_conv_bwd_data",
                                  gate=x if ctx.in_act is not None else None,
-                                 gate_slope=ctx.in_act[1] if ctx.in_act is not None else 0.0) or ctx.in_act is None
+                                 gate_slope=ctx.in_act[1] if ctx.in_act is not None else 0.0, variant=var) or ctx.in_act is None
         elif ctx.needs_input_grad[0]:
             wt = ctx.packs[1] if ctx.packs is not None else \
                 weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]
@@ -368,8 +384,20 @@ def pack_conv_weight(weight):
     w = F.pad(weight.detach(), (0, 0, 0, 0, 0, pc)) if pc else weight.detach()
     out = (w.permute(0, 2, 3, 1).contiguous(), w.permute(1, 2, 3, 0).contiguous())
     if WINO_ENABLED and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[0] % 4 == 0:
-        out = out + (wino_pack(w, False), wino_pack(w, True))
+        # F(2x2,3x3) operands now; the F(4x4,3x3) ones (maps >= 32 wide) are added on first use (_frozen_pack)
+        out = out + (wino_pack(w, False), wino_pack(w, True), {"w": w})
     return out
+
+
+def _frozen_pack(packs, backward_data, variant):
+    """The Winograd operand of a frozen weight for the kernel variant a call site runs (packs from pack_conv_weight)."""
+    if variant == 2:
+        return packs[3 if backward_data else 2]
+    cache = packs[4]
+    key = ("bwd" if backward_data else "fwd", variant)
+    if key not in cache:
+        cache[key] = wino_pack(cache["w"], backward_data, None, variant)
+    return cache[key]
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, residual=None, packs=None,

@@ -46,6 +46,7 @@ const char* csg_last_error(void);
 
 /* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline) -------
  * mode 0 = off, 1 = every launch, 2 = only the dominant convolution kernels (k_wino_conv2<*> and k_igemm_fwd<128>):
+ * 3 = only the streaming (HBM-bound) kernels: normalisation, activation, layout, graph gathers, resampling;
  * an event pair costs ~9 us of queue time, 10 ms per step when all ~1100 launches carry one, 2 ms in mode 2. */
 int csg_prof_enable(int mode);
 int csg_prof_reset(void);
@@ -219,6 +220,21 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
 int64_t csg_wino_bwd_weight_workspace(const csg_wino_desc* d);
 int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy, float* dw, float* db, float* workspace,
                         int64_t workspace_bytes, void* stream);
+
+/* ---- K8w4: the same 3x3 / stride 1 / pad 1 layers by Winograd F(4x4,3x3) (csrc/wino4.hip) ------------------------
+ * 36 multiplications per 4x4 output tile and (cin,cout) pair — 2.25 per output where F(2x2,3x3) needs 4 — on maps at
+ * least 32 pixels wide (H, W multiples of 4, H >= 16, Cin a multiple of 8); interpolation points {0, 1, -1, 1/2, -2,
+ * inf}, error against fp64 < 1e-5 of the output scale (tests/test_gpu_wino4.py).  Same descriptor, arguments and
+ * epilogue as csg_wino_conv; the packed operand has 36 positions (csg_wino4_pack_bytes / csg_wino4_pack_weights, same
+ * arguments as the F(2x2,3x3) pack).  csg_wino4_supported(d) = 1 when a layer is served (0 also when CSG_WINO4=0).   */
+int32_t csg_wino4_supported(const csg_wino_desc* d);
+int64_t csg_wino4_pack_bytes(int64_t N, int64_t K);
+int csg_wino4_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int64_t Cout, int64_t Cin,
+                           int32_t backward_data, const float* sigma, float* packed, void* stream);
+int64_t csg_wino4_conv_workspace(const csg_wino_desc* d);
+int csg_wino4_conv(const csg_wino_desc* d, const float* x, const float* packed, const float* bias,
+                   const float* residual, const float* gate, float gate_slope, float* y, float* workspace,
+                   int64_t workspace_bytes, void* stream);
 
 /* ---- K8n: stride-1 convolutions with at most four output channels (csrc/fewn.hip) --------------------------------
  * `conv_img` (generator.py:46,120-121: 64 -> 3, 3x3, pad 1, tanh behind it) and the PatchGAN prediction heads

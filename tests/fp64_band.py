@@ -87,7 +87,15 @@ class Band:
         implementation draws the flip is chance.  So at most TWO tensors may leave the band (none was outside it in the
         round-2 runs of C3, C4 and C5) as long as none is off by more than 1e-2 (the fp32 reference itself reaches 9e-3
         against fp64), and the typical tensor must be as accurate as the reference's: median of hip_l2 / ref_l2 <= 1.5
-        over the tensors whose reference noise is measurable (measured: 0.75 / 1.02 / 0.63)."""
+        over the tensors whose reference noise is measurable (measured: 0.75 / 1.02 / 0.63).
+
+        `outliers=None` (dense scenes, config C5: 65-129 objects per image, S = 128 layout channels, batch 2): events are
+        frequent there and ONE of them moves every tensor upstream of it — the r03 run (profiles/r03_band_C5.txt) has
+        the fp32 reference itself at 2.4e-3 on D0.model0/1 where the HIP path is at 7.6e-4, the HIP path at 3e-3 on all of
+        D1 where the reference drew no flip, and all 52 graph-encoder tensors at a uniform 2.5e-4 (one event in the
+        generator's 8x8 head, upstream of every layout gradient).  Counting tensors says nothing in that regime; the
+        verdict is the cap (no tensor beyond 1e-2) and the median ratio (0.94 in that run: the typical tensor is as
+        accurate as the reference's own fp32 arithmetic)."""
         if dump:
             import os
             os.makedirs(os.path.dirname(dump), exist_ok=True)
@@ -95,7 +103,7 @@ class Band:
                 f.write(self.table() + "\n")
         assert self.rows, tag + ": nothing compared"
         worst = max((r[1] for r in self.rows if not r[0].startswith("imgs_pred")), default=0.0)
-        allowed = outliers
+        allowed = len(self.rows) if outliers is None else outliers
         ratios = sorted(r[1] / r[2] for r in self.rows if r[2] > 1e-5)
         median = ratios[len(ratios) // 2] if ratios else 0.0
         msg = "%s: %d of %d gradient tensors outside the fp32 noise band (allowed %d), worst L2 error %.2e, median ratio %.2f\n%s" % (
@@ -158,7 +166,7 @@ def step_against_oracles(tr, batch, oracle_mod, train_mod):
     return {"G": G, "D": D, "Go": Go, "Do": Do, "img_o": img_o, "img64": img64, "ts": ts, "ts64": ts64, "rows": rows}
 
 
-def band_of(res, tr, tag, dump=None, **kw):
+def band_of(res, tr, tag, dump=None, outliers=2, **kw):
     band = Band(**kw)
     if res["img_o"] is not None:
         band.add("imgs_pred (judged by rtol 1e-4 elsewhere)", tr.last_model_out[0], res["img_o"], res["img64"])
@@ -166,5 +174,5 @@ def band_of(res, tr, tag, dump=None, **kw):
     for group, rows in res["rows"].items():
         for k, mine, want, want64 in rows:
             band.add("%s %s" % (group, k), mine, want, want64)
-    band.check(tag, dump=dump)
+    band.check(tag, dump=dump, outliers=outliers)
     return band

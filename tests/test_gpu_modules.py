@@ -75,7 +75,9 @@ def test_spade_resblock_vs_reference(cuda):
     sd = blk.state_dict()
     for k, p in blk.named_parameters():
         if ("grad:" + k) in a:
-            assert_close(p.grad, a["grad:" + k], RTOL, 1e-5 * float(a["grad:" + k].abs().max()) + 1e-6, "d" + k)
+            # conv_0 / conv_1 biases sit in front of a BatchNorm: their true gradient is zero and both sides hold rounding
+            # noise of the size of the summed terms (~1e-6 here), hence the absolute 1e-5
+            assert_close(p.grad, a["grad:" + k], RTOL, 1e-5 * float(a["grad:" + k].abs().max()) + 1e-5, "d" + k)
     for k, v in a.items():
         if k.startswith("after:"):
             assert_close(sd[k[6:]], v, RTOL, 1e-6, "state " + k[6:])

@@ -1,0 +1,171 @@
+"""Winograd F(4x4,3x3) convolution (csrc/wino4.hip) on a real MI355X, raw C-ABI calls against an fp64 convolution.
+
+Acceptance gate of the kernel: the error against fp64 stays below 1e-5 of the output scale — on
+the shapes the generator runs (Cin = 128 SPADE gamma/beta layers, Cin up to 1024 in conv_0, 2048 input channels in
+the gamma/beta backward-data pass, split over the input channels) — next to the error of F(2x2,3x3) and of the direct
+MFMA kernel on the same data.  Geometry: ragged regions (W, H not multiples of the 32 x 16 pixel block region),
+output-channel counts that are not multiples of 32, the fused epilogue (bias, LeakyReLU, tanh, residual, gate), and
+the backward-data pass through the autograd op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+GATE = 1e-5                       # max |y - fp64| / max |fp64|
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from canonicalsg2im_amd import ops as O
+    return O
+
+
+def _desc(B, H, W, Cin, Cout, act=0, slope=0.0):
+    from canonicalsg2im_amd._lib import WinoDesc
+    d = WinoDesc()
+    d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, H, W, Cin, Cin, Cout, Cout, act, slope
+    return d
+
+
+def _raw_wino4(ops, x, w, bias=None, res=None, act=0, slope=0.0, gate=None, gate_slope=0.0, workspace=False):
+    """Direct call of the C ABI: pack + conv (forward operand)."""
+    from canonicalsg2im_amd._lib import check, lib, ptr, stream
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    d = _desc(B, H, W, Cin, Cout, act, slope)
+    assert lib.csg_wino4_supported(d) == 1
+    xd = ops.nhwc(x.cuda())
+    up = ops.wino_pack(w.cuda(), False, None, 4)
+    y = ops.empty_nhwc(B, Cout, H, W, xd.device)
+    bd = bias.cuda() if bias is not None else None
+    rd = ops.nhwc(res.cuda()) if res is not None else None
+    gd = ops.nhwc(gate.cuda()) if gate is not None else None
+    ws, nws = None, 0
+    if workspace:
+        nws = lib.csg_wino4_conv_workspace(d)
+        assert nws > 0
+        ws = torch.full((nws // 4,), float("nan"), device="cuda")
+    check(lib.csg_wino4_conv(d, ptr(xd), ptr(up), ptr(bd), ptr(rd), ptr(gd), gate_slope, ptr(y), ptr(ws), nws, stream()),
+          "wino4_conv")
+    return y
+
+
+def _data(shape, relu_in=False):
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    if relu_in:
+        x = x.clamp_min(0)                       # SPADE: the gamma/beta convolutions read actv = ReLU(mlp_shared(seg))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    return x, w, b
+
+
+def _err(y, ref64):
+    return float((y.detach().cpu().double() - ref64).abs().max() / ref64.abs().max())
+
+
+SHAPES = [
+    # B, Cin, Cout, H,  W
+    (2, 128, 256, 64, 64),      # the SPADE gamma/beta shape (Cin = 128), whole regions
+    (1, 128, 64, 32, 32),
+    (2, 32, 128, 16, 32),       # mlp_shared: 4 stages, one region row
+    (1, 64, 36, 20, 40),        # ragged regions in both directions, Cout not a multiple of 32
+    (1, 8, 32, 128, 36),        # a single stage, tall map, W = 36
+    (1, 1024, 64, 32, 32),      # long reduction: conv_0 of up_0
+    (1, 72, 100, 24, 48),       # Cin = 9 stages (odd stage count), Cout = 100
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_wino4_forward_vs_fp64(ops, shape):
+    x, w, b = _data(shape, relu_in=shape[1] == 128)
+    ref64 = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    y = _raw_wino4(ops, x, w, b)
+    e = _err(y, ref64)
+    assert e < GATE, "F(4x4,3x3) %s: error %.2e of the output scale" % (shape, e)
+    assert_close(y, ref64.float(), 1e-4, 1e-5 * float(ref64.abs().max()) + 1e-5, "wino4 fwd %s" % (shape,))
+
+
+def test_wino4_error_next_to_f2_and_direct(ops):
+    """The three fp32 paths on the same data against fp64 (printed with -s; the table is quoted in DESIGN.md)."""
+    from canonicalsg2im_amd._lib import check, lib, ptr, stream
+    rows = []
+    for shape in [(2, 128, 256, 64, 64), (1, 512, 256, 64, 64), (1, 1024, 512, 32, 32)]:
+        B, Cin, Cout, H, W = shape
+        x, w, _ = _data(shape, relu_in=Cin == 128)
+        ref64 = F.conv2d(x.double(), w.double(), None, padding=1)
+        y4 = _raw_wino4(ops, x, w)
+        xd = ops.nhwc(x.cuda())
+        y2 = ops.empty_nhwc(B, Cout, H, W, xd.device)
+        up2 = ops.wino_pack(w.cuda(), False, None, 2)
+        check(lib.csg_wino_conv(_desc(B, H, W, Cin, Cout), ptr(xd), ptr(up2), None, None, None, 0.0, ptr(y2), None, 0,
+                                stream()), "wino_conv")
+        saved = ops.WINO_ENABLED
+        ops.WINO_ENABLED = False                 # wino_eligible() reads it per call: the direct MFMA kernel runs
+        try:
+            yd = ops.conv2d(xd, w.cuda(), None, 1, 1)
+        finally:
+            ops.WINO_ENABLED = saved
+        rows.append((shape, _err(y4, ref64), _err(y2, ref64), _err(yd, ref64)))
+    print("\\nshape (B,Cin,Cout,H,W)            F(4x4,3x3)  F(2x2,3x3)  direct MFMA   (max |y - fp64| / max |fp64|)")
+    for shape, e4, e2, ed in rows:
+        print("%-32s  %.2e    %.2e    %.2e" % (shape, e4, e2, ed))
+        assert e4 < GATE and e2 < GATE and ed < GATE
+
+
+def test_wino4_epilogue(ops):
+    shape = (2, 64, 96, 32, 32)
+    x, w, b = _data(shape)
+    g = torch.Generator().manual_seed(11)
+    r = torch.randn(2, 96, 32, 32, generator=g)
+    gt = torch.randn(2, 96, 32, 32, generator=g)
+    pre = F.conv2d(x, w, b, padding=1)
+    assert_close(_raw_wino4(ops, x, w, b, None, ops.ACT_LEAKY, 0.2), F.leaky_relu(pre, 0.2), 1e-4, 2e-5, "leaky epilogue")
+    assert_close(_raw_wino4(ops, x, w, b, None, ops.ACT_TANH, 0.0), torch.tanh(pre), 1e-4, 2e-5, "tanh epilogue")
+    assert_close(_raw_wino4(ops, x, w, b, r), pre + r, 1e-4, 2e-5, "residual epilogue")
+    want = F.conv2d(x, w, None, padding=1) * torch.where(gt > 0, torch.ones_like(gt), torch.full_like(gt, 0.2))
+    assert_close(_raw_wino4(ops, x, w, None, None, gate=gt, gate_slope=0.2), want, 1e-4, 2e-5, "gate epilogue")
+
+
+@pytest.mark.parametrize("shape", [(1, 2048, 128, 32, 32), (2, 1024, 64, 16, 32)])
+def test_wino4_split_over_input_channels(ops, shape):
+    """Backward-data of the gamma/beta convolutions at 32 x 32: few blocks, 2048 input channels — slabs over the input
+    channels + an ordered sum; bit-identical from run to run, same values as the unsplit launch up to association."""
+    from canonicalsg2im_amd._lib import lib
+    B, Cin, Cout, H, W = shape
+    x, w, _ = _data(shape)
+    ref64 = F.conv2d(x.double(), w.double(), None, padding=1)
+    d = _desc(B, H, W, Cin, Cout)
+    nws = lib.csg_wino4_conv_workspace(d)
+    assert nws > 0 and nws % (B * H * W * Cout * 4) == 0 and nws // (B * H * W * Cout * 4) >= 2
+    a = _raw_wino4(ops, x, w, workspace=True)
+    b2 = _raw_wino4(ops, x, w, workspace=True)
+    assert torch.equal(a, b2)
+    y0 = _raw_wino4(ops, x, w)                                   # no workspace: unsplit
+    assert _err(a, ref64) < GATE and _err(y0, ref64) < GATE
+    scale = float(ref64.abs().max())
+    assert_close(a, y0, 1e-4, 1e-5 * scale + 1e-5, "wino4 split vs unsplit %s" % (shape,))
+    d.act = 1
+    assert lib.csg_wino4_conv_workspace(d) == 0                  # with an epilogue the plan never splits
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 256, 32, 64), (1, 64, 64, 64, 32)])
+def test_wino4_backward_data_through_autograd(ops, shape):
+    """conv2d on a >= 32-wide map: forward and backward-data both run F(4x4,3x3) (the weight gradient stays on
+    F(3x3,2x2)); gradients against the fp64 reference."""
+    B, Cin, Cout, H, W = shape
+    assert ops.wino_variant(B, H, W, Cin, Cout) == 4 and ops.wino_variant(B, H, W, Cout, Cin) == 4
+    x, w, b = _data(shape)
+    gy = torch.randn(B, Cout, H, W, generator=torch.Generator().manual_seed(3))
+    xr, wr, br = [t.clone().double().requires_grad_(True) for t in (x, w, b)]
+    F.conv2d(xr, wr, br, padding=1).backward(gy.double())
+    xd, wd, bd = [t.clone().cuda().requires_grad_(True) for t in (x, w, b)]
+    y = ops.conv2d(ops.nhwc(xd), wd, bd, 1, 1)
+    y.backward(ops.nhwc(gy.cuda()))
+    for name, mine, want in (("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
+        e = _err(mine, want.detach())
+        assert e < GATE, "%s %s: error %.2e of the gradient scale" % (name, shape, e)

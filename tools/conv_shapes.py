@@ -45,16 +45,22 @@ def shapes(H, S=32, ngf=64, ndf=64):
     return out
 
 
-def timeit(fn, iters=3):
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+def timeit(fn, iters=12, warmup=3):
+    """Median of `iters` individually timed calls after `warmup` untimed ones.  All calls are enqueued back to back
+    with their own event pair and resolved after ONE synchronisation, so the host runs ahead of the GPU (no launch
+    latency inside a pair) and the caching allocator is in steady state (every call re-uses the blocks the warm-ups
+    left).  The median drops the occasional outlier (an allocator miss, a clock ramp) that a 3-call mean let through."""
+    for _ in range(warmup):
         fn()
-    e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for e0, e1 in ev:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    return ts[len(ts) // 2]
 
 
 def main():
