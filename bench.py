@@ -226,9 +226,9 @@ def main():
             torch.cuda.synchronize()
             pg = _lib.prof_read()
             _lib.prof_enable(0)
-            alg = sum(pg.get(k, (0.0, 0, 0.0))[2] for k in ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad"))
-            exe = sum(pg.get(k, (0.0, 0, 0.0))[2] * (4.0 / 9.0 if k.startswith("wino") else 1.0)
-                      for k in ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad"))
+            alg = sum(pg.get(k, (0.0, 0, 0.0))[2] for k in ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad", "wino4_conv"))
+            exe = sum(pg.get(k, (0.0, 0, 0.0))[2] * {"wino_conv": 4.0 / 9.0, "wino_wgrad": 4.0 / 9.0, "wino4_conv": 0.25}.get(k, 1.0)
+                      for k in ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad", "wino4_conv"))
             gen_exec_ratio = exe / alg if alg > 0 else None
 
     # the reference's DEFAULT recipe keeps the VGG perceptual term (scripts/args.py:153-154); the headline above is
@@ -285,8 +285,9 @@ def main():
     # is the ALGORITHMIC FLOP count (2*M*9*Cin*Cout, what FlopCounterMode counts for the layer); the matrix pipe EXECUTES
     # 4/9 of it.  Every `frac` below is executed FLOPs / time / peak (a hardware utilisation, <= 1 by construction);
     # the algorithmic rate is reported beside it as `algorithmic` / `algorithmic_over_peak` (it may exceed 1).
-    EXEC = {"wino_conv": 4.0 / 9.0, "wino_wgrad": 4.0 / 9.0}
-    mfma_kernels = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad")
+    # (F(4x4,3x3): 36 multiplications per 16 outputs where the direct sum needs 144 -> 1/4)
+    EXEC = {"wino_conv": 4.0 / 9.0, "wino_wgrad": 4.0 / 9.0, "wino4_conv": 0.25}
+    mfma_kernels = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad", "wino4_conv")
 
     def mfma_rates(table, names, seconds):
         """(algorithmic TFLOP/s, executed TFLOP/s) of the launches `names` in a prof table over `seconds`."""
@@ -308,13 +309,13 @@ def main():
                           "avg_us": round(1000.0 * ms / n, 2)}
         # the dominant kernel of the step (timed inside the timed region): the Winograd 3x3 convolution when it is on,
         # else the direct implicit GEMM
-        dom = max(("wino_conv", "igemm_fwd"), key=lambda k: prof.get(k, (0.0, 0, 0.0))[0])
+        dom = max(("wino4_conv", "wino_conv", "igemm_fwd"), key=lambda k: prof.get(k, (0.0, 0, 0.0))[0])
         ms, n, work = prof.get(dom, (0.0, 0, 0.0))
         traffic = None                      # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if args.config == "C3" and H == 256 and args.batch == 16 and not args.use_img_disc and not args.vgg_loss:
-                key = "k_wino_conv2<16, 2>" if dom == "wino_conv" else "k_igemm_fwd<128>"      # the launches on maps >= 32 wide
+                key = {"wino4_conv": "k_wino4_conv_v", "wino_conv": "k_wino_conv2<16, 2>"}.get(dom, "k_igemm_fwd<128>")
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -322,10 +323,13 @@ def main():
             alg, exe = mfma_rates(prof, (dom,), ms * 1e-3)
             out["roofline"] = roof(
                 alg, exe,
-                kernel=("k_wino_conv2 (3x3 convolutions forward + backward-data, Winograd F(2x2,3x3) on fp32 MFMA, all "
-                        "instantiations)" if dom == "wino_conv" else "k_igemm_fwd (conv forward + backward-data, all shapes)"),
-                achieved_note="EXECUTED MFMA FLOPs (4/9 of the algorithmic 2*M*9*Cin*Cout for Winograd) / HIP-event time "
-                              "of the kernel's launches inside the timed region",
+                kernel={"wino4_conv": "k_wino4_conv_v (3x3 convolutions on maps >= 32 wide, forward + backward-data, Winograd "
+                                      "F(4x4,3x3) on fp32 MFMA)",
+                        "wino_conv": "k_wino_conv2 (3x3 convolutions forward + backward-data, Winograd F(2x2,3x3) on fp32 "
+                                     "MFMA, all instantiations)"}.get(dom, "k_igemm_fwd (conv forward + backward-data, all shapes)"),
+                achieved_note="EXECUTED MFMA FLOPs (1/4 of the algorithmic 2*M*9*Cin*Cout for F(4x4,3x3), 4/9 for "
+                              "F(2x2,3x3)) / kernel time of its launches inside the timed region (start/stop events bound "
+                              "to the dispatches)",
                 traffic=traffic,
                 traffic_note="HBM bytes per launch (read x2-corrected FETCH_SIZE + WRITE_SIZE, two rocprofv3 --pmc passes "
                              "of this workload, profiles/pmc_traffic.json)",

@@ -323,7 +323,7 @@ int csg_canon_build(const int64_t* objs0, const float* boxes, const float* cente
               "csg_canon_build: the eight predicate ids must be distinct");
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_CANON_BUILD, (double)B * O * O, s);
-  hipLaunchKernelGGL(k_canon_build, dim3((unsigned)B), dim3(256), 0, s, P, objs0, boxes, centers, n_objs, workspace,
+  CSG_LAUNCH(k_canon_build, dim3((unsigned)B), dim3(256), 0, s, P, objs0, boxes, centers, n_objs, workspace,
                      counts);
   return check_launch("csg_canon_build");
 }
@@ -339,7 +339,7 @@ int csg_canon_emit(const int64_t* objs0, const int64_t* n_objs, int64_t B, int64
               "csg_canon_emit: the eight predicate ids must be distinct");
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_CANON_EMIT, (double)B * T * 32, s);
-  hipLaunchKernelGGL(k_canon_emit, dim3((unsigned)B), dim3(256), 0, s, P, objs0, n_objs, workspace, counts, T,
+  CSG_LAUNCH(k_canon_emit, dim3((unsigned)B), dim3(256), 0, s, P, objs0, n_objs, workspace, counts, T,
                      triplets, triplet_type);
   return check_launch("csg_canon_emit");
 }

@@ -109,7 +109,7 @@ int csg_crop_fwd(const float* img, int64_t B, int64_t H, int64_t W, int64_t img_
   ProfScope p(K_CROP_FWD, (double)total * (C * 4 + out_cs) * 4, s);
   int64_t g = cdiv(total, 256);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(k_crop_fwd, dim3((unsigned)g), dim3(256), 0, s, img, (int)H, (int)W, (int)img_cs, (int)C, boxes,
+  CSG_LAUNCH(k_crop_fwd, dim3((unsigned)g), dim3(256), 0, s, img, (int)H, (int)W, (int)img_cs, (int)C, boxes,
                      img_idx, total, (int)HH, (int)WW, (int)out_cs, out);
   return check_launch("csg_crop_fwd");
 }
@@ -124,7 +124,7 @@ int csg_crop_bwd(const float* dout, int64_t B, int64_t H, int64_t W, int64_t img
   ProfScope p(K_CROP_BWD, (double)total * (C * 4 + out_cs) * 4, s);
   int64_t g = cdiv(total, 256);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(k_crop_bwd, dim3((unsigned)g), dim3(256), 0, s, dout, (int)H, (int)W, (int)img_cs, (int)C, boxes,
+  CSG_LAUNCH(k_crop_bwd, dim3((unsigned)g), dim3(256), 0, s, dout, (int)H, (int)W, (int)img_cs, (int)C, boxes,
                      img_idx, total, (int)HH, (int)WW, (int)out_cs, dimg);
   return check_launch("csg_crop_bwd");
 }

@@ -27,20 +27,20 @@ int check_launch(const char* what) {
   return CSG_OK;
 }
 
-// ---- timing: a pair of events per launch, resolved lazily in csg_prof_read -------------------
+// ---- timing: start / stop events bound to the kernel's own dispatch (hipExtLaunchKernel), resolved lazily in
+// csg_prof_read
 struct Rec {
   int kid;
   double work;
   hipEvent_t e0, e1;
 };
-static int g_prof = 0;   // 0 off, 1 every kernel, 2 only the dominant convolution kernels (k_wino_conv, k_igemm_fwd<128>), 3 only the streaming (HBM-bound) kernels
+static int g_prof = 0;   // 0 off, 1 every kernel, 2 only the dominant convolution kernels (k_wino*_conv, k_igemm_fwd<128>), 3 only the streaming (HBM-bound) kernels
 static std::mutex g_mu;
 static std::vector<Rec> g_pending;
 static std::vector<hipEvent_t> g_free;
 static double g_ms[K_COUNT];
 static double g_work[K_COUNT];
 static int64_t g_n[K_COUNT];
-static Rec g_cur;
 
 static bool hbm_kernel(int kid) {
   switch (kid) {
@@ -54,10 +54,17 @@ static bool hbm_kernel(int kid) {
 }
 
 bool prof_on(int kid) {
-  return g_prof == 1 || (g_prof == 2 && (kid == K_IGEMM_FWD || kid == K_WINO_CONV || kid == K_WINO4_CONV)) || (g_prof == 3 && hbm_kernel(kid));
+  return g_prof == 1 || (g_prof == 2 && (kid == K_IGEMM_FWD || kid == K_WINO_CONV || kid == K_WINO4_CONV)) ||
+         (g_prof == 3 && hbm_kernel(kid));
+}
+
+ProfCur& prof_cur() {
+  static thread_local ProfCur cur = {0, 0.0, nullptr, nullptr, false, false};
+  return cur;
 }
 
 static hipEvent_t get_event() {
+  std::lock_guard<std::mutex> lk(g_mu);
   if (!g_free.empty()) {
     hipEvent_t e = g_free.back();
     g_free.pop_back();
@@ -68,19 +75,26 @@ static hipEvent_t get_event() {
   return e;
 }
 
-void prof_begin(int kid, double work, hipStream_t s) {
-  g_mu.lock();
-  g_cur.kid = kid;
-  g_cur.work = work;
-  g_cur.e0 = get_event();
-  g_cur.e1 = get_event();
-  hipEventRecord(g_cur.e0, s);
+void prof_begin(int kid, double work) {
+  ProfCur& c = prof_cur();
+  c.kid = kid;
+  c.work = work;
+  c.e0 = get_event();
+  c.e1 = get_event();
+  c.armed = true;
+  c.used = false;
 }
 
-void prof_end(hipStream_t s) {
-  hipEventRecord(g_cur.e1, s);
-  g_pending.push_back(g_cur);
-  g_mu.unlock();
+void prof_end() {
+  ProfCur& c = prof_cur();
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (c.used) {
+    g_pending.push_back(Rec{c.kid, c.work, c.e0, c.e1});
+  } else {              // the scope launched nothing
+    g_free.push_back(c.e0);
+    g_free.push_back(c.e1);
+  }
+  c.armed = c.used = false;
 }
 
 static void resolve() {

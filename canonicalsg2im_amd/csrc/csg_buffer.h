@@ -12,6 +12,8 @@ typedef int csg_i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ csg_f32x4 csg_buf_load_x4(csg_i32x4 rsrc, int voffset, int soffset, int aux) __asm(
     "llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ csg_f32x2 csg_buf_load_x2(csg_i32x4 rsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.v2f32");
 __device__ float csg_buf_load_x1(csg_i32x4 rsrc, int voffset, int soffset, int aux) __asm(
     "llvm.amdgcn.raw.buffer.load.f32");
 

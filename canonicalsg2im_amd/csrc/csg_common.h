@@ -1,8 +1,12 @@
 // Shared host-side plumbing of libcsg_hip.so: error text, launch checking, per-kernel timing.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
+
+#include <tuple>
+#include <utility>
 
 #include "../../include/csg_hip.h"
 
@@ -60,25 +64,59 @@ enum KernelId {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
-// profiling hooks (csg_api.hip)
+// ---- per-kernel timing (csg_api.hip).  A ProfScope arms ONE launch: the next CSG_LAUNCH on this thread goes out through
+// hipExtLaunchKernel with a start and a stop event bound to the kernel's own dispatch packet, so the pair reads the
+// kernel's begin and end timestamps — what rocprofv3 reads.  The first implementation bracketed the launch with two
+// hipEventRecord markers: those are barrier packets with a system-scope release/acquire, which write back and invalidate
+// the L2 between a producer and its consumer; k_norm_apply_fwd, which normally reads the gamma/beta map its producer
+// left in L2, ran 1.7x slower under them (profiles/README.md, "what an event pair times").
 bool prof_on(int kid);
-void prof_begin(int kid, double work, hipStream_t s);
-void prof_end(hipStream_t s);
+struct ProfCur {
+  int kid;
+  double work;
+  hipEvent_t e0, e1;
+  bool armed, used;
+};
+ProfCur& prof_cur();
+void prof_begin(int kid, double work);
+void prof_end();
 
 struct ProfScope {
-  hipStream_t s;
   bool on;
-  ProfScope(int kid, double work, hipStream_t st) : s(st), on(prof_on(kid)) {
-    if (on) prof_begin(kid, work, s);
+  ProfScope(int kid, double work, hipStream_t) : on(prof_on(kid)) {
+    if (on) prof_begin(kid, work);
   }
   ~ProfScope() {
-    if (on) prof_end(s);
+    if (on) prof_end();
   }
 };
+
+template <size_t... I, typename... KArgs>
+static inline void launch_ext_impl(const void* fn, dim3 g, dim3 b, size_t shm, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                                   std::tuple<KArgs...>& stored, std::index_sequence<I...>) {
+  void* ptrs[] = {(void*)&std::get<I>(stored)...};
+  (void)hipExtLaunchKernel(fn, g, b, ptrs, shm, s, e0, e1, 0);
+}
+
+// kernel<<<g, b, shm, s>>>(args...) — or, when a ProfScope is armed on this thread, the same launch carrying its events
+template <typename... KArgs, typename... Args>
+static inline void launch(void (*kernel)(KArgs...), dim3 g, dim3 b, size_t shm, hipStream_t s, Args&&... args) {
+  ProfCur& pc = prof_cur();
+  if (pc.armed) {
+    pc.armed = false;
+    pc.used = true;
+    std::tuple<KArgs...> stored(static_cast<KArgs>(std::forward<Args>(args))...);
+    launch_ext_impl((const void*)kernel, g, b, shm, s, pc.e0, pc.e1, stored, std::index_sequence_for<KArgs...>{});
+  } else {
+    hipLaunchKernelGGL(kernel, g, b, shm, s, static_cast<KArgs>(std::forward<Args>(args))...);
+  }
+}
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace csg
+
+#define CSG_LAUNCH(kernel, grid, block, shm, stream, ...) csg::launch(kernel, grid, block, shm, stream, __VA_ARGS__)
 
 #define CSG_REQUIRE(cond, code, ...)  \
   do {                                \

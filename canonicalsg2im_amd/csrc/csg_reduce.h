@@ -74,9 +74,9 @@ static inline void launch_slab_reduce(const float* ws_w, int64_t n_w, float* out
   SlabSeg b{(const float4*)ws_b, (float4*)out_b, n_b / 4, (int)((n_b / 4 + per - 1) / per)};
   const unsigned grid = (unsigned)(a.blocks + b.blocks);
   if (wide)
-    hipLaunchKernelGGL(k_slab_reduce<1>, dim3(grid), dim3(256), 0, s, a, b, nsplit);
+    CSG_LAUNCH(k_slab_reduce<1>, dim3(grid), dim3(256), 0, s, a, b, nsplit);
   else
-    hipLaunchKernelGGL(k_slab_reduce<0>, dim3(grid), dim3(256), 0, s, a, b, nsplit);
+    CSG_LAUNCH(k_slab_reduce<0>, dim3(grid), dim3(256), 0, s, a, b, nsplit);
 }
 
 }  // namespace csg

@@ -350,7 +350,7 @@ static void few_launch_fwd(const FewParams& p, const FewFwdPlan& f, const float*
     (void)hipFuncSetAttribute((const void*)k_few_fwd<KH, KW, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_few_fwd<KH, KW, NR>), dim3((unsigned)f.grid), dim3(256), f.shm, s, p, x, w, bias, out, f.TX, f.ksplit,
+  CSG_LAUNCH((k_few_fwd<KH, KW, NR>), dim3((unsigned)f.grid), dim3(256), f.shm, s, p, x, w, bias, out, f.TX, f.ksplit,
                      f.cps, f.slab);
 }
 
@@ -397,7 +397,7 @@ int csg_conv_few_fwd(const csg_few_desc* d, const float* x, const float* w, cons
   rc = check_launch("csg_conv_few_fwd");
   if (rc == CSG_OK && f.ksplit > 1) {
     const int64_t npix = (int64_t)p.B * p.OH * p.OW;
-    hipLaunchKernelGGL(k_few_finish, dim3((unsigned)cdiv(npix, 256)), dim3(256), 0, s, p, (const float4*)workspace, f.ksplit,
+    CSG_LAUNCH(k_few_finish, dim3((unsigned)cdiv(npix, 256)), dim3(256), 0, s, p, (const float4*)workspace, f.ksplit,
                        npix, bias, (float4*)y);
     rc = check_launch("csg_conv_few_fwd(finish)");
   }
@@ -407,13 +407,13 @@ int csg_conv_few_fwd(const csg_few_desc* d, const float* x, const float* w, cons
 #define FEW_DISPATCH(KERNEL, ...)                                                                  \
   do {                                                                                             \
     if (d->KH == 3) {                                                                              \
-      if (p.nreal == 1) hipLaunchKernelGGL((KERNEL<3, 3, 1>), __VA_ARGS__);                        \
-      else if (p.nreal == 2) hipLaunchKernelGGL((KERNEL<3, 3, 2>), __VA_ARGS__);                   \
-      else if (p.nreal == 3) hipLaunchKernelGGL((KERNEL<3, 3, 3>), __VA_ARGS__);                   \
-      else hipLaunchKernelGGL((KERNEL<3, 3, 4>), __VA_ARGS__);                                     \
+      if (p.nreal == 1) CSG_LAUNCH((KERNEL<3, 3, 1>), __VA_ARGS__);                        \
+      else if (p.nreal == 2) CSG_LAUNCH((KERNEL<3, 3, 2>), __VA_ARGS__);                   \
+      else if (p.nreal == 3) CSG_LAUNCH((KERNEL<3, 3, 3>), __VA_ARGS__);                   \
+      else CSG_LAUNCH((KERNEL<3, 3, 4>), __VA_ARGS__);                                     \
     } else {                                                                                       \
-      if (p.nreal == 1) hipLaunchKernelGGL((KERNEL<4, 4, 1>), __VA_ARGS__);                        \
-      else hipLaunchKernelGGL((KERNEL<4, 4, 2>), __VA_ARGS__);                                     \
+      if (p.nreal == 1) CSG_LAUNCH((KERNEL<4, 4, 1>), __VA_ARGS__);                        \
+      else CSG_LAUNCH((KERNEL<4, 4, 2>), __VA_ARGS__);                                     \
     }                                                                                              \
   } while (0)
 

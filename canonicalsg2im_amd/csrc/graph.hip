@@ -555,7 +555,7 @@ int csg_embed_fwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const fl
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_EMBED_FWD, (double)rows * dim * 8, s);
   int64_t n = rows * dim;
-  hipLaunchKernelGGL(k_embed_fwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, idx, rows, idx_stride, table, num_emb,
+  CSG_LAUNCH(k_embed_fwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, idx, rows, idx_stride, table, num_emb,
                      dim, out, out_stride, out_off);
   return check_launch("csg_embed_fwd");
 }
@@ -568,11 +568,11 @@ int csg_embed_bwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const fl
   ProfScope p(K_EMBED_BWD, (double)rows * dim * 8, s);
   int64_t n = rows * dim;
   if (num_emb * dim <= 8192 && rows >= 4 * EMB_ROWS_PER_BLOCK) {
-    hipLaunchKernelGGL(k_embed_bwd_lds, dim3((unsigned)cdiv(rows, EMB_ROWS_PER_BLOCK)), dim3(256),
+    CSG_LAUNCH(k_embed_bwd_lds, dim3((unsigned)cdiv(rows, EMB_ROWS_PER_BLOCK)), dim3(256),
                        (size_t)(num_emb * dim) * sizeof(float), s, idx, rows, idx_stride, dout, out_stride, out_off,
                        (int)num_emb, (int)dim, dtable);
   } else {
-    hipLaunchKernelGGL(k_embed_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, idx, rows, idx_stride, dout,
+    CSG_LAUNCH(k_embed_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, idx, rows, idx_stride, dout,
                        out_stride, out_off, num_emb, dim, dtable);
   }
   return check_launch("csg_embed_bwd");
@@ -584,7 +584,7 @@ int csg_real_object_mask(const int64_t* objs, int64_t B, int64_t O, int64_t A, i
   if (B * O == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_OBJ_MASK, (double)B * O * 9, s);
-  hipLaunchKernelGGL(k_obj_mask, dim3((unsigned)cdiv(B * O, 256)), dim3(256), 0, s, objs, B * O, A, image_id, mask);
+  CSG_LAUNCH(k_obj_mask, dim3((unsigned)cdiv(B * O, 256)), dim3(256), 0, s, objs, B * O, A, image_id, mask);
   return check_launch("csg_real_object_mask");
 }
 
@@ -604,10 +604,10 @@ int csg_graph_csr_build(const int64_t* triplets, int64_t B, int64_t T, int64_t O
       (void)hipFuncSetAttribute((const void*)k_csr_build_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       attr = shm;
     }
-    hipLaunchKernelGGL(k_csr_build_sorted, dim3((unsigned)B), dim3(256), shm, s, triplets, (int)T, (int)O, row_ptr,
+    CSG_LAUNCH(k_csr_build_sorted, dim3((unsigned)B), dim3(256), shm, s, triplets, (int)T, (int)O, row_ptr,
                        col);
   } else {
-    hipLaunchKernelGGL(k_csr_build, dim3((unsigned)B), dim3(256), 0, s, triplets, (int)T, (int)O, row_ptr, col);
+    CSG_LAUNCH(k_csr_build, dim3((unsigned)B), dim3(256), 0, s, triplets, (int)T, (int)O, row_ptr, col);
   }
   return check_launch("csg_graph_csr_build");
 }
@@ -619,7 +619,7 @@ int csg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* tr
   hipStream_t s = (hipStream_t)stream;
   int64_t n = B * T * (2 * Din + Dp);
   ProfScope p(K_GATHER_FWD, (double)n * 8, s);
-  hipLaunchKernelGGL(k_gather_concat_fwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, obj, pred, triplets, B * T,
+  CSG_LAUNCH(k_gather_concat_fwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, obj, pred, triplets, B * T,
                      (int)O, (int)T, (int)Din, (int)Dp, out);
   return check_launch("csg_gather_concat_fwd");
 }
@@ -644,18 +644,18 @@ int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32
                 "csg_gather_concat_bwd: workspace too small (%ld bytes, need %ld)", (long)workspace_bytes, (long)need);
     float* part = (float*)workspace;
     int32_t* seg_info = ns ? (int32_t*)(part + B * ns * Din) : nullptr;
-    hipLaunchKernelGGL(k_csr_rowsum<false>, dim3((unsigned)(ns ? ns : O), (unsigned)B), dim3(256), 0, s, dcat,
+    CSG_LAUNCH(k_csr_rowsum<false>, dim3((unsigned)(ns ? ns : O), (unsigned)B), dim3(256), 0, s, dcat,
                        (const float*)nullptr, (const uint8_t*)nullptr, row_ptr, col, (int)O, (int)T, (int)Din,
                        (int)(2 * Din + Dp), 0, (int)(Din + Dp), rowsum_lpe(Din), (int)ns, dobj, (float*)nullptr, part,
                        (float*)nullptr, seg_info);
     if (ns)
-      hipLaunchKernelGGL(k_rowsum_finish<false>, dim3((unsigned)(B * O)), dim3(1024), 0, s, (const float*)part,
+      CSG_LAUNCH(k_rowsum_finish<false>, dim3((unsigned)(B * O)), dim3(1024), 0, s, (const float*)part,
                          (const float*)nullptr, (const int32_t*)seg_info, (int)O, (int)Din, rowsum_lpe(Din), (int)ns, dobj,
                          (float*)nullptr);
   }
   if (dpred && T > 0) {
     int64_t n = B * T * Dp;
-    hipLaunchKernelGGL(k_slice_copy, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, dcat, B * T,
+    CSG_LAUNCH(k_slice_copy, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, dcat, B * T,
                        (int)(2 * Din + Dp), (int)Din, (int)Dp, dpred);
   }
   return check_launch("csg_gather_concat_bwd");
@@ -682,16 +682,16 @@ int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid,
   float* part = (float*)workspace;
   float* part_cnt = ns ? part + B * ns * H : nullptr;
   int32_t* seg_info = ns ? (int32_t*)(part_cnt + B * ns) : nullptr;
-  hipLaunchKernelGGL(k_csr_rowsum<true>, dim3((unsigned)(ns ? ns : O), (unsigned)B), dim3(256), 0, s, h, conf, valid,
+  CSG_LAUNCH(k_csr_rowsum<true>, dim3((unsigned)(ns ? ns : O), (unsigned)B), dim3(256), 0, s, h, conf, valid,
                      row_ptr, col, (int)O, (int)T, (int)H, (int)(2 * H + Dp), 0, (int)(H + Dp), rowsum_lpe(H), (int)ns,
                      pooled, cnt, part, part_cnt, seg_info);
   if (ns)
-    hipLaunchKernelGGL(k_rowsum_finish<true>, dim3((unsigned)(B * O)), dim3(1024), 0, s, (const float*)part,
+    CSG_LAUNCH(k_rowsum_finish<true>, dim3((unsigned)(B * O)), dim3(1024), 0, s, (const float*)part,
                        (const float*)part_cnt, (const int32_t*)seg_info, (int)O, (int)H, rowsum_lpe(H), (int)ns, pooled,
                        cnt);
   if (new_p && Dp > 0 && T > 0) {
     int64_t n = B * T * Dp;
-    hipLaunchKernelGGL(k_scale_slice, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, h, conf, B * T,
+    CSG_LAUNCH(k_scale_slice, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, h, conf, B * T,
                        (int)(2 * H + Dp), (int)H, (int)Dp, new_p);
   }
   return check_launch("csg_segment_avg_fwd");
@@ -705,9 +705,9 @@ int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* 
   if (T == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_SEGAVG_BWD, (double)B * T * (2.0 * H + Dp) * 8, s);   // h read + dh written (dpooled rows are L2 hits)
-  hipLaunchKernelGGL(k_segavg_dcnt, dim3((unsigned)(B * O)), dim3(64), 0, s, dpooled, pooled, cnt, (int)H,
+  CSG_LAUNCH(k_segavg_dcnt, dim3((unsigned)(B * O)), dim3(64), 0, s, dpooled, pooled, cnt, (int)H,
                      dcnt_scratch);
-  hipLaunchKernelGGL(k_segment_avg_bwd, dim3((unsigned)(B * T)), dim3(64), 0, s, dpooled, dnew_p, h, conf, valid,
+  CSG_LAUNCH(k_segment_avg_bwd, dim3((unsigned)(B * T)), dim3(64), 0, s, dpooled, dnew_p, h, conf, valid,
                      triplets, cnt, dcnt_scratch, (int)O, (int)T, (int)H, (int)Dp, dh, dconf);
   return check_launch("csg_segment_avg_bwd");
 }

@@ -850,7 +850,7 @@ static int launch_fwd(IgemmParams& p, const float* x, const float* w, const floa
     CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_conv_fwd: hipFuncSetAttribute(%zu bytes of LDS): %s", shm, hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_igemm_fwd<BN>, dim3((unsigned)fwd_grid(p)), dim3(256), shm, s, p, x, w, bias, res, y, ws);
+  CSG_LAUNCH(k_igemm_fwd<BN>, dim3((unsigned)fwd_grid(p)), dim3(256), shm, s, p, x, w, bias, res, y, ws);
   return check_launch("csg_conv_fwd");
 }
 
@@ -873,7 +873,7 @@ static int launch_wgrad(IgemmParams& p, const float* x, const float* dy, float* 
     CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_conv_bwd_weight: hipFuncSetAttribute(%zu bytes of LDS): %s", shm, hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_igemm_wgrad<BI>, dim3((unsigned)(itiles * jtiles * nsplit)), dim3(256), shm, s, p, x, dy, out,
+  CSG_LAUNCH(k_igemm_wgrad<BI>, dim3((unsigned)(itiles * jtiles * nsplit)), dim3(256), shm, s, p, x, dy, out,
                      itiles, jtiles, nsplit, cps, dbp);
   return check_launch("csg_conv_bwd_weight");
 }
@@ -926,7 +926,7 @@ static int launch_fwd_multi(IgemmMulti& mp, int n, int max_blocks, const float* 
     CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_conv_fwd_multi: hipFuncSetAttribute(%zu bytes of LDS): %s", shm, hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_igemm_fwd<BN, true>), dim3((unsigned)max_blocks, (unsigned)n), dim3(256), shm, s, mp, x, w, bias, res,
+  CSG_LAUNCH((k_igemm_fwd<BN, true>), dim3((unsigned)max_blocks, (unsigned)n), dim3(256), shm, s, mp, x, w, bias, res,
                      y, ws);
   return check_launch("csg_conv_fwd_multi");
 }
@@ -972,7 +972,7 @@ int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const f
     const int64_t n4 = (int64_t)(p.M - p.tail_m0) * d->Cout / 4;
     int64_t g = cdiv(n4, 256);
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_splitk_epilogue<false>, dim3((unsigned)g), dim3(256), 0, s, p, workspace, bias, residual, y);
+    CSG_LAUNCH(k_splitk_epilogue<false>, dim3((unsigned)g), dim3(256), 0, s, p, workspace, bias, residual, y);
     rc = check_launch("csg_conv_fwd(split-K epilogue)");
   }
   return rc;
@@ -1022,7 +1022,7 @@ int csg_conv_fwd_multi(const csg_conv_desc* descs, int32_t n, const float* x, co
     ProfScope ps(K_SPLITK_EPI, (double)wsf * 4, s);
     int64_t g = cdiv(max_n4, 256);
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_splitk_epilogue<true>, dim3((unsigned)g, (unsigned)n), dim3(256), 0, s, mp, workspace, bias, residual,
+    CSG_LAUNCH(k_splitk_epilogue<true>, dim3((unsigned)g, (unsigned)n), dim3(256), 0, s, mp, workspace, bias, residual,
                        y);
     rc = check_launch("csg_conv_fwd_multi(split-K epilogue)");
   }

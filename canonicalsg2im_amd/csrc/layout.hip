@@ -805,7 +805,7 @@ int csg_layout_mass(const float* vecs, const float* boxes, const uint8_t* valid,
   CSG_REQUIRE(masks != nullptr && M >= 1 && M <= 1024, CSG_E_BADSHAPE, "csg_layout_mass: bad mask size %ld", (long)M);
   CSG_REQUIRE(B > 0 && B <= 65535 && O >= 0 && S > 0 && H > 0 && W > 0, CSG_E_BADSHAPE, "csg_layout_mass: bad shape");
   if (O == 0) return CSG_OK;
-  hipLaunchKernelGGL(k_layout_mass, dim3((unsigned)O, (unsigned)B), dim3(256), 0, (hipStream_t)stream, vecs, boxes, valid,
+  CSG_LAUNCH(k_layout_mass, dim3((unsigned)O, (unsigned)B), dim3(256), 0, (hipStream_t)stream, vecs, boxes, valid,
                      masks, (int)M, (int)O, (int)S, (int)H, (int)W, mass);
   return check_launch("csg_layout_mass");
 }
@@ -819,7 +819,7 @@ int csg_layout_paint(const float* vecs, const float* boxes, const float* masks, 
   CSG_REQUIRE(S % 4 == 0 && out_cs % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)out % 16) == 0, CSG_E_UNSUPPORTED,
               "csg_layout_paint: S, out_cs, out_off must be multiples of 4 (16-byte rows)");
   CSG_REQUIRE(OH <= 65535 && B <= 65535, CSG_E_UNSUPPORTED, "csg_layout_paint: OH/B too large");
-  hipLaunchKernelGGL(k_layout_paint, dim3((unsigned)cdiv(OW, 256), (unsigned)OH, (unsigned)B), dim3(256), 0,
+  CSG_LAUNCH(k_layout_paint, dim3((unsigned)cdiv(OW, 256), (unsigned)OH, (unsigned)B), dim3(256), 0,
                      (hipStream_t)stream, vecs, boxes, masks, (int)M, order, (int)O, (int)S, (int)H, (int)W, (int)OH,
                      (int)OW, out, (int)out_cs, (int)out_off);
   return check_launch("csg_layout_paint");
@@ -848,12 +848,12 @@ int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, 
     constexpr int ROWS = 4;
     const size_t shm4 = (size_t)(LAY_OB * pxc + LAY_OB * S) * 4 + (size_t)LAY_CULL * ROWS * 4 + (size_t)LAY_CULL * 4 + 16;
     dim3 grid4((unsigned)cdiv(OW, pxc), (unsigned)cdiv(OH, ROWS), (unsigned)B);
-    hipLaunchKernelGGL(k_layout_fwd_rows<ROWS>, grid4, dim3(256), shm4, s, vecs, boxes, valid, (int)O, (int)S, (int)H, (int)W,
+    CSG_LAUNCH(k_layout_fwd_rows<ROWS>, grid4, dim3(256), shm4, s, vecs, boxes, valid, (int)O, (int)S, (int)H, (int)W,
                        (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off);
     return check_launch("csg_layout_fwd");
   }
   dim3 grid((unsigned)cdiv(OW, pxc), (unsigned)OH, (unsigned)B);
-  hipLaunchKernelGGL(k_layout_fwd, grid, dim3(256), shm, s, vecs, boxes, valid, masks, (int)M, (int)O, (int)S, (int)H,
+  CSG_LAUNCH(k_layout_fwd, grid, dim3(256), shm, s, vecs, boxes, valid, masks, (int)M, (int)O, (int)S, (int)H,
                      (int)W, (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off);
   return check_launch("csg_layout_fwd");
 }
@@ -901,11 +901,11 @@ int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const flo
                          (size_t)LAY_CULL * 4 + 16;
       ProfScope p(K_LAYOUT_BWD, (double)B * OH * OW * S * 4, s);
       dim3 grid((unsigned)cdiv(OW, pxc), (unsigned)cdiv(OH, ROWS), (unsigned)B);
-      hipLaunchKernelGGL(k_layout_bwd_tiles<ROWS>, grid, dim3(256), shm, s, dout, (int)out_cs, (int)out_off, boxes, valid,
+      CSG_LAUNCH(k_layout_bwd_tiles<ROWS>, grid, dim3(256), shm, s, dout, (int)out_cs, (int)out_off, boxes, valid,
                          (int)O, (int)S, (int)H, (int)W, (int)OH, (int)OW, pxc, partial, flags);
       int rc = check_launch("csg_layout_bwd(tiles)");
       if (rc) return rc;
-      hipLaunchKernelGGL(k_layout_bwd_gather, dim3((unsigned)O, (unsigned)B), dim3(256), 0, s, partial, flags, valid, (int)O,
+      CSG_LAUNCH(k_layout_bwd_gather, dim3((unsigned)O, (unsigned)B), dim3(256), 0, s, partial, flags, valid, (int)O,
                          (int)S, ntiles, dvecs, accumulate);
       return check_launch("csg_layout_bwd(gather)");
     }
@@ -926,7 +926,7 @@ int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const flo
   const size_t red = (size_t)npl * S > (size_t)bd * 4 ? (size_t)npl * S : (size_t)bd * 4;
   size_t shm = (size_t)(((OH + OW + 4) + 3) & ~3) * 4 + red * 4 + (dboxes != nullptr ? (size_t)(OH + OW) * 4 : 0);
   ProfScope p(K_LAYOUT_BWD, (double)B * OH * OW * S * 4, s);
-  hipLaunchKernelGGL(k_layout_bwd, dim3((unsigned)O, (unsigned)B), dim3((unsigned)bd), shm, s, dout, (int)out_cs, (int)out_off,
+  CSG_LAUNCH(k_layout_bwd, dim3((unsigned)O, (unsigned)B), dim3((unsigned)bd), shm, s, dout, (int)out_cs, (int)out_off,
                      boxes, valid, masks, (int)M, (int)O, (int)S, (int)H, (int)W, (int)OH, (int)OW, dvecs, accumulate,
                      vecs, dboxes);
   return check_launch("csg_layout_bwd");

@@ -417,10 +417,10 @@ int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums
   hipStream_t s = (hipStream_t)stream;
   {
     ProfScope p(K_NORM_STATS, (double)G * P * C * 4, s);
-    hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 8, s, x, P,
+    CSG_LAUNCH(k_norm_stats_partial, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 8, s, x, P,
                        (int)C, C, (int)nchunk, partial);
   }
-  hipLaunchKernelGGL(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
+  CSG_LAUNCH(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
                      (int)(2 * C), (int)nchunk, (int)(2 * C), sums);
   return check_launch("csg_norm_stats");
 }
@@ -431,7 +431,7 @@ int csg_norm_finalize(const double* sums, int64_t G, int64_t C, double count, fl
   CSG_REQUIRE(running_mean == nullptr || G == 1, CSG_E_UNSUPPORTED, "csg_norm_finalize: running stats need G == 1");
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_NORM_FINALIZE, (double)G * C * 24, s);
-  hipLaunchKernelGGL(k_norm_finalize, dim3((unsigned)cdiv(G * C, 256)), dim3(256), 0, s, sums, (int)G, (int)C, count,
+  CSG_LAUNCH(k_norm_finalize, dim3((unsigned)cdiv(G * C, 256)), dim3(256), 0, s, sums, (int)G, (int)C, count,
                      eps, mode, mean, invstd, running_mean, running_var, momentum);
   return check_launch("csg_norm_finalize");
 }
@@ -444,7 +444,7 @@ int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, c
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = G * P * C / 4;
   ProfScope p(K_NORM_APPLY_FWD, (double)G * P * C * 4 * ((gb ? 4 : 2) + (y2 ? 3 : 0)), s);
-  hipLaunchKernelGGL(k_norm_apply_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, mean, invstd, gb, slope, P, (int)C, n4, y, gb2,
+  CSG_LAUNCH(k_norm_apply_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, mean, invstd, gb, slope, P, (int)C, n4, y, gb2,
                      slope2, y2);
   return check_launch("csg_norm_apply_fwd");
 }
@@ -458,10 +458,10 @@ int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean
   hipStream_t s = (hipStream_t)stream;
   {
     ProfScope p(K_NORM_BWD_REDUCE, (double)G * P * C * 4 * (gb ? 6 : 2), s);
-    hipLaunchKernelGGL(k_norm_bwd_reduce, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 8, s, dy, x, mean,
+    CSG_LAUNCH(k_norm_bwd_reduce, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 8, s, dy, x, mean,
                        invstd, gb, slope, P, (int)C, (int)nchunk, dgb, partial);
   }
-  hipLaunchKernelGGL(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
+  CSG_LAUNCH(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
                      (int)(2 * C), (int)nchunk, (int)(2 * C), dsums);
   return check_launch("csg_norm_apply_bwd_reduce");
 }
@@ -475,7 +475,7 @@ int csg_norm_apply_bwd_dx(const float* dy, const float* x, const float* mean, co
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = G * P * C / 4;
   ProfScope p(K_NORM_BWD_DX, (double)G * P * C * 4 * ((gb ? (dgb ? 4 : 5) : 3) + (dy2 ? (dgb2 ? 2 : 3) : 0)), s);
-  hipLaunchKernelGGL(k_norm_bwd_dx, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, mean, invstd, gb, slope, dsums,
+  CSG_LAUNCH(k_norm_bwd_dx, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, mean, invstd, gb, slope, dsums,
                      1.0 / count, P, (int)C, n4, dx, dy2, gb2, slope2, dgb, dgb2);
   return check_launch("csg_norm_apply_bwd_dx");
 }
@@ -485,7 +485,7 @@ int csg_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float s
   if (n == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_ACT_BWD, (double)n * 12, s);
-  hipLaunchKernelGGL(k_act_bwd, dim3(ew_grid(n)), dim3(256), 0, s, dy, y, n, act, slope, dpre);
+  CSG_LAUNCH(k_act_bwd, dim3(ew_grid(n)), dim3(256), 0, s, dy, y, n, act, slope, dpre);
   return check_launch("csg_act_bwd");
 }
 
@@ -495,9 +495,9 @@ int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out
   CSG_REQUIRE(nchunk >= 1 && nchunk <= 65535, CSG_E_BADSHAPE, "csg_colsum: bad nchunk");
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_COLSUM, (double)rows * C * 4, s);
-  hipLaunchKernelGGL(k_norm_stats_partial, dim3((unsigned)nchunk, 1), dim3(256), 256 * 8 * 8, s, x, rows, (int)C, x_cs,
+  CSG_LAUNCH(k_norm_stats_partial, dim3((unsigned)nchunk, 1), dim3(256), 256 * 8 * 8, s, x, rows, (int)C, x_cs,
                      (int)nchunk, partial);
-  hipLaunchKernelGGL(k_partial_reduce<float>, dim3((unsigned)cdiv(C, 32), 1), dim3(256), 0, s, partial, (int)(2 * C),
+  CSG_LAUNCH(k_partial_reduce<float>, dim3((unsigned)cdiv(C, 32), 1), dim3(256), 0, s, partial, (int)(2 * C),
                      (int)nchunk, (int)C, out);
   return check_launch("csg_colsum");
 }
@@ -507,7 +507,7 @@ int csg_upsample2x_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t 
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = B * 4 * H * W * C / 4;
   ProfScope p(K_UPSAMPLE_FWD, (double)n4 * 16 * 1.25, s);
-  hipLaunchKernelGGL(k_upsample2x_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, (int)H, (int)W, (int)(C / 4), n4, y);
+  CSG_LAUNCH(k_upsample2x_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, (int)H, (int)W, (int)(C / 4), n4, y);
   return check_launch("csg_upsample2x_fwd");
 }
 
@@ -516,7 +516,7 @@ int csg_upsample2x_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = B * H * W * C / 4;
   ProfScope p(K_UPSAMPLE_BWD, (double)n4 * 16 * 5, s);
-  hipLaunchKernelGGL(k_upsample2x_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, (int)H, (int)W, (int)(C / 4), n4, dx);
+  CSG_LAUNCH(k_upsample2x_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, (int)H, (int)W, (int)(C / 4), n4, dx);
   return check_launch("csg_upsample2x_bwd");
 }
 
@@ -526,7 +526,7 @@ int csg_avgpool3s2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t 
   const int64_t OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const int64_t n4 = B * OH * OW * C / 4;
   ProfScope p(K_AVGPOOL_FWD, (double)(B * H * W * C + n4 * 4) * 4, s);
-  hipLaunchKernelGGL(k_avgpool3s2_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, (int)H, (int)W, (int)OH, (int)OW,
+  CSG_LAUNCH(k_avgpool3s2_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, (int)H, (int)W, (int)OH, (int)OW,
                      (int)(C / 4), n4, y);
   return check_launch("csg_avgpool3s2_fwd");
 }
@@ -537,7 +537,7 @@ int csg_avgpool3s2_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t
   const int64_t OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const int64_t n4 = B * H * W * C / 4;
   ProfScope p(K_AVGPOOL_BWD, (double)(B * H * W * C + B * OH * OW * C) * 4, s);
-  hipLaunchKernelGGL(k_avgpool3s2_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, (int)H, (int)W, (int)OH, (int)OW,
+  CSG_LAUNCH(k_avgpool3s2_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, (int)H, (int)W, (int)OH, (int)OW,
                      (int)(C / 4), n4, dx);
   return check_launch("csg_avgpool3s2_bwd");
 }

@@ -136,7 +136,7 @@ int csg_maxpool2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C,
   const int64_t OH = H / 2, OW = W / 2;
   const int64_t n4 = B * OH * OW * C / 4;
   ProfScope p(K_MAXPOOL_FWD, (double)(B * OH * OW * C) * 5 * 4, s);
-  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, (int)H, (int)W, (int)OH, (int)OW,
+  CSG_LAUNCH(k_maxpool2_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, (int)H, (int)W, (int)OH, (int)OW,
                      (int)(C / 4), n4, y);
   return check_launch("csg_maxpool2_fwd");
 }
@@ -149,7 +149,7 @@ int csg_maxpool2_bwd(const float* dy, const float* x, int64_t B, int64_t H, int6
   const int64_t OH = H / 2, OW = W / 2;
   const int64_t n4 = B * H * W * C / 4;
   ProfScope p(K_MAXPOOL_BWD, (double)(B * H * W * C) * 2.25 * 4, s);
-  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, (int)H, (int)W, (int)OH, (int)OW,
+  CSG_LAUNCH(k_maxpool2_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, (int)H, (int)W, (int)OH, (int)OW,
                      (int)(C / 4), n4, dx);
   return check_launch("csg_maxpool2_bwd");
 }
@@ -168,8 +168,8 @@ int csg_l1_mean_fwd(const float* a, const float* b, int64_t n, float* out, void*
               (long)(nblk * sizeof(double)));
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_L1_FWD, (double)n * 2 * 4, s);
-  hipLaunchKernelGGL(k_l1_partial, dim3(nblk), dim3(256), 0, s, a, b, n / 4, (double*)workspace);
-  hipLaunchKernelGGL(k_l1_final, dim3(1), dim3(256), 0, s, (const double*)workspace, (int)nblk, 1.0 / (double)n, out);
+  CSG_LAUNCH(k_l1_partial, dim3(nblk), dim3(256), 0, s, a, b, n / 4, (double*)workspace);
+  CSG_LAUNCH(k_l1_final, dim3(1), dim3(256), 0, s, (const double*)workspace, (int)nblk, 1.0 / (double)n, out);
   return check_launch("csg_l1_mean_fwd");
 }
 
@@ -177,7 +177,7 @@ int csg_l1_mean_bwd(const float* a, const float* b, const float* gout, int64_t n
   CSG_REQUIRE(n > 0 && n % 4 == 0, CSG_E_BADSHAPE, "csg_l1_mean_bwd: n=%ld must be a positive multiple of 4", (long)n);
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_L1_BWD, (double)n * 3 * 4, s);
-  hipLaunchKernelGGL(k_l1_bwd, dim3(ew_grid(n / 4)), dim3(256), 0, s, a, b, gout, (float)(1.0 / (double)n), n / 4, da);
+  CSG_LAUNCH(k_l1_bwd, dim3(ew_grid(n / 4)), dim3(256), 0, s, a, b, gout, (float)(1.0 / (double)n), n / 4, da);
   return check_launch("csg_l1_mean_bwd");
 }
 

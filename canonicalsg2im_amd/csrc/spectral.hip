@@ -254,11 +254,11 @@ int csg_spectral_norm_fwd(const float* w, float* u, float* v, int64_t Cout, int6
   float* t = part + (int64_t)R * K;
   float* sv = t + K;
   if (iterate) {
-    hipLaunchKernelGGL(k_sn_wtu_partial, dim3((unsigned)cdiv(K, 1024), (unsigned)R), dim3(256), 0, s, w, u, (int)Cout,
+    CSG_LAUNCH(k_sn_wtu_partial, dim3((unsigned)cdiv(K, 1024), (unsigned)R), dim3(256), 0, s, w, u, (int)Cout,
                        (int)K, R, part);
-    hipLaunchKernelGGL(k_sn_wtu_reduce, dim3((unsigned)cdiv(K, 256)), dim3(64), 0, s, part, (int)K, R, t);
+    CSG_LAUNCH(k_sn_wtu_reduce, dim3((unsigned)cdiv(K, 256)), dim3(64), 0, s, part, (int)K, R, t);
   }
-  hipLaunchKernelGGL(k_sn_rowdot, dim3((unsigned)Cout), dim3(256), 0, s, w, t, (int)Cout, (int)K, eps, iterate,
+  CSG_LAUNCH(k_sn_rowdot, dim3((unsigned)Cout), dim3(256), 0, s, w, t, (int)Cout, (int)K, eps, iterate,
                      v, v_used, sv);
   const int64_t n4 = Cout * K / 4;
   int64_t grid = cdiv(n4, 256 * 4);
@@ -272,7 +272,7 @@ int csg_spectral_norm_fwd(const float* w, float* u, float* v, int64_t Cout, int6
                 (long)K);
     grid = Cout < 2048 ? Cout : 2048;
   }
-  hipLaunchKernelGGL(k_sn_scale, dim3((unsigned)grid), dim3(256), shm, s, w, sv, (int)Cout, eps, iterate, u, u_used, sigma,
+  CSG_LAUNCH(k_sn_scale, dim3((unsigned)grid), dim3(256), shm, s, w, sv, (int)Cout, eps, iterate, u, u_used, sigma,
                      n4, w_eff, (int)cl_Cin, cl_Cin ? (int)(K / cl_Cin) : 1);
   return check_launch("csg_spectral_norm_fwd");
 }
@@ -309,8 +309,8 @@ int csg_spectral_norm_bwd(const float* dweff, int64_t Cout, int64_t Cin, int64_t
   ProfScope p(K_SPECTRAL_BWD, (double)Cout * K * 4 * 4, s);
   SnGeom g{(int)Cout, (int)Cin, (int)KH, (int)KW, s0, s1, s2, s3};
   const size_t shm = (size_t)K * sizeof(float);
-  hipLaunchKernelGGL(k_sn_bwd_dot, dim3((unsigned)Cout), dim3(256), shm, s, g, dweff, w, (int)K, (double*)workspace);
-  hipLaunchKernelGGL(k_sn_bwd_dw, dim3((unsigned)Cout), dim3(256), shm, s, g, dweff, u_used, v_used, sigma,
+  CSG_LAUNCH(k_sn_bwd_dot, dim3((unsigned)Cout), dim3(256), shm, s, g, dweff, w, (int)K, (double*)workspace);
+  CSG_LAUNCH(k_sn_bwd_dw, dim3((unsigned)Cout), dim3(256), shm, s, g, dweff, u_used, v_used, sigma,
                      (const double*)workspace, (int)K, dw);
   return check_launch("csg_spectral_norm_bwd");
 }

@@ -740,7 +740,7 @@ int csg_wino_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h,
   const int64_t total = (int64_t)16 * NT32 * Q8 * 64;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(K_WINO_PACK, (double)Cout * Cin * 9 * 4 + (double)total * 16, s);
-  hipLaunchKernelGGL(k_wino_pack, dim3((unsigned)cdiv(Q8, 4), (unsigned)NT32), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
+  CSG_LAUNCH(k_wino_pack, dim3((unsigned)cdiv(Q8, 4), (unsigned)NT32), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
                      backward_data ? 1 : 0, (int)N, (int)K, sigma, NT32, Q8, (float4*)packed);
   return check_launch("csg_wino_pack_weights");
 }
@@ -811,17 +811,17 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
   if (p.variant == 2) {
     if (p.ntb == 1) {
       if (p.TW == 16)
-        hipLaunchKernelGGL((k_wino_conv2<16, 1>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+        CSG_LAUNCH((k_wino_conv2<16, 1>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
       else if (p.TW == 8)
-        hipLaunchKernelGGL((k_wino_conv2<8, 1>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+        CSG_LAUNCH((k_wino_conv2<8, 1>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
       else
-        hipLaunchKernelGGL((k_wino_conv2<4, 1>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+        CSG_LAUNCH((k_wino_conv2<4, 1>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
     } else if (p.TW == 16)
-      hipLaunchKernelGGL((k_wino_conv2<16, 2>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+      CSG_LAUNCH((k_wino_conv2<16, 2>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
     else if (p.TW == 8)
-      hipLaunchKernelGGL((k_wino_conv2<8, 2>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+      CSG_LAUNCH((k_wino_conv2<8, 2>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
     else
-      hipLaunchKernelGGL((k_wino_conv2<4, 2>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+      CSG_LAUNCH((k_wino_conv2<4, 2>), dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
     rc = check_launch("csg_wino_conv");
     if (rc == CSG_OK && p.ksplit > 1) {
       launch_slab_reduce(workspace, p.slab, y_final, nullptr, 0, nullptr, p.ksplit, s);
@@ -830,13 +830,13 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
     return rc;
   }
   if (p.TW == 32)
-    hipLaunchKernelGGL(k_wino_conv<32>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+    CSG_LAUNCH(k_wino_conv<32>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
   else if (p.TW == 16)
-    hipLaunchKernelGGL(k_wino_conv<16>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+    CSG_LAUNCH(k_wino_conv<16>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
   else if (p.TW == 8)
-    hipLaunchKernelGGL(k_wino_conv<8>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+    CSG_LAUNCH(k_wino_conv<8>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
   else
-    hipLaunchKernelGGL(k_wino_conv<4>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
+    CSG_LAUNCH(k_wino_conv<4>, dim3((unsigned)grid), dim3(256), shm, s, p, x, up, bias, residual, gate, y);
   return check_launch("csg_wino_conv");
 }
 
@@ -1188,18 +1188,18 @@ int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy,
     const dim3 grid((unsigned)(p.cblocks * p.kblocks * p.nsplit));
     if (p.nt == 2) {
       if (tsx == 16)
-        hipLaunchKernelGGL((k_wino_wgrad<16, 2>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+        CSG_LAUNCH((k_wino_wgrad<16, 2>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
       else if (tsx == 8)
-        hipLaunchKernelGGL((k_wino_wgrad<8, 2>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+        CSG_LAUNCH((k_wino_wgrad<8, 2>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
       else
-        hipLaunchKernelGGL((k_wino_wgrad<4, 2>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+        CSG_LAUNCH((k_wino_wgrad<4, 2>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
     } else {
       if (tsx == 16)
-        hipLaunchKernelGGL((k_wino_wgrad<16, 1>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+        CSG_LAUNCH((k_wino_wgrad<16, 1>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
       else if (tsx == 8)
-        hipLaunchKernelGGL((k_wino_wgrad<8, 1>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+        CSG_LAUNCH((k_wino_wgrad<8, 1>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
       else
-        hipLaunchKernelGGL((k_wino_wgrad<4, 1>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
+        CSG_LAUNCH((k_wino_wgrad<4, 1>), grid, dim3(256), shm, s, p, x, dy, workspace, dbslabs);
     }
     rc = check_launch("csg_wino_bwd_weight");
     if (rc) return rc;

@@ -15,21 +15,39 @@
 // F(2x2,3x3) 0.4e-6 / 1.3e-6; the textbook {0, +-1, +-2} reads 6.3e-6 / 1.4e-5).  tests/test_gpu_wino4.py holds the
 // kernel to < 1e-5 of the output scale against fp64.
 //
-// Work decomposition.  A block owns 32 tiles (8 x 4: 32 x 16 output pixels of one image) x 32 output channels x all 36
-// positions with SIX waves: wave w owns row xi = w — six accumulators of 32x32 (96 registers) — and two blocks are
-// resident per CU (three waves per SIMD: the partner waves' MFMAs run under a wave's transform arithmetic).
+// Work decomposition.  A block owns 32 tiles (8 x 4: 32 x 16 output pixels of one image) x 64 output channels x all 36
+// positions with TWELVE waves, one block per CU (three waves per SIMD, placed evenly by construction).
+//   * MFMA role: wave w owns row xi = w mod 6 of channel group w / 6: six accumulators of 32x32 (96 registers).
 //   * B operand (U): as in wino.hip every (position, channel group) is consumed by exactly one wave, so U never goes
-//     through LDS: MFMA operand order [xi][nu][cout/32][cin/8][lane][4], one 16-byte load per four MFMAs, L2 resident.
+//     through LDS: MFMA operand order [xi][nu][cout/32][cin/8][lane][4], one 16-byte load per four MFMAs, L2 resident,
+//     fetched three positions ahead through a ring of three registers quads.
 //   * A operand (V): the raw input region (18 x 34 pixels x 8 channels per stage) is staged in LDS with the columns
-//     de-interleaved modulo 4 (tile tx reads column 4 tx + c: consecutive tiles are consecutive 32-byte pixels of class
-//     c & 3) and the row groups skewed by two words (word(y, x, ch) = 288 y + 2 (y >> 2) + 8 ((x & 3) * 9 + (x >> 2)) +
-//     ch), which makes every ds_read_b64 of a half-wave (8 x 4 tiles) hit 32 different bank pairs.  Row xi of B^T d is
-//     a combination of five input rows with wave-uniform coefficients (scalar registers); the column transform has
-//     compile-time coefficients.  ~8 VALU per MFMA per wave.
-//   * K loop: 8 channels per LDS stage (24 MFMAs per wave), double-buffered, global loads of stage s+1 issued before
-//     the MFMAs of stage s and written to LDS after them, one barrier per stage.
+//     de-interleaved modulo 4 and the row groups skewed by two words (word(y, x, ch) = 288 y + 2 (y >> 2) +
+//     8 ((x & 3) * 9 + (x >> 2)) + ch): every ds_read_b64 of a half-wave (8 x 4 tiles) hits 32 different bank pairs.
+//     Transform role: wave w forms row xi = w mod 6 of V = B^T d B for the channel pairs 2 (w / 6) + {0, 1} (one per
+//     half-wave) — five input rows with wave-uniform coefficients (scalar registers), then the column transform with
+//     compile-time coefficients, ~96 VALU per wave and stage — and writes it to LDS in MFMA operand order
+//     [xi][nu][half][tile][4]; one stage later every wave reads the six operands of its row with one conflict-free
+//     ds_read_b128 each (four MFMAs per read).  The transform of a stage is computed ONCE per block.
+//   * K loop: 8 channels per stage (24 MFMAs per wave).  Stage k: V[k+1] from raw[k+1]; MFMAs out of V[k]; raw[k+2]
+//     (global loads issued a stage earlier) into the buffer raw[k] left; one barrier.
 //   * Epilogue: each wave reduces its row over nu (M A), the six rows meet in LDS (A^T .) two output columns at a
 //     time, 16-byte stores.
+//
+// How it got here (MI355X, B = 16; profiles/r03_wino4_notes.md).  (1) Six-wave blocks, two per CU, V formed in
+// registers by every wave: the dispatcher never co-scheduled two six-wave workgroups (a six-wave group lands 2+2+1+1 on
+// the four SIMDs and the next one needs the mirror image): half occupancy, 31 % matrix-pipe busy, 1.4x SLOWER than
+// F(2x2,3x3).  (2) Twelve-wave blocks (two channel groups): full occupancy, par with F(2x2,3x3).  Ablations of that
+// kernel on 512 -> 256 channels at 64 x 64: everything 0.64 ms; without the LDS reads of the transform 0.43; without
+// MFMAs 0.34; MFMAs + column transform only 0.38; nothing but prologue + epilogue 0.09 — the transform and the MFMAs
+// ADD UP, also when the row transform is software-pipelined one half-stage ahead into a second register set, and a
+// half-stage stagger of waves 4-7 (MI355X_MICROARCH.md, two waves per SIMD, item 9) buys 1-4 %: on this chip the fp32
+// MFMA runs at the fp32 VALU rate and VALU work of the same SIMD does not hide under it.  (3) Hence this form: the
+// transform is computed once per block instead of once per channel group (~4 instead of ~8 VALU per MFMA): 1.19-1.40x
+// FASTER than F(2x2,3x3) on the generator's shapes (128 -> 256 channels at 256 x 256: 2.07 vs 2.46 ms).
+// Two details that cost 10 %: a volatile LDS read through a GENERIC pointer becomes a FLAT load with a 64-bit address
+// of its own (w4_lds_cv2 below), and hipcc merges neighbouring ds_read_b64 into ds_read2_b64, which is served on a
+// 32-bank map in 16-lane groups where the skewed layout is 2-way conflicted.
 #include <stddef.h>
 #include <stdlib.h>
 
@@ -42,6 +60,10 @@
 using namespace csg;
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+// LDS reads that must stay single ds_read_b64 instructions: volatile (no ds_read2 merging) THROUGH an address-space-3
+// pointer — a volatile access through a generic pointer is not rewritten to LDS by the compiler and becomes a FLAT load
+// with a 64-bit address of its own (dozens of address pairs, spilled)
+typedef const volatile __attribute__((address_space(3))) csg_f32x2* w4_lds_cv2;
 
 #define W4_TW 8
 #define W4_TH 4
@@ -52,19 +74,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define W4_RS 288                 // words per staged row: 4 classes x 9 columns x 8 words (a multiple of 16)
 #define W4_BUFW (W4_R * W4_RS + 8 + 16)   // + the skew of the last row group + a dump slot for idle staging lanes
 #define W4_RSE 36                 // words per tile row of the epilogue exchange buffer (32 channels + 4)
-#define W4_NLD 4                  // float4 global loads per thread and stage (18 * 34 * 2 / 384 rounded up)
-#define W4_THREADS 384
-#ifndef W4_COLBAR
-#define W4_COLBAR 1
-#endif
-#ifndef W4_OCC
-#define W4_OCC 3
-#endif
+#define W4_NLD 2                  // float4 global loads per thread and stage (18 * 34 * 2 / 768 rounded up)
+#define W4_THREADS 768             // twelve waves: two channel groups x six rows xi
+#define W4_RBUF (6 * 2 * 32 * W4_RSE)       // words of one channel group's epilogue exchange buffer
 
 struct Wino4Params {
   int B, H, W, Cin, x_cs, Cout, y_cs;
   int tbx, tby;        // block regions per image
-  int nblocks;         // ceil(Cout / 32)
+  int nblocks;         // ceil(Cout / 64)
   int NT32, Q8;        // extents of the packed weights
   int act;
   float slope;
@@ -153,173 +170,16 @@ __global__ __launch_bounds__(256) void k_wino4_pack(const float* __restrict__ w,
     }
 }
 
-// ------------------------------------------------------------------------------------ convolution
-__global__ __launch_bounds__(W4_THREADS, W4_OCC) void k_wino4_conv(Wino4Params p, const float* __restrict__ x,
-                                                               const float4* __restrict__ up,
-                                                               const float* __restrict__ bias,
-                                                               const float* __restrict__ res,
-                                                               const float* __restrict__ gate, float* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // row xi of the transformed domain
-
-  int bid = w4_xcd_remap(blockIdx.x, gridDim.x);
-  const int split = bid % p.ksplit;              // splits of one tile are neighbours: they share the input in L2
-  bid /= p.ksplit;
-  const int nb = bid % p.nblocks;                // channel blocks of one region are adjacent (same XCD: input reuse)
-  bid /= p.nblocks;
-  const int bx = bid % p.tbx;
-  bid /= p.tbx;
-  const int by = bid % p.tby;
-  const int img = bid / p.tby;
-  const int X0 = bx * 4 * W4_TW, Y0 = by * 4 * W4_TH;
-
-  const csg_i32x4 rsX = csg_make_srd(x, (long long)p.B * p.H * p.W * p.x_cs * 4);
-  const csg_i32x4 rsU = csg_make_srd(up, (long long)36 * p.NT32 * p.Q8 * 64 * 16);
-
-  // ---- staging plan (k-invariant): element e = tid + 384 i -> (pixel, channel quad) of the 18 x 34 x 8 region
-  unsigned goff[W4_NLD];
-  unsigned loffp[W4_NLD / 2];                    // LDS word offsets / 4, two per register
-#pragma unroll
-  for (int i = 0; i < W4_NLD; ++i) {
-    const int e = tid + W4_THREADS * i;
-    goff[i] = CSG_OOB_OFF;
-    int lo = (W4_BUFW - 16) / 4 + (tid & 3);
-    if (e < W4_R * W4_C * 2) {
-      const int pix = e >> 1, c4 = e & 1;
-      const int row = pix / W4_C, col = pix - row * W4_C;
-      const int iy = Y0 + row - 1, ix = X0 + col - 1;
-      // the two-word skew of the row groups is not a multiple of a float4: it is added back when the offset is unpacked
-      lo = (row * W4_RS + ((col & 3) * W4_CQ + (col >> 2)) * W4_PS + c4 * 4) / 4 + ((row >> 2) << 13);
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-        goff[i] = (unsigned)(((img * p.H + iy) * p.W + ix) * p.x_cs + c4 * 4) * 4u;
-    }
-    if (i & 1)
-      loffp[i >> 1] |= (unsigned)lo << 16;
-    else
-      loffp[i >> 1] = (unsigned)lo;
-  }
-  csg_f32x4 st[W4_NLD];
-  auto load_stage = [&](int s) {                 // s past the end: finite garbage or zeros, never consumed
-#pragma unroll
-    for (int i = 0; i < W4_NLD; ++i) st[i] = csg_buf_load_x4(rsX, (int)goff[i], s * (W4_PS * 4), 0);
-  };
-  auto store_stage = [&](float* base) {
-#pragma unroll
-    for (int i = 0; i < W4_NLD; ++i) {
-      const unsigned lo = (i & 1) ? (loffp[i >> 1] >> 16) : (loffp[i >> 1] & 0xffffu);
-      float* dst = base + (lo & 0x1fffu) * 4 + (lo >> 13) * 2;      // float4 offset + 2 words per row group
-      *(float2*)dst = make_float2(st[i].x, st[i].y);
-      *(float2*)(dst + 2) = make_float2(st[i].z, st[i].w);
-    }
-  };
-
-  // ---- this lane's tile, the five input rows its wave combines and their coefficients (scalar registers)
-  const int j = lane & 31, h = lane >> 5;
-  const int tx = j & (W4_TW - 1), ty = j >> 3;
-  const int rb = wave == 0 ? 0 : 1;
-  const float c0 = W4_BT5[wave][0], c1 = W4_BT5[wave][1], c2 = W4_BT5[wave][2], c3 = W4_BT5[wave][3], c4c = W4_BT5[wave][4];
-  // word offset of (row 4 ty + rb, column 4 tx, channel pair h); rows 4 ty + q with q >= 4 sit in the next row group
-  // (two words of skew): of the five rows rb .. rb+4 only the fourth (q = 3 or 4) has an rb-dependent skew — it gets a
-  // base pointer of its own, every other offset is an instruction immediate
-  const float* p0 = smem + (4 * ty + rb) * W4_RS + 2 * ty + tx * W4_PS + 2 * h;
-  const float* p3 = p0 + 3 * W4_RS + 2 * rb;
-
-  // packed weights of this wave: [xi = wave][nu][nt32][q][lane]; nu and q ride in the SCALAR offset of the load
-  const unsigned uoff = nb < p.NT32 ? (unsigned)((((wave * 6) * p.NT32 + nb) * p.Q8) * 64 + lane) * 16u : CSG_OOB_OFF;
-  const int ustride = p.NT32 * p.Q8 * 1024;      // bytes between positions
-  csg_f32x4 u[6];
-  auto load_u = [&](int nu, int q) {             // operands of position nu for k-oct q (clamped past the end)
-    const int qq = min(q, p.Q8 - 1);
-    u[nu] = csg_buf_load_x4(rsU, (int)uoff, nu * ustride + qq * 1024, 0);
-  };
-
-  f32x16 acc[6];
-#pragma unroll
-  for (int nu = 0; nu < 6; ++nu)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
-
-  // Row xi of B^T d for channel pair cp of the staged oct, all six columns: 30 ds_read_b64, 60 VALU
-  float2 t[6];
-  auto rows = [&](int bufsel, int cp) {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const int co = bufsel * W4_BUFW + ((c & 3) * W4_CQ + (c >> 2)) * W4_PS + 4 * cp;
-      const float2 d0 = *(const float2*)(p0 + co);
-      const float2 d1 = *(const float2*)(p0 + co + W4_RS);
-      const float2 d2 = *(const float2*)(p0 + co + 2 * W4_RS);
-      const float2 d3 = *(const float2*)(p3 + co);
-      const float2 d4 = *(const float2*)(p0 + co + 4 * W4_RS + 2);
-      t[c].x = fmaf(c4c, d4.x, fmaf(c3, d3.x, fmaf(c2, d2.x, fmaf(c1, d1.x, c0 * d0.x))));
-      t[c].y = fmaf(c4c, d4.y, fmaf(c3, d3.y, fmaf(c2, d2.y, fmaf(c1, d1.y, c0 * d0.y))));
-#if W4_COLBAR
-      if (c & 1) __builtin_amdgcn_sched_barrier(0);   // at most two columns of raw reads in flight (registers)
-#endif
-    }
-  };
-  // column nu of (B^T d) B: v = sum_c B^T[nu][c] t[c], formed right before the two MFMAs that consume it
-  auto col = [&](int nu) -> float2 {
-    float2 v;
-#define W4_COL(F)                                                                                     \
-    {                                                                                                 \
-      const float s42 = t[4].F - t[2].F, s31 = t[3].F - t[1].F;                                        \
-      if (nu == 0) v.F = fmaf(1.5f, s31, fmaf(-2.0f, t[2].F, t[0].F + t[4].F));                        \
-      else if (nu == 1) v.F = fmaf(2.5f, t[3].F, fmaf(0.5f, t[2].F, t[4].F - t[1].F));                 \
-      else if (nu == 2) v.F = fmaf(0.5f, t[3].F, fmaf(-2.5f, t[2].F, t[4].F + t[1].F));                \
-      else if (nu == 3) v.F = fmaf(2.0f, s31, s42);                                                   \
-      else if (nu == 4) v.F = fmaf(-0.5f, s31, s42);                                                  \
-      else v.F = fmaf(1.5f, s42, fmaf(-2.0f, t[3].F, t[1].F + t[5].F));                               \
-    }
-    W4_COL(x)
-    W4_COL(y)
-#undef W4_COL
-    return v;
-  };
-  // the two MFMAs of a position are dependent (same accumulator) — free on this pipe: issue interval and dependent
-  // latency of v_mfma_f32_32x32x2_f32 are both 64 cycles
-  auto mfma_cp = [&](auto cp_tag) {
-    constexpr int cp = decltype(cp_tag)::value;
-#pragma unroll
-    for (int nu = 0; nu < 6; ++nu) {
-      const float2 v = col(nu);
-      acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(cp ? u[nu].z : u[nu].x, v.x, acc[nu], 0, 0, 0);
-      acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(cp ? u[nu].w : u[nu].y, v.y, acc[nu], 0, 0, 0);
-    }
-  };
-  auto stage = [&](int s, auto bufsel_tag) {
-    constexpr int bufsel = decltype(bufsel_tag)::value;
-    rows(bufsel, 0);
-    mfma_cp(std::integral_constant<int, 0>());
-    __builtin_amdgcn_sched_barrier(0);
-    rows(bufsel, 1);
-    load_stage(s + 1);
-    mfma_cp(std::integral_constant<int, 1>());
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int nu = 0; nu < 6; ++nu) load_u(nu, s + 1);
-    store_stage(smem + (bufsel ^ 1) * W4_BUFW);
-    __syncthreads();
-  };
-
-  const int s_begin = split * p.sps, s_end = min(p.nstage, s_begin + p.sps);
-  y += (long long)split * p.slab;
-  load_stage(s_begin);
-#pragma unroll
-  for (int nu = 0; nu < 6; ++nu) load_u(nu, s_begin);
-  store_stage(smem);
-  __syncthreads();
-  int s = s_begin;
-  for (; s + 1 < s_end; s += 2) {
-    stage(s, std::integral_constant<int, 0>());
-    stage(s + 1, std::integral_constant<int, 1>());
-  }
-  if (s < s_end) stage(s, std::integral_constant<int, 0>());
-
-  // ---- epilogue.  A^T = [[1,1,1,1,1,0],[0,1,-1,1/2,-2,0],[0,1,1,1/4,4,0],[0,1,-1,1/8,-8,1]].
+// ---- epilogue shared by the kernels below.  A^T = [[1,1,1,1,1,0],[0,1,-1,1/2,-2,0],[0,1,1,1/4,4,0],[0,1,-1,1/8,-8,1]].
+__device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[6], const Wino4Params& p, float* smem, int tid, int wave, int grp,
+                                            int j, int h, int nt32, int img, int X0, int Y0, const float* __restrict__ bias,
+                                            const float* __restrict__ res, const float* __restrict__ gate,
+                                            float* __restrict__ y) {
   // Per wave (row xi): R[b] = sum_nu M[xi][nu] A^T[b][nu]; then Y[a][b] = sum_xi A^T[a][xi] R_xi[b] through LDS, two
   // output columns b per round: rbuf[xi][b & 1][32 tiles][W4_RSE]
-  float* rbuf = smem;
+  float* rbuf = smem + grp * W4_RBUF;            // this channel group's exchange buffer
+  const int tig = tid - grp * (W4_THREADS / 2);  // thread index inside the channel group
+  __syncthreads();                               // every wave is done reading the staging buffers
 #pragma unroll
   for (int round = 0; round < 2; ++round) {
 #pragma unroll
@@ -342,9 +202,9 @@ __global__ __launch_bounds__(W4_THREADS, W4_OCC) void k_wino4_conv(Wino4Params p
       *(float4*)(rbuf + ((wave * 2 + 1) * 32 + j) * W4_RSE + ch) = make_float4(r1[0], r1[1], r1[2], r1[3]);
     }
     __syncthreads();
-    for (int item = tid; item < 512; item += W4_THREADS) {      // 32 tiles x 8 channel quads x 2 columns
+    for (int item = tig; item < 512; item += W4_THREADS / 2) {  // 32 tiles x 8 channel quads x 2 columns
       const int cq = item & 7, tile = (item >> 3) & 31, bb = item >> 8;
-      const int n = nb * 32 + cq * 4;
+      const int n = nt32 * 32 + cq * 4;
       const int ttx = tile & (W4_TW - 1), tty = tile >> 3;
       const int oy = Y0 + 4 * tty, ox = X0 + 4 * ttx + 2 * round + bb;
       if (n < p.Cout && oy < p.H && ox < p.W) {      // H and W are multiples of 4: a tile is wholly inside or outside
@@ -392,6 +252,186 @@ __global__ __launch_bounds__(W4_THREADS, W4_OCC) void k_wino4_conv(Wino4Params p
   }
 }
 
+// ------------------------------------------------------------------------------------ convolution
+// On this chip the fp32 MFMA and the fp32 VALU do not overlap on a SIMD the way the bf16 matrix pipe and the VALU do:
+// the ablations of k_wino4_conv add up (transform without MFMAs 0.25 ms + MFMAs with the column transform 0.29 ms =
+// 0.48 ms measured, software-pipelined or not), i.e. every VALU instruction of the transform costs matrix-pipe time.
+// So the transform must be computed ONCE: in k_wino4_conv both channel groups of a block form the same V in registers
+// (~8 VALU per MFMA).  Here the twelve waves split the transform of a stage without redundancy — wave w forms row
+// xi = w mod 6 of V for the channel pairs 2 (w / 6) + {0, 1} (one per half-wave) — and write it to LDS in MFMA operand
+// order; a stage later every wave reads the six operands of its own row with one conflict-free ds_read_b128 each
+// (four MFMAs per read).  ~4 VALU per MFMA, and the transform of stage s+1 is independent of the MFMAs of stage s.
+//   LDS (words): raw[2] (2 x W4_BUFW) | V[2] (2 x 9216: [xi][nu][half h][tile][4]) | per-thread offset table.
+//   Stage k (local index): produce V[k+1] from raw[k+1]; MFMAs out of V[k]; store raw[k+2]; barrier; load raw[k+3].
+#define W4_VBUF (36 * 2 * 32 * 4)
+#define W4V_RAW0 0
+#define W4V_V0 (2 * W4_BUFW)
+#define W4V_OFFTAB (2 * W4_BUFW + 2 * W4_VBUF)
+__global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, const float* __restrict__ x,
+                                                                 const float4* __restrict__ up,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ res,
+                                                                 const float* __restrict__ gate, float* __restrict__ y) {
+  static_assert(W4V_OFFTAB >= 2 * W4_RBUF, "the epilogue exchange buffers fit in front of the offset table");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave12 >= 6 ? 1 : 0;           // consumer: channel group; producer: channel pairs 2 grp + {0, 1}
+  const int wave = wave12 - 6 * grp;             // row xi of the transformed domain (both roles)
+
+  int bid = w4_xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid % p.ksplit;
+  bid /= p.ksplit;
+  const int nb = bid % p.nblocks;
+  bid /= p.nblocks;
+  const int bx = bid % p.tbx;
+  bid /= p.tbx;
+  const int by = bid % p.tby;
+  const int img = bid / p.tby;
+  const int X0 = bx * 4 * W4_TW, Y0 = by * 4 * W4_TH;
+
+  const csg_i32x4 rsX = csg_make_srd(x, (long long)p.B * p.H * p.W * p.x_cs * 4);
+  const csg_i32x4 rsU = csg_make_srd(up, (long long)36 * p.NT32 * p.Q8 * 64 * 16);
+
+  // ---- staging plan (as k_wino4_conv: two 16-byte pieces per thread and stage, offsets parked in LDS)
+  unsigned* s_off = (unsigned*)(smem + W4V_OFFTAB) + tid * 4;
+  {
+    unsigned goff[W4_NLD], loffp = 0;
+#pragma unroll
+    for (int i = 0; i < W4_NLD; ++i) {
+      const int e = tid + W4_THREADS * i;
+      goff[i] = CSG_OOB_OFF;
+      int lo = (W4_BUFW - 16) / 4 + (tid & 3);
+      if (e < W4_R * W4_C * 2) {
+        const int pix = e >> 1, c4 = e & 1;
+        const int row = pix / W4_C, col = pix - row * W4_C;
+        const int iy = Y0 + row - 1, ix = X0 + col - 1;
+        lo = (row * W4_RS + ((col & 3) * W4_CQ + (col >> 2)) * W4_PS + c4 * 4) / 4 + ((row >> 2) << 13);
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+          goff[i] = (unsigned)(((img * p.H + iy) * p.W + ix) * p.x_cs + c4 * 4) * 4u;
+      }
+      loffp |= (unsigned)lo << (16 * i);
+    }
+    *(uint4*)s_off = make_uint4(goff[0], goff[1], loffp, 0u);
+  }
+  csg_f32x4 st[W4_NLD];
+  auto load_stage = [&](int s) {                 // s past the end: finite garbage or zeros, never consumed
+    const uint2 go = *(const uint2*)s_off;
+    st[0] = csg_buf_load_x4(rsX, (int)go.x, s * (W4_PS * 4), 0);
+    st[1] = csg_buf_load_x4(rsX, (int)go.y, s * (W4_PS * 4), 0);
+  };
+  auto store_stage = [&](float* base) {
+    const unsigned lp = s_off[2];
+#pragma unroll
+    for (int i = 0; i < W4_NLD; ++i) {
+      const unsigned lo = (i & 1) ? (lp >> 16) : (lp & 0xffffu);
+      float* dst = base + (lo & 0x1fffu) * 4 + (lo >> 13) * 2;
+      *(float2*)dst = make_float2(st[i].x, st[i].y);
+      *(float2*)(dst + 2) = make_float2(st[i].z, st[i].w);
+    }
+  };
+
+  const int j = lane & 31, h = lane >> 5;
+  const int tx = j & (W4_TW - 1), ty = j >> 3;
+  const int rb = wave == 0 ? 0 : 1;
+  const float c0 = W4_BT5[wave][0], c1 = W4_BT5[wave][1], c2 = W4_BT5[wave][2], c3 = W4_BT5[wave][3], c4c = W4_BT5[wave][4];
+  // producer: raw words of (row 4 ty + rb, column 4 tx, channel pair q = 2 grp + h)
+  const float* p0 = smem + W4V_RAW0 + (4 * ty + rb) * W4_RS + 2 * ty + tx * W4_PS + 4 * grp + 2 * h;
+  const float* p3 = p0 + 3 * W4_RS + 2 * rb;
+  // producer: V words of (xi = wave, nu = 0, half h, tile j), channel pair slot grp;  consumer: the same row, float4
+  float* pv = smem + W4V_V0 + (((wave * 6) * 2 + h) * 32 + j) * 4;
+
+  const int nt32 = nb * 2 + grp;
+  const unsigned uoff = nt32 < p.NT32 ? (unsigned)((((wave * 6) * p.NT32 + nt32) * p.Q8) * 64 + lane) * 16u : CSG_OOB_OFF;
+  const int ustride = p.NT32 * p.Q8 * 1024;
+  csg_f32x4 ur[3];                               // ring: the operands of position nu are fetched three positions ahead
+  auto load_ur = [&](int slot, int nu, int s) {
+    const int qq = min(s, p.Q8 - 1);
+    ur[slot] = csg_buf_load_x4(rsU, (int)uoff, nu * ustride + qq * 1024, 0);
+  };
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
+
+  // V[xi = wave][0..5] of (tile j, channel pair 2 grp + h) out of raw buffer rbufsel, into V buffer vbufsel
+  auto produce = [&](int rbufsel, int vbufsel) {
+    float2 t[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int co = rbufsel * W4_BUFW + ((c & 3) * W4_CQ + (c >> 2)) * W4_PS;
+      const csg_f32x2 e0 = *(w4_lds_cv2)(p0 + co);
+      const csg_f32x2 e1 = *(w4_lds_cv2)(p0 + co + W4_RS);
+      const csg_f32x2 e2 = *(w4_lds_cv2)(p0 + co + 2 * W4_RS);
+      const csg_f32x2 e3 = *(w4_lds_cv2)(p3 + co);
+      const csg_f32x2 e4 = *(w4_lds_cv2)(p0 + co + 4 * W4_RS + 2);
+      t[c].x = fmaf(c4c, e4.x, fmaf(c3, e3.x, fmaf(c2, e2.x, fmaf(c1, e1.x, c0 * e0.x))));
+      t[c].y = fmaf(c4c, e4.y, fmaf(c3, e3.y, fmaf(c2, e2.y, fmaf(c1, e1.y, c0 * e0.y))));
+    }
+    float2 v[6];
+#define W4_COLV(F)                                                                  \
+    {                                                                               \
+      const float s42 = t[4].F - t[2].F, s31 = t[3].F - t[1].F;                      \
+      v[0].F = fmaf(1.5f, s31, fmaf(-2.0f, t[2].F, t[0].F + t[4].F));               \
+      v[1].F = fmaf(2.5f, t[3].F, fmaf(0.5f, t[2].F, t[4].F - t[1].F));             \
+      v[2].F = fmaf(0.5f, t[3].F, fmaf(-2.5f, t[2].F, t[4].F + t[1].F));            \
+      v[3].F = fmaf(2.0f, s31, s42);                                                \
+      v[4].F = fmaf(-0.5f, s31, s42);                                               \
+      v[5].F = fmaf(1.5f, s42, fmaf(-2.0f, t[3].F, t[1].F + t[5].F));               \
+    }
+    W4_COLV(x)
+    W4_COLV(y)
+#undef W4_COLV
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu)
+      *(float2*)(pv + vbufsel * W4_VBUF + nu * 256 + 2 * grp) = v[nu];
+  };
+  // 24 MFMAs out of V buffer vbufsel with the U operands of k-oct s; refills the ring for k-oct s (positions 3..5)
+  // and s + 1 (positions 0..2)
+  auto consume = [&](int vbufsel, int s) {
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) {
+      const float4 v = *(const float4*)(pv + vbufsel * W4_VBUF + nu * 256);
+      const int slot = nu % 3;
+      acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[slot].x, v.x, acc[nu], 0, 0, 0);
+      acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[slot].y, v.y, acc[nu], 0, 0, 0);
+      acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[slot].z, v.z, acc[nu], 0, 0, 0);
+      acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[slot].w, v.w, acc[nu], 0, 0, 0);
+      if (nu < 3) load_ur(slot, nu + 3, s); else load_ur(slot, nu - 3, s + 1);
+    }
+  };
+  auto stage = [&](int s, auto par_tag) {        // par = (s - s_begin) & 1
+    constexpr int par = decltype(par_tag)::value;
+    produce(par ^ 1, par ^ 1);                   // V[k+1] from raw[k+1]
+    consume(par, s);                             // MFMAs of stage k out of V[k]
+    store_stage(smem + W4V_RAW0 + par * W4_BUFW);   // raw[k+2] takes the buffer raw[k] left
+    __syncthreads();
+    load_stage(s + 3);
+  };
+
+  const int s_begin = split * p.sps, s_end = min(p.nstage, s_begin + p.sps);
+  y += (long long)split * p.slab;
+  load_stage(s_begin);
+#pragma unroll
+  for (int nu = 0; nu < 3; ++nu) load_ur(nu, nu, s_begin);
+  store_stage(smem + W4V_RAW0);
+  __syncthreads();
+  load_stage(s_begin + 1);
+  produce(0, 0);                                 // V[0] from raw[0]
+  store_stage(smem + W4V_RAW0 + W4_BUFW);        // raw[1]
+  __syncthreads();
+  load_stage(s_begin + 2);
+  int s = s_begin;
+  for (; s + 1 < s_end; s += 2) {
+    stage(s, std::integral_constant<int, 0>());
+    stage(s + 1, std::integral_constant<int, 1>());
+  }
+  if (s < s_end) stage(s, std::integral_constant<int, 0>());
+  w4_epilogue(acc, p, smem, tid, wave, grp, j, h, nt32, img, X0, Y0, bias, res, gate, y);
+}
+
 // ------------------------------------------------------------------------------------ host side
 static int w4_plan(const csg_wino_desc* d, Wino4Params& p, size_t& shm, const char* who) {
   CSG_REQUIRE(d != nullptr, CSG_E_BADSHAPE, "%s: null descriptor", who);
@@ -408,7 +448,7 @@ static int w4_plan(const csg_wino_desc* d, Wino4Params& p, size_t& shm, const ch
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_cs = d->x_cs; p.Cout = d->Cout; p.y_cs = d->y_cs;
   p.tbx = (d->W + 4 * W4_TW - 1) / (4 * W4_TW);
   p.tby = (d->H + 4 * W4_TH - 1) / (4 * W4_TH);
-  p.nblocks = (d->Cout + 31) / 32;
+  p.nblocks = (d->Cout + 63) / 64;
   p.NT32 = (d->Cout + 31) / 32;
   p.Q8 = (d->Cin + 7) / 8;
   p.act = d->act; p.slope = d->slope; p.gate_slope = 0.f;
@@ -416,9 +456,7 @@ static int w4_plan(const csg_wino_desc* d, Wino4Params& p, size_t& shm, const ch
   p.ksplit = 1;
   p.sps = p.nstage;
   p.slab = (long long)d->B * d->H * d->W * d->y_cs;
-  const size_t in_bytes = (size_t)2 * W4_BUFW * 4;
-  const size_t ep_bytes = (size_t)6 * 2 * 32 * W4_RSE * 4;
-  shm = in_bytes > ep_bytes ? in_bytes : ep_bytes;
+  shm = (size_t)(W4V_OFFTAB + W4_THREADS * 4) * 4;
   return CSG_OK;
 }
 
@@ -457,7 +495,7 @@ int csg_wino4_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h
   const int64_t total = (int64_t)36 * NT32 * Q8 * 64;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(K_WINO_PACK, (double)Cout * Cin * 9 * 4 + (double)total * 16, s);
-  hipLaunchKernelGGL(k_wino4_pack, dim3((unsigned)cdiv(Q8, 4), (unsigned)NT32), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
+  CSG_LAUNCH(k_wino4_pack, dim3((unsigned)cdiv(Q8, 4), (unsigned)NT32), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
                      backward_data ? 1 : 0, (int)N, (int)K, sigma, NT32, Q8, (float4*)packed);
   return check_launch("csg_wino4_pack_weights");
 }
@@ -494,18 +532,18 @@ int csg_wino4_conv(const csg_wino_desc* d, const float* x, const float* packed, 
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wino4_conv, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_wino4_conv_v, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino4_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set[dev] = true;
   }
-  CSG_REQUIRE(shm <= 64 * 1024, CSG_E_UNSUPPORTED, "csg_wino4_conv: %zu bytes of LDS", shm);
+  CSG_REQUIRE(shm <= 128 * 1024, CSG_E_UNSUPPORTED, "csg_wino4_conv: %zu bytes of LDS", shm);
   hipStream_t s = (hipStream_t)stream;
   const int64_t grid = (int64_t)p.B * p.tby * p.tbx * p.nblocks * p.ksplit;
   CSG_REQUIRE(grid < (1ll << 31), CSG_E_UNSUPPORTED, "csg_wino4_conv: grid too large");
   // algorithmic FLOPs of the DIRECT convolution this replaces (2 * M * 9*Cin * Cout): what FlopCounterMode counts
   ProfScope ps(K_WINO4_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
-  hipLaunchKernelGGL(k_wino4_conv, dim3((unsigned)grid), dim3(W4_THREADS), shm, s, p, x, (const float4*)packed, bias, residual,
-                     gate, y);
+  CSG_LAUNCH(k_wino4_conv_v, dim3((unsigned)grid), dim3(W4_THREADS), shm, s, p, x, (const float4*)packed, bias, residual,
+             gate, y);
   rc = check_launch("csg_wino4_conv");
   if (rc == CSG_OK && p.ksplit > 1) {
     launch_slab_reduce(workspace, p.slab, y_final, nullptr, 0, nullptr, p.ksplit, s);
