@@ -104,6 +104,8 @@ SIGNATURES = {
                                           c_p]),
     "csg_norm_apply_bwd_dx": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_f64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_f32,
                                       c_p, c_p, c_p]),
+    "csg_nearest_resize_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_nearest_resize_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_upsample2x_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_upsample2x_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_avgpool3s2_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),

@@ -311,6 +311,48 @@ __global__ void k_act_bwd(const float* __restrict__ dy, const float* __restrict_
   }
 }
 
+// F.interpolate(x, size=(OH, OW), mode='nearest') on NHWC maps (reference normalization.py:98: the segmentation map is
+// resized to every SPADE layer's resolution): source index = min(floor(dst * (in / out)), in - 1) with the scale in
+// fp32, as ATen computes it.
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in) { return min((int)floorf(dst * scale), in - 1); }
+
+__global__ void k_nearest_fwd(const float* __restrict__ x, int IH, int IW, int OH, int OW, int Q, float sy, float sx,
+                              int64_t n4, float* __restrict__ y) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = e / Q;
+    const int q = (int)(e - pix * Q);
+    const int X = (int)(pix % OW);
+    const int64_t t = pix / OW;
+    const int Y = (int)(t % OH);
+    const int64_t b = t / OH;
+    st4(y + e * 4, ld4(x + (((b * IH + nearest_src(Y, sy, IH)) * IW + nearest_src(X, sx, IW)) * (int64_t)Q + q) * 4));
+  }
+}
+
+// dx[iy][ix] = sum of dy over the output pixels that read (iy, ix): a thread per input element walks its (contiguous)
+// range of output rows and columns in order — no atomics, bit-reproducible
+__global__ void k_nearest_bwd(const float* __restrict__ dy, int IH, int IW, int OH, int OW, int Q, float sy, float sx,
+                              int64_t n4, float* __restrict__ dx) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = e / Q;
+    const int q = (int)(e - pix * Q);
+    const int ix = (int)(pix % IW);
+    const int64_t t = pix / IW;
+    const int iy = (int)(t % IH);
+    const int64_t b = t / IH;
+    int y0 = max(0, (int)((float)iy / sy) - 2), x0 = max(0, (int)((float)ix / sx) - 2);
+    while (y0 < OH && nearest_src(y0, sy, IH) < iy) ++y0;
+    while (x0 < OW && nearest_src(x0, sx, IW) < ix) ++x0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int Y = y0; Y < OH && nearest_src(Y, sy, IH) == iy; ++Y)
+      for (int X = x0; X < OW && nearest_src(X, sx, IW) == ix; ++X) {
+        const float4 g = ld4(dy + (((b * OH + Y) * OW + X) * (int64_t)Q + q) * 4);
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+      }
+    st4(dx + e * 4, acc);
+  }
+}
+
 __global__ void k_upsample2x_fwd(const float* __restrict__ x, int H, int W, int Q, int64_t n4, float* __restrict__ y) {
   // y is (B, 2H, 2W, C)
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
@@ -500,6 +542,30 @@ int csg_colsum(const float* x, int64_t rows, int64_t C, int64_t x_cs, float* out
   CSG_LAUNCH(k_partial_reduce<float>, dim3((unsigned)cdiv(C, 32), 1), dim3(256), 0, s, partial, (int)(2 * C),
                      (int)nchunk, (int)C, out);
   return check_launch("csg_colsum");
+}
+
+int csg_nearest_resize_fwd(const float* x, int64_t B, int64_t IH, int64_t IW, int64_t C, int64_t OH, int64_t OW, float* y,
+                           void* stream) {
+  CSG_REQUIRE(B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE,
+              "csg_nearest_resize_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n4 = B * OH * OW * C / 4;
+  ProfScope p(K_UPSAMPLE_FWD, (double)n4 * 32, s);
+  CSG_LAUNCH(k_nearest_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, (int)IH, (int)IW, (int)OH, (int)OW, (int)(C / 4),
+             (float)IH / (float)OH, (float)IW / (float)OW, n4, y);
+  return check_launch("csg_nearest_resize_fwd");
+}
+
+int csg_nearest_resize_bwd(const float* dy, int64_t B, int64_t IH, int64_t IW, int64_t C, int64_t OH, int64_t OW, float* dx,
+                           void* stream) {
+  CSG_REQUIRE(B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE,
+              "csg_nearest_resize_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n4 = B * IH * IW * C / 4;
+  ProfScope p(K_UPSAMPLE_BWD, (double)(n4 + B * OH * OW * C / 4) * 16, s);
+  CSG_LAUNCH(k_nearest_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, (int)IH, (int)IW, (int)OH, (int)OW, (int)(C / 4),
+             (float)IH / (float)OH, (float)IW / (float)OW, n4, dx);
+  return check_launch("csg_nearest_resize_bwd");
 }
 
 int csg_upsample2x_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream) {

@@ -18,7 +18,7 @@ from . import dist as csg_dist
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, WinoDesc, check, lib, ptr, stream
 
 __all__ = [
-    "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "avgpool3s2", "embed", "real_object_mask",
+    "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "nearest_resize", "avgpool3s2", "embed", "real_object_mask",
     "norm_act_pair", "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "l1_mean",
     "invalidate_weight_caches", "pack_conv_weight", "wino_pack", "wino_eligible", "wino_variant", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
@@ -676,6 +676,33 @@ class _Upsample2x(torch.autograd.Function):
 
 def upsample2x(x):
     return _Upsample2x.apply(x)
+
+
+class _NearestResize(torch.autograd.Function):
+    """F.interpolate(x, size=(OH, OW), mode='nearest') (reference normalization.py:98)."""
+
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        x = nhwc(_f32(x))
+        B, C, IH, IW = x.shape
+        if C % 4:
+            raise RuntimeError("nearest_resize: the channel count must be a multiple of 4")
+        y = empty_nhwc(B, C, OH, OW, x.device)
+        check(lib.csg_nearest_resize_fwd(ptr(x), B, IH, IW, C, OH, OW, ptr(y), stream()), "nearest_resize_fwd")
+        ctx.shape = (B, C, IH, IW, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, IH, IW, OH, OW = ctx.shape
+        dy = nhwc(dy)
+        dx = empty_nhwc(B, C, IH, IW, dy.device)
+        check(lib.csg_nearest_resize_bwd(ptr(dy), B, IH, IW, C, OH, OW, ptr(dx), stream()), "nearest_resize_bwd")
+        return dx, None, None
+
+
+def nearest_resize(x, size):
+    return _NearestResize.apply(x, int(size[0]), int(size[1]))
 
 
 class _AvgPool3s2(torch.autograd.Function):

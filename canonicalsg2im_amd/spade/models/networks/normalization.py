@@ -7,7 +7,6 @@ import re
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .... import ops
 from ....spectral_norm import spectral_norm
@@ -38,11 +37,22 @@ class InstanceNormAct(nn.InstanceNorm2d):
         return ops.norm_act(x, gb, None, None, instance=True, training=self.training, slope=slope, eps=self.eps)
 
 
+class SyncBatchNormAct(SynchronizedBatchNorm2d):
+    """SynchronizedBatchNorm2d(affine=True) with an optional fused LeakyReLU (`fused_slope`, set by the PatchGAN)."""
+
+    def __init__(self, num_features, fused_slope=1.0):
+        super().__init__(num_features, affine=True)
+        self.fused_slope = fused_slope
+
+    def forward(self, x):
+        return super().forward(x, None, self.fused_slope)
+
+
 def get_nonspade_norm_layer(opt, norm_type='instance'):
     """Returns `wrap(conv)` for the PatchGAN layers (reference normalization.py:16-50): an optional
     `spectral` prefix applies spectral normalisation, the remainder names the activation norm that
-    follows the conv (whose bias is then dropped).  Only 'instance' (fused with the LeakyReLU behind
-    it) and 'none' are on the hot path."""
+    follows the conv (whose bias is then dropped): 'instance' (the default `spectralinstance`), 'batch',
+    'sync_batch' or 'none'; the LeakyReLU behind the norm is fused into its apply pass."""
     use_sn = norm_type.startswith('spectral')
     after = norm_type[len('spectral'):] if use_sn else norm_type
 
@@ -51,13 +61,17 @@ def get_nonspade_norm_layer(opt, norm_type='instance'):
             conv = spectral_norm(conv)
         if after in ('', 'none'):
             return conv
-        if after != 'instance':
-            raise NotImplementedError('normalization layer %s is not on the hot path (norm_D default is '
-                                      'spectralinstance)' % after)
+        if after not in ('instance', 'batch', 'sync_batch'):
+            raise ValueError('normalization layer %s is not recognized' % after)
         if getattr(conv, 'bias', None) is not None:          # a bias in front of a normalisation is a no-op
             del conv.bias
             conv.register_parameter('bias', None)
         width = getattr(conv, 'out_channels', None) or conv.weight.size(0)
+        if after == 'batch':                                 # nn.BatchNorm2d(affine=True), normalization.py:41-42
+            from ....sg2im.layers import BatchNormAct
+            return nn.Sequential(conv, BatchNormAct(width))
+        if after == 'sync_batch':                            # SynchronizedBatchNorm2d(affine=True), :43-44
+            return nn.Sequential(conv, SyncBatchNormAct(width))
         return nn.Sequential(conv, InstanceNormAct(width))
 
     return wrap
@@ -134,7 +148,7 @@ class SPADE(nn.Module):
         if isinstance(segmap, SegPyramid):
             seg = segmap.at(x.size(2))
         else:
-            seg = segmap if segmap.shape[2:] == x.shape[2:] else F.interpolate(segmap, size=x.shape[2:], mode='nearest')
+            seg = segmap if segmap.shape[2:] == x.shape[2:] else ops.nearest_resize(segmap, x.shape[2:])
         # actv = ReLU(mlp_shared(seg)) has ONE consumer, the gamma||beta convolution: the ReLU derivative is folded into
         # that convolution's backward-data epilogue (in_act), and mlp_shared's backward receives the gradient of its
         # pre-activation directly (grad_is_pre) — no separate pass over the 128-channel maps

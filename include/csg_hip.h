@@ -303,6 +303,13 @@ int csg_norm_apply_bwd_dx(const float* dy, const float* x, const float* mean, co
 
 /* ---- K7 / pooling ------------------------------------------------------------------------------
  * nearest 2x upsample (generator.py:48,102-121) and its adjoint */
+/* F.interpolate(x, size=(OH, OW), mode='nearest') of an NHWC map (B,IH,IW,C), C a multiple of 4 — the resize of the
+ * segmentation map in SPADE.forward (spade/models/networks/normalization.py:98) when the caller passes a plain tensor
+ * instead of the layout pyramid; the backward sums dy over the output pixels that read each input pixel, in order. */
+int csg_nearest_resize_fwd(const float* x, int64_t B, int64_t IH, int64_t IW, int64_t C, int64_t OH, int64_t OW, float* y,
+                           void* stream);
+int csg_nearest_resize_bwd(const float* dy, int64_t B, int64_t IH, int64_t IW, int64_t C, int64_t OH, int64_t OW, float* dx,
+                           void* stream);
 int csg_upsample2x_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
 int csg_upsample2x_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream);
 /* F.avg_pool2d(3, stride 2, pad 1, count_include_pad=False) (discriminator.py:92-93) */

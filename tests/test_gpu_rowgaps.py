@@ -153,3 +153,113 @@ def test_affine_synchronized_batchnorm_vs_reference():
     bn.eval()
     with torch.no_grad():
         assert_close(bn(a["bn_x"].cuda()), a["bn_y_eval"], RTOL, 2e-6, "affine syncbn eval")
+
+
+# ------------------------------------------------------------------ round 3: the rest of the config space
+@pytest.mark.parametrize("shape", [(2, 8, 256, 256, 8, 8), (1, 32, 64, 64, 16, 16), (2, 4, 7, 9, 20, 31), (1, 12, 33, 17, 5, 100),
+                                   (1, 4, 96, 40, 35, 13)])
+def test_nearest_resize_vs_interpolate(shape):
+    """ops.nearest_resize == F.interpolate(mode='nearest') bit for bit (forward), and its backward sums the gradient
+    over the output pixels that read an input pixel (reference normalization.py:98, when SPADE is handed a plain
+    segmentation tensor instead of the layout pyramid): integer and non-integer ratios, up- and down-sampling."""
+    from canonicalsg2im_amd import ops
+    B, C, IH, IW, OH, OW = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, C, IH, IW, generator=g)
+    w = torch.randn(B, C, OH, OW, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(OH, OW), mode='nearest')
+    (yr * w).sum().backward()
+    xd = x.clone().cuda().requires_grad_(True)
+    yd = ops.nearest_resize(xd, (OH, OW))
+    (yd * w.cuda()).sum().backward()
+    assert torch.equal(yd.detach().cpu(), yr.detach()), shape
+    assert_close(xd.grad, xr.grad, 1e-5, 1e-6, "nearest dx %s" % (shape,))
+
+
+def test_spade_with_plain_segmap_resamples_on_the_device():
+    """SPADE.forward with a (B,S,H,W) tensor as segmap — the reference's calling convention — goes through
+    ops.nearest_resize (no ATen interpolate kernel) and equals the pyramid path."""
+    from canonicalsg2im_amd import ops
+    from canonicalsg2im_amd.spade.models.networks.normalization import SPADE, SegPyramid
+    torch.manual_seed(3)
+    sp = SPADE('spadesyncbatch3x3', 32, 8).cuda().train()
+    g = torch.Generator().manual_seed(4)
+    x = ops.nhwc(torch.randn(2, 32, 16, 16, generator=g).cuda())
+    seg = ops.nhwc(torch.randn(2, 8, 64, 64, generator=g).cuda())
+    y_plain = sp(x, seg)
+    seg16 = ops.nhwc(F.interpolate(seg, size=(16, 16), mode='nearest'))
+    sp2 = SPADE('spadesyncbatch3x3', 32, 8).cuda().train()
+    sp2.load_state_dict(sp.state_dict())
+    y_pyr = sp2(x, SegPyramid({16: seg16}))
+    assert torch.equal(y_plain, y_pyr)
+
+
+@pytest.mark.parametrize("norm_D", ["spectralbatch", "spectralsync_batch", "batch", "spectralnone", "instance"])
+def test_nlayer_discriminator_norm_variants_vs_torch(norm_D):
+    """NLayerDiscriminator with every `norm_D` the reference accepts (spade/models/networks/normalization.py:16-50)
+    against the same stack built from torch.nn layers on the CPU (the reference's own construction: spectral_norm(conv)
+    -> BatchNorm2d(affine) / InstanceNorm2d -> LeakyReLU): feature maps of a training-mode forward, and the gradients
+    of the first and last weights."""
+    import argparse
+    import torch.nn as nn
+    from canonicalsg2im_amd.spade.models.networks.discriminator import NLayerDiscriminator
+    opt = argparse.Namespace(ndf=8, n_layers_D=4, norm_D=norm_D, semantic_nc=5, no_ganFeat_loss=False)
+    torch.manual_seed(11)
+    D = NLayerDiscriminator(opt).cuda().train()
+    # the torch twin
+    use_sn = norm_D.startswith("spectral")
+    sub = norm_D[len("spectral"):] if use_sn else norm_D
+    seq, nf, cin = [], 8, 8
+    first = nn.Conv2d(8, nf, 4, 2, 2)
+    seq.append([first, nn.LeakyReLU(0.2)])
+    for n in range(1, 4):
+        nf_prev, nf = nf, min(nf * 2, 512)
+        conv = nn.Conv2d(nf_prev, nf, 4, 1 if n == 3 else 2, 2, bias=sub in ("", "none"))
+        layers = [torch.nn.utils.spectral_norm(conv) if use_sn else conv]
+        if sub in ("batch", "sync_batch"):
+            layers.append(nn.BatchNorm2d(nf))
+        elif sub == "instance":
+            layers.append(nn.InstanceNorm2d(nf))
+        seq.append(layers + [nn.LeakyReLU(0.2)])
+    seq.append([nn.Conv2d(nf, 1, 4, 1, 2)])
+    ref = nn.ModuleList([nn.Sequential(*l) for l in seq]).train()
+    sd = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    twin = {}
+    for k, v in sd.items():
+        m = k.split(".")                       # model<i>.<j>... -> <i>.<j>...
+        twin[m[0][len("model"):] + "." + ".".join(m[1:])] = v
+    # our Sequential(conv, norm) block sits at index 0 of model<i>: torch twin has conv at <i>.0 and norm at <i>.1
+    remap = {}
+    for k, v in twin.items():
+        parts = k.split(".")
+        if len(parts) >= 3 and parts[1] == "0" and parts[2] in ("0", "1"):      # model<i>.0.<0|1>.<name>
+            remap[parts[0] + "." + parts[2] + "." + ".".join(parts[3:])] = v
+        else:
+            remap[k] = v
+    missing, unexpected = ref.load_state_dict(remap, strict=False)
+    assert not unexpected, unexpected
+    assert all("num_batches_tracked" in m for m in missing), missing
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 8, 40, 40, generator=g)
+    xr = x.clone().requires_grad_(True)
+    feats_r, h = [], xr
+    for blk in ref:
+        h = blk(h)
+        feats_r.append(h)
+    from canonicalsg2im_amd import ops
+    xd = ops.nhwc(x.clone().cuda()).requires_grad_(True)
+    feats = D(xd)
+    assert len(feats) == len(feats_r)
+    for i, (a, b) in enumerate(zip(feats, feats_r)):
+        assert_close(a, b.detach(), RTOL, 1e-5 * float(b.detach().abs().max()) + 1e-6, "%s feature %d" % (norm_D, i))
+    wgt = torch.randn(feats_r[-1].shape, generator=g)
+    (feats_r[-1] * wgt).sum().backward()
+    (feats[-1] * wgt.cuda()).sum().backward()
+    assert_close(xd.grad, xr.grad, RTOL, 1e-5 * float(xr.grad.abs().max()) + 1e-7, "%s dx" % norm_D)
+    gd = dict(D.named_parameters())
+    gr = dict(ref.named_parameters())
+    k0 = "model0.0.weight"
+    assert_close(gd[k0].grad, gr["0.0.weight"].grad, RTOL, 1e-5 * float(gr["0.0.weight"].grad.abs().max()) + 1e-7, "%s dW0" % norm_D)
+    assert_close(gd["model4.0.weight"].grad, gr["4.0.weight"].grad, RTOL, 1e-5 * float(gr["4.0.weight"].grad.abs().max()) + 1e-7,
+                 "%s dW4" % norm_D)
