@@ -81,9 +81,11 @@ def test_conv2d_forward_backward(ops, case):
     code = {"none": (ops.ACT_NONE, 0.0), "relu": (ops.ACT_LEAKY, 0.0), "lrelu": (ops.ACT_LEAKY, 0.2),
             "tanh": (ops.ACT_TANH, 0.0)}[act]
     y = ops.conv2d(xd, wd, bd, s, p, code[0], code[1], rd)
-    assert_close(y, y_ref, RTOL, 2e-5, "conv y %s" % (case,))
+    # absolute term scaled to the tensor (long reductions; Winograd F(4x4,3x3) on maps >= 32 wide has ~3x the rounding
+    # error of the direct sum, tests/test_gpu_wino4.py): 1e-5 of the largest entry, as for dw below
+    assert_close(y, y_ref, RTOL, 1e-5 * float(y_ref.abs().max()) + 1e-5, "conv y %s" % (case,))
     y.backward(gy.cuda())
-    assert_close(xd.grad, xr.grad, RTOL, 2e-5, "conv dx %s" % (case,))
+    assert_close(xd.grad, xr.grad, RTOL, 1e-5 * float(xr.grad.abs().max()) + 1e-5, "conv dx %s" % (case,))
     # dw sums B*OH*OW products: absolute rounding noise scales with the largest entries
     assert_close(wd.grad, wr.grad, RTOL, 1e-5 * float(wr.grad.abs().max()) + 1e-5, "conv dw %s" % (case,))
     if has_bias:
