@@ -97,16 +97,10 @@ __device__ __forceinline__ int w4_xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// B^T of F(4,3) on the points {0, 1, -1, 1/2, -2, inf}; row xi combines input rows rb .. rb+4 (rb = 0 for xi = 0,
-// else 1) with these five coefficients (the sixth entry of every row of B^T is outside that window only as a zero)
-__constant__ float W4_BT5[6][5] = {
-    {1.0f, -1.5f, -2.0f, 1.5f, 1.0f},      // xi = 0: d0 .. d4
-    {-1.0f, 0.5f, 2.5f, 1.0f, 0.0f},       // xi = 1: d1 .. d5
-    {1.0f, -2.5f, 0.5f, 1.0f, 0.0f},
-    {-2.0f, -1.0f, 2.0f, 1.0f, 0.0f},
-    {0.5f, -1.0f, -0.5f, 1.0f, 0.0f},
-    {1.0f, -1.5f, -2.0f, 1.5f, 1.0f},      // xi = 5: d1 .. d5
-};
+// B^T of F(4,3) on the points {0, 1, -1, 1/2, -2, inf} (rows = xi, columns = input rows d0..d5):
+//   [ 1  -1.5  -2    1.5   1    0 ]      [ 0  -1    0.5   2.5   1   0 ]      [ 0   1   -2.5   0.5   1   0 ]
+//   [ 0  -2    -1    2     1    0 ]      [ 0   0.5  -1   -0.5   1   0 ]      [ 0   1   -1.5  -2     1.5 1 ]
+// row xi touches input rows rb .. rb+4 with rb = 0 for xi = 0, else 1 (rows 1..4 only rb .. rb+3)
 
 // ------------------------------------------------------------------------------------ weight packing
 // up[(((xi*6+nu)*NT32 + nt)*Q8 + q)*64 + lane] (float4) = U[xi][nu][n = nt*32 + (lane&31)][k], k = 8q + 2h + {0,1}
@@ -334,7 +328,6 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   const int j = lane & 31, h = lane >> 5;
   const int tx = j & (W4_TW - 1), ty = j >> 3;
   const int rb = wave == 0 ? 0 : 1;
-  const float c0 = W4_BT5[wave][0], c1 = W4_BT5[wave][1], c2 = W4_BT5[wave][2], c3 = W4_BT5[wave][3], c4c = W4_BT5[wave][4];
   // producer: raw words of (row 4 ty + rb, column 4 tx, channel pair q = 2 grp + h)
   const float* p0 = smem + W4V_RAW0 + (4 * ty + rb) * W4_RS + 2 * ty + tx * W4_PS + 4 * grp + 2 * h;
   const float* p3 = p0 + 3 * W4_RS + 2 * rb;
@@ -356,8 +349,14 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
 
-  // V[xi = wave][0..5] of (tile j, channel pair 2 grp + h) out of raw buffer rbufsel, into V buffer vbufsel
-  auto produce = [&](int rbufsel, int vbufsel) {
+  // V[xi = wave][0..5] of (tile j, channel pair 2 grp + h) out of raw buffer rbufsel, into V buffer vbufsel.  The row
+  // combination is specialised per xi (a scalar switch around six copies of this code): rows 1..4 of B^T touch four
+  // input rows and every row factors into 3-4 operations where the generic five-coefficient chain costs 5.
+  //   xi = 0, 5: (e0 + e4) - 2 e2 + 1.5 (e3 - e1)      (window e = d0..d4 / d1..d5)
+  //   xi = 1: (e3 - e0) + 0.5 e1 + 2.5 e2    xi = 2: (e3 + e0) - 2.5 e1 + 0.5 e2      (window e = d1..d4)
+  //   xi = 3: (e3 - e1) + 2 (e2 - e0)        xi = 4: (e3 - e1) - 0.5 (e2 - e0)
+  auto produce_xi = [&](auto xi_tag, int rbufsel, int vbufsel) {
+    constexpr int XI = decltype(xi_tag)::value;
     float2 t[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -366,9 +365,23 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       const csg_f32x2 e1 = *(w4_lds_cv2)(p0 + co + W4_RS);
       const csg_f32x2 e2 = *(w4_lds_cv2)(p0 + co + 2 * W4_RS);
       const csg_f32x2 e3 = *(w4_lds_cv2)(p3 + co);
-      const csg_f32x2 e4 = *(w4_lds_cv2)(p0 + co + 4 * W4_RS + 2);
-      t[c].x = fmaf(c4c, e4.x, fmaf(c3, e3.x, fmaf(c2, e2.x, fmaf(c1, e1.x, c0 * e0.x))));
-      t[c].y = fmaf(c4c, e4.y, fmaf(c3, e3.y, fmaf(c2, e2.y, fmaf(c1, e1.y, c0 * e0.y))));
+      if (XI == 0 || XI == 5) {
+        const csg_f32x2 e4 = *(w4_lds_cv2)(p0 + co + 4 * W4_RS + 2);
+        t[c].x = fmaf(1.5f, e3.x - e1.x, fmaf(-2.0f, e2.x, e0.x + e4.x));
+        t[c].y = fmaf(1.5f, e3.y - e1.y, fmaf(-2.0f, e2.y, e0.y + e4.y));
+      } else if (XI == 1) {
+        t[c].x = fmaf(2.5f, e2.x, fmaf(0.5f, e1.x, e3.x - e0.x));
+        t[c].y = fmaf(2.5f, e2.y, fmaf(0.5f, e1.y, e3.y - e0.y));
+      } else if (XI == 2) {
+        t[c].x = fmaf(0.5f, e2.x, fmaf(-2.5f, e1.x, e3.x + e0.x));
+        t[c].y = fmaf(0.5f, e2.y, fmaf(-2.5f, e1.y, e3.y + e0.y));
+      } else if (XI == 3) {
+        t[c].x = fmaf(2.0f, e2.x - e0.x, e3.x - e1.x);
+        t[c].y = fmaf(2.0f, e2.y - e0.y, e3.y - e1.y);
+      } else {
+        t[c].x = fmaf(-0.5f, e2.x - e0.x, e3.x - e1.x);
+        t[c].y = fmaf(-0.5f, e2.y - e0.y, e3.y - e1.y);
+      }
     }
     float2 v[6];
 #define W4_COLV(F)                                                                  \
@@ -387,6 +400,16 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 #pragma unroll
     for (int nu = 0; nu < 6; ++nu)
       *(float2*)(pv + vbufsel * W4_VBUF + nu * 256 + 2 * grp) = v[nu];
+  };
+  auto produce = [&](int rbufsel, int vbufsel) {
+    switch (wave) {
+      case 0: produce_xi(std::integral_constant<int, 0>(), rbufsel, vbufsel); break;
+      case 1: produce_xi(std::integral_constant<int, 1>(), rbufsel, vbufsel); break;
+      case 2: produce_xi(std::integral_constant<int, 2>(), rbufsel, vbufsel); break;
+      case 3: produce_xi(std::integral_constant<int, 3>(), rbufsel, vbufsel); break;
+      case 4: produce_xi(std::integral_constant<int, 4>(), rbufsel, vbufsel); break;
+      default: produce_xi(std::integral_constant<int, 5>(), rbufsel, vbufsel); break;
+    }
   };
   // 24 MFMAs out of V buffer vbufsel with the U operands of k-oct s; refills the ring for k-oct s (positions 3..5)
   // and s + 1 (positions 0..2)
@@ -413,16 +436,26 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 
   const int s_begin = split * p.sps, s_end = min(p.nstage, s_begin + p.sps);
   y += (long long)split * p.slab;
-  load_stage(s_begin);
+  {
+    // prologue: the first two stages travel together (one exposed memory latency instead of two)
+    const uint2 go = *(const uint2*)s_off;
+    const csg_f32x4 a0 = csg_buf_load_x4(rsX, (int)go.x, s_begin * (W4_PS * 4), 0);
+    const csg_f32x4 a1 = csg_buf_load_x4(rsX, (int)go.y, s_begin * (W4_PS * 4), 0);
+    load_stage(s_begin + 1);
 #pragma unroll
-  for (int nu = 0; nu < 3; ++nu) load_ur(nu, nu, s_begin);
-  store_stage(smem + W4V_RAW0);
-  __syncthreads();
-  load_stage(s_begin + 1);
-  produce(0, 0);                                 // V[0] from raw[0]
-  store_stage(smem + W4V_RAW0 + W4_BUFW);        // raw[1]
-  __syncthreads();
-  load_stage(s_begin + 2);
+    for (int nu = 0; nu < 3; ++nu) load_ur(nu, nu, s_begin);
+    const csg_f32x4 b0 = st[0], b1 = st[1];
+    st[0] = a0;
+    st[1] = a1;
+    store_stage(smem + W4V_RAW0);
+    __syncthreads();
+    st[0] = b0;
+    st[1] = b1;
+    produce(0, 0);                               // V[0] from raw[0]
+    store_stage(smem + W4V_RAW0 + W4_BUFW);      // raw[1]
+    __syncthreads();
+    load_stage(s_begin + 2);
+  }
   int s = s_begin;
   for (; s + 1 < s_end; s += 2) {
     stage(s, std::integral_constant<int, 0>());
