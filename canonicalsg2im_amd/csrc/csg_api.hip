@@ -58,6 +58,8 @@ bool prof_on(int kid) {
          (g_prof == 3 && hbm_kernel(kid));
 }
 
+bool prof_serialize() { return g_prof == 1 || g_prof == 3; }
+
 ProfCur& prof_cur() {
   static thread_local ProfCur cur = {0, 0.0, nullptr, nullptr, false, false};
   return cur;

@@ -81,10 +81,18 @@ ProfCur& prof_cur();
 void prof_begin(int kid, double work);
 void prof_end();
 
+bool prof_serialize();   // modes 1 and 3 (the untimed per-kernel table): drain the stream before the timed launch
 struct ProfScope {
   bool on;
-  ProfScope(int kid, double work, hipStream_t) : on(prof_on(kid)) {
-    if (on) prof_begin(kid, work);
+  ProfScope(int kid, double work, hipStream_t s) : on(prof_on(kid)) {
+    if (on) {
+      // A dispatch's start timestamp is taken when the command processor picks the packet up, which can be while the
+      // previous kernel of the stream is still draining: a short consumer right behind a long producer (k_norm_apply_fwd
+      // behind the gamma/beta convolution, k_splitk_epilogue behind its GEMM) then reads ~2x its own duration.
+      // rocprofv3 serialises dispatches and does not see this; the table modes do the same here.
+      if (prof_serialize()) (void)hipStreamSynchronize(s);
+      prof_begin(kid, work);
+    }
   }
   ~ProfScope() {
     if (on) prof_end();
