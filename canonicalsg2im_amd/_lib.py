@@ -69,6 +69,8 @@ SIGNATURES = {
     "csg_layout_bwd_workspace": (c_i64, [c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32]),
     "csg_layout_bwd": (c_i32, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                c_i64, c_p, c_i32, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_layout_bwd_masks": (c_i32, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                     c_p, c_p, c_i32, c_p]),
     "csg_layout_mass": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_layout_paint": (c_i32, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64,
                                  c_i64, c_p]),
@@ -112,6 +114,8 @@ SIGNATURES = {
     "csg_avgpool3s2_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_crop_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p]),
     "csg_crop_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_crop_bwd_boxes": (c_i32, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p,
+                                   c_p]),
     "csg_maxpool2_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_maxpool2_bwd": (c_i32, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_l1_mean_workspace": (c_i64, [c_i64]),

@@ -97,7 +97,74 @@ __global__ void k_crop_bwd(const float* __restrict__ dout, int H, int W, int cs,
   }
 }
 
+// Gradient w.r.t. the boxes (the sampling grid of crop_bbox is differentiable in x0, y0, w, h: bilinear.py:83-94).
+// With fx = ((gx + 1) W - 1) / 2 and gx = lin_down(x) (2 x0 - 1) + lin_up(x) (2 (x0 + w) - 1):
+//   d out / d fx = (v01 - v00) (1 - ty) + (v11 - v10) ty   (out-of-image taps count as zeros, as in ATen's
+//   grid_sampler backward), d fx / d x0 = W (lin_down + lin_up), d fx / d w = W lin_up; likewise in y.
+// One block per crop; every thread sums its pixels in order, the block combines the 256 partial sums in thread order:
+// bit-reproducible.
+__global__ __launch_bounds__(256) void k_crop_bwd_boxes(const float* __restrict__ dout, const float* __restrict__ img,
+                                                         int H, int W, int cs, int C, const float* __restrict__ boxes,
+                                                         const int64_t* __restrict__ img_idx, int HH, int WW, int out_cs,
+                                                         float* __restrict__ dboxes) {
+  __shared__ float4 s_red[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* box = boxes + (int64_t)n * 4;
+  const float* base = img + (int64_t)img_idx[n] * H * W * cs;
+  const float bx0 = 2.0f * box[0] - 1.0f, by0 = 2.0f * box[1] - 1.0f;
+  const float bx1 = 2.0f * (box[0] + box[2]) - 1.0f, by1 = 2.0f * (box[1] + box[3]) - 1.0f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);       // d x0, d y0, d w, d h
+  for (int e = tid; e < HH * WW; e += 256) {
+    const int y = e / WW, x = e - y * WW;
+    const float ldx = lin_down(x, WW), lux = lin_up(x, WW), ldy = lin_down(y, HH), luy = lin_up(y, HH);
+    const float gx = ldx * bx0 + lux * bx1, gy = ldy * by0 + luy * by1;
+    const float fx = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, fy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    const float x0f = fminf(fmaxf(floorf(fx), -2.0f), (float)W), y0f = fminf(fmaxf(floorf(fy), -2.0f), (float)H);
+    const float tx = fx - floorf(fx), ty = fy - floorf(fy);
+    const int ix0 = (int)x0f, iy0 = (int)y0f;
+    const bool x0ok = ix0 >= 0 && ix0 < W, x1ok = ix0 + 1 >= 0 && ix0 + 1 < W;
+    const bool y0ok = iy0 >= 0 && iy0 < H, y1ok = iy0 + 1 >= 0 && iy0 + 1 < H;
+    const float* g = dout + ((int64_t)n * HH * WW + e) * out_cs;
+    float dfx = 0.f, dfy = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v00 = (x0ok && y0ok) ? base[((int64_t)iy0 * W + ix0) * cs + c] : 0.f;
+      const float v01 = (x1ok && y0ok) ? base[((int64_t)iy0 * W + ix0 + 1) * cs + c] : 0.f;
+      const float v10 = (x0ok && y1ok) ? base[((int64_t)(iy0 + 1) * W + ix0) * cs + c] : 0.f;
+      const float v11 = (x1ok && y1ok) ? base[((int64_t)(iy0 + 1) * W + ix0 + 1) * cs + c] : 0.f;
+      const float go = g[c];
+      dfx += go * ((v01 - v00) * (1.f - ty) + (v11 - v10) * ty);
+      dfy += go * ((v10 - v00) * (1.f - tx) + (v11 - v01) * tx);
+    }
+    const float ax = dfx * (float)W, ay = dfy * (float)H;       // d fx / d gx = W / 2, d gx / d x0 = 2 (ld + lu), ...
+    acc.x += ax * (ldx + lux);
+    acc.y += ay * (ldy + luy);
+    acc.z += ax * lux;
+    acc.w += ay * luy;
+  }
+  s_red[tid] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float4 t = s_red[0];
+    for (int i = 1; i < 256; ++i) { t.x += s_red[i].x; t.y += s_red[i].y; t.z += s_red[i].z; t.w += s_red[i].w; }
+    *(float4*)(dboxes + (int64_t)n * 4) = t;
+  }
+}
+
 extern "C" {
+
+int csg_crop_bwd_boxes(const float* dout, const float* img, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C,
+                       const float* boxes, const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, int64_t out_cs,
+                       float* dboxes, void* stream) {
+  CSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && img_cs >= C && out_cs >= C && HH > 0 && WW > 0 && N >= 0,
+              CSG_E_BADSHAPE, "csg_crop_bwd_boxes: bad shape");
+  CSG_REQUIRE(((uintptr_t)dboxes % 16) == 0, CSG_E_UNSUPPORTED, "csg_crop_bwd_boxes: dboxes must be 16-byte aligned");
+  if (N == 0) return CSG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_CROP_BWD, (double)N * HH * WW * (C * 4 + out_cs) * 4, s);
+  CSG_LAUNCH(k_crop_bwd_boxes, dim3((unsigned)N), dim3(256), 0, s, dout, img, (int)H, (int)W, (int)img_cs, (int)C, boxes,
+             img_idx, (int)HH, (int)WW, (int)out_cs, dboxes);
+  return check_launch("csg_crop_bwd_boxes");
+}
 
 int csg_crop_fwd(const float* img, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C, const float* boxes,
                  const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, float* out, int64_t out_cs, void* stream) {

@@ -706,6 +706,78 @@ __global__ __launch_bounds__(1024) void k_layout_bwd(const float* __restrict__ d
   }
 }
 
+// Gradient w.r.t. the masks (masks_to_layout, layout.py:48-77: grid_sample is differentiable in its input):
+//   dmask[m][n] = sum_{y,x} G(y,x) * Wy(y,m) * Wx(x,n),   G(y,x) = sum_d dout[d,y,x] * vec[d],
+// Wy(y,m) the bilinear weight output row y puts on mask row m (at most two rows per y).  One block per (object, image),
+// one thread per mask cell at a time; every cell sums its pixels in ascending (y, x) order: bit-reproducible.  G is
+// recomputed by the (up to four) cells a pixel touches — this pass exists for callers that train through predicted
+// masks (model.py's mask_net), not for the benchmarked GT-mask configurations.
+__global__ __launch_bounds__(256) void k_layout_bwd_masks(const float* __restrict__ dout, int out_cs, int out_off,
+                                                           const float* __restrict__ boxes,
+                                                           const uint8_t* __restrict__ valid, int M, int O, int S, int H,
+                                                           int W, int OH, int OW, const float* __restrict__ vecs,
+                                                           float* __restrict__ dmasks, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_wy0 = sm;                 // [OH]
+  float* s_wy1 = s_wy0 + OH;         // [OH]
+  float* s_wx0 = s_wy1 + OH;         // [OW]
+  float* s_wx1 = s_wx0 + OW;         // [OW]
+  int* s_iy = (int*)(s_wx1 + OW);    // [OH]
+  int* s_ix = s_iy + OH;             // [OW]
+  float* s_vec = (float*)(s_ix + OW);  // [S]
+  const int tid = threadIdx.x;
+  const int o = blockIdx.x, b = blockIdx.y;
+  float* dm = dmasks + ((int64_t)b * O + o) * M * M;
+  if (!valid[(int64_t)b * O + o]) {
+    if (!accumulate)
+      for (int c = tid; c < M * M; c += 256) dm[c] = 0.f;
+    return;
+  }
+  const float* bx = boxes + ((int64_t)b * O + o) * 4;
+  const float x0 = bx[0], y0 = bx[1], ww = bx[2], hh = bx[3];
+  for (int y = tid; y < OH; y += 256) {
+    const int ysrc = min((int)(((int64_t)y * H) / OH), H - 1);
+    int i0;
+    float w0, w1;
+    axis_taps(lin01(ysrc, H), y0, hh, M, i0, w0, w1);
+    s_iy[y] = i0; s_wy0[y] = w0; s_wy1[y] = w1;
+  }
+  for (int x = tid; x < OW; x += 256) {
+    const int xsrc = min((int)(((int64_t)x * W) / OW), W - 1);
+    int i0;
+    float w0, w1;
+    axis_taps(lin01(xsrc, W), x0, ww, M, i0, w0, w1);
+    s_ix[x] = i0; s_wx0[x] = w0; s_wx1[x] = w1;
+  }
+  for (int d = tid; d < S; d += 256) s_vec[d] = vecs[((int64_t)b * O + o) * S + d];
+  __syncthreads();
+  const float* base = dout + (int64_t)b * OH * OW * out_cs + out_off;
+  for (int c = tid; c < M * M; c += 256) {
+    const int m = c / M, n = c - m * M;
+    float acc = 0.f;
+    for (int y = 0; y < OH; ++y) {
+      const int iy = s_iy[y];
+      const float wy = iy == m ? s_wy0[y] : (iy + 1 == m ? s_wy1[y] : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int x = 0; x < OW; ++x) {
+        const int ix = s_ix[x];
+        const float wx = ix == n ? s_wx0[x] : (ix + 1 == n ? s_wx1[x] : 0.f);
+        if (wx == 0.f) continue;
+        const float4* g4 = (const float4*)&base[((int64_t)y * OW + x) * out_cs];
+        float g = 0.f;
+        for (int q = 0; q < (S >> 2); ++q) {
+          const float4 v = g4[q];
+          g += v.x * s_vec[4 * q] + v.y * s_vec[4 * q + 1] + v.z * s_vec[4 * q + 2] + v.w * s_vec[4 * q + 3];
+        }
+        row += g * wx;
+      }
+      acc += row * wy;
+    }
+    dm[c] = accumulate ? dm[c] + acc : acc;
+  }
+}
+
 // ---------------------------------------------------------------------------------- test mode
 // masks_to_layout(test_mode=True) (reference sg2im/layout.py:71-74,135-151): objects are painted in ascending
 // order of their "mass" sum(samples[j]); a pixel belongs to the FIRST object in that order whose bilinearly
@@ -881,6 +953,24 @@ int64_t csg_layout_bwd_workspace(int64_t B, int64_t O, int64_t S, int64_t OH, in
   const int64_t part = B * ntiles * O * S * 4;
   const int64_t flags = (B * ntiles * O + 15) / 16 * 16;
   return part + flags;
+}
+
+int csg_layout_bwd_masks(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,
+                         int64_t M, int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW,
+                         const float* vecs, float* dmasks, int accumulate, void* stream) {
+  CSG_REQUIRE(M >= 1 && M <= 1024, CSG_E_BADSHAPE, "csg_layout_bwd_masks: bad mask size %ld", (long)M);
+  CSG_REQUIRE(B > 0 && O >= 0 && S > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, CSG_E_BADSHAPE,
+              "csg_layout_bwd_masks: bad shape");
+  CSG_REQUIRE(S % 4 == 0 && out_cs % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)dout % 16) == 0, CSG_E_UNSUPPORTED,
+              "csg_layout_bwd_masks: S, out_cs, out_off must be multiples of 4");
+  CSG_REQUIRE(S <= 1024 && OH <= 4096 && OW <= 4096 && B <= 65535, CSG_E_UNSUPPORTED, "csg_layout_bwd_masks: too large");
+  if (O == 0) return CSG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t shm = (size_t)(3 * (OH + OW) + S) * 4;
+  ProfScope p(K_LAYOUT_BWD, (double)B * OH * OW * S * 4, s);
+  CSG_LAUNCH(k_layout_bwd_masks, dim3((unsigned)O, (unsigned)B), dim3(256), shm, s, dout, (int)out_cs, (int)out_off, boxes,
+             valid, (int)M, (int)O, (int)S, (int)H, (int)W, (int)OH, (int)OW, vecs, dmasks, accumulate);
+  return check_launch("csg_layout_bwd_masks");
 }
 
 int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,

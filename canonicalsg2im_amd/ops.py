@@ -932,10 +932,15 @@ def _prep_masks(masks):
     """(B,O,M,M) int64/float masks -> contiguous fp32 (what the reference's `.float()` does), or None."""
     if masks is None:
         return None, 0
-    m = masks.to(torch.float32).contiguous()
-    if m.requires_grad:
-        raise NotImplementedError("layout: gradients w.r.t. masks are not implemented (training feeds GT masks)")
+    m = masks.detach().to(torch.float32).contiguous()
     return m, int(m.shape[-1])
+
+
+def _layout_bwd_masks(g, cs, boxes, valid, vecs, dims, hw, dmasks, accumulate):
+    """Accumulates d loss / d masks of one layout output (layout.py:48-77 is differentiable in the masks)."""
+    B, O, S, H, W, M = dims
+    check(lib.csg_layout_bwd_masks(ptr(g), cs, 0, ptr(boxes), ptr(valid), M, B, O, S, H, W, hw[0], hw[1], ptr(vecs),
+                                   ptr(dmasks), 1 if accumulate else 0, stream()), "layout_bwd_masks")
 
 
 def _hw(size):
@@ -959,7 +964,7 @@ class _LayoutPyramid(torch.autograd.Function):
             check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, W, h, w, ptr(seg), S,
                                      0, stream()), "layout_fwd")
             outs.append(seg)
-        ctx.save_for_backward(boxes, valid, masks, vecs if ctx.needs_input_grad[1] else None)
+        ctx.save_for_backward(boxes, valid, masks, vecs if ctx.needs_input_grad[1] or ctx.needs_input_grad[3] else None)
         ctx.meta = (B, O, S, H, W, M, tuple(sizes))
         return tuple(outs)
 
@@ -969,15 +974,20 @@ class _LayoutPyramid(torch.autograd.Function):
         B, O, S, H, W, M, sizes = ctx.meta
         dvecs = torch.zeros((B, O, S), device=boxes.device, dtype=torch.float32)
         dboxes = torch.zeros((B, O, 4), device=boxes.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        dmasks = None
+        if masks is not None and ctx.needs_input_grad[3]:
+            dmasks = torch.zeros((B, O, M, M), device=boxes.device, dtype=torch.float32)
         for (h, w), g in zip(sizes, douts):
             if g is None:
                 continue
             g = nhwc(g)
+            if dmasks is not None:
+                _layout_bwd_masks(g, S, boxes, valid, vecs, (B, O, S, H, W, M), (h, w), dmasks, True)
             nws = lib.csg_layout_bwd_workspace(B, O, S, h, w, 0 if masks is None else 1, 0 if dboxes is None else 1)
             ws = torch.empty(nws // 4, device=boxes.device, dtype=torch.float32) if nws > 0 else None
             check(lib.csg_layout_bwd(ptr(g), S, 0, ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, W, h, w,
                                      ptr(dvecs), 1, ptr(vecs), ptr(dboxes), ptr(ws), nws, stream()), "layout_bwd")
-        return dvecs, dboxes, None, None, None, None, None
+        return dvecs, dboxes, None, dmasks, None, None, None
 
 
 def layout_pyramid(vecs, boxes, valid, H, sizes, masks=None, W=None):
@@ -1030,7 +1040,7 @@ class _DiscInput(torch.autograd.Function):
             buf[..., S + 3:] = 0.0
         check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, H, H, ptr(buf), Ct, 0,
                                  stream()), "layout_fwd")
-        ctx.save_for_backward(boxes, valid, masks, vecs if ctx.needs_input_grad[2] else None)
+        ctx.save_for_backward(boxes, valid, masks, vecs if ctx.needs_input_grad[2] or ctx.needs_input_grad[4] else None)
         ctx.meta = (B, O, S, H, Ct, M)
         return buf.permute(0, 3, 1, 2)
 
@@ -1039,9 +1049,12 @@ class _DiscInput(torch.autograd.Function):
         boxes, valid, masks, vecs = ctx.saved_tensors
         B, O, S, H, Ct, M = ctx.meta
         dbuf = nhwc(dbuf)
-        dimg = dvecs = dboxes = None
+        dimg = dvecs = dboxes = dmasks = None
         if ctx.needs_input_grad[0]:
             dimg = dbuf[:, S:S + 3].contiguous()
+        if masks is not None and ctx.needs_input_grad[4]:
+            dmasks = torch.empty((B, O, M, M), device=dbuf.device, dtype=torch.float32)
+            _layout_bwd_masks(dbuf, Ct, boxes, valid, vecs, (B, O, S, H, H, M), (H, H), dmasks, False)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dvecs = torch.empty((B, O, S), device=dbuf.device, dtype=torch.float32)
             if ctx.needs_input_grad[2]:
@@ -1050,7 +1063,7 @@ class _DiscInput(torch.autograd.Function):
             ws = torch.empty(nws // 4, device=dbuf.device, dtype=torch.float32) if nws > 0 else None
             check(lib.csg_layout_bwd(ptr(dbuf), Ct, 0, ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, H, H,
                                      ptr(dvecs), 0, ptr(vecs), ptr(dboxes), ptr(ws), nws, stream()), "layout_bwd")
-        return dimg, dvecs, dboxes, None, None, None
+        return dimg, dvecs, dboxes, None, dmasks, None
 
 
 def disc_input(img, vecs, boxes, valid, H, masks=None):
@@ -1072,26 +1085,27 @@ class _CropObjects(torch.autograd.Function):
         out = empty_nhwc(N, Cp, HH, HH, img.device)
         check(lib.csg_crop_fwd(ptr(img), B, H, W, C, C, ptr(boxes), ptr(img_idx), N, HH, HH, ptr(out), Cp, stream()),
               "crop_fwd")
-        ctx.save_for_backward(boxes, img_idx)
+        ctx.save_for_backward(boxes, img_idx, img if ctx.needs_input_grad[1] else None)
         ctx.meta = (B, C, H, W, N, HH, Cp)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        boxes, img_idx = ctx.saved_tensors
+        boxes, img_idx, img = ctx.saved_tensors
         B, C, H, W, N, HH, Cp = ctx.meta
-        dimg = None
+        dimg = dboxes = None
+        dout = nhwc(dout)
         if ctx.needs_input_grad[0]:
-            dout = nhwc(dout)
             dimg = empty_nhwc(B, C, H, W, dout.device, zero=True)
             check(lib.csg_crop_bwd(ptr(dout), B, H, W, C, C, ptr(boxes), ptr(img_idx), N, HH, HH, Cp, ptr(dimg),
                                    stream()), "crop_bwd")
-        return dimg, None, None, None
+        if ctx.needs_input_grad[1]:                      # the sampling grid is differentiable in the boxes (bilinear.py:83-94)
+            dboxes = torch.zeros((N, 4), device=dout.device, dtype=torch.float32)
+            check(lib.csg_crop_bwd_boxes(ptr(dout), ptr(img), B, H, W, C, C, ptr(boxes), ptr(img_idx), N, HH, HH, Cp,
+                                         ptr(dboxes), stream()), "crop_bwd_boxes")
+        return dimg, dboxes, None, None
 
 
 def crop_objects(img, boxes, img_idx, HH):
     """img (B,C,H,W); boxes (N,4) xywh of the real objects in (image, object) order; img_idx (N,) int64."""
-    if boxes.requires_grad:
-        raise NotImplementedError("crop_objects: gradients w.r.t. boxes are not implemented (the object discriminator "
-                                  "crops GT boxes, sg2im/pix2pix_model.py:115,178)")
     return _CropObjects.apply(img, boxes, img_idx.contiguous(), int(HH))

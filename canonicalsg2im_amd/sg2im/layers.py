@@ -9,12 +9,17 @@ from .. import ops
 
 
 class Linear(nn.Linear):
-    def __init__(self, din, dout, bias=True, fused_relu=False):
+    """nn.Linear surface; `fused_relu` / `fused_slope` fuse a ReLU / LeakyReLU(slope) into the GEMM epilogue."""
+
+    def __init__(self, din, dout, bias=True, fused_relu=False, fused_slope=None):
         super().__init__(din, dout, bias=bias)
         self.fused_relu = fused_relu
+        self.fused_slope = 0.0 if (fused_relu and fused_slope is None) else fused_slope
 
     def forward(self, x):
-        return ops.linear(x, self.weight, self.bias, ops.ACT_LEAKY if self.fused_relu else ops.ACT_NONE, 0.0)
+        if self.fused_slope is None:
+            return ops.linear(x, self.weight, self.bias, ops.ACT_NONE, 0.0)
+        return ops.linear(x, self.weight, self.bias, ops.ACT_LEAKY, float(self.fused_slope))
 
 
 class Conv2d(nn.Conv2d):
@@ -53,26 +58,49 @@ def get_activation(name):
     return table[name.lower()](**kwargs)
 
 
+def _fusable_slope(name):
+    """Negative slope of an activation the kernels fuse (ReLU = 0, LeakyReLU-x = x), else None."""
+    if name is None:
+        return None
+    low = name.lower()
+    if low == 'relu':
+        return 0.0
+    if low.startswith('leakyrelu'):
+        return float(name.split('-')[1]) if '-' in name else 0.01
+    return None
+
+
 def build_mlp(dim_list, activation='relu', batch_norm='none', dropout=0, final_nonlinearity='relu'):
-    """[Linear, (BatchNorm1d), ReLU]* Linear [ReLU] (reference sg2im/layers.py:6-25) with the same nn.Sequential
-    indices (state_dict keys `net.0`, `net.2` — or `net.0`, `net.1`, `net.3` with batch_norm='batch').  Every ReLU is
-    fused: into the GEMM epilogue, or into the BatchNorm apply pass when a BatchNorm1d sits in between."""
-    if dropout > 0 or activation != 'relu' or final_nonlinearity not in (None, 'relu'):
-        raise NotImplementedError("build_mlp: only relu activations without dropout (the trainer's settings) are "
-                                  "on the hot path")
+    """[Linear, (BatchNorm1d), act, (Dropout)]* Linear (Dropout) [act] (reference sg2im/layers.py:6-25) with the same
+    nn.Sequential indices (state_dict keys `net.0`, `net.2` — or `net.0`, `net.1`, `net.3` with batch_norm='batch').
+    ReLU / LeakyReLU-x are fused: into the GEMM epilogue, or into the BatchNorm apply pass when a BatchNorm1d sits in
+    between (a `_FusedActivation` placeholder keeps the index); sigmoid and dropout — not used by any recipe of the
+    reference — are plain torch modules on the (per-object, tiny) outputs of the HIP GEMM."""
     if batch_norm not in ('none', 'batch'):
         raise ValueError('Invalid mlp normalization "%s"' % batch_norm)
+    if activation is not None:
+        get_activation(activation)                       # raises ValueError('Invalid activation ...') like the reference
+    if final_nonlinearity is not None:
+        get_activation(final_nonlinearity)
     layers = []
     n = len(dim_list) - 1
     for i in range(n):
         last = i == n - 1
         bn = (not last) and batch_norm == 'batch'
-        relu = (not last) or final_nonlinearity == 'relu'
-        layers.append(Linear(dim_list[i], dim_list[i + 1], fused_relu=relu and not bn))
+        inner = None if last else activation
+        # the final non-linearity sits behind the last layer's dropout in the reference: fusable only without dropout
+        tail = final_nonlinearity if (last and dropout == 0) else None
+        slope = _fusable_slope(inner if not last else tail)
+        layers.append(Linear(dim_list[i], dim_list[i + 1], fused_slope=None if bn else slope))
         if bn:
-            layers.append(BatchNorm1dAct(dim_list[i + 1], fused_slope=0.0))
-        if relu:
-            layers.append(_FusedActivation())
+            layers.append(BatchNorm1dAct(dim_list[i + 1], fused_slope=1.0 if slope is None else slope))
+        if inner is not None:
+            layers.append(_FusedActivation() if slope is not None else get_activation(inner))
+        if dropout > 0:
+            layers.append(nn.Dropout(p=dropout))
+        if last and final_nonlinearity is not None:
+            fused = tail is not None and slope is not None
+            layers.append(_FusedActivation() if fused else get_activation(final_nonlinearity))
     return nn.Sequential(*layers)
 
 
@@ -89,6 +117,10 @@ class Interpolate(nn.Module):
     def forward(self, x):
         if self.mode == 'nearest' and self.scale_factor == 2 and x.is_cuda:
             return ops.upsample2x(x)
+        if self.mode == 'nearest' and x.is_cuda and x.dim() == 4 and x.size(1) % 4 == 0:
+            size = self.size if self.size is not None else (int(x.size(2) * self.scale_factor), int(x.size(3) * self.scale_factor))
+            size = (size, size) if isinstance(size, int) else size
+            return ops.nearest_resize(x, size)
         return nn.functional.interpolate(x, size=self.size, scale_factor=self.scale_factor, mode=self.mode,
                                          align_corners=self.align_corners)
 
@@ -142,64 +174,81 @@ class BatchNorm1dAct(nn.BatchNorm1d):
                                  self.fused_slope, self.eps, self.momentum, sync=False)
 
 
-def build_hot_cnn(arch, normalization='batch', activation='leakyrelu-0.2', padding='valid'):
-    """build_cnn for the object discriminator (arch 'C4-64-2,C4-128-2,C4-256-2'): same nn.Sequential
-    indices and state_dict keys as the reference builder, executed on the HIP kernels — Conv2d on the
-    implicit GEMM, BatchNorm + LeakyReLU fused in one pass."""
-    if isinstance(arch, str):
-        arch = arch.split(',')
-    if normalization != 'batch' or not activation.lower().startswith('leakyrelu'):
-        raise NotImplementedError("object discriminator: only d_normalization=batch, d_activation=leakyrelu-* "
-                                  "(the trainer defaults) are on the hot path")
-    slope = float(activation.split('-')[1]) if '-' in activation else 0.01
-    cur, first, layers = 3, True, []
-    for s in arch:
-        if s[0] != 'C':
-            raise NotImplementedError('build_hot_cnn: layer "%s" is not on the hot path' % s)
-        if not first:
-            layers.append(BatchNormAct(cur, fused_slope=slope))
-            layers.append(_FusedActivation())
-        first = False
-        vals = [int(v) for v in s[1:].split('-')]
-        K, nxt = vals[0], vals[1]
-        stride = vals[2] if len(vals) == 3 else 1
-        pad = (K - 1) // 2 if padding == 'same' else 0
-        layers.append(Conv2d(cur, nxt, kernel_size=K, padding=pad, stride=stride))
-        cur = nxt
-    return nn.Sequential(*layers), cur
+class InstanceNorm2dAct(nn.InstanceNorm2d):
+    """nn.InstanceNorm2d (no affine, no running statistics: `get_normalization_2d(.., 'instance')`) on the HIP
+    statistics + apply kernels, with an optional fused LeakyReLU (`fused_slope`)."""
+
+    def __init__(self, num_features, fused_slope=1.0):
+        super().__init__(num_features)
+        self.fused_slope = fused_slope
+
+    def forward(self, x):
+        return ops.norm_act(x, None, None, None, instance=True, training=self.training, slope=self.fused_slope, eps=self.eps)
+
+
+class MaxPool2(nn.Module):
+    """nn.MaxPool2d(kernel_size=2, stride=2) on csrc/perceptual.hip (first-maximum routing like ATen)."""
+
+    def forward(self, x):
+        return ops.maxpool2(x)
 
 
 def build_cnn(arch, normalization='batch', activation='relu', padding='same', pooling='max', init='default'):
-    """Arch-string CNN ('C4-64-2,C4-128-2,...', reference sg2im/layers.py:28-112).  On the hot path it
-    only creates the never-executed `image_encoder` parameters of G and D (generator.py:50-62), so
-    plain nn layers are used; the C/P/U/FC subset of the grammar is supported."""
+    """Arch-string CNN (reference sg2im/layers.py:28-112) with the same nn.Sequential indices and state_dict keys as the
+    reference builder, executed on the HIP kernels: IX (input channels), CK-X[-S] (Conv2d on the implicit GEMM /
+    Winograd kernels; every convolution except the first is preceded by normalisation and non-linearity — BatchNorm2d
+    or InstanceNorm2d with ReLU / LeakyReLU-x fused into its apply pass, or, with normalization='none', the activation
+    fused into the previous convolution's epilogue), UX (nearest-neighbour upsampling), P2 with max pooling.  Residual
+    blocks, FC layers, average pooling and pooling factors other than 2 are used by no call site of the reference
+    (`AcCropDiscriminator`: 'C4-64-2,C4-128-2,C4-256-2', `AppearanceEncoder` likewise) and raise."""
     if isinstance(arch, str):
         arch = arch.split(',')
+    if normalization not in ('batch', 'instance', 'none'):
+        raise ValueError('Unrecognized normalization type "%s"' % normalization)
+    get_activation(activation)                                # ValueError on an unknown name, like the reference
+    slope = _fusable_slope(activation)
     cur = 3
-    if arch and arch[0][0] == 'I':
+    if len(arch) > 0 and arch[0][0] == 'I':
         cur = int(arch[0][1:])
         arch = arch[1:]
-    first, layers = True, []
-    for i, s in enumerate(arch):
+    first, layers, prev_conv = True, [], None
+    for s in arch:
         if s[0] == 'C':
             if not first:
                 if normalization == 'batch':
-                    layers.append(nn.BatchNorm2d(cur))
+                    layers.append(BatchNormAct(cur, fused_slope=1.0 if slope is None else slope))
                 elif normalization == 'instance':
-                    layers.append(nn.InstanceNorm2d(cur))
-                layers.append(get_activation(activation))
+                    layers.append(InstanceNorm2dAct(cur, fused_slope=1.0 if slope is None else slope))
+                elif slope is not None and prev_conv is not None and prev_conv is layers[-1]:
+                    prev_conv.act, prev_conv.slope = ops.ACT_LEAKY, slope      # no norm in between: the conv's own epilogue
+                fused = slope is not None and (normalization != 'none' or (prev_conv is not None and prev_conv is layers[-1]))
+                layers.append(_FusedActivation() if fused else get_activation(activation))
             first = False
             vals = [int(v) for v in s[1:].split('-')]
             K, nxt = vals[0], vals[1]
             stride = vals[2] if len(vals) == 3 else 1
+            if padding == 'same':
+                assert K % 2 == 1, 'Invalid kernel size %d for "same" padding' % K
             pad = (K - 1) // 2 if padding == 'same' else 0
-            layers.append(nn.Conv2d(cur, nxt, kernel_size=K, padding=pad, stride=stride))
+            prev_conv = Conv2d(cur, nxt, kernel_size=K, padding=pad, stride=stride)
+            if init == 'kaiming-normal':
+                nn.init.kaiming_normal_(prev_conv.weight)
+            elif init == 'kaiming-uniform':
+                nn.init.kaiming_uniform_(prev_conv.weight)
+            layers.append(prev_conv)
             cur = nxt
         elif s[0] == 'U':
             layers.append(Interpolate(scale_factor=int(s[1:]), mode='nearest'))
-        elif s[0] == 'P':
-            f = int(s[1:])
-            layers.append(nn.MaxPool2d(f, f) if pooling == 'max' else nn.AvgPool2d(f, f))
+        elif s[0] == 'P' and int(s[1:]) == 2 and pooling == 'max':
+            layers.append(MaxPool2())
+        elif s[0] in ('R', 'P') or s[:2] == 'FC':
+            raise NotImplementedError('build_cnn: layer "%s" (pooling=%s) is used by no call site of the reference and is '
+                                      'not built on the HIP kernels' % (s, pooling))
         else:
-            raise NotImplementedError('build_cnn: layer "%s" is not on the hot path' % s)
+            raise ValueError('Invalid layer "%s"' % s)
     return nn.Sequential(*layers), cur
+
+
+def build_hot_cnn(arch, normalization='batch', activation='leakyrelu-0.2', padding='valid'):
+    """The object discriminator's CNN (arch 'C4-64-2,C4-128-2,C4-256-2'): `build_cnn` under its round-1 name."""
+    return build_cnn(arch, normalization=normalization, activation=activation, padding=padding)

@@ -126,6 +126,12 @@ int csg_layout_bwd(const float* dout, int64_t out_cs, int64_t out_off, const flo
                    const float* masks, int64_t M, int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH,
                    int64_t OW, float* dvecs, int accumulate, const float* vecs, float* dboxes, void* workspace,
                    int64_t workspace_bytes, void* stream);
+/* dmasks (B,O,M,M) = (accumulate ? dmasks : 0) + the gradient of masks_to_layout (layout.py:48-77) w.r.t. the masks:
+ * grid_sample's backward w.r.t. its input, summed over the embedding channels (dout . vecs per pixel).  One block per
+ * (object, image), every mask cell an ordered sum.  Rows of invalid objects are zero.                         */
+int csg_layout_bwd_masks(const float* dout, int64_t out_cs, int64_t out_off, const float* boxes, const uint8_t* valid,
+                         int64_t M, int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW,
+                         const float* vecs, float* dmasks, int accumulate, void* stream);
 /* masks_to_layout(test_mode=True) (layout.py:71-74,135-151): painter's compositing, one object per pixel.
  * csg_layout_mass: mass[b,o] = sum(samples[o]) at full resolution (+inf for invalid objects) — the caller sorts it
  * (ascending, stable) into `order` (B,O) int32, -1 after the last valid object.
@@ -325,6 +331,11 @@ int csg_crop_fwd(const float* img, int64_t B, int64_t H, int64_t W, int64_t img_
                  const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, float* out, int64_t out_cs, void* stream);
 int csg_crop_bwd(const float* dout, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C, const float* boxes,
                  const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, int64_t out_cs, float* dimg, void* stream);
+/* Gradient w.r.t. the crop boxes (N,4) [x0,y0,w,h] — the sampling grid of crop_bbox is differentiable in them
+ * (sg2im/bilinear.py:83-94); img is the forward's image, dboxes (N,4) is overwritten.  One block per crop, ordered sums. */
+int csg_crop_bwd_boxes(const float* dout, const float* img, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C,
+                       const float* boxes, const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, int64_t out_cs,
+                       float* dboxes, void* stream);
 
 /* ---- perceptual loss helpers (spade/models/networks/architecture.py:93-123, loss.py:102-117) --------
  * nn.MaxPool2d(kernel 2, stride 2) of torchvision's vgg19().features (floor mode; the backward

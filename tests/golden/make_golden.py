@@ -670,6 +670,43 @@ def fx_row_gaps():
                       "mlp_shapes": shapes_of(mlp)}, **arrays)
 
 
+def fx_row_gaps_r3():
+    """Round-3 row gaps: gradients w.r.t. the masks of masks_to_layout (layout.py:48-77) and w.r.t. the boxes of
+    crop_bbox_batch (bilinear.py:44-94)."""
+    from sg2im.bilinear import crop_bbox_batch
+    torch.manual_seed(31)
+    arrays = {}
+    vecs = torch.randn(5, 8, requires_grad=True)
+    boxes = torch.tensor([[0.10, 0.20, 0.50, 0.40], [0.00, 0.00, 1.00, 1.00], [0.60, 0.55, 0.35, 0.30],
+                          [0.30, 0.30, 0.07, 0.90], [-0.2, 0.40, 0.60, 0.20]], requires_grad=True)
+    for M in (16, 5):
+        soft = torch.rand(5, M, M, requires_grad=True)
+        arrays["soft_%d" % M] = npy(soft)
+        for H, W in ((32, 32), (24, 40)):
+            out = masks_to_layout(vecs, boxes, soft, H, W)
+            w = torch.randn_like(out)
+            gv, gb, gm = torch.autograd.grad((out * w).sum(), [vecs, boxes, soft])
+            tag = "%d_%dx%d" % (M, H, W)
+            arrays.update({"out_" + tag: npy(out), "w_" + tag: npy(w), "gvecs_" + tag: npy(gv), "gboxes_" + tag: npy(gb),
+                           "gmasks_" + tag: npy(gm)})
+    arrays.update({"vecs": npy(vecs), "boxes": npy(boxes)})
+    # crops: gradients w.r.t. image AND boxes
+    vocab = make_vocab("tiny")
+    batch = make_batch(vocab, BatchConfig(3, 32, 1, 4, "random"), seed=9)
+    imgs, objs = batch[0].clone().requires_grad_(True), batch[1]
+    cb = batch[2].clone()
+    cb[0, 0] = torch.tensor([0.7, 0.6, 0.5, 0.6])            # runs off the image: zero padding
+    cb[1, 0] = torch.tensor([0.013, 0.027, 0.41, 0.33])
+    cb = cb.requires_grad_(True)
+    crops = crop_bbox_batch(imgs, objs, cb, 16, vocab=vocab)
+    cw = torch.randn_like(crops)
+    gi, gcb = torch.autograd.grad((crops * cw).sum(), [imgs, cb])
+    arrays.update({"c_imgs": npy(imgs), "c_objs": npy(objs), "c_boxes": npy(cb), "c_crops": npy(crops), "c_w": npy(cw),
+                   "c_gimgs": npy(gi), "c_gboxes": npy(gcb)})
+    save("row_gaps_r3", {"ref": "sg2im/layout.py:48-77, sg2im/bilinear.py:12-94", "mask_sizes": [16, 5],
+                         "sizes": [[32, 32], [24, 40]], "vocab": "tiny", "crop_size": 16}, **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1:                      # regenerate selected fixtures: make_golden.py fx_vgg ...
@@ -690,3 +727,4 @@ if __name__ == "__main__":
     fx_canon_graph()
     fx_converse()
     fx_row_gaps()
+    fx_row_gaps_r3()

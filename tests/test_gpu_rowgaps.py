@@ -263,3 +263,208 @@ def test_nlayer_discriminator_norm_variants_vs_torch(norm_D):
     assert_close(gd[k0].grad, gr["0.0.weight"].grad, RTOL, 1e-5 * float(gr["0.0.weight"].grad.abs().max()) + 1e-7, "%s dW0" % norm_D)
     assert_close(gd["model4.0.weight"].grad, gr["4.0.weight"].grad, RTOL, 1e-5 * float(gr["4.0.weight"].grad.abs().max()) + 1e-7,
                  "%s dW4" % norm_D)
+
+
+def _ref_build_mlp(dim_list, activation='relu', batch_norm='none', dropout=0, final_nonlinearity='relu'):
+    """The reference's construction (sg2im/layers.py:6-25), restated with torch.nn for the test."""
+    import torch.nn as nn
+
+    def act(name):
+        if name.lower().startswith('leakyrelu'):
+            return nn.LeakyReLU(float(name.split('-')[1])) if '-' in name else nn.LeakyReLU()
+        return {'relu': nn.ReLU, 'sigmoid': nn.Sigmoid}[name.lower()]()
+    layers = []
+    for i in range(len(dim_list) - 1):
+        layers.append(nn.Linear(dim_list[i], dim_list[i + 1]))
+        if i != len(dim_list) - 2:
+            if batch_norm == 'batch':
+                layers.append(nn.BatchNorm1d(dim_list[i + 1]))
+            if activation is not None:
+                layers.append(act(activation))
+        if dropout > 0:
+            layers.append(nn.Dropout(p=dropout))
+    if final_nonlinearity is not None:
+        layers.append(act(final_nonlinearity))
+    return nn.Sequential(*layers)
+
+
+@pytest.mark.parametrize("kw", [dict(activation='leakyrelu-0.2', final_nonlinearity=None),
+                                dict(activation='sigmoid', final_nonlinearity='sigmoid'),
+                                dict(batch_norm='batch', activation='leakyrelu-0.3', final_nonlinearity='leakyrelu'),
+                                dict(dropout=0.5, final_nonlinearity='relu')])
+def test_build_mlp_activation_and_dropout_variants_vs_torch(kw):
+    """build_mlp beyond the trainer's settings (reference sg2im/layers.py:6-25): LeakyReLU-x / sigmoid activations, a
+    final non-linearity of another kind, dropout (compared in eval mode: the masks of two RNGs cannot agree): same
+    nn.Sequential layout and state_dict keys as the reference's construction, outputs and gradients vs torch."""
+    from canonicalsg2im_amd.sg2im.layers import build_mlp
+    dims = [12, 32, 24, 8]
+    torch.manual_seed(7)
+    mine = build_mlp(dims, **kw).cuda()
+    ref = _ref_build_mlp(dims, **kw)
+    assert len(mine) == len(ref) and list(mine.state_dict().keys()) == list(ref.state_dict().keys())
+    ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
+    train = kw.get('dropout', 0) == 0
+    mine.train(train)
+    ref.train(train)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(40, 12, generator=g)
+    w = torch.randn(40, 8, generator=g)
+    xr = x.clone().requires_grad_(True)
+    (ref(xr) * w).sum().backward()
+    xd = x.clone().cuda().requires_grad_(True)
+    y = mine(xd)
+    (y * w.cuda()).sum().backward()
+    assert_close(y, ref(x).detach(), RTOL, 1e-5, "mlp out %s" % (kw,))
+    assert_close(xd.grad, xr.grad, RTOL, 1e-5 * float(xr.grad.abs().max()) + 1e-6, "mlp dx %s" % (kw,))
+    for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, RTOL, 1e-5 * float(q.grad.abs().max()) + 1e-6, "mlp d%s %s" % (k, kw))
+
+
+@pytest.mark.parametrize("case", [('I8,C3-16,C3-32-2,U2,C3-8,P2,C1-4', dict(normalization='instance', activation='relu')),
+                                  ('I8,C3-16,C3-32', dict(normalization='none', activation='leakyrelu-0.1')),
+                                  ('C4-16-2,C4-32-2', dict(normalization='batch', activation='sigmoid', padding='valid')),
+                                  ('I4,C3-8,U3,C3-8', dict(normalization='batch', activation='leakyrelu-0.2'))])
+def test_build_cnn_grammar_vs_torch(case):
+    """build_cnn's I / C / U / P grammar on the HIP layers (reference sg2im/layers.py:28-112) against the reference's
+    own torch.nn construction restated in the test: same Sequential indices and state_dict keys, outputs and gradients."""
+    import torch.nn as nn
+    from canonicalsg2im_amd import ops
+    from canonicalsg2im_amd.sg2im.layers import build_cnn
+    arch, kw = case
+    torch.manual_seed(9)
+    mine, cout = build_cnn(arch, **kw)
+    mine = mine.cuda().train()
+    # the reference builder, restated
+    norm, actn, padding = kw.get('normalization', 'batch'), kw.get('activation', 'relu'), kw.get('padding', 'same')
+    parts = arch.split(',')
+    cur = 3
+    if parts[0][0] == 'I':
+        cur, parts = int(parts[0][1:]), parts[1:]
+    cin = cur
+    layers, first = [], True
+    for s in parts:
+        if s[0] == 'C':
+            if not first:
+                if norm == 'batch':
+                    layers.append(nn.BatchNorm2d(cur))
+                elif norm == 'instance':
+                    layers.append(nn.InstanceNorm2d(cur))
+                if actn.lower().startswith('leakyrelu'):
+                    layers.append(nn.LeakyReLU(float(actn.split('-')[1])))
+                else:
+                    layers.append({'relu': nn.ReLU, 'sigmoid': nn.Sigmoid}[actn]())
+            first = False
+            v = [int(t) for t in s[1:].split('-')]
+            layers.append(nn.Conv2d(cur, v[1], v[0], padding=(v[0] - 1) // 2 if padding == 'same' else 0,
+                                    stride=v[2] if len(v) == 3 else 1))
+            cur = v[1]
+        elif s[0] == 'U':
+            layers.append(nn.Upsample(scale_factor=int(s[1:]), mode='nearest'))
+        elif s[0] == 'P':
+            layers.append(nn.MaxPool2d(2, 2))
+    ref = nn.Sequential(*layers).train()
+    assert cur == cout and len(ref) == len(mine)
+    assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+    ref.load_state_dict({k: v.detach().cpu().contiguous() for k, v in mine.state_dict().items()})
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(3, cin, 24, 20, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    w = torch.randn(yr.shape, generator=g)
+    (yr * w).sum().backward()
+    xd = ops.nhwc(x.clone().cuda()).requires_grad_(True)
+    y = mine(xd)
+    (y * w.cuda()).sum().backward()
+    assert_close(y, yr.detach(), RTOL, 1e-5 * float(yr.detach().abs().max()) + 1e-6, "cnn out %s" % (case,))
+    assert_close(xd.grad, xr.grad, RTOL, 1e-5 * float(xr.grad.abs().max()) + 1e-6, "cnn dx %s" % (case,))
+    def feeds_norm(i):               # a per-channel shift passes through nearest upsampling and max pooling unchanged
+        j = i + 1
+        while j < len(ref) and isinstance(ref[j], (nn.Upsample, nn.MaxPool2d)):
+            j += 1
+        return j < len(ref) and isinstance(ref[j], (nn.BatchNorm2d, nn.InstanceNorm2d))
+    normed = {str(i) + ".bias" for i in range(len(ref)) if isinstance(ref[i], nn.Conv2d) and feeds_norm(i)}   # gradient is
+    for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        if k in normed:                                                    # analytically zero, both sides hold rounding noise
+            scale = float(dict(ref.named_parameters())[k.replace("bias", "weight")].grad.abs().max())
+            assert float(p.grad.abs().max()) < 1e-4 * scale + 1e-4 and float(q.grad.abs().max()) < 1e-4 * scale + 1e-4
+            continue
+        assert_close(p.grad, q.grad, RTOL, 1e-5 * float(q.grad.abs().max()) + 1e-5, "cnn d%s %s" % (k, case))
+
+
+def test_masks_to_layout_mask_gradients_vs_reference():
+    """masks_to_layout (layout.py:48-77) is differentiable in the masks (model.py trains mask_net through it): forward,
+    d vecs, d boxes and d masks against the reference's autograd; 16 x 16 and 5 x 5 masks, square and non-square maps;
+    the mask gradient is an ordered sum (bit-identical from run to run)."""
+    from canonicalsg2im_amd.sg2im.layout import masks_to_layout
+    meta, a = load_golden("row_gaps_r3")
+    for M in meta["mask_sizes"]:
+        for (H, W) in meta["sizes"]:
+            t = "%d_%dx%d" % (M, H, W)
+            runs = []
+            for _ in range(2):
+                vecs, boxes, soft = [a[k].cuda().requires_grad_(True) for k in ("vecs", "boxes", "soft_%d" % M)]
+                out = masks_to_layout(vecs, boxes, soft, H, W)
+                assert_close(out, a["out_" + t], RTOL, 2e-6, "masks layout " + t)
+                runs.append(torch.autograd.grad((out * a["w_" + t].cuda()).sum(), [vecs, boxes, soft]))
+            gv, gb, gm = runs[0]
+            assert_close(gv, a["gvecs_" + t], RTOL, 1e-5, "dvecs " + t)
+            assert_close(gb, a["gboxes_" + t], RTOL, 1e-5 * float(a["gboxes_" + t].abs().max()), "dboxes " + t)
+            assert_close(gm, a["gmasks_" + t], RTOL, 1e-5, "dmasks " + t)
+            assert torch.equal(gm, runs[1][2])
+
+
+def test_mask_gradients_through_pyramid_and_disc_input_vs_oracle():
+    """The batched entry points the generator / discriminator use (several sizes at once, padded object rows,
+    the [layout | image] buffer) against the oracle's per-sample masks_to_layout + nearest resize."""
+    import oracle
+    import torch.nn.functional as F
+    from canonicalsg2im_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, O, S, M, H = 2, 4, 8, 16, 32
+    vecs = torch.randn(B, O, S, generator=g)
+    boxes = torch.rand(B, O, 4, generator=g) * 0.5 + 0.05
+    masks = torch.rand(B, O, M, M, generator=g)
+    valid = torch.tensor([[1, 1, 1, 0], [1, 0, 1, 1]], dtype=torch.uint8)
+    img = torch.randn(B, 3, H, H, generator=g)
+    sizes = (8, 16, 32)
+    ws = [torch.randn(B, S, s, s, generator=g) for s in sizes]
+    wd = torch.randn(B, S + 3, H, H, generator=g)
+    mo = masks.clone().requires_grad_(True)
+    loss = 0
+    for b in range(B):
+        keep = valid[b].bool()
+        full = oracle.masks_to_layout(vecs[b][keep], boxes[b][keep], mo[b][keep], H)
+        for s, w in zip(sizes, ws):
+            loss = loss + (F.interpolate(full, size=(s, s), mode="nearest") * w[b:b + 1]).sum()
+        loss = loss + (full * wd[b:b + 1, :S]).sum()
+    (want,) = torch.autograd.grad(loss, [mo])
+    md = masks.cuda().requires_grad_(True)
+    outs = ops.layout_pyramid(vecs.cuda(), boxes.cuda(), valid.cuda(), H, sizes, masks=md)
+    buf = ops.disc_input(img.cuda(), vecs.cuda(), boxes.cuda(), valid.cuda(), H, masks=md)
+    wdc = wd.cuda()
+    lg = sum((o * w.cuda()).sum() for o, w in zip(outs, ws)) + (buf[:, :S] * wdc[:, :S]).sum()
+    (got,) = torch.autograd.grad(lg, [md])
+    assert_close(got, want, RTOL, 1e-5, "dmasks through pyramid + disc input")
+    assert float(got[0, 3].abs().max()) == 0.0 and float(got[1, 1].abs().max()) == 0.0      # padded rows
+
+
+def test_object_crop_box_gradients_vs_reference():
+    """crop_bbox's sampling grid is differentiable in the boxes (bilinear.py:83-94): d boxes against the reference's
+    autograd (a box running off the image included), ordered sums (bit-identical from run to run)."""
+    from canonicalsg2im_amd import ops
+    from canonicalsg2im_amd.synth import make_vocab
+    meta, a = load_golden("row_gaps_r3")
+    vocab = make_vocab(meta["vocab"])
+    objs = a["c_objs"].cuda()
+    valid = ops.real_object_mask(objs, vocab["object_name_to_idx"]["__image__"])
+    nz = valid.nonzero()
+    runs = []
+    for _ in range(2):
+        imgs, boxes = a["c_imgs"].cuda().requires_grad_(True), a["c_boxes"].cuda().requires_grad_(True)
+        crops = ops.crop_objects(imgs, boxes[nz[:, 0], nz[:, 1]], nz[:, 0].contiguous(), meta["crop_size"])
+        assert_close(crops[:, :3], a["c_crops"], RTOL, 2e-6, "crops")
+        runs.append(torch.autograd.grad((crops[:, :3] * a["c_w"].cuda()).sum(), [imgs, boxes]))
+    gi, gb = runs[0]
+    assert_close(gi, a["c_gimgs"], RTOL, 1e-5, "d imgs")
+    assert_close(gb, a["c_gboxes"], RTOL, 1e-5 * float(a["c_gboxes"].abs().max()), "d crop boxes")
+    assert torch.equal(gb, runs[1][1])

@@ -233,6 +233,29 @@ def test_row_gap_fixtures():
         assert_close(oracle.syncbn_affine_single_device(bn, "", a["bn_x"], False), a["bn_y_eval"], RTOL, ATOL, "eval")
 
 
+def test_row_gap_r3_fixtures():
+    """Gradients w.r.t. the masks (and boxes) of masks_to_layout and w.r.t. the boxes of the object crops — oracle vs
+    the reference's autograd outputs."""
+    meta, a = load_golden("row_gaps_r3")
+    for M in meta["mask_sizes"]:
+        for (H, W) in meta["sizes"]:
+            t = "%d_%dx%d" % (M, H, W)
+            vecs, boxes, soft = [a[k].clone().requires_grad_(True) for k in ("vecs", "boxes", "soft_%d" % M)]
+            out = oracle.masks_to_layout(vecs, boxes, soft, H, W)
+            assert_close(out, a["out_" + t], RTOL, ATOL, "masks layout " + t)
+            gv, gb, gm = torch.autograd.grad((out * a["w_" + t]).sum(), [vecs, boxes, soft])
+            assert_close(gv, a["gvecs_" + t], RTOL, 1e-5, "dvecs " + t)
+            assert_close(gb, a["gboxes_" + t], RTOL, 1e-5 * float(a["gboxes_" + t].abs().max()), "dboxes " + t)
+            assert_close(gm, a["gmasks_" + t], RTOL, 1e-5, "dmasks " + t)
+    vocab = make_vocab(meta["vocab"])
+    imgs, cb = a["c_imgs"].clone().requires_grad_(True), a["c_boxes"].clone().requires_grad_(True)
+    crops, _ = oracle.crop_objects(imgs, a["c_objs"], cb, vocab, meta["crop_size"])
+    assert_close(crops, a["c_crops"], RTOL, ATOL, "crops")
+    gi, gcb = torch.autograd.grad((crops * a["c_w"]).sum(), [imgs, cb])
+    assert_close(gi, a["c_gimgs"], RTOL, 1e-5, "d imgs")
+    assert_close(gcb, a["c_gboxes"], RTOL, 1e-5 * float(a["c_gboxes"].abs().max()), "d crop boxes")
+
+
 def test_object_crops():
     meta, a = load_golden("crops")
     vocab = make_vocab(meta["vocab"])
