@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsg_hip.so")
+LIB_PATH = os.environ.get("CSG_HIP_LIB") or os.path.join(_HERE, "libcsg_hip.so")    # override: developer builds (tools/)
 
 MAX_TAPS = 16
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2

@@ -78,6 +78,16 @@ typedef const volatile __attribute__((address_space(3))) csg_f32x2* w4_lds_cv2;
 #define W4_THREADS 768             // twelve waves: two channel groups x six rows xi
 #define W4_RBUF (6 * 2 * 32 * W4_RSE)       // words of one channel group's epilogue exchange buffer
 
+// Developer build (-DW4_TRACE, tools/wino4_trace.py): thread 0 of the first 8192 blocks leaves shader-clock timestamps
+// at the phase boundaries of the kernel; csg_wino4_trace_read copies them out.
+#ifdef W4_TRACE
+__device__ unsigned long long w4_trace[8192 * 8];
+#define W4_T(i)                                                                                   \
+  if (threadIdx.x == 0 && blockIdx.x < 8192) w4_trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();
+#else
+#define W4_T(i)
+#endif
+
 struct Wino4Params {
   int B, H, W, Cin, x_cs, Cout, y_cs;
   int tbx, tby;        // block regions per image
@@ -164,7 +174,86 @@ __global__ __launch_bounds__(256) void k_wino4_pack(const float* __restrict__ w,
     }
 }
 
-// ---- epilogue shared by the kernels below.  A^T = [[1,1,1,1,1,0],[0,1,-1,1/2,-2,0],[0,1,1,1/4,4,0],[0,1,-1,1/8,-8,1]].
+// Two fp32 lanes per VALU instruction (v_pk_fma_f32 / v_pk_add_f32): on this chip every VALU cycle of a SIMD is a cycle
+// its matrix pipe does not get (see below), and the transforms are all pairs — (channel, channel + 1) in the input
+// transform, neighbouring output channels in the output transform.  Same IEEE fma per lane as fmaf: bit-identical.
+__device__ __forceinline__ csg_f32x2 w4_pfma(float c, csg_f32x2 a, csg_f32x2 b) {
+  return __builtin_elementwise_fma(csg_f32x2{c, c}, a, b);
+}
+
+// ---- epilogue.  A^T = [[1,1,1,1,1,0],[0,1,-1,1/2,-2,0],[0,1,1,1/4,4,0],[0,1,-1,1/8,-8,1]].
+// Second half of a round: Y[a][b] = sum_xi A^T[a][xi] R_xi[b] for two output columns b, out of the exchange buffer.
+// PLAIN = bias only (the SPADE gamma / beta convolutions and every backward-data pass without a gate): no per-element
+// branches on the activation / residual / gate.
+template <bool PLAIN>
+__device__ __forceinline__ void w4_store_columns(const Wino4Params& p, const float* rbuf, int tig, int round, int nt32,
+                                                 int img, int X0, int Y0, const float* __restrict__ bias,
+                                                 const float* __restrict__ res, const float* __restrict__ gate,
+                                                 float* __restrict__ y) {
+  for (int item = tig; item < 512; item += W4_THREADS / 2) {  // 32 tiles x 8 channel quads x 2 columns
+    const int cq = item & 7, tile = (item >> 3) & 31, bb = item >> 8;
+    const int n = nt32 * 32 + cq * 4;
+    const int ttx = tile & (W4_TW - 1), tty = tile >> 3;
+    const int oy = Y0 + 4 * tty, ox = X0 + 4 * ttx + 2 * round + bb;
+    if (n < p.Cout && oy < p.H && ox < p.W) {      // H and W are multiples of 4: a tile is wholly inside or outside
+      csg_f32x2 lo[6], hi[6];
+#pragma unroll
+      for (int xi = 0; xi < 6; ++xi) {
+        const csg_f32x4 r = *(const csg_f32x4*)(rbuf + ((xi * 2 + bb) * 32 + tile) * W4_RSE + cq * 4);
+        lo[xi] = __builtin_shufflevector(r, r, 0, 1);
+        hi[xi] = __builtin_shufflevector(r, r, 2, 3);
+      }
+      csg_f32x2 blo = {0.f, 0.f}, bhi = {0.f, 0.f};
+      if (bias != nullptr) {
+        const csg_f32x4 bv = *(const csg_f32x4*)(bias + n);
+        blo = __builtin_shufflevector(bv, bv, 0, 1);
+        bhi = __builtin_shufflevector(bv, bv, 2, 3);
+      }
+      const int64_t rowstride = (int64_t)p.W * p.y_cs;
+      int64_t off = (((int64_t)img * p.H + oy) * p.W + ox) * p.y_cs + n;
+#pragma unroll
+      for (int a = 0; a < 4; ++a, off += rowstride) {
+        csg_f32x2 vl, vh;
+        if (a == 0) {
+          vl = ((lo[0] + lo[1]) + (lo[2] + lo[3])) + lo[4];
+          vh = ((hi[0] + hi[1]) + (hi[2] + hi[3])) + hi[4];
+        } else if (a == 1) {
+          vl = w4_pfma(-2.0f, lo[4], w4_pfma(0.5f, lo[3], lo[1] - lo[2]));
+          vh = w4_pfma(-2.0f, hi[4], w4_pfma(0.5f, hi[3], hi[1] - hi[2]));
+        } else if (a == 2) {
+          vl = w4_pfma(4.0f, lo[4], w4_pfma(0.25f, lo[3], lo[1] + lo[2]));
+          vh = w4_pfma(4.0f, hi[4], w4_pfma(0.25f, hi[3], hi[1] + hi[2]));
+        } else {
+          vl = w4_pfma(-8.0f, lo[4], w4_pfma(0.125f, lo[3], lo[1] - lo[2])) + lo[5];
+          vh = w4_pfma(-8.0f, hi[4], w4_pfma(0.125f, hi[3], hi[1] - hi[2])) + hi[5];
+        }
+        vl += blo;
+        vh += bhi;
+        float vv[4] = {vl.x, vl.y, vh.x, vh.y};
+        if (!PLAIN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (p.act == CSG_ACT_LEAKY)
+              vv[e] = vv[e] > 0.f ? vv[e] : vv[e] * p.slope;
+            else if (p.act == CSG_ACT_TANH)
+              vv[e] = tanhf(vv[e]);
+          }
+          if (res != nullptr) {
+            const float4 rv = *(const float4*)(res + off);
+            vv[0] += rv.x; vv[1] += rv.y; vv[2] += rv.z; vv[3] += rv.w;
+          }
+          if (gate != nullptr) {
+            const float4 gv = *(const float4*)(gate + off);
+            vv[0] *= gv.x > 0.f ? 1.f : p.gate_slope; vv[1] *= gv.y > 0.f ? 1.f : p.gate_slope;
+            vv[2] *= gv.z > 0.f ? 1.f : p.gate_slope; vv[3] *= gv.w > 0.f ? 1.f : p.gate_slope;
+          }
+        }
+        *(float4*)(y + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[6], const Wino4Params& p, float* smem, int tid, int wave, int grp,
                                             int j, int h, int nt32, int img, int X0, int Y0, const float* __restrict__ bias,
                                             const float* __restrict__ res, const float* __restrict__ gate,
@@ -173,77 +262,43 @@ __device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[6], const Wino4Params&
   // output columns b per round: rbuf[xi][b & 1][32 tiles][W4_RSE]
   float* rbuf = smem + grp * W4_RBUF;            // this channel group's exchange buffer
   const int tig = tid - grp * (W4_THREADS / 2);  // thread index inside the channel group
+  const bool plain = p.act == CSG_ACT_NONE && res == nullptr && gate == nullptr;
   __syncthreads();                               // every wave is done reading the staging buffers
+  W4_T(3)
 #pragma unroll
   for (int round = 0; round < 2; ++round) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float r0[4], r1[4];
+      csg_f32x2 r0[2], r1[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float m0 = acc[0][4 * g + e], m1 = acc[1][4 * g + e], m2 = acc[2][4 * g + e], m3 = acc[3][4 * g + e],
-                    m4 = acc[4][4 * g + e], m5 = acc[5][4 * g + e];
+      for (int e = 0; e < 2; ++e) {
+#define W4_M(K) csg_f32x2{acc[K][4 * g + 2 * e], acc[K][4 * g + 2 * e + 1]}
+        const csg_f32x2 m0 = W4_M(0), m1 = W4_M(1), m2 = W4_M(2), m3 = W4_M(3), m4 = W4_M(4), m5 = W4_M(5);
+#undef W4_M
         if (round == 0) {
           r0[e] = ((m0 + m1) + (m2 + m3)) + m4;
-          r1[e] = fmaf(-2.0f, m4, fmaf(0.5f, m3, m1 - m2));
+          r1[e] = w4_pfma(-2.0f, m4, w4_pfma(0.5f, m3, m1 - m2));
         } else {
-          r0[e] = fmaf(4.0f, m4, fmaf(0.25f, m3, m1 + m2));
-          r1[e] = fmaf(-8.0f, m4, fmaf(0.125f, m3, m1 - m2)) + m5;
+          r0[e] = w4_pfma(4.0f, m4, w4_pfma(0.25f, m3, m1 + m2));
+          r1[e] = w4_pfma(-8.0f, m4, w4_pfma(0.125f, m3, m1 - m2)) + m5;
         }
       }
       const int ch = 8 * g + 4 * h;
-      *(float4*)(rbuf + ((wave * 2 + 0) * 32 + j) * W4_RSE + ch) = make_float4(r0[0], r0[1], r0[2], r0[3]);
-      *(float4*)(rbuf + ((wave * 2 + 1) * 32 + j) * W4_RSE + ch) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+      *(float4*)(rbuf + ((wave * 2 + 0) * 32 + j) * W4_RSE + ch) = make_float4(r0[0].x, r0[0].y, r0[1].x, r0[1].y);
+      *(float4*)(rbuf + ((wave * 2 + 1) * 32 + j) * W4_RSE + ch) = make_float4(r1[0].x, r1[0].y, r1[1].x, r1[1].y);
     }
     __syncthreads();
-    for (int item = tig; item < 512; item += W4_THREADS / 2) {  // 32 tiles x 8 channel quads x 2 columns
-      const int cq = item & 7, tile = (item >> 3) & 31, bb = item >> 8;
-      const int n = nt32 * 32 + cq * 4;
-      const int ttx = tile & (W4_TW - 1), tty = tile >> 3;
-      const int oy = Y0 + 4 * tty, ox = X0 + 4 * ttx + 2 * round + bb;
-      if (n < p.Cout && oy < p.H && ox < p.W) {      // H and W are multiples of 4: a tile is wholly inside or outside
-        float4 rr[6];
-#pragma unroll
-        for (int xi = 0; xi < 6; ++xi) rr[xi] = *(const float4*)(rbuf + ((xi * 2 + bb) * 32 + tile) * W4_RSE + cq * 4);
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias != nullptr) bv = *(const float4*)(bias + n);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          float vv[4];
-#define W4_ROW(F, I)                                                                                         \
-          if (a == 0) vv[I] = ((rr[0].F + rr[1].F) + (rr[2].F + rr[3].F)) + rr[4].F;                           \
-          else if (a == 1) vv[I] = fmaf(-2.0f, rr[4].F, fmaf(0.5f, rr[3].F, rr[1].F - rr[2].F));              \
-          else if (a == 2) vv[I] = fmaf(4.0f, rr[4].F, fmaf(0.25f, rr[3].F, rr[1].F + rr[2].F));              \
-          else vv[I] = fmaf(-8.0f, rr[4].F, fmaf(0.125f, rr[3].F, rr[1].F - rr[2].F)) + rr[5].F;
-          W4_ROW(x, 0)
-          W4_ROW(y, 1)
-          W4_ROW(z, 2)
-          W4_ROW(w, 3)
-#undef W4_ROW
-          vv[0] += bv.x; vv[1] += bv.y; vv[2] += bv.z; vv[3] += bv.w;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (p.act == CSG_ACT_LEAKY)
-              vv[e] = vv[e] > 0.f ? vv[e] : vv[e] * p.slope;
-            else if (p.act == CSG_ACT_TANH)
-              vv[e] = tanhf(vv[e]);
-          }
-          const int64_t pix = ((int64_t)img * p.H + (oy + a)) * p.W + ox;
-          if (res != nullptr) {
-            const float4 rv = *(const float4*)(res + pix * p.y_cs + n);
-            vv[0] += rv.x; vv[1] += rv.y; vv[2] += rv.z; vv[3] += rv.w;
-          }
-          if (gate != nullptr) {
-            const float4 gv = *(const float4*)(gate + pix * p.y_cs + n);
-            vv[0] *= gv.x > 0.f ? 1.f : p.gate_slope; vv[1] *= gv.y > 0.f ? 1.f : p.gate_slope;
-            vv[2] *= gv.z > 0.f ? 1.f : p.gate_slope; vv[3] *= gv.w > 0.f ? 1.f : p.gate_slope;
-          }
-          *(float4*)(y + pix * p.y_cs + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        }
-      }
+    if (round == 0) { W4_T(4) }
+    if (plain)
+      w4_store_columns<true>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
+    else
+      w4_store_columns<false>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
+    if (round == 0) {
+      __syncthreads();                           // the exchange buffer is rewritten by round 1
+      W4_T(5)
     }
-    __syncthreads();
   }
+  W4_T(6)
 }
 
 // ------------------------------------------------------------------------------------ convolution
@@ -269,6 +324,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   static_assert(W4V_OFFTAB >= 2 * W4_RBUF, "the epilogue exchange buffers fit in front of the offset table");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
+  W4_T(0)
   const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave12 >= 6 ? 1 : 0;           // consumer: channel group; producer: channel pairs 2 grp + {0, 1}
   const int wave = wave12 - 6 * grp;             // row xi of the transformed domain (both roles)
@@ -357,7 +413,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   //   xi = 3: (e3 - e1) + 2 (e2 - e0)        xi = 4: (e3 - e1) - 0.5 (e2 - e0)
   auto produce_xi = [&](auto xi_tag, int rbufsel, int vbufsel) {
     constexpr int XI = decltype(xi_tag)::value;
-    float2 t[6];
+    csg_f32x2 t[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const int co = rbufsel * W4_BUFW + ((c & 3) * W4_CQ + (c >> 2)) * W4_PS;
@@ -367,39 +423,30 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       const csg_f32x2 e3 = *(w4_lds_cv2)(p3 + co);
       if (XI == 0 || XI == 5) {
         const csg_f32x2 e4 = *(w4_lds_cv2)(p0 + co + 4 * W4_RS + 2);
-        t[c].x = fmaf(1.5f, e3.x - e1.x, fmaf(-2.0f, e2.x, e0.x + e4.x));
-        t[c].y = fmaf(1.5f, e3.y - e1.y, fmaf(-2.0f, e2.y, e0.y + e4.y));
+        t[c] = w4_pfma(1.5f, e3 - e1, w4_pfma(-2.0f, e2, e0 + e4));
       } else if (XI == 1) {
-        t[c].x = fmaf(2.5f, e2.x, fmaf(0.5f, e1.x, e3.x - e0.x));
-        t[c].y = fmaf(2.5f, e2.y, fmaf(0.5f, e1.y, e3.y - e0.y));
+        t[c] = w4_pfma(2.5f, e2, w4_pfma(0.5f, e1, e3 - e0));
       } else if (XI == 2) {
-        t[c].x = fmaf(0.5f, e2.x, fmaf(-2.5f, e1.x, e3.x + e0.x));
-        t[c].y = fmaf(0.5f, e2.y, fmaf(-2.5f, e1.y, e3.y + e0.y));
+        t[c] = w4_pfma(0.5f, e2, w4_pfma(-2.5f, e1, e3 + e0));
       } else if (XI == 3) {
-        t[c].x = fmaf(2.0f, e2.x - e0.x, e3.x - e1.x);
-        t[c].y = fmaf(2.0f, e2.y - e0.y, e3.y - e1.y);
+        t[c] = w4_pfma(2.0f, e2 - e0, e3 - e1);
       } else {
-        t[c].x = fmaf(-0.5f, e2.x - e0.x, e3.x - e1.x);
-        t[c].y = fmaf(-0.5f, e2.y - e0.y, e3.y - e1.y);
+        t[c] = w4_pfma(-0.5f, e2 - e0, e3 - e1);
       }
     }
-    float2 v[6];
-#define W4_COLV(F)                                                                  \
-    {                                                                               \
-      const float s42 = t[4].F - t[2].F, s31 = t[3].F - t[1].F;                      \
-      v[0].F = fmaf(1.5f, s31, fmaf(-2.0f, t[2].F, t[0].F + t[4].F));               \
-      v[1].F = fmaf(2.5f, t[3].F, fmaf(0.5f, t[2].F, t[4].F - t[1].F));             \
-      v[2].F = fmaf(0.5f, t[3].F, fmaf(-2.5f, t[2].F, t[4].F + t[1].F));            \
-      v[3].F = fmaf(2.0f, s31, s42);                                                \
-      v[4].F = fmaf(-0.5f, s31, s42);                                               \
-      v[5].F = fmaf(1.5f, s42, fmaf(-2.0f, t[3].F, t[1].F + t[5].F));               \
+    csg_f32x2 v[6];
+    {
+      const csg_f32x2 s42 = t[4] - t[2], s31 = t[3] - t[1];
+      v[0] = w4_pfma(1.5f, s31, w4_pfma(-2.0f, t[2], t[0] + t[4]));
+      v[1] = w4_pfma(2.5f, t[3], w4_pfma(0.5f, t[2], t[4] - t[1]));
+      v[2] = w4_pfma(0.5f, t[3], w4_pfma(-2.5f, t[2], t[4] + t[1]));
+      v[3] = w4_pfma(2.0f, s31, s42);
+      v[4] = w4_pfma(-0.5f, s31, s42);
+      v[5] = w4_pfma(1.5f, s42, w4_pfma(-2.0f, t[3], t[1] + t[5]));
     }
-    W4_COLV(x)
-    W4_COLV(y)
-#undef W4_COLV
 #pragma unroll
     for (int nu = 0; nu < 6; ++nu)
-      *(float2*)(pv + vbufsel * W4_VBUF + nu * 256 + 2 * grp) = v[nu];
+      *(csg_f32x2*)(pv + vbufsel * W4_VBUF + nu * 256 + 2 * grp) = v[nu];
   };
   auto produce = [&](int rbufsel, int vbufsel) {
     switch (wave) {
@@ -411,11 +458,11 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       default: produce_xi(std::integral_constant<int, 5>(), rbufsel, vbufsel); break;
     }
   };
-  // 24 MFMAs out of V buffer vbufsel with the U operands of k-oct s; refills the ring for k-oct s (positions 3..5)
-  // and s + 1 (positions 0..2)
-  auto consume = [&](int vbufsel, int s) {
+  // MFMAs of positions nu in [LO, HI) out of V buffer vbufsel with the U operands of k-oct s (four per position);
+  // refills the ring for k-oct s (positions 3..5) and s + 1 (positions 0..2)
+  auto consume = [&](auto lo_tag, auto hi_tag, int vbufsel, int s) {
 #pragma unroll
-    for (int nu = 0; nu < 6; ++nu) {
+    for (int nu = decltype(lo_tag)::value; nu < decltype(hi_tag)::value; ++nu) {
       const float4 v = *(const float4*)(pv + vbufsel * W4_VBUF + nu * 256);
       const int slot = nu % 3;
       acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[slot].x, v.x, acc[nu], 0, 0, 0);
@@ -425,10 +472,28 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       if (nu < 3) load_ur(slot, nu + 3, s); else load_ur(slot, nu - 3, s + 1);
     }
   };
+  // One stage.  The transform of stage k+1 sits BETWEEN the MFMAs of stage k (W4_SPLIT positions in front of it): after
+  // the barrier every wave has matrix work at once (V[k] is complete) and again after its transform, instead of all
+  // twelve waves issuing their 166 KB of transform reads together while the matrix pipes wait.
+#ifndef W4_SPLIT
+#define W4_SPLIT 3
+#endif
   auto stage = [&](int s, auto par_tag) {        // par = (s - s_begin) & 1
     constexpr int par = decltype(par_tag)::value;
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, W4_SPLIT> IS;
+    typedef std::integral_constant<int, 6> I6;
+#ifndef W4_NO_MFMA
+    consume(I0(), IS(), par, s);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef W4_NO_PRODUCE
     produce(par ^ 1, par ^ 1);                   // V[k+1] from raw[k+1]
-    consume(par, s);                             // MFMAs of stage k out of V[k]
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef W4_NO_MFMA
+    consume(IS(), I6(), par, s);
+#endif
     store_stage(smem + W4V_RAW0 + par * W4_BUFW);   // raw[k+2] takes the buffer raw[k] left
     __syncthreads();
     load_stage(s + 3);
@@ -449,6 +514,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     st[1] = a1;
     store_stage(smem + W4V_RAW0);
     __syncthreads();
+    W4_T(1)
     st[0] = b0;
     st[1] = b1;
     produce(0, 0);                               // V[0] from raw[0]
@@ -456,6 +522,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     __syncthreads();
     load_stage(s_begin + 2);
   }
+  W4_T(2)
   int s = s_begin;
   for (; s + 1 < s_end; s += 2) {
     stage(s, std::integral_constant<int, 0>());
@@ -464,6 +531,12 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   if (s < s_end) stage(s, std::integral_constant<int, 0>());
   w4_epilogue(acc, p, smem, tid, wave, grp, j, h, nt32, img, X0, Y0, bias, res, gate, y);
 }
+
+#ifdef W4_TRACE
+extern "C" int csg_wino4_trace_read(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w4_trace), (size_t)n * 8);
+}
+#endif
 
 // ------------------------------------------------------------------------------------ host side
 static int w4_plan(const csg_wino_desc* d, Wino4Params& p, size_t& shm, const char* who) {
