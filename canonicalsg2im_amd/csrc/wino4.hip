@@ -67,12 +67,8 @@ typedef const volatile __attribute__((address_space(3))) csg_f32x2* w4_lds_cv2;
 
 #define W4_TW 8
 #define W4_TH 4
-#define W4_R (4 * W4_TH + 2)      // 18 staged rows
-#define W4_C (4 * W4_TW + 2)      // 34 staged columns
 #define W4_CQ 9                   // columns per class (x & 3): ceil(34 / 4)
 #define W4_PS 8                   // words per staged pixel = channels per stage
-#define W4_RS 288                 // words per staged row: 4 classes x 9 columns x 8 words (a multiple of 16)
-#define W4_BUFW (W4_R * W4_RS + 8 + 16)   // + the skew of the last row group + a dump slot for idle staging lanes
 #define W4_RSE 36                 // words per tile row of the epilogue exchange buffer (32 channels + 4)
 #define W4_NLD 2                  // float4 global loads per thread and stage (18 * 34 * 2 / 768 rounded up)
 #define W4_THREADS 768             // twelve waves: two channel groups x six rows xi
@@ -90,6 +86,7 @@ __device__ unsigned long long w4_trace[8192 * 8];
 
 struct Wino4Params {
   int B, H, W, Cin, x_cs, Cout, y_cs;
+  int Ho, Wo, pad;     // output size and zero padding (F(4x4,3x3): Ho = H, Wo = W, pad = 1)
   int tbx, tby;        // block regions per image
   int nblocks;         // ceil(Cout / 64)
   int NT32, Q8;        // extents of the packed weights
@@ -117,59 +114,72 @@ __device__ __forceinline__ int w4_xcd_remap(int bid, int nblk) {
 // (.x,.y) and 8q + 4 + 2h + {0,1} (.z,.w), h = lane>>5; zero beyond N / K — the layout of k_wino_pack with 36
 // positions.  G = [[1,0,0],[1/3,1/3,1/3],[-1/3,1/3,-1/3],[-16/15,-8/15,-4/15],[1/15,-2/15,4/15],[0,0,1]].
 #define WP4_LD 33
+// RT = 3: F(4x4,3x3); RT = 4: F(3x3,4x4) — the same six points, G = rows c_k (1, p_k, .., p_k^(RT-1)), last row e_(RT-1)
+template <int RT>
 __global__ __launch_bounds__(256) void k_wino4_pack(const float* __restrict__ w, int64_t s_n, int64_t s_k, int64_t s_h,
                                                      int64_t s_w, int flip, int N, int K, const float* __restrict__ sigma,
                                                      int NT32, int Q8, float4* __restrict__ up) {
-  __shared__ float g[9][32][WP4_LD];
+  __shared__ float g[RT][32][WP4_LD];                  // the RT row taps of one column tap b
   const int tid = threadIdx.x;
   const int qb = blockIdx.x, nt = blockIdx.y;         // k range [32 qb, 32 qb + 32), n range [32 nt, 32 nt + 32)
   const bool k_fast = s_k <= s_n;
   const float sg = sigma != nullptr ? sigma[0] : 1.0f;
-  float stage[36];
-#pragma unroll
-  for (int it = 0; it < 36; ++it) {
-    const int t = it >> 2, r = tid + 256 * (it & 3);
-    const int nl = k_fast ? (r >> 5) : (r & 31), kl = k_fast ? (r & 31) : (r >> 5);
-    const int n = nt * 32 + nl, k = qb * 32 + kl;
-    const int a = t / 3, b = t - 3 * a;
-    const int aa = flip ? 2 - a : a, bb = flip ? 2 - b : b;
-    stage[it] = (n < N && k < K) ? w[(int64_t)n * s_n + (int64_t)k * s_k + aa * s_h + bb * s_w] : 0.f;
-  }
-#pragma unroll
-  for (int it = 0; it < 36; ++it) {
-    const int t = it >> 2, r = tid + 256 * (it & 3);
-    const int nl = k_fast ? (r >> 5) : (r & 31), kl = k_fast ? (r & 31) : (r >> 5);
-    g[t][nl][kl] = sigma != nullptr ? stage[it] / sg : stage[it];
-  }
-  __syncthreads();
   const int lane = tid & 63, ql = tid >> 6;            // 4 q per block, one per wave
   const int q = qb * 4 + ql;
-  if (q >= Q8) return;
   const int nl = lane & 31, h = lane >> 5;
-  const float G[6][3] = {{1.0f, 0.0f, 0.0f},
-                         {(float)(1.0 / 3.0), (float)(1.0 / 3.0), (float)(1.0 / 3.0)},
-                         {(float)(-1.0 / 3.0), (float)(1.0 / 3.0), (float)(-1.0 / 3.0)},
-                         {(float)(-16.0 / 15.0), (float)(-8.0 / 15.0), (float)(-4.0 / 15.0)},
-                         {(float)(1.0 / 15.0), (float)(-2.0 / 15.0), (float)(4.0 / 15.0)},
-                         {0.0f, 0.0f, 1.0f}};
-  float t[4][6][3];                                     // [e][xi][b] = (G g)[xi][b]
+  const float Gp[5] = {0.0f, 1.0f, -1.0f, 0.5f, -2.0f};
+  const float Gc[5] = {1.0f, (float)(1.0 / 3.0), (float)(-1.0 / 3.0), (float)(-16.0 / 15.0), (float)(1.0 / 15.0)};
+  float G[6][RT];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int kl = 8 * ql + (e >> 1) * 4 + 2 * h + (e & 1);
+  for (int k = 0; k < 5; ++k) {
+    float pw = 1.0f;
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const float g0 = g[b][nl][kl], g1 = g[3 + b][nl][kl], g2 = g[6 + b][nl][kl];
-#pragma unroll
-      for (int xi = 0; xi < 6; ++xi) t[e][xi][b] = G[xi][0] * g0 + G[xi][1] * g1 + G[xi][2] * g2;
+    for (int a = 0; a < RT; ++a) {
+      G[k][a] = (float)((double)Gc[k] * (double)pw);
+      pw *= Gp[k];
     }
   }
+#pragma unroll
+  for (int a = 0; a < RT; ++a) G[5][a] = a == RT - 1 ? 1.0f : 0.0f;
+  float t[4][6][RT];                                    // [e][xi][b] = (G g)[xi][b]
+#pragma unroll
+  for (int b = 0; b < RT; ++b) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RT * 4; ++it) {
+      const int a = it >> 2, r = tid + 256 * (it & 3);
+      const int nl2 = k_fast ? (r >> 5) : (r & 31), kl = k_fast ? (r & 31) : (r >> 5);
+      const int n = nt * 32 + nl2, k = qb * 32 + kl;
+      const int aa = flip ? RT - 1 - a : a, bb = flip ? RT - 1 - b : b;
+      const float v = (n < N && k < K) ? w[(int64_t)n * s_n + (int64_t)k * s_k + aa * s_h + bb * s_w] : 0.f;
+      g[a][nl2][kl] = sigma != nullptr ? v / sg : v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kl = 8 * ql + (e >> 1) * 4 + 2 * h + (e & 1);
+#pragma unroll
+      for (int xi = 0; xi < 6; ++xi) {
+        float acc = G[xi][0] * g[0][nl][kl];
+#pragma unroll
+        for (int a = 1; a < RT; ++a) acc += G[xi][a] * g[a][nl][kl];
+        t[e][xi][b] = acc;
+      }
+    }
+  }
+  if (q >= Q8) return;
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi)
 #pragma unroll
     for (int nu = 0; nu < 6; ++nu) {
       float u[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) u[e] = t[e][xi][0] * G[nu][0] + t[e][xi][1] * G[nu][1] + t[e][xi][2] * G[nu][2];
+      for (int e = 0; e < 4; ++e) {
+        float acc = t[e][xi][0] * G[nu][0];
+#pragma unroll
+        for (int b = 1; b < RT; ++b) acc += t[e][xi][b] * G[nu][b];
+        u[e] = acc;
+      }
       up[(((int64_t)(xi * 6 + nu) * NT32 + nt) * Q8 + q) * 64 + lane] = make_float4(u[0], u[1], u[2], u[3]);
     }
 }
@@ -195,7 +205,7 @@ __device__ __forceinline__ void w4_store_columns(const Wino4Params& p, const flo
     const int n = nt32 * 32 + cq * 4;
     const int ttx = tile & (W4_TW - 1), tty = tile >> 3;
     const int oy = Y0 + 4 * tty, ox = X0 + 4 * ttx + 2 * round + bb;
-    if (n < p.Cout && oy < p.H && ox < p.W) {      // H and W are multiples of 4: a tile is wholly inside or outside
+    if (n < p.Cout && oy < p.Ho && ox < p.Wo) {    // Ho and Wo are multiples of 4: a tile is wholly inside or outside
       csg_f32x2 lo[6], hi[6];
 #pragma unroll
       for (int xi = 0; xi < 6; ++xi) {
@@ -209,8 +219,8 @@ __device__ __forceinline__ void w4_store_columns(const Wino4Params& p, const flo
         blo = __builtin_shufflevector(bv, bv, 0, 1);
         bhi = __builtin_shufflevector(bv, bv, 2, 3);
       }
-      const int64_t rowstride = (int64_t)p.W * p.y_cs;
-      int64_t off = (((int64_t)img * p.H + oy) * p.W + ox) * p.y_cs + n;
+      const int64_t rowstride = (int64_t)p.Wo * p.y_cs;
+      int64_t off = (((int64_t)img * p.Ho + oy) * p.Wo + ox) * p.y_cs + n;
 #pragma unroll
       for (int a = 0; a < 4; ++a, off += rowstride) {
         csg_f32x2 vl, vh;
@@ -301,6 +311,108 @@ __device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[6], const Wino4Params&
   W4_T(6)
 }
 
+// ---- epilogue of F(3x3,4x4): A^T = [[1,1,1,1,1,0],[0,1,-1,1/2,-2,0],[0,1,1,1/4,4,1]] (the first three rows of the
+// F(4x4,3x3) matrix, the point at infinity moved into the last one).  Round 0 forms output columns 0 and 1 of every
+// 3 x 3 tile, round 1 column 2; output sizes need not be multiples of 3: every pixel is bounds-checked.
+__device__ __forceinline__ void w3_epilogue(f32x16 (&acc)[6], const Wino4Params& p, float* smem, int tid, int wave, int grp,
+                                            int j, int h, int nt32, int img, int X0, int Y0, const float* __restrict__ bias,
+                                            const float* __restrict__ res, const float* __restrict__ gate,
+                                            float* __restrict__ y) {
+  float* rbuf = smem + grp * W4_RBUF;
+  const int tig = tid - grp * (W4_THREADS / 2);
+  __syncthreads();                               // every wave is done reading the staging buffers
+  W4_T(3)
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      csg_f32x2 r0[2], r1[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+#define W4_M(K) csg_f32x2{acc[K][4 * g + 2 * e], acc[K][4 * g + 2 * e + 1]}
+        const csg_f32x2 m0 = W4_M(0), m1 = W4_M(1), m2 = W4_M(2), m3 = W4_M(3), m4 = W4_M(4), m5 = W4_M(5);
+#undef W4_M
+        if (round == 0) {
+          r0[e] = ((m0 + m1) + (m2 + m3)) + m4;
+          r1[e] = w4_pfma(-2.0f, m4, w4_pfma(0.5f, m3, m1 - m2));
+        } else {
+          r0[e] = w4_pfma(4.0f, m4, w4_pfma(0.25f, m3, m1 + m2)) + m5;
+        }
+      }
+      const int ch = 8 * g + 4 * h;
+      *(float4*)(rbuf + ((wave * 2 + 0) * 32 + j) * W4_RSE + ch) = make_float4(r0[0].x, r0[0].y, r0[1].x, r0[1].y);
+      if (round == 0)
+        *(float4*)(rbuf + ((wave * 2 + 1) * 32 + j) * W4_RSE + ch) = make_float4(r1[0].x, r1[0].y, r1[1].x, r1[1].y);
+    }
+    __syncthreads();
+    if (round == 0) { W4_T(4) }
+    const int nitem = round == 0 ? 512 : 256;      // 32 tiles x 8 channel quads x (2 | 1) columns
+    for (int item = tig; item < nitem; item += W4_THREADS / 2) {
+      const int cq = item & 7, tile = (item >> 3) & 31, bb = item >> 8;
+      const int n = nt32 * 32 + cq * 4;
+      const int ttx = tile & (W4_TW - 1), tty = tile >> 3;
+      const int oy = Y0 + 3 * tty, ox = X0 + 3 * ttx + 2 * round + bb;
+      if (n < p.Cout && oy < p.Ho && ox < p.Wo) {
+        csg_f32x2 lo[6], hi[6];
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi) {
+          const csg_f32x4 r = *(const csg_f32x4*)(rbuf + ((xi * 2 + bb) * 32 + tile) * W4_RSE + cq * 4);
+          lo[xi] = __builtin_shufflevector(r, r, 0, 1);
+          hi[xi] = __builtin_shufflevector(r, r, 2, 3);
+        }
+        csg_f32x2 blo = {0.f, 0.f}, bhi = {0.f, 0.f};
+        if (bias != nullptr) {
+          const csg_f32x4 bv = *(const csg_f32x4*)(bias + n);
+          blo = __builtin_shufflevector(bv, bv, 0, 1);
+          bhi = __builtin_shufflevector(bv, bv, 2, 3);
+        }
+        const int64_t rowstride = (int64_t)p.Wo * p.y_cs;
+        int64_t off = (((int64_t)img * p.Ho + oy) * p.Wo + ox) * p.y_cs + n;
+#pragma unroll
+        for (int a = 0; a < 3; ++a, off += rowstride) {
+          if (oy + a >= p.Ho) break;
+          csg_f32x2 vl, vh;
+          if (a == 0) {
+            vl = ((lo[0] + lo[1]) + (lo[2] + lo[3])) + lo[4];
+            vh = ((hi[0] + hi[1]) + (hi[2] + hi[3])) + hi[4];
+          } else if (a == 1) {
+            vl = w4_pfma(-2.0f, lo[4], w4_pfma(0.5f, lo[3], lo[1] - lo[2]));
+            vh = w4_pfma(-2.0f, hi[4], w4_pfma(0.5f, hi[3], hi[1] - hi[2]));
+          } else {
+            vl = w4_pfma(4.0f, lo[4], w4_pfma(0.25f, lo[3], lo[1] + lo[2])) + lo[5];
+            vh = w4_pfma(4.0f, hi[4], w4_pfma(0.25f, hi[3], hi[1] + hi[2])) + hi[5];
+          }
+          vl += blo;
+          vh += bhi;
+          float vv[4] = {vl.x, vl.y, vh.x, vh.y};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (p.act == CSG_ACT_LEAKY)
+              vv[e] = vv[e] > 0.f ? vv[e] : vv[e] * p.slope;
+            else if (p.act == CSG_ACT_TANH)
+              vv[e] = tanhf(vv[e]);
+          }
+          if (res != nullptr) {
+            const float4 rv = *(const float4*)(res + off);
+            vv[0] += rv.x; vv[1] += rv.y; vv[2] += rv.z; vv[3] += rv.w;
+          }
+          if (gate != nullptr) {
+            const float4 gv = *(const float4*)(gate + off);
+            vv[0] *= gv.x > 0.f ? 1.f : p.gate_slope; vv[1] *= gv.y > 0.f ? 1.f : p.gate_slope;
+            vv[2] *= gv.z > 0.f ? 1.f : p.gate_slope; vv[3] *= gv.w > 0.f ? 1.f : p.gate_slope;
+          }
+          *(float4*)(y + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
+      }
+    }
+    if (round == 0) {
+      __syncthreads();                           // the exchange buffer is rewritten by round 1
+      W4_T(5)
+    }
+  }
+  W4_T(6)
+}
+
 // ------------------------------------------------------------------------------------ convolution
 // On this chip the fp32 MFMA and the fp32 VALU do not overlap on a SIMD the way the bf16 matrix pipe and the VALU do:
 // the ablations of k_wino4_conv add up (transform without MFMAs 0.25 ms + MFMAs with the column transform 0.29 ms =
@@ -313,15 +425,29 @@ __device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[6], const Wino4Params&
 //   LDS (words): raw[2] (2 x W4_BUFW) | V[2] (2 x 9216: [xi][nu][half h][tile][4]) | per-thread offset table.
 //   Stage k (local index): produce V[k+1] from raw[k+1]; MFMAs out of V[k]; store raw[k+2]; barrier; load raw[k+3].
 #define W4_VBUF (36 * 2 * 32 * 4)
+// Geometry of the staged region for output tiles of T x T pixels out of 6 x 6 input tiles: T = 4 is F(4x4,3x3), T = 3 is
+// F(3x3,4x4) (the PatchGAN's 4x4 / stride 1 layers) — same points, same input transform, same 36 positions.  Columns
+// are de-interleaved modulo T and the row groups of T rows skewed by two words: the words of the 32 tiles a half-wave
+// reads with one ds_read_b64 sit in 32 different bank pairs (T * RS is a multiple of 64 words).
+template <int T>
+struct W4Geo {
+  static constexpr int R = T * W4_TH + 6 - T;          // staged rows: 18 / 15
+  static constexpr int C = T * W4_TW + 6 - T;          // staged columns: 34 / 27
+  static constexpr int RS = T == 4 ? 288 : 256;        // words per staged row (T classes x 9 columns x 8 words, padded)
+  static constexpr int BUFW = R * RS + 8 + 16;         // + the skew of the last row group + a dump slot
+  static constexpr int V0 = 2 * BUFW;
+  static constexpr int OFFTAB = (2 * BUFW + 2 * W4_VBUF) > 2 * W4_RBUF ? (2 * BUFW + 2 * W4_VBUF) : 2 * W4_RBUF;
+  static_assert((T * RS) % 64 == 0 && R * C * 2 <= W4_NLD * W4_THREADS && (C + T - 1) / T <= W4_CQ, "staging geometry");
+};
 #define W4V_RAW0 0
-#define W4V_V0 (2 * W4_BUFW)
-#define W4V_OFFTAB (2 * W4_BUFW + 2 * W4_VBUF)
+template <int T>
 __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, const float* __restrict__ x,
                                                                  const float4* __restrict__ up,
                                                                  const float* __restrict__ bias,
                                                                  const float* __restrict__ res,
                                                                  const float* __restrict__ gate, float* __restrict__ y) {
-  static_assert(W4V_OFFTAB >= 2 * W4_RBUF, "the epilogue exchange buffers fit in front of the offset table");
+  typedef W4Geo<T> Geo;
+  constexpr int W4_RS = Geo::RS, W4_BUFW = Geo::BUFW, W4V_V0 = Geo::V0, W4V_OFFTAB = Geo::OFFTAB;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   W4_T(0)
@@ -338,7 +464,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   bid /= p.tbx;
   const int by = bid % p.tby;
   const int img = bid / p.tby;
-  const int X0 = bx * 4 * W4_TW, Y0 = by * 4 * W4_TH;
+  const int X0 = bx * T * W4_TW, Y0 = by * T * W4_TH;
 
   const csg_i32x4 rsX = csg_make_srd(x, (long long)p.B * p.H * p.W * p.x_cs * 4);
   const csg_i32x4 rsU = csg_make_srd(up, (long long)36 * p.NT32 * p.Q8 * 64 * 16);
@@ -352,11 +478,11 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       const int e = tid + W4_THREADS * i;
       goff[i] = CSG_OOB_OFF;
       int lo = (W4_BUFW - 16) / 4 + (tid & 3);
-      if (e < W4_R * W4_C * 2) {
+      if (e < Geo::R * Geo::C * 2) {
         const int pix = e >> 1, c4 = e & 1;
-        const int row = pix / W4_C, col = pix - row * W4_C;
-        const int iy = Y0 + row - 1, ix = X0 + col - 1;
-        lo = (row * W4_RS + ((col & 3) * W4_CQ + (col >> 2)) * W4_PS + c4 * 4) / 4 + ((row >> 2) << 13);
+        const int row = pix / Geo::C, col = pix - row * Geo::C;
+        const int iy = Y0 + row - p.pad, ix = X0 + col - p.pad;
+        lo = (row * W4_RS + ((col % T) * W4_CQ + (col / T)) * W4_PS + c4 * 4) / 4 + ((row / T) << 13);
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
           goff[i] = (unsigned)(((img * p.H + iy) * p.W + ix) * p.x_cs + c4 * 4) * 4u;
       }
@@ -384,9 +510,11 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   const int j = lane & 31, h = lane >> 5;
   const int tx = j & (W4_TW - 1), ty = j >> 3;
   const int rb = wave == 0 ? 0 : 1;
-  // producer: raw words of (row 4 ty + rb, column 4 tx, channel pair q = 2 grp + h)
-  const float* p0 = smem + W4V_RAW0 + (4 * ty + rb) * W4_RS + 2 * ty + tx * W4_PS + 4 * grp + 2 * h;
-  const float* p3 = p0 + 3 * W4_RS + 2 * rb;
+  // producer: raw words of (row T ty + rb, column T tx, channel pair q = 2 grp + h); rows rb + i of the window sit in the
+  // next row group (two more words of skew) from i = T - rb on
+  const float* p0 = smem + W4V_RAW0 + (T * ty + rb) * W4_RS + 2 * ty + tx * W4_PS + 4 * grp + 2 * h;
+  const float* p2 = p0 + 2 * W4_RS + (T == 3 ? 2 * rb : 0);
+  const float* p3 = p0 + 3 * W4_RS + (T == 3 ? 2 : 2 * rb);
   // producer: V words of (xi = wave, nu = 0, half h, tile j), channel pair slot grp;  consumer: the same row, float4
   float* pv = smem + W4V_V0 + (((wave * 6) * 2 + h) * 32 + j) * 4;
 
@@ -416,10 +544,10 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     csg_f32x2 t[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const int co = rbufsel * W4_BUFW + ((c & 3) * W4_CQ + (c >> 2)) * W4_PS;
+      const int co = rbufsel * W4_BUFW + ((c % T) * W4_CQ + (c / T)) * W4_PS;
       const csg_f32x2 e0 = *(w4_lds_cv2)(p0 + co);
       const csg_f32x2 e1 = *(w4_lds_cv2)(p0 + co + W4_RS);
-      const csg_f32x2 e2 = *(w4_lds_cv2)(p0 + co + 2 * W4_RS);
+      const csg_f32x2 e2 = *(w4_lds_cv2)(p2 + co);
       const csg_f32x2 e3 = *(w4_lds_cv2)(p3 + co);
       if (XI == 0 || XI == 5) {
         const csg_f32x2 e4 = *(w4_lds_cv2)(p0 + co + 4 * W4_RS + 2);
@@ -529,7 +657,10 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     stage(s + 1, std::integral_constant<int, 1>());
   }
   if (s < s_end) stage(s, std::integral_constant<int, 0>());
-  w4_epilogue(acc, p, smem, tid, wave, grp, j, h, nt32, img, X0, Y0, bias, res, gate, y);
+  if (T == 4)
+    w4_epilogue(acc, p, smem, tid, wave, grp, j, h, nt32, img, X0, Y0, bias, res, gate, y);
+  else
+    w3_epilogue(acc, p, smem, tid, wave, grp, j, h, nt32, img, X0, Y0, bias, res, gate, y);
 }
 
 #ifdef W4_TRACE
@@ -539,21 +670,28 @@ extern "C" int csg_wino4_trace_read(unsigned long long* out, int n) {
 #endif
 
 // ------------------------------------------------------------------------------------ host side
-static int w4_plan(const csg_wino_desc* d, Wino4Params& p, size_t& shm, const char* who) {
+// T = 4: F(4x4,3x3), pad 1, output = input size.  T = 3: F(3x3,4x4), pad 1 or 2, output = input + 2 pad - 3.
+static int w4_plan(const csg_wino_desc* d, int T, int pad, Wino4Params& p, size_t& shm, const char* who) {
   CSG_REQUIRE(d != nullptr, CSG_E_BADSHAPE, "%s: null descriptor", who);
   CSG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, CSG_E_BADSHAPE, "%s: non-positive dimension", who);
-  CSG_REQUIRE(d->H % 4 == 0 && d->W % 4 == 0 && d->W >= 32 && d->H >= 16, CSG_E_UNSUPPORTED,
-              "%s: F(4x4,3x3) needs H=%d, W=%d multiples of 4, W >= 32, H >= 16", who, d->H, d->W);
+  if (T == 4)
+    CSG_REQUIRE(d->H % 4 == 0 && d->W % 4 == 0 && d->W >= 32 && d->H >= 16, CSG_E_UNSUPPORTED,
+                "%s: F(4x4,3x3) needs H=%d, W=%d multiples of 4, W >= 32, H >= 16", who, d->H, d->W);
+  else
+    CSG_REQUIRE((pad == 1 || pad == 2) && d->H + 2 * pad >= 4 && d->W + 2 * pad >= 4, CSG_E_UNSUPPORTED,
+                "%s: F(3x3,4x4) serves pad 1 or 2 (got %d) on maps of at least 4 - 2 pad pixels", who, pad);
+  const int Ho = T == 4 ? d->H : d->H + 2 * pad - 3, Wo = T == 4 ? d->W : d->W + 2 * pad - 3;
   CSG_REQUIRE(d->Cin % 8 == 0 && d->x_cs % 4 == 0 && d->x_cs >= d->Cin && d->Cout % 4 == 0 && d->y_cs % 4 == 0 &&
                   d->y_cs >= d->Cout,
               CSG_E_UNSUPPORTED, "%s: Cin must be a multiple of 8, the other channel counts and strides of 4", who);
-  CSG_REQUIRE((int64_t)d->B * d->H * d->W * (int64_t)(d->x_cs > d->y_cs ? d->x_cs : d->y_cs) * 4 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
-              "%s: tensor too large for 32-bit byte offsets", who);
+  CSG_REQUIRE((int64_t)d->B * (d->H + 1) * (d->W + 1) * (int64_t)(d->x_cs > d->y_cs ? d->x_cs : d->y_cs) * 4 < CSG_MAX_RECORDS,
+              CSG_E_UNSUPPORTED, "%s: tensor too large for 32-bit byte offsets", who);
   CSG_REQUIRE((int64_t)36 * ((d->Cout + 31) / 32) * ((d->Cin + 7) / 8) * 1024 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
               "%s: packed weights too large for 32-bit byte offsets", who);
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_cs = d->x_cs; p.Cout = d->Cout; p.y_cs = d->y_cs;
-  p.tbx = (d->W + 4 * W4_TW - 1) / (4 * W4_TW);
-  p.tby = (d->H + 4 * W4_TH - 1) / (4 * W4_TH);
+  p.Ho = Ho; p.Wo = Wo; p.pad = pad;
+  p.tbx = (Wo + T * W4_TW - 1) / (T * W4_TW);
+  p.tby = (Ho + T * W4_TH - 1) / (T * W4_TH);
   p.nblocks = (d->Cout + 63) / 64;
   p.NT32 = (d->Cout + 31) / 32;
   p.Q8 = (d->Cin + 7) / 8;
@@ -561,9 +699,36 @@ static int w4_plan(const csg_wino_desc* d, Wino4Params& p, size_t& shm, const ch
   p.nstage = d->Cin / W4_PS;
   p.ksplit = 1;
   p.sps = p.nstage;
-  p.slab = (long long)d->B * d->H * d->W * d->y_cs;
-  shm = (size_t)(W4V_OFFTAB + W4_THREADS * 4) * 4;
+  p.slab = (long long)d->B * Ho * Wo * d->y_cs;
+  shm = (size_t)((T == 4 ? W4Geo<4>::OFFTAB : W4Geo<3>::OFFTAB) + W4_THREADS * 4) * 4;
   return CSG_OK;
+}
+
+// the launch shared by both tile sizes
+template <int T>
+static int w4_launch(Wino4Params& p, size_t shm, int kid, double flops, const float* x, const float* packed,
+                     const float* bias, const float* residual, const float* gate, float* y, float* workspace,
+                     float* y_final, hipStream_t s, const char* who) {
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_wino4_conv_v<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(e));
+    attr_set[dev] = true;
+  }
+  CSG_REQUIRE(shm <= 128 * 1024, CSG_E_UNSUPPORTED, "%s: %zu bytes of LDS", who, shm);
+  const int64_t grid = (int64_t)p.B * p.tby * p.tbx * p.nblocks * p.ksplit;
+  CSG_REQUIRE(grid < (1ll << 31), CSG_E_UNSUPPORTED, "%s: grid too large", who);
+  ProfScope ps(kid, flops, s);
+  CSG_LAUNCH(k_wino4_conv_v<T>, dim3((unsigned)grid), dim3(W4_THREADS), shm, s, p, x, (const float4*)packed, bias, residual,
+             gate, y);
+  int rc = check_launch(who);
+  if (rc == CSG_OK && p.ksplit > 1) {
+    launch_slab_reduce(workspace, p.slab, y_final, nullptr, 0, nullptr, p.ksplit, s);
+    rc = check_launch("csg_wino4_conv(slab sum)");
+  }
+  return rc;
 }
 
 // Split over the input channels when the tile grid alone cannot fill the chip (see wn_split_plan in wino.hip)
@@ -601,15 +766,53 @@ int csg_wino4_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h
   const int64_t total = (int64_t)36 * NT32 * Q8 * 64;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(K_WINO_PACK, (double)Cout * Cin * 9 * 4 + (double)total * 16, s);
-  CSG_LAUNCH(k_wino4_pack, dim3((unsigned)cdiv(Q8, 4), (unsigned)NT32), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
+  CSG_LAUNCH(k_wino4_pack<3>, dim3((unsigned)cdiv(Q8, 4), (unsigned)NT32), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
                      backward_data ? 1 : 0, (int)N, (int)K, sigma, NT32, Q8, (float4*)packed);
   return check_launch("csg_wino4_pack_weights");
+}
+
+int csg_wino34_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int64_t Cout, int64_t Cin,
+                            int32_t backward_data, const float* sigma, float* packed, void* stream) {
+  CSG_REQUIRE(w != nullptr && packed != nullptr && Cout > 0 && Cin > 0, CSG_E_BADSHAPE, "csg_wino34_pack_weights: bad arguments");
+  CSG_REQUIRE(((uintptr_t)packed % 16) == 0, CSG_E_UNSUPPORTED, "csg_wino34_pack_weights: packed must be 16-byte aligned");
+  const int64_t N = backward_data ? Cin : Cout, K = backward_data ? Cout : Cin;
+  const int64_t s_n = backward_data ? s_i : s_o, s_k = backward_data ? s_o : s_i;
+  const int NT32 = (int)cdiv(N, 32), Q8 = (int)cdiv(K, 8);
+  const int64_t total = (int64_t)36 * NT32 * Q8 * 64;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(K_WINO_PACK, (double)Cout * Cin * 16 * 4 + (double)total * 16, s);
+  CSG_LAUNCH(k_wino4_pack<4>, dim3((unsigned)cdiv(Q8, 4), (unsigned)NT32), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
+                     backward_data ? 1 : 0, (int)N, (int)K, sigma, NT32, Q8, (float4*)packed);
+  return check_launch("csg_wino34_pack_weights");
+}
+
+int32_t csg_wino34_supported(const csg_wino_desc* d, int32_t pad) {
+  static const int on = getenv("CSG_WINO34") ? atoi(getenv("CSG_WINO34")) : 1;
+  if (!on || d == nullptr) return 0;
+  // the tile grid of 24 x 12 output pixels per block should not be mostly padding: maps from 16 pixels up
+  return ((pad == 1 || pad == 2) && d->H >= 15 && d->W >= 15 && d->Cin % 8 == 0 && d->Cout % 4 == 0 && d->Cin >= 64 &&
+          d->Cout >= 32) ? 1 : 0;
+}
+
+int csg_wino34_conv(const csg_wino_desc* d, int32_t pad, const float* x, const float* packed, const float* bias,
+                    const float* residual, const float* gate, float gate_slope, float* y, void* stream) {
+  Wino4Params p;
+  size_t shm = 0;
+  int rc = w4_plan(d, 3, pad, p, shm, "csg_wino34_conv");
+  if (rc) return rc;
+  p.gate_slope = gate_slope;
+  CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                  (gate == nullptr || ((uintptr_t)gate % 16) == 0),
+              CSG_E_UNSUPPORTED, "csg_wino34_conv: pointers must be 16-byte aligned");
+  // algorithmic FLOPs of the DIRECT convolution this replaces (2 * M * 16*Cin * Cout)
+  return w4_launch<3>(p, shm, K_WINO4_CONV, 2.0 * p.B * p.Ho * p.Wo * 16.0 * p.Cin * p.Cout, x, packed, bias, residual, gate,
+                      y, nullptr, y, (hipStream_t)stream, "csg_wino34_conv");
 }
 
 int64_t csg_wino4_conv_workspace(const csg_wino_desc* d) {
   Wino4Params p;
   size_t shm = 0;
-  if (w4_plan(d, p, shm, "csg_wino4_conv_workspace")) return -1;
+  if (w4_plan(d, 4, 1, p, shm, "csg_wino4_conv_workspace")) return -1;
   w4_split_plan(p, d->act == CSG_ACT_NONE);
   return p.ksplit > 1 ? (int64_t)p.ksplit * p.slab * 4 : 0;
 }
@@ -618,7 +821,7 @@ int csg_wino4_conv(const csg_wino_desc* d, const float* x, const float* packed, 
                    const float* gate, float gate_slope, float* y, float* workspace, int64_t workspace_bytes, void* stream) {
   Wino4Params p;
   size_t shm = 0;
-  int rc = w4_plan(d, p, shm, "csg_wino4_conv");
+  int rc = w4_plan(d, 4, 1, p, shm, "csg_wino4_conv");
   if (rc) return rc;
   w4_split_plan(p, d->act == CSG_ACT_NONE && bias == nullptr && residual == nullptr && gate == nullptr);
   p.gate_slope = gate_slope;
@@ -634,28 +837,9 @@ int csg_wino4_conv(const csg_wino_desc* d, const float* x, const float* packed, 
   }
   CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 16) == 0, CSG_E_UNSUPPORTED,
               "csg_wino4_conv: pointers must be 16-byte aligned");
-  static bool attr_set[16] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wino4_conv_v, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino4_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-    attr_set[dev] = true;
-  }
-  CSG_REQUIRE(shm <= 128 * 1024, CSG_E_UNSUPPORTED, "csg_wino4_conv: %zu bytes of LDS", shm);
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t grid = (int64_t)p.B * p.tby * p.tbx * p.nblocks * p.ksplit;
-  CSG_REQUIRE(grid < (1ll << 31), CSG_E_UNSUPPORTED, "csg_wino4_conv: grid too large");
   // algorithmic FLOPs of the DIRECT convolution this replaces (2 * M * 9*Cin * Cout): what FlopCounterMode counts
-  ProfScope ps(K_WINO4_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
-  CSG_LAUNCH(k_wino4_conv_v, dim3((unsigned)grid), dim3(W4_THREADS), shm, s, p, x, (const float4*)packed, bias, residual,
-             gate, y);
-  rc = check_launch("csg_wino4_conv");
-  if (rc == CSG_OK && p.ksplit > 1) {
-    launch_slab_reduce(workspace, p.slab, y_final, nullptr, 0, nullptr, p.ksplit, s);
-    rc = check_launch("csg_wino4_conv(slab sum)");
-  }
-  return rc;
+  return w4_launch<4>(p, shm, K_WINO4_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, x, packed, bias, residual, gate, y,
+                      workspace, y_final, (hipStream_t)stream, "csg_wino4_conv");
 }
 
 }  // extern "C"

@@ -153,16 +153,30 @@ def wino_variant(B, H, W, Cin, Cout):
     return 4 if lib.csg_wino4_supported(_wino_desc(B, H, W, Cin, Cout)) == 1 else 2
 
 
+WINO34_MODE = int(os.environ.get("CSG_WINO34_MODE", "2"))      # bit 0: forward passes, bit 1: backward-data passes (see below)
+
+
+def wino34_eligible(B, H, W, Cin, Cout, KH, KW, stride, pad, backward=False):
+    """4x4 / stride 1 / pad 1 or 2 layers served by Winograd F(3x3,4x4) (csrc/wino4.hip; the PatchGAN's fourth layer and
+    its backward-data pass).  Default: the backward-data passes only.  The forward pass is 1.9x faster too, but its error
+    (3e-6 of the output scale, the direct kernel 5e-7) sits in front of the discriminator's LeakyReLU(0.2) gates: on the
+    C3 full-width step one more gate flips than in the fp32 reference and seven D gradient tensors leave the fp64 noise
+    band (tests/test_gpu_fullwidth.py); a backward-data error passes no gate.  CSG_WINO34_MODE=3 turns both on."""
+    return (WINO_ENABLED and (WINO34_MODE & (2 if backward else 1)) and KH == 4 and KW == 4 and stride == 1 and pad in (1, 2)
+            and lib.csg_wino34_supported(_wino_desc(B, H, W, Cin, Cout), pad) == 1)
+
+
 def wino_pack(weight, backward_data, sigma=None, variant=2):
     """Transformed weights U = G g G^T of a (Cout,Cin,3,3) weight in the MFMA operand order of k_wino_conv
-    (variant 2: 16 positions) or k_wino4_conv (variant 4: 36 positions)."""
+    (variant 2: 16 positions) or k_wino4_conv (variant 4: 36 positions); variant 34: a (Cout,Cin,4,4) weight for
+    F(3x3,4x4), 36 positions."""
     w = _f32(weight.detach())                    # any strides: contiguous and channels-last parameters alike
     Cout, Cin = w.shape[0], w.shape[1]
     N, K = (Cin, Cout) if backward_data else (Cout, Cin)
-    nbytes = lib.csg_wino4_pack_bytes(N, K) if variant == 4 else lib.csg_wino_pack_bytes(N, K)
+    nbytes = lib.csg_wino4_pack_bytes(N, K) if variant in (4, 34) else lib.csg_wino_pack_bytes(N, K)
     packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
     st = w.stride()
-    fn = lib.csg_wino4_pack_weights if variant == 4 else lib.csg_wino_pack_weights
+    fn = {4: lib.csg_wino4_pack_weights, 34: lib.csg_wino34_pack_weights}.get(variant, lib.csg_wino_pack_weights)
     check(fn(ptr(w), st[0], st[1], st[2], st[3], Cout, Cin, 1 if backward_data else 0, ptr(sigma), ptr(packed), stream()),
           "wino_pack_weights")
     return packed
@@ -263,6 +277,15 @@ class _Conv2d(torch.autograd.Function):
             up = _frozen_pack(packs, False, var) if (packs is not None and len(packs) > 2) else wino_pack(weight, False, None, var)
             _wino_launch(x, up, bias.detach() if bias is not None else None, res, y, B, IH, IW, Cin, Cout, act, slope,
                          "wino_conv_fwd", variant=var)
+        elif dx_range is None and packs is None and wino34_eligible(
+                B, IH, IW, Cin, Cout, KH, KW, stride, pad, backward=not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])):
+            # (a forward pass nothing is differentiated through — the discriminator on the real images in the generator
+            # step, inference — counts as a backward-class pass: its error meets no gate of a backward pass)
+            OH, OW = IH + 2 * pad - 3, IW + 2 * pad - 3
+            y = empty_nhwc(B, Cout, OH, OW, x.device)
+            check(lib.csg_wino34_conv(_wino_desc(B, IH, IW, Cin, Cout, act, slope), pad, ptr(x),
+                                      ptr(wino_pack(weight, False, None, 34)), ptr(bias.detach() if bias is not None else None),
+                                      ptr(res), None, 0.0, ptr(y), stream()), "wino34_conv_fwd")
         else:
             # [Cout][KH][KW][Cin]: free for channels-last parameters (sg2im.layers.Conv2d keeps them that way)
             wp = packs[0] if packs is not None else weight.detach().permute(0, 2, 3, 1).contiguous()
@@ -328,6 +351,15 @@ class _Conv2d(torch.autograd.Function):
             gated = _wino_launch(dpre, ut, None, None, dx, B, IH, IW, Cout, Cin, ACT_NONE, 0.0, "wino_conv_bwd_data",
                                  gate=x if ctx.in_act is not None else None,
                                  gate_slope=ctx.in_act[1] if ctx.in_act is not None else 0.0, variant=var) or ctx.in_act is None
+        elif ctx.needs_input_grad[0] and ctx.packs is None and wino34_eligible(B, OH, OW, Cout, Cin, KH, KW, stride, 3 - pad,
+                                                                                    backward=True):
+            # dX = conv4x4(dY, flipped W^T) with padding 3 - pad: the same F(3x3,4x4) kernel, channel counts swapped
+            dx = empty_nhwc(B, Cin, IH, IW, dy.device)
+            has_gate = ctx.in_act is not None
+            check(lib.csg_wino34_conv(_wino_desc(B, OH, OW, Cout, Cin), 3 - pad, ptr(dpre), ptr(wino_pack(weight, True, None, 34)),
+                                      None, None, ptr(x) if has_gate else None, ctx.in_act[1] if has_gate else 0.0, ptr(dx),
+                                      stream()), "wino34_conv_bwd_data")
+            gated = True
         elif ctx.needs_input_grad[0]:
             wt = ctx.packs[1] if ctx.packs is not None else \
                 weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]

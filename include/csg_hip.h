@@ -242,6 +242,18 @@ int csg_wino4_conv(const csg_wino_desc* d, const float* x, const float* packed, 
                    const float* residual, const float* gate, float gate_slope, float* y, float* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* ---- K8w34: 4x4 / stride 1 convolutions by Winograd F(3x3,4x4) (csrc/wino4.hip, the same kernel on 3x3 output tiles)
+ * The PatchGAN's fourth layer (discriminator.py:184-189: 4x4, stride 1, padding 2, 256 -> 512 channels at 1/8
+ * resolution) and its backward-data pass (the 4x4 correlation with the flipped, transposed weight and padding 1):
+ * 36 multiplications per 3x3 output tile instead of 144.  d->H, d->W are the INPUT size; `pad` is 2 (output (H+1) x
+ * (W+1)) or 1 (output (H-1) x (W-1)); x (B,H,W,x_cs), y (B,Ho,Wo,y_cs), residual / gate in y's layout.  Same points,
+ * input transform and positions as F(4x4,3x3): the packed operand has csg_wino4_pack_bytes bytes.                    */
+int32_t csg_wino34_supported(const csg_wino_desc* d, int32_t pad);
+int csg_wino34_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int64_t Cout, int64_t Cin,
+                            int32_t backward_data, const float* sigma, float* packed, void* stream);
+int csg_wino34_conv(const csg_wino_desc* d, int32_t pad, const float* x, const float* packed, const float* bias,
+                    const float* residual, const float* gate, float gate_slope, float* y, void* stream);
+
 /* ---- K8n: stride-1 convolutions with at most four output channels (csrc/fewn.hip) --------------------------------
  * `conv_img` (generator.py:46,120-121: 64 -> 3, 3x3, pad 1, tanh behind it) and the PatchGAN prediction heads
  * (discriminator.py:185-187: 512 -> 1, 4x4, pad 2): a 32-wide MFMA tile wastes 29 (31) of its columns on them; these

@@ -171,3 +171,116 @@ def test_wino4_backward_data_through_autograd(ops, shape):
     for name, mine, want in (("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
         e = _err(mine, want.detach())
         assert e < GATE, "%s %s: error %.2e of the gradient scale" % (name, shape, e)
+
+
+# ------------------------------------------------------------------------------------ F(3x3,4x4): 4x4 / stride 1 layers
+def _raw_wino34(ops, x, w, pad, bias=None, res=None, act=0, slope=0.0, gate=None, gate_slope=0.0, backward_data=False):
+    from canonicalsg2im_amd._lib import check, lib, ptr, stream
+    B, Cx, H, W = x.shape
+    Cout = w.shape[1] if backward_data else w.shape[0]
+    d = _desc(B, H, W, Cx, Cout, act, slope)
+    assert lib.csg_wino34_supported(d, pad) == 1
+    xd = ops.nhwc(x.cuda())
+    up = ops.wino_pack(w.cuda(), backward_data, None, 34)
+    y = ops.empty_nhwc(B, Cout, H + 2 * pad - 3, W + 2 * pad - 3, xd.device)
+    bd = bias.cuda() if bias is not None else None
+    rd = ops.nhwc(res.cuda()) if res is not None else None
+    gd = ops.nhwc(gate.cuda()) if gate is not None else None
+    check(lib.csg_wino34_conv(d, pad, ptr(xd), ptr(up), ptr(bd), ptr(rd), ptr(gd), gate_slope, ptr(y), stream()),
+          "wino34_conv")
+    return y
+
+
+def _data44(shape, seed=0):
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + seed)
+    x = F.leaky_relu(torch.randn(B, Cin, H, W, generator=g), 0.2)      # what the PatchGAN's fourth layer reads
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) / (4.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    return x, w, b
+
+
+SHAPES44 = [
+    # B, Cin, Cout, H,  W,  pad
+    (2, 256, 512, 32, 32, 2),     # D0.model3 at 256 x 256 (output 33 x 33 = 11 x 11 tiles)
+    (2, 256, 512, 16, 16, 2),     # D1.model3 (output 17 x 17: ragged tiles)
+    (1, 64, 36, 20, 29, 2),       # ragged in both directions, Cout not a multiple of 32
+    (1, 72, 100, 23, 41, 1),      # padding 1 (the geometry of the backward-data pass), odd stage count
+    (1, 512, 64, 33, 33, 1),      # backward-data shape of D0.model3: 512 -> (256), output 32 x 32
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES44)
+def test_wino34_forward_vs_fp64(ops, shape):
+    x, w, b = _data44(shape[:5])
+    pad = shape[5]
+    ref64 = F.conv2d(x.double(), w.double(), b.double(), padding=pad)
+    y = _raw_wino34(ops, x, w, pad, b)
+    assert tuple(y.shape) == tuple(ref64.shape)
+    e = _err(y, ref64)
+    assert e < GATE, "F(3x3,4x4) %s: error %.2e of the output scale" % (shape, e)
+    assert_close(y, ref64.float(), 1e-4, 1e-5 * float(ref64.abs().max()) + 1e-5, "wino34 fwd %s" % (shape,))
+
+
+def test_wino34_epilogue_and_determinism(ops):
+    shape = (2, 64, 96, 17, 22)
+    x, w, b = _data44(shape)
+    g = torch.Generator().manual_seed(12)
+    r = torch.randn(2, 96, 18, 23, generator=g)
+    gt = torch.randn(2, 96, 18, 23, generator=g)
+    pre = F.conv2d(x, w, b, padding=2)
+    tol = 1e-5 * float(pre.abs().max()) + 1e-5
+    assert_close(_raw_wino34(ops, x, w, 2, b, None, ops.ACT_LEAKY, 0.2), F.leaky_relu(pre, 0.2), 1e-4, tol, "leaky epilogue")
+    assert_close(_raw_wino34(ops, x, w, 2, b, r), pre + r, 1e-4, tol, "residual epilogue")
+    want = F.conv2d(x, w, None, padding=2) * torch.where(gt > 0, torch.ones_like(gt), torch.full_like(gt, 0.2))
+    assert_close(_raw_wino34(ops, x, w, 2, None, None, gate=gt, gate_slope=0.2), want, 1e-4, tol, "gate epilogue")
+    assert torch.equal(_raw_wino34(ops, x, w, 2, b), _raw_wino34(ops, x, w, 2, b))
+
+
+def test_wino34_error_next_to_direct(ops):
+    """F(3x3,4x4) and the direct MFMA kernel on the PatchGAN shapes against fp64 (printed with -s)."""
+    rows = []
+    for shape in [(2, 256, 512, 32, 32), (2, 256, 512, 16, 16)]:
+        x, w, _ = _data44(shape)
+        ref64 = F.conv2d(x.double(), w.double(), None, padding=2)
+        yw = _raw_wino34(ops, x, w, 2)
+        saved = ops.WINO_ENABLED
+        ops.WINO_ENABLED = False
+        try:
+            yd = ops.conv2d(ops.nhwc(x.cuda()), w.cuda(), None, 1, 2)
+        finally:
+            ops.WINO_ENABLED = saved
+        rows.append((shape, _err(yw, ref64), _err(yd, ref64)))
+    print("\nshape (B,Cin,Cout,H,W)            F(3x3,4x4)  direct MFMA   (max |y - fp64| / max |fp64|)")
+    for shape, ew, ed in rows:
+        print("%-32s  %.2e    %.2e" % (shape, ew, ed))
+        assert ew < GATE and ed < GATE
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("shape", [(2, 256, 512, 32, 32), (1, 64, 64, 16, 19)])
+def test_wino34_through_autograd(ops, shape, mode):
+    """conv2d with a 4x4 / stride 1 / pad 2 weight: backward-data on F(3x3,4x4) (default mode) and the forward too
+    (mode 3; the weight gradient stays on the direct kernel); against fp64."""
+    B, Cin, Cout, H, W = shape
+    monkey = ops.WINO34_MODE
+    ops.WINO34_MODE = mode
+    try:
+        _wino34_autograd_case(ops, shape)
+    finally:
+        ops.WINO34_MODE = monkey
+
+
+def _wino34_autograd_case(ops, shape):
+    B, Cin, Cout, H, W = shape
+    assert ops.wino34_eligible(B, H + 1, W + 1, Cout, Cin, 4, 4, 1, 1, backward=True)
+    x, w, b = _data44(shape, seed=1)
+    gy = torch.randn(B, Cout, H + 1, W + 1, generator=torch.Generator().manual_seed(3))
+    xr, wr, br = [t.clone().double().requires_grad_(True) for t in (x, w, b)]
+    F.conv2d(xr, wr, br, padding=2).backward(gy.double())
+    xd, wd, bd = [t.clone().cuda().requires_grad_(True) for t in (x, w, b)]
+    y = ops.conv2d(ops.nhwc(xd), wd, bd, 1, 2)
+    y.backward(ops.nhwc(gy.cuda()))
+    for name, mine, want in (("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
+        e = _err(mine, want.detach())
+        assert e < GATE, "%s %s: error %.2e of the gradient scale" % (name, shape, e)
