@@ -141,17 +141,25 @@ __global__ __launch_bounds__(256) void k_wino4_pack(const float* __restrict__ w,
   }
 #pragma unroll
   for (int a = 0; a < RT; ++a) G[5][a] = a == RT - 1 ? 1.0f : 0.0f;
+  float stage[RT * RT * 4];                             // every tap of the 32 x 32 (n, k) block: all loads in flight at once
+#pragma unroll
+  for (int it = 0; it < RT * RT * 4; ++it) {
+    const int tap = it >> 2, r = tid + 256 * (it & 3);
+    const int nl2 = k_fast ? (r >> 5) : (r & 31), kl = k_fast ? (r & 31) : (r >> 5);
+    const int n = nt * 32 + nl2, k = qb * 32 + kl;
+    const int a = tap / RT, b = tap - RT * a;
+    const int aa = flip ? RT - 1 - a : a, bb = flip ? RT - 1 - b : b;
+    stage[it] = (n < N && k < K) ? w[(int64_t)n * s_n + (int64_t)k * s_k + aa * s_h + bb * s_w] : 0.f;
+  }
   float t[4][6][RT];                                    // [e][xi][b] = (G g)[xi][b]
 #pragma unroll
   for (int b = 0; b < RT; ++b) {
-    __syncthreads();
+    if (b) __syncthreads();
 #pragma unroll
     for (int it = 0; it < RT * 4; ++it) {
       const int a = it >> 2, r = tid + 256 * (it & 3);
       const int nl2 = k_fast ? (r >> 5) : (r & 31), kl = k_fast ? (r & 31) : (r >> 5);
-      const int n = nt * 32 + nl2, k = qb * 32 + kl;
-      const int aa = flip ? RT - 1 - a : a, bb = flip ? RT - 1 - b : b;
-      const float v = (n < N && k < K) ? w[(int64_t)n * s_n + (int64_t)k * s_k + aa * s_h + bb * s_w] : 0.f;
+      const float v = stage[(a * RT + b) * 4 + (it & 3)];
       g[a][nl2][kl] = sigma != nullptr ? v / sg : v;
     }
     __syncthreads();
