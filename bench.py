@@ -315,7 +315,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if args.config == "C3" and H == 256 and args.batch == 16 and not args.use_img_disc and not args.vgg_loss:
-                key = {"wino4_conv": "k_wino4_conv_v", "wino_conv": "k_wino_conv2<16, 2>"}.get(dom, "k_igemm_fwd<128>")
+                key = {"wino4_conv": "k_wino4_conv_v<4>", "wino_conv": "k_wino_conv2<16, 2>"}.get(dom, "k_igemm_fwd<128>")
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
