@@ -31,8 +31,9 @@ int check_launch(const char* what) {
 // csg_prof_read
 struct Rec {
   int kid;
-  double work;
+  double work;          // the scope's work rides on its first launch
   hipEvent_t e0, e1;
+  bool first;           // first launch of its scope: counts as one call of the entry point
 };
 static int g_prof = 0;   // 0 off, 1 every kernel, 2 only the dominant convolution kernels (k_wino*_conv, k_igemm_fwd<128>), 3 only the streaming (HBM-bound) kernels
 static std::mutex g_mu;
@@ -61,7 +62,7 @@ bool prof_on(int kid) {
 bool prof_serialize() { return g_prof == 1 || g_prof == 3; }
 
 ProfCur& prof_cur() {
-  static thread_local ProfCur cur = {0, 0.0, nullptr, nullptr, false, false};
+  static thread_local ProfCur cur = {0, 0.0, false, false};
   return cur;
 }
 
@@ -81,21 +82,21 @@ void prof_begin(int kid, double work) {
   ProfCur& c = prof_cur();
   c.kid = kid;
   c.work = work;
-  c.e0 = get_event();
-  c.e1 = get_event();
   c.armed = true;
   c.used = false;
 }
 
+void prof_next(hipEvent_t& e0, hipEvent_t& e1) {
+  ProfCur& c = prof_cur();
+  e0 = get_event();
+  e1 = get_event();
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_pending.push_back(Rec{c.kid, c.used ? 0.0 : c.work, e0, e1, !c.used});
+  c.used = true;
+}
+
 void prof_end() {
   ProfCur& c = prof_cur();
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (c.used) {
-    g_pending.push_back(Rec{c.kid, c.work, c.e0, c.e1});
-  } else {              // the scope launched nothing
-    g_free.push_back(c.e0);
-    g_free.push_back(c.e1);
-  }
   c.armed = c.used = false;
 }
 
@@ -107,7 +108,7 @@ static void resolve() {
     hipEventElapsedTime(&ms, r.e0, r.e1);
     g_ms[r.kid] += ms;
     g_work[r.kid] += r.work;
-    g_n[r.kid] += 1;
+    g_n[r.kid] += r.first ? 1 : 0;
     g_free.push_back(r.e0);
     g_free.push_back(r.e1);
   }

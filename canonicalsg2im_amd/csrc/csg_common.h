@@ -74,12 +74,14 @@ bool prof_on(int kid);
 struct ProfCur {
   int kid;
   double work;
-  hipEvent_t e0, e1;
   bool armed, used;
 };
 ProfCur& prof_cur();
 void prof_begin(int kid, double work);
 void prof_end();
+// the event pair of the next launch of the armed scope (every launch of a scope is timed: an entry point may be several
+// kernels — partial sums + their ordered reduction, a split launch + its slab sum — and all of them are its time)
+void prof_next(hipEvent_t& e0, hipEvent_t& e1);
 
 bool prof_serialize();   // modes 1 and 3 (the untimed per-kernel table): drain the stream before the timed launch
 struct ProfScope {
@@ -111,10 +113,11 @@ template <typename... KArgs, typename... Args>
 static inline void launch(void (*kernel)(KArgs...), dim3 g, dim3 b, size_t shm, hipStream_t s, Args&&... args) {
   ProfCur& pc = prof_cur();
   if (pc.armed) {
-    pc.armed = false;
-    pc.used = true;
+    if (pc.used && prof_serialize()) (void)hipStreamSynchronize(s);     // as in ProfScope: start stamps at pickup
+    hipEvent_t e0, e1;
+    prof_next(e0, e1);
     std::tuple<KArgs...> stored(static_cast<KArgs>(std::forward<Args>(args))...);
-    launch_ext_impl((const void*)kernel, g, b, shm, s, pc.e0, pc.e1, stored, std::index_sequence_for<KArgs...>{});
+    launch_ext_impl((const void*)kernel, g, b, shm, s, e0, e1, stored, std::index_sequence_for<KArgs...>{});
   } else {
     hipLaunchKernelGGL(kernel, g, b, shm, s, static_cast<KArgs>(std::forward<Args>(args))...);
   }

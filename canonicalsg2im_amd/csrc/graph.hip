@@ -636,7 +636,8 @@ int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32
   CSG_REQUIRE(Din % 4 == 0 && Dp % 4 == 0, CSG_E_BADSHAPE,
               "csg_gather_concat_bwd: Din=%ld and Dp=%ld must be multiples of 4", (long)Din, (long)Dp);
   hipStream_t s = (hipStream_t)stream;
-  ProfScope p(K_GATHER_BWD, (double)B * T * (2 * Din + Dp) * 8, s);
+  // algorithmic bytes: dcat read once, dobj (O x Din) and dpred (T x Dp) written
+  ProfScope p(K_GATHER_BWD, (double)B * (T * (2.0 * Din + Dp) * 4 + O * Din * 4.0 + T * Dp * 4.0), s);
   if (dobj) {
     const int64_t ns = rowsum_nseg(O, T);
     const int64_t need = rowsum_ws_bytes(B, O, T, Din, false);
