@@ -97,6 +97,8 @@ SIGNATURES = {
     "csg_wino4_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
     "csg_wino4_conv_workspace": (c_i64, [ctypes.POINTER(WinoDesc)]),
     "csg_wino4_conv": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_i64, c_p]),
+    "csg_wino4_conv_part": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_f32,
+                                    c_p, c_p]),
     "csg_wino34_supported": (c_i32, [ctypes.POINTER(WinoDesc), c_i32]),
     "csg_wino34_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
     "csg_wino34_conv": (c_i32, [ctypes.POINTER(WinoDesc), c_i32, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p]),
@@ -105,7 +107,7 @@ SIGNATURES = {
     "csg_norm_stats": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_norm_finalize": (c_i32, [c_p, c_i64, c_i64, c_f64, c_f32, c_i32, c_p, c_p, c_p, c_p, c_f32, c_p]),
     "csg_norm_apply_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_f32, c_p, c_p]),
-    "csg_norm_apply_bwd_reduce": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64,
+    "csg_norm_apply_bwd_reduce": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64,
                                           c_p]),
     "csg_norm_apply_bwd_dx": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_f64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_f32,
                                       c_p, c_p, c_p]),

@@ -176,9 +176,13 @@ __global__ __launch_bounds__(256) void k_norm_apply_fwd(const float* __restrict_
 __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ invstd,
-                                                          const float* __restrict__ gb, float slope, int64_t P, int C,
+                                                          const float* __restrict__ gb,
+                                                          const float* __restrict__ yact, float slope, int64_t P, int C,
                                                           int nchunk, float* __restrict__ dgb,
                                                           double* __restrict__ partial) {
+  // yact (nullable): the activated output y of the forward.  With it the LeakyReLU gate is read off y's sign (y > 0 iff
+  // the pre-activation was) and the beta half of gb is never touched — the fused forward (csg_wino4_conv_part) does not
+  // write beta.
   extern __shared__ __attribute__((aligned(16))) double smd[];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, g = blockIdx.y;
@@ -202,10 +206,16 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const float* __restrict
         float4 xh = make_float4((xv.x - m.x) * r.x, (xv.y - m.y) * r.y, (xv.z - m.z) * r.z, (xv.w - m.w) * r.w);
         float4 dn = d;
         if (gb != nullptr) {
-          const float4 ga = ld4(gb + pix * 2 * C + co), be = ld4(gb + pix * 2 * C + C + co);
+          const float4 ga = ld4(gb + pix * 2 * C + co);
           if (slope != 1.0f) {
-            d.x *= lrelu_g(xh.x * (1.f + ga.x) + be.x, slope); d.y *= lrelu_g(xh.y * (1.f + ga.y) + be.y, slope);
-            d.z *= lrelu_g(xh.z * (1.f + ga.z) + be.z, slope); d.w *= lrelu_g(xh.w * (1.f + ga.w) + be.w, slope);
+            if (yact != nullptr) {
+              const float4 yv = ld4(yact + pix * C + co);
+              d.x *= lrelu_g(yv.x, slope); d.y *= lrelu_g(yv.y, slope); d.z *= lrelu_g(yv.z, slope); d.w *= lrelu_g(yv.w, slope);
+            } else {
+              const float4 be = ld4(gb + pix * 2 * C + C + co);
+              d.x *= lrelu_g(xh.x * (1.f + ga.x) + be.x, slope); d.y *= lrelu_g(xh.y * (1.f + ga.y) + be.y, slope);
+              d.z *= lrelu_g(xh.z * (1.f + ga.z) + be.z, slope); d.w *= lrelu_g(xh.w * (1.f + ga.w) + be.w, slope);
+            }
           }
           st4(dgb + pix * 2 * C + co, make_float4(d.x * xh.x, d.y * xh.y, d.z * xh.z, d.w * xh.w));
           st4(dgb + pix * 2 * C + C + co, d);
@@ -492,8 +502,9 @@ int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, c
 }
 
 int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
-                              const float* gb, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
+                              const float* gb, const float* yact, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
                               double* dsums, double* partial, int64_t nchunk, void* stream) {
+  CSG_REQUIRE(yact == nullptr || gb != nullptr, CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: yact goes with a modulation");
   CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: bad shape");
   CSG_REQUIRE((gb == nullptr) == (dgb == nullptr), CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: gb/dgb mismatch");
   CSG_REQUIRE(nchunk >= 1 && nchunk <= 65535 && G <= 65535, CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: bad nchunk");
@@ -501,7 +512,7 @@ int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean
   {
     ProfScope p(K_NORM_BWD_REDUCE, (double)G * P * C * 4 * (gb ? 6 : 2), s);
     CSG_LAUNCH(k_norm_bwd_reduce, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 8, s, dy, x, mean,
-                       invstd, gb, slope, P, (int)C, (int)nchunk, dgb, partial);
+                       invstd, gb, yact, slope, P, (int)C, (int)nchunk, dgb, partial);
   }
   CSG_LAUNCH(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
                      (int)(2 * C), (int)nchunk, (int)(2 * C), dsums);

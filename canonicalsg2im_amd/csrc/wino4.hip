@@ -93,6 +93,11 @@ struct Wino4Params {
   int act;
   float slope;
   float gate_slope;
+  int nt_off;          // first 32-channel tile of the packed operand this launch computes (a slice of the outputs)
+  int mod, g_cs;       // SPADE modulation in the epilogue (below); pixel stride of the gamma tensor
+  float mod_slope;
+  const float* mod_mean;
+  const float* mod_invstd;
   int nstage;          // Cin / 8
   int ksplit, sps;     // input-channel stages cut into ksplit ranges of sps stages, one output slab each
   long long slab;      // floats per slab (B*H*W*y_cs)
@@ -203,7 +208,12 @@ __device__ __forceinline__ csg_f32x2 w4_pfma(float c, csg_f32x2 a, csg_f32x2 b) 
 // Second half of a round: Y[a][b] = sum_xi A^T[a][xi] R_xi[b] for two output columns b, out of the exchange buffer.
 // PLAIN = bias only (the SPADE gamma / beta convolutions and every backward-data pass without a gate): no per-element
 // branches on the activation / residual / gate.
-template <bool PLAIN>
+// MODE 0: bias only; 1: activation / residual / gate; 2: SPADE modulation (normalization.py:96-110) — the launch computes
+// the BETA half of the gamma || beta convolution and writes  leaky(xhat (1 + gamma) + beta)  directly: `res` is x (the
+// map being normalised, laid out like y), `gate` the gamma map an earlier launch of the same operand wrote (pixel stride
+// g_cs), mod_mean / mod_invstd the batch statistics per channel.  beta never reaches memory, and the separate apply pass
+// (x, gamma, beta read; y written) is gone.
+template <int MODE>
 __device__ __forceinline__ void w4_store_columns(const Wino4Params& p, const float* rbuf, int tig, int round, int nt32,
                                                  int img, int X0, int Y0, const float* __restrict__ bias,
                                                  const float* __restrict__ res, const float* __restrict__ gate,
@@ -228,7 +238,18 @@ __device__ __forceinline__ void w4_store_columns(const Wino4Params& p, const flo
         bhi = __builtin_shufflevector(bv, bv, 2, 3);
       }
       const int64_t rowstride = (int64_t)p.Wo * p.y_cs;
-      int64_t off = (((int64_t)img * p.Ho + oy) * p.Wo + ox) * p.y_cs + n;
+      const int64_t pix0 = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
+      int64_t off = pix0 * p.y_cs + n;
+      float4 mx[4], mg[4], mm, mr;
+      if (MODE == 2) {                             // the modulation's operands travel while the rows are formed
+        mm = *(const float4*)(p.mod_mean + n);
+        mr = *(const float4*)(p.mod_invstd + n);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          mx[a] = *(const float4*)(res + off + a * rowstride);
+          mg[a] = *(const float4*)(gate + (pix0 + (int64_t)a * p.Wo) * p.g_cs + n);
+        }
+      }
 #pragma unroll
       for (int a = 0; a < 4; ++a, off += rowstride) {
         csg_f32x2 vl, vh;
@@ -248,7 +269,19 @@ __device__ __forceinline__ void w4_store_columns(const Wino4Params& p, const flo
         vl += blo;
         vh += bhi;
         float vv[4] = {vl.x, vl.y, vh.x, vh.y};
-        if (!PLAIN) {
+        if (MODE == 2) {
+          // as k_norm_apply_fwd: v = (x - mean) * invstd;  v = v * (1 + gamma) + beta;  LeakyReLU
+          const float xs[4] = {mx[a].x, mx[a].y, mx[a].z, mx[a].w}, gs[4] = {mg[a].x, mg[a].y, mg[a].z, mg[a].w};
+          const float ms[4] = {mm.x, mm.y, mm.z, mm.w}, rs[4] = {mr.x, mr.y, mr.z, mr.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (xs[e] - ms[e]) * rs[e];
+            float o = xh * (1.f + gs[e]) + vv[e];
+            if (p.mod_slope != 1.0f) o = o > 0.f ? o : o * p.mod_slope;
+            vv[e] = o;
+          }
+        }
+        if (MODE == 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (p.act == CSG_ACT_LEAKY)
@@ -307,10 +340,12 @@ __device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[6], const Wino4Params&
     }
     __syncthreads();
     if (round == 0) { W4_T(4) }
-    if (plain)
-      w4_store_columns<true>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
+    if (p.mod)
+      w4_store_columns<2>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
+    else if (plain)
+      w4_store_columns<0>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
     else
-      w4_store_columns<false>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
+      w4_store_columns<1>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
     if (round == 0) {
       __syncthreads();                           // the exchange buffer is rewritten by round 1
       W4_T(5)
@@ -527,7 +562,8 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   float* pv = smem + W4V_V0 + (((wave * 6) * 2 + h) * 32 + j) * 4;
 
   const int nt32 = nb * 2 + grp;
-  const unsigned uoff = nt32 < p.NT32 ? (unsigned)((((wave * 6) * p.NT32 + nt32) * p.Q8) * 64 + lane) * 16u : CSG_OOB_OFF;
+  const int nt32u = nt32 + p.nt_off;             // tile of the packed operand (a launch may compute a slice of the outputs)
+  const unsigned uoff = nt32u < p.NT32 ? (unsigned)((((wave * 6) * p.NT32 + nt32u) * p.Q8) * 64 + lane) * 16u : CSG_OOB_OFF;
   const int ustride = p.NT32 * p.Q8 * 1024;
   csg_f32x4 ur[3];                               // ring: the operands of position nu are fetched three positions ahead
   auto load_ur = [&](int slot, int nu, int s) {
@@ -704,6 +740,7 @@ static int w4_plan(const csg_wino_desc* d, int T, int pad, Wino4Params& p, size_
   p.NT32 = (d->Cout + 31) / 32;
   p.Q8 = (d->Cin + 7) / 8;
   p.act = d->act; p.slope = d->slope; p.gate_slope = 0.f;
+  p.nt_off = 0; p.mod = 0; p.g_cs = 0; p.mod_slope = 1.f; p.mod_mean = nullptr; p.mod_invstd = nullptr;
   p.nstage = d->Cin / W4_PS;
   p.ksplit = 1;
   p.sps = p.nstage;
@@ -848,6 +885,37 @@ int csg_wino4_conv(const csg_wino_desc* d, const float* x, const float* packed, 
   // algorithmic FLOPs of the DIRECT convolution this replaces (2 * M * 9*Cin * Cout): what FlopCounterMode counts
   return w4_launch<4>(p, shm, K_WINO4_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, x, packed, bias, residual, gate, y,
                       workspace, y_final, (hipStream_t)stream, "csg_wino4_conv");
+}
+
+int csg_wino4_conv_part(const csg_wino_desc* d, const float* x, const float* packed, int64_t tile_off, int64_t tiles_total,
+                        const float* bias, const float* mod_x, const float* mod_gamma, int64_t gamma_cs,
+                        const float* mod_mean, const float* mod_invstd, float mod_slope, float* y, void* stream) {
+  Wino4Params p;
+  size_t shm = 0;
+  int rc = w4_plan(d, 4, 1, p, shm, "csg_wino4_conv_part");
+  if (rc) return rc;
+  CSG_REQUIRE(d->act == CSG_ACT_NONE, CSG_E_UNSUPPORTED, "csg_wino4_conv_part: no activation (the modulation has its own)");
+  CSG_REQUIRE(tile_off >= 0 && tiles_total >= tile_off + p.NT32 && d->Cout % 32 == 0, CSG_E_BADSHAPE,
+              "csg_wino4_conv_part: tiles [%ld, %ld) of %ld with Cout=%d", (long)tile_off, (long)(tile_off + p.NT32),
+              (long)tiles_total, d->Cout);
+  CSG_REQUIRE((int64_t)36 * tiles_total * p.Q8 * 1024 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
+              "csg_wino4_conv_part: packed weights too large for 32-bit byte offsets");
+  p.nt_off = (int)tile_off;
+  p.NT32 = (int)tiles_total;                       // the stride of the packed operand
+  if (mod_x != nullptr) {
+    CSG_REQUIRE(mod_gamma != nullptr && mod_mean != nullptr && mod_invstd != nullptr && gamma_cs >= d->Cout &&
+                    gamma_cs % 4 == 0,
+                CSG_E_BADSHAPE, "csg_wino4_conv_part: the modulation needs gamma, mean, invstd");
+    CSG_REQUIRE(((uintptr_t)mod_x % 16) == 0 && ((uintptr_t)mod_gamma % 16) == 0 && ((uintptr_t)mod_mean % 16) == 0 &&
+                    ((uintptr_t)mod_invstd % 16) == 0,
+                CSG_E_UNSUPPORTED, "csg_wino4_conv_part: pointers must be 16-byte aligned");
+    p.mod = 1; p.g_cs = (int)gamma_cs; p.mod_slope = mod_slope; p.mod_mean = mod_mean; p.mod_invstd = mod_invstd;
+  }
+  CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                  (bias == nullptr || ((uintptr_t)bias % 16) == 0),
+              CSG_E_UNSUPPORTED, "csg_wino4_conv_part: pointers must be 16-byte aligned");
+  return w4_launch<4>(p, shm, K_WINO4_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, x, packed, bias, mod_x, mod_gamma, y,
+                      nullptr, y, (hipStream_t)stream, "csg_wino4_conv_part");
 }
 
 }  // extern "C"

@@ -601,7 +601,7 @@ class _NormAct(torch.autograd.Function):
         nch = _chunks(P, G)
         part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float64)
         dsums = torch.empty(G * 2 * C, device=dev, dtype=torch.float64)
-        check(lib.csg_norm_apply_bwd_reduce(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, G, P, C, ptr(dgb),
+        check(lib.csg_norm_apply_bwd_reduce(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), None, slope, G, P, C, ptr(dgb),
                                             ptr(dsums), ptr(part), nch, stream()), "norm_bwd_reduce")
         dx = None
         if ctx.needs_input_grad[0]:
@@ -658,9 +658,9 @@ class _NormActPair(torch.autograd.Function):
         part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
         dsums = torch.empty(2, 2 * C, device=dev, dtype=torch.float64)
         dgb0, dgb1 = torch.empty_like(gb0), torch.empty_like(gb1)
-        check(lib.csg_norm_apply_bwd_reduce(ptr(dy0), ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, 1, P, C, ptr(dgb0),
+        check(lib.csg_norm_apply_bwd_reduce(ptr(dy0), ptr(x), ptr(mean), ptr(invstd), ptr(gb0), None, slope0, 1, P, C, ptr(dgb0),
                                             ptr(dsums[0]), ptr(part), nch, stream()), "norm_bwd_reduce")
-        check(lib.csg_norm_apply_bwd_reduce(ptr(dy1), ptr(x), ptr(mean), ptr(invstd), ptr(gb1), slope1, 1, P, C, ptr(dgb1),
+        check(lib.csg_norm_apply_bwd_reduce(ptr(dy1), ptr(x), ptr(mean), ptr(invstd), ptr(gb1), None, slope1, 1, P, C, ptr(dgb1),
                                             ptr(dsums[1]), ptr(part), nch, stream()), "norm_bwd_reduce")
         dx = None
         if ctx.needs_input_grad[0]:
@@ -672,6 +672,131 @@ class _NormActPair(torch.autograd.Function):
                                             1, P, C, ptr(dx), ptr(dy1), ptr(gb1), slope1, ptr(dgb0), ptr(dgb1), stream()),
                   "norm_bwd_dx")
         return dx, dgb0, dgb1, None, None, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------ SPADE with the modulation in the
+# gamma || beta convolution's epilogue
+SPADE_FUSED = os.environ.get("CSG_SPADE_FUSED", "1") != "0"
+
+
+def spade_fused_eligible(x, nhidden, C, ks, training):
+    """Training-mode SPADE layers whose gamma || beta convolution runs Winograd F(4x4,3x3) (maps >= 32 wide): the beta half
+    of the convolution writes leaky(xhat (1 + gamma) + beta) itself (csg_wino4_conv_part)."""
+    if not (SPADE_FUSED and WINO_ENABLED and training and ks == 3 and x.dim() == 4 and C % 32 == 0):
+        return False
+    B, _, H, W = x.shape
+    return lib.csg_wino4_supported(_wino_desc(B, H, W, nhidden, C)) == 1
+
+
+class _SpadeFused(torch.autograd.Function):
+    """K = 1 or 2 SPADE modulations of ONE batch-normalised x (reference normalization.py:96-110; K = 2: norm_s and norm_0
+    of a residual block, architecture.py:37-47), each `leaky(xhat (1 + gamma_k) + beta_k, slope_k)` with gamma_k || beta_k =
+    conv3x3(actv_k, w_k) + b_k.  Forward per modulation: the gamma half of the convolution into a (B,H,W,2C) buffer (its
+    beta half is never written), then the beta half with the modulation as its epilogue.  Backward: the two norm passes of
+    _NormAct / _NormActPair (the LeakyReLU gate read off y's sign), then the joined convolution's backward-data and
+    weight-gradient passes on d(gamma || beta)."""
+
+    NARG = 7          # per modulation: actv, w, b, running_mean, running_var, slope, in_slope
+
+    @staticmethod
+    def forward(ctx, x, eps, momentum, sync, *mods):
+        K = len(mods) // _SpadeFused.NARG
+        x = nhwc(_f32(x))
+        B, C, H, W = x.shape
+        P = B * H * W
+        dev = x.device
+        world = _sync_world() if sync else 1
+        count = float(P * world)
+        mean = torch.empty(C, device=dev, dtype=torch.float32)
+        invstd = torch.empty(C, device=dev, dtype=torch.float32)
+        nch = _chunks(P, 1)
+        part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
+        sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+        check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
+        if world > 1:
+            csg_dist.all_reduce_stats(sums)
+        saved, outs, cfg = [x, mean, invstd], [], []
+        for k in range(K):
+            actv, w, b, rm, rv, slope, in_slope = mods[k * 7:(k + 1) * 7]
+            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if world > 1 else 0, ptr(mean), ptr(invstd), ptr(rm),
+                                        ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
+        for k in range(K):
+            actv, w, b, rm, rv, slope, in_slope = mods[k * 7:(k + 1) * 7]
+            actv = nhwc(_f32(actv))
+            nh = actv.shape[1]
+            if tuple(w.shape) != (2 * C, nh, 3, 3) or tuple(actv.shape) != (B, nh, H, W):
+                raise RuntimeError("spade_fused: weight %s / actv %s do not fit x %s" % (tuple(w.shape), tuple(actv.shape),
+                                                                                         tuple(x.shape)))
+            up = wino_pack(w, False, None, 4)
+            bd = b.detach().contiguous()
+            gbuf = empty_nhwc(B, 2 * C, H, W, dev)            # [gamma | (beta: never written, never read)]
+            y = torch.empty_like(x)
+            d = _wino_desc(B, H, W, nh, C)
+            d.y_cs = 2 * C
+            check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), 0, 2 * C // 32, ptr(bd), None, None, 0, None, None, 1.0,
+                                          ptr(gbuf), stream()), "wino4_conv_part(gamma)")
+            d.y_cs = C
+            check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), C // 32, 2 * C // 32, ptr(bd[C:]), ptr(x), ptr(gbuf), 2 * C,
+                                          ptr(mean), ptr(invstd), slope, ptr(y), stream()), "wino4_conv_part(beta)")
+            saved += [actv, w, gbuf, y]
+            outs.append(y)
+            cfg.append((slope, in_slope, nh))
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (K, P, C, B, H, W, world, count, tuple(cfg))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        import types
+        K, P, C, B, H, W, world, count, cfg = ctx.cfg
+        sv = ctx.saved_tensors
+        x, mean, invstd = sv[0], sv[1], sv[2]
+        dev = x.device
+        nch = _chunks(P, 1)
+        part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
+        dsums = torch.empty(K, 2 * C, device=dev, dtype=torch.float64)
+        dys = [nhwc(dy) for dy in dys]
+        dgbs = []
+        for k in range(K):
+            actv, w, gbuf, y = sv[3 + 4 * k:7 + 4 * k]
+            dgb = torch.empty_like(gbuf)
+            check(lib.csg_norm_apply_bwd_reduce(ptr(dys[k]), ptr(x), ptr(mean), ptr(invstd), ptr(gbuf), ptr(y), cfg[k][0], 1, P,
+                                                C, ptr(dgb), ptr(dsums[k]), ptr(part), nch, stream()), "norm_bwd_reduce")
+            dgbs.append(dgb)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            both = dsums[0] + dsums[1] if K == 2 else dsums[0]
+            if world > 1:
+                csg_dist.all_reduce_stats(both)
+            dx = torch.empty_like(x)
+            two = K == 2
+            check(lib.csg_norm_apply_bwd_dx(ptr(dys[0]), ptr(x), ptr(mean), ptr(invstd), ptr(sv[5]), cfg[0][0], ptr(both), count,
+                                            1, P, C, ptr(dx), ptr(dys[1]) if two else None, ptr(sv[9]) if two else None,
+                                            cfg[1][0] if two else 1.0, ptr(dgbs[0]), ptr(dgbs[1]) if two else None, stream()),
+                  "norm_bwd_dx")
+        grads = [dx, None, None, None]
+        for k in range(K):
+            actv, w, gbuf, y = sv[3 + 4 * k:7 + 4 * k]
+            slope, in_slope, nh = cfg[k]
+            base = 4 + 7 * k
+            need = ctx.needs_input_grad[base:base + 3]
+            # the joined gamma || beta convolution's backward on d(gamma || beta): _Conv2d.backward on a stand-in context
+            fake = types.SimpleNamespace(
+                saved_tensors=(actv, w, None), geom=(B, H, W, nh, 2 * C, 3, 3, 1, 1, H, W, ACT_NONE, 0.0),
+                in_act=(ACT_LEAKY, in_slope) if in_slope is not None else None, grad_is_pre=False, few=None, dx_range=None,
+                packs=None, needs_input_grad=(need[0], need[1], need[2], False), has_bias=True, has_res=False, cout_w=2 * C)
+            r = _Conv2d.backward(fake, dgbs[k])
+            grads += [r[0], r[1], r[2], None, None, None, None]
+        return tuple(grads)
+
+
+def spade_fused(x, mods, eps=1e-5, momentum=0.1, sync=True):
+    """mods: one or two tuples (actv, w, b, running_mean, running_var, slope, in_slope) — see _SpadeFused.  Returns the
+    list of modulated maps."""
+    flat = []
+    for (actv, w, b, rm, rv, slope, in_slope) in mods:
+        flat += [actv, w, b, rm, rv, float(slope), None if in_slope is None else float(in_slope)]
+    return list(_SpadeFused.apply(x, float(eps), float(momentum), bool(sync), *flat))
 
 
 def norm_act_pair(x, gb0, gb1, rm0, rv0, rm1, rv1, slope0, slope1, eps=1e-5, momentum=0.1, sync=True):

@@ -141,7 +141,30 @@ class SPADE(nn.Module):
         self.mlp_beta = Conv2d(nhidden, norm_nc, kernel_size=ks, padding=self.pw)
 
     def forward(self, x, segmap, fused_slope=1.0):
+        if self.fusable(x):
+            return ops.spade_fused(x, [self.fused_operands(x, segmap, fused_slope)], self.param_free_norm.eps,
+                                   self.param_free_norm.momentum, getattr(self.param_free_norm, "sync", True))[0]
         return self.param_free_norm(x, gb=self.modulation(x, segmap), fused_slope=fused_slope)
+
+    def fusable(self, x):
+        """The modulation can ride in the epilogue of the gamma || beta convolution (ops._SpadeFused): a param-free
+        BatchNorm in training mode, 3x3 convolutions on a map F(4x4,3x3) serves."""
+        pn = self.param_free_norm
+        return (isinstance(pn, (SynchronizedBatchNorm2d, LocalBatchNorm2d)) and not pn.affine and pn.training
+                and ops.spade_fused_eligible(x, self.mlp_gamma.weight.shape[1], self.mlp_gamma.weight.shape[0],
+                                             self.mlp_gamma.weight.shape[2], pn.training))
+
+    def fused_operands(self, x, segmap, slope):
+        if isinstance(segmap, SegPyramid):
+            seg = segmap.at(x.size(2))
+        else:
+            seg = segmap if segmap.shape[2:] == x.shape[2:] else ops.nearest_resize(segmap, x.shape[2:])
+        sh = self.mlp_shared[0]
+        actv = ops.conv2d(seg, sh.weight, sh.bias, 1, sh.padding[0], sh.act, sh.slope, grad_is_pre=True)
+        w = _joined(self, "_joined_w", self.mlp_gamma.weight, self.mlp_beta.weight)
+        b = _joined(self, "_joined_b", self.mlp_gamma.bias, self.mlp_beta.bias)
+        pn = self.param_free_norm
+        return (actv, w, b, pn.running_mean, pn.running_var, slope, sh.slope)
 
     def modulation(self, x, segmap):
         """gamma || beta (B, 2C, h, w) of this SPADE for a feature map shaped like x."""
@@ -172,6 +195,10 @@ def spade_pair(norm_a, norm_b, x, segmap, slope_a, slope_b):
             and getattr(pa, "sync", True) == getattr(pb, "sync", True) and x.dim() == 4)
     if not same:
         return norm_a(x, segmap, fused_slope=slope_a), norm_b(x, segmap, fused_slope=slope_b)
+    if norm_a.fusable(x) and norm_b.fusable(x):
+        ya, yb = ops.spade_fused(x, [norm_a.fused_operands(x, segmap, slope_a), norm_b.fused_operands(x, segmap, slope_b)],
+                                 pa.eps, pa.momentum, getattr(pa, "sync", True))
+        return ya, yb
     return ops.norm_act_pair(x, norm_a.modulation(x, segmap), norm_b.modulation(x, segmap), pa.running_mean, pa.running_var,
                              pb.running_mean, pb.running_var, slope_a, slope_b, pa.eps, pa.momentum,
                              getattr(pa, "sync", True))

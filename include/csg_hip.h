@@ -242,6 +242,17 @@ int csg_wino4_conv(const csg_wino_desc* d, const float* x, const float* packed, 
                    const float* residual, const float* gate, float gate_slope, float* y, float* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* A slice of the outputs of an F(4x4,3x3) convolution — 32-channel tiles [tile_off, tile_off + Cout/32) of a packed
+ * operand of `tiles_total` tiles — optionally with the SPADE modulation (normalization.py:96-110) as its epilogue:
+ * with mod_x != NULL the launch is the BETA half of the gamma || beta convolution and writes
+ *     y = leaky(((mod_x - mean) * invstd) * (1 + gamma) + (conv + bias), mod_slope)
+ * where `mod_gamma` (pixel stride gamma_cs) is the gamma map a plain launch of this entry point (tile_off 0, y_cs =
+ * gamma_cs) wrote before, mod_x has y's layout and mean / invstd are the (C,) batch statistics.  beta never reaches
+ * memory and the apply pass of csg_norm_apply_fwd is not needed.  `bias` points at the slice's first channel.      */
+int csg_wino4_conv_part(const csg_wino_desc* d, const float* x, const float* packed, int64_t tile_off, int64_t tiles_total,
+                        const float* bias, const float* mod_x, const float* mod_gamma, int64_t gamma_cs,
+                        const float* mod_mean, const float* mod_invstd, float mod_slope, float* y, void* stream);
+
 /* ---- K8w34: 4x4 / stride 1 convolutions by Winograd F(3x3,4x4) (csrc/wino4.hip, the same kernel on 3x3 output tiles)
  * The PatchGAN's fourth layer (discriminator.py:184-189: 4x4, stride 1, padding 2, 256 -> 512 channels at 1/8
  * resolution) and its backward-data pass (the 4x4 correlation with the flipped, transposed weight and padding 1):
@@ -305,9 +316,11 @@ int csg_norm_finalize(const double* sums, int64_t G, int64_t C, double count, fl
 int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gb, float slope,
                        int64_t G, int64_t P, int64_t C, float* y, const float* gb2, float slope2, float* y2,
                        void* stream);
-/* pass 1: dgb (if gb) and dsums (G,2C) double = [sum dn | sum dn*xhat]                          */
+/* pass 1: dgb (if gb) and dsums (G,2C) double = [sum dn | sum dn*xhat].  `yact` (nullable, with gb): the activated
+ * output y of the forward — the LeakyReLU gate is then read off y's sign and the beta half of gb is never read (the
+ * fused forward csg_wino4_conv_part does not write it).                                                        */
 int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
-                              const float* gb, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
+                              const float* gb, const float* yact, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
                               double* dsums, double* partial, int64_t nchunk, void* stream);
 /* pass 2: dx = invstd*(dn - dsum0/count - xhat*dsum1/count).  (dy2, gb2, slope2), nullable: a second SPADE modulation
  * of the SAME normalised x (norm_0 and norm_s of a residual block with a learned shortcut, architecture.py:37-47, see
