@@ -2,7 +2,7 @@
 D forward (training mode, one call) on the REAL image: HIP vs oracle fp32 vs oracle fp64, every feature map; then the
 gradients of sum(all prediction maps)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import __graft_entry__ as ge
 ge.build()
