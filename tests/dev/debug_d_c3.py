@@ -3,7 +3,7 @@ D forward (training mode, one call) on the REAL image: HIP vs oracle fp32 vs ora
 gradients of sum(all prediction maps)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.build()
 import oracle
