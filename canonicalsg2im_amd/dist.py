@@ -77,6 +77,18 @@ def all_reduce_stats(sums):
     return sums
 
 
+def all_reduce_stats_async(sums):
+    """all_reduce_stats as an asynchronous collective: returns a handle whose wait() makes the current stream wait for the
+    total (None on a single rank) — the caller enqueues work that does not need the statistics in between (the gamma half of
+    the SPADE convolution in forward, the gamma || beta convolution's backward passes in backward), so the latency of the
+    2C-value message hides under a convolution instead of stalling the compute stream."""
+    if world_size() > 1:
+        work = dist.all_reduce(sums, async_op=True)
+        comm_note("syncbn_allreduce", sums.numel() * sums.element_size())
+        return work
+    return None
+
+
 class GradBuckets:
     """Gradient exchange of one optimiser's parameters: persistent flat fp32 buckets, `.grad` kept as VIEWS into
     them, one all-reduce per bucket launched asynchronously from a post-accumulate hook as soon as the bucket's last

@@ -713,13 +713,9 @@ class _SpadeFused(torch.autograd.Function):
         part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
         sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
         check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-        if world > 1:
-            csg_dist.all_reduce_stats(sums)
-        saved, outs, cfg = [x, mean, invstd], [], []
-        for k in range(K):
-            actv, w, b, rm, rv, slope, in_slope = mods[k * 7:(k + 1) * 7]
-            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if world > 1 else 0, ptr(mean), ptr(invstd), ptr(rm),
-                                        ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
+        # N > 1: the statistics travel while the gamma halves (which do not need them) are computed
+        pending = csg_dist.all_reduce_stats_async(sums) if world > 1 else None
+        saved, outs, cfg, launches = [x, mean, invstd], [], [], []
         for k in range(K):
             actv, w, b, rm, rv, slope, in_slope = mods[k * 7:(k + 1) * 7]
             actv = nhwc(_f32(actv))
@@ -730,11 +726,20 @@ class _SpadeFused(torch.autograd.Function):
             up = wino_pack(w, False, None, 4)
             bd = b.detach().contiguous()
             gbuf = empty_nhwc(B, 2 * C, H, W, dev)            # [gamma | (beta: never written, never read)]
-            y = torch.empty_like(x)
             d = _wino_desc(B, H, W, nh, C)
             d.y_cs = 2 * C
             check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), 0, 2 * C // 32, ptr(bd), None, None, 0, None, None, 1.0,
                                           ptr(gbuf), stream()), "wino4_conv_part(gamma)")
+            launches.append((actv, w, up, bd, gbuf, nh, slope, in_slope))
+        if pending is not None:
+            pending.wait()
+        for k in range(K):
+            rm, rv = mods[k * 7 + 3], mods[k * 7 + 4]
+            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if world > 1 else 0, ptr(mean), ptr(invstd), ptr(rm),
+                                        ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
+        for (actv, w, up, bd, gbuf, nh, slope, in_slope) in launches:
+            y = torch.empty_like(x)
+            d = _wino_desc(B, H, W, nh, C)
             d.y_cs = C
             check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), C // 32, 2 * C // 32, ptr(bd[C:]), ptr(x), ptr(gbuf), 2 * C,
                                           ptr(mean), ptr(invstd), slope, ptr(y), stream()), "wino4_conv_part(beta)")
@@ -763,18 +768,12 @@ class _SpadeFused(torch.autograd.Function):
             check(lib.csg_norm_apply_bwd_reduce(ptr(dys[k]), ptr(x), ptr(mean), ptr(invstd), ptr(gbuf), ptr(y), cfg[k][0], 1, P,
                                                 C, ptr(dgb), ptr(dsums[k]), ptr(part), nch, stream()), "norm_bwd_reduce")
             dgbs.append(dgb)
-        dx = None
+        dx, both, pending = None, None, None
         if ctx.needs_input_grad[0]:
             both = dsums[0] + dsums[1] if K == 2 else dsums[0]
-            if world > 1:
-                csg_dist.all_reduce_stats(both)
-            dx = torch.empty_like(x)
-            two = K == 2
-            check(lib.csg_norm_apply_bwd_dx(ptr(dys[0]), ptr(x), ptr(mean), ptr(invstd), ptr(sv[5]), cfg[0][0], ptr(both), count,
-                                            1, P, C, ptr(dx), ptr(dys[1]) if two else None, ptr(sv[9]) if two else None,
-                                            cfg[1][0] if two else 1.0, ptr(dgbs[0]), ptr(dgbs[1]) if two else None, stream()),
-                  "norm_bwd_dx")
-        grads = [dx, None, None, None]
+            # N > 1: the reductions travel while the convolution's backward passes (which need only d(gamma || beta)) run
+            pending = csg_dist.all_reduce_stats_async(both) if world > 1 else None
+        grads = [None, None, None, None]
         for k in range(K):
             actv, w, gbuf, y = sv[3 + 4 * k:7 + 4 * k]
             slope, in_slope, nh = cfg[k]
@@ -787,6 +786,16 @@ class _SpadeFused(torch.autograd.Function):
                 packs=None, needs_input_grad=(need[0], need[1], need[2], False), has_bias=True, has_res=False, cout_w=2 * C)
             r = _Conv2d.backward(fake, dgbs[k])
             grads += [r[0], r[1], r[2], None, None, None, None]
+        if ctx.needs_input_grad[0]:
+            if pending is not None:
+                pending.wait()
+            dx = torch.empty_like(x)
+            two = K == 2
+            check(lib.csg_norm_apply_bwd_dx(ptr(dys[0]), ptr(x), ptr(mean), ptr(invstd), ptr(sv[5]), cfg[0][0], ptr(both), count,
+                                            1, P, C, ptr(dx), ptr(dys[1]) if two else None, ptr(sv[9]) if two else None,
+                                            cfg[1][0] if two else 1.0, ptr(dgbs[0]), ptr(dgbs[1]) if two else None, stream()),
+                  "norm_bwd_dx")
+            grads[0] = dx
         return tuple(grads)
 
 
