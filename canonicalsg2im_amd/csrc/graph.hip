@@ -213,26 +213,27 @@ static inline size_t csr_sorted_lds(int64_t T, int64_t O) {
 }
 
 // ------------------------------------------------------------------------------------ K2
-__global__ void k_gather_concat_fwd(const float* __restrict__ obj, const float* __restrict__ pred,
-                                    const int64_t* __restrict__ triplets, int64_t BT, int O, int T, int Din, int Dp,
-                                    float* __restrict__ out) {
-  const int Dc = 2 * Din + Dp;
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= BT * Dc) return;
-  int64_t bt = e / Dc;
-  int j = (int)(e - bt * Dc);
-  int64_t b = bt / T;
-  float v;
-  if (j < Din) {
-    int64_t s = triplets[bt * 3 + 0];
-    v = obj[(b * O + s) * Din + j];
-  } else if (j < Din + Dp) {
-    v = pred[bt * Dp + (j - Din)];
+// one float4 per thread (Din, Dp are multiples of 4: host-checked), one row = Dc / 4 quads
+__global__ __launch_bounds__(256) void k_gather_concat_fwd(const float* __restrict__ obj, const float* __restrict__ pred,
+                                                            const int64_t* __restrict__ triplets, int64_t BT, int O, int T,
+                                                            int Din, int Dp, float* __restrict__ out) {
+  const int Qc = (2 * Din + Dp) >> 2, Qi = Din >> 2, Qp = Dp >> 2;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= BT * Qc) return;
+  const int64_t bt = e / Qc;
+  const int j = (int)(e - bt * Qc);
+  const int64_t b = bt / T;
+  float4 v;
+  if (j < Qi) {
+    const int64_t s = triplets[bt * 3 + 0];
+    v = *(const float4*)(obj + (b * O + s) * Din + j * 4);
+  } else if (j < Qi + Qp) {
+    v = *(const float4*)(pred + bt * Dp + (j - Qi) * 4);
   } else {
-    int64_t o = triplets[bt * 3 + 2];
-    v = obj[(b * O + o) * Din + (j - Din - Dp)];
+    const int64_t o = triplets[bt * 3 + 2];
+    v = *(const float4*)(obj + (b * O + o) * Din + (j - Qi - Qp) * 4);
   }
-  out[e] = v;
+  *(float4*)(out + e * 4) = v;
 }
 
 // ---- CSR row sums (K5 forward, K2 backward) ---------------------------------------------------
@@ -461,23 +462,29 @@ static inline int64_t rowsum_ws_bytes(int64_t B, int64_t O, int64_t T, int64_t D
   return (B * ns * (D + (weighted ? 1 : 0))) * (int64_t)sizeof(float) + B * O * 2 * (int64_t)sizeof(int32_t);
 }
 
-__global__ void k_slice_copy(const float* __restrict__ src, int64_t rows, int src_stride, int src_off, int width,
-                             float* __restrict__ dst) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= rows * width) return;
-  int64_t r = e / width;
-  int j = (int)(e - r * width);
-  dst[e] = src[r * src_stride + src_off + j];
+// float4 per thread: widths, strides and offsets are multiples of 4 (host-checked)
+__global__ __launch_bounds__(256) void k_slice_copy(const float* __restrict__ src, int64_t rows, int src_stride,
+                                                     int src_off, int width, float* __restrict__ dst) {
+  const int Qw = width >> 2;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * Qw) return;
+  const int64_t r = e / Qw;
+  const int j = (int)(e - r * Qw);
+  *(float4*)(dst + e * 4) = *(const float4*)(src + r * src_stride + src_off + j * 4);
 }
 
 // ------------------------------------------------------------------------------------ K4+K5
-__global__ void k_scale_slice(const float* __restrict__ h, const float* __restrict__ conf, int64_t BT, int Dh,
-                              int off, int Dp, float* __restrict__ out) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= BT * Dp) return;
-  int64_t bt = e / Dp;
-  int j = (int)(e - bt * Dp);
-  out[e] = h[bt * Dh + off + j] * conf[bt];
+__global__ __launch_bounds__(256) void k_scale_slice(const float* __restrict__ h, const float* __restrict__ conf,
+                                                      int64_t BT, int Dh, int off, int Dp, float* __restrict__ out) {
+  const int Qp = Dp >> 2;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= BT * Qp) return;
+  const int64_t bt = e / Qp;
+  const int j = (int)(e - bt * Qp);
+  const float c = conf[bt];
+  float4 v = *(const float4*)(h + bt * Dh + off + j * 4);
+  v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+  *(float4*)(out + e * 4) = v;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -615,11 +622,15 @@ int csg_graph_csr_build(const int64_t* triplets, int64_t B, int64_t T, int64_t O
 int csg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* triplets, int64_t B, int64_t O,
                           int64_t T, int64_t Din, int64_t Dp, float* out, void* stream) {
   CSG_REQUIRE(B > 0 && O > 0 && T >= 0 && Din > 0 && Dp > 0, CSG_E_BADSHAPE, "csg_gather_concat_fwd: bad shape");
+  CSG_REQUIRE(Din % 4 == 0 && Dp % 4 == 0 && ((uintptr_t)obj % 16) == 0 && ((uintptr_t)pred % 16) == 0 &&
+                  ((uintptr_t)out % 16) == 0,
+              CSG_E_BADSHAPE, "csg_gather_concat_fwd: Din=%ld and Dp=%ld must be multiples of 4, pointers 16-byte aligned",
+              (long)Din, (long)Dp);
   if (T == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
   int64_t n = B * T * (2 * Din + Dp);
   ProfScope p(K_GATHER_FWD, (double)n * 8, s);
-  CSG_LAUNCH(k_gather_concat_fwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, obj, pred, triplets, B * T,
+  CSG_LAUNCH(k_gather_concat_fwd, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, s, obj, pred, triplets, B * T,
                      (int)O, (int)T, (int)Din, (int)Dp, out);
   return check_launch("csg_gather_concat_fwd");
 }
@@ -656,7 +667,7 @@ int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32
   }
   if (dpred && T > 0) {
     int64_t n = B * T * Dp;
-    CSG_LAUNCH(k_slice_copy, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, dcat, B * T,
+    CSG_LAUNCH(k_slice_copy, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, s, dcat, B * T,
                        (int)(2 * Din + Dp), (int)Din, (int)Dp, dpred);
   }
   return check_launch("csg_gather_concat_bwd");
@@ -692,7 +703,7 @@ int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid,
                        cnt);
   if (new_p && Dp > 0 && T > 0) {
     int64_t n = B * T * Dp;
-    CSG_LAUNCH(k_scale_slice, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, h, conf, B * T,
+    CSG_LAUNCH(k_scale_slice, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, s, h, conf, B * T,
                        (int)(2 * H + Dp), (int)H, (int)Dp, new_p);
   }
   return check_launch("csg_segment_avg_fwd");
