@@ -101,7 +101,8 @@ SIGNATURES = {
                                     c_p, c_p]),
     "csg_wino34_supported": (c_i32, [ctypes.POINTER(WinoDesc), c_i32]),
     "csg_wino34_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
-    "csg_wino34_conv": (c_i32, [ctypes.POINTER(WinoDesc), c_i32, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p]),
+    "csg_wino34_conv_workspace": (c_i64, [ctypes.POINTER(WinoDesc), c_i32]),
+    "csg_wino34_conv": (c_i32, [ctypes.POINTER(WinoDesc), c_i32, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_i64, c_p]),
     "csg_act_bwd": (c_i32, [c_p, c_p, c_i64, c_i32, c_f32, c_p, c_p]),
     "csg_colsum": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_norm_stats": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),

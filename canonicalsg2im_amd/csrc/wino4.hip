@@ -839,19 +839,38 @@ int32_t csg_wino34_supported(const csg_wino_desc* d, int32_t pad) {
           d->Cout >= 32) ? 1 : 0;
 }
 
+int64_t csg_wino34_conv_workspace(const csg_wino_desc* d, int32_t pad) {
+  Wino4Params p;
+  size_t shm = 0;
+  if (w4_plan(d, 3, pad, p, shm, "csg_wino34_conv_workspace")) return -1;
+  w4_split_plan(p, d->act == CSG_ACT_NONE);
+  return p.ksplit > 1 ? (int64_t)p.ksplit * p.slab * 4 : 0;
+}
+
 int csg_wino34_conv(const csg_wino_desc* d, int32_t pad, const float* x, const float* packed, const float* bias,
-                    const float* residual, const float* gate, float gate_slope, float* y, void* stream) {
+                    const float* residual, const float* gate, float gate_slope, float* y, float* workspace,
+                    int64_t workspace_bytes, void* stream) {
   Wino4Params p;
   size_t shm = 0;
   int rc = w4_plan(d, 3, pad, p, shm, "csg_wino34_conv");
   if (rc) return rc;
+  w4_split_plan(p, d->act == CSG_ACT_NONE && bias == nullptr && residual == nullptr && gate == nullptr);
   p.gate_slope = gate_slope;
+  if (p.ksplit > 1 && (workspace == nullptr || workspace_bytes < (int64_t)p.ksplit * p.slab * 4)) {   // no slabs: unsplit
+    p.ksplit = 1;
+    p.sps = p.nstage;
+  }
+  float* const y_final = y;
+  if (p.ksplit > 1) {
+    CSG_REQUIRE(((uintptr_t)workspace % 16) == 0, CSG_E_UNSUPPORTED, "csg_wino34_conv: workspace must be 16-byte aligned");
+    y = workspace;
+  }
   CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
                   (gate == nullptr || ((uintptr_t)gate % 16) == 0),
               CSG_E_UNSUPPORTED, "csg_wino34_conv: pointers must be 16-byte aligned");
   // algorithmic FLOPs of the DIRECT convolution this replaces (2 * M * 16*Cin * Cout)
   return w4_launch<3>(p, shm, K_WINO4_CONV, 2.0 * p.B * p.Ho * p.Wo * 16.0 * p.Cin * p.Cout, x, packed, bias, residual, gate,
-                      y, nullptr, y, (hipStream_t)stream, "csg_wino34_conv");
+                      y, workspace, y_final, (hipStream_t)stream, "csg_wino34_conv");
 }
 
 int64_t csg_wino4_conv_workspace(const csg_wino_desc* d) {

@@ -285,7 +285,7 @@ class _Conv2d(torch.autograd.Function):
             y = empty_nhwc(B, Cout, OH, OW, x.device)
             check(lib.csg_wino34_conv(_wino_desc(B, IH, IW, Cin, Cout, act, slope), pad, ptr(x),
                                       ptr(wino_pack(weight, False, None, 34)), ptr(bias.detach() if bias is not None else None),
-                                      ptr(res), None, 0.0, ptr(y), stream()), "wino34_conv_fwd")
+                                      ptr(res), None, 0.0, ptr(y), None, 0, stream()), "wino34_conv_fwd")
         else:
             # [Cout][KH][KW][Cin]: free for channels-last parameters (sg2im.layers.Conv2d keeps them that way)
             wp = packs[0] if packs is not None else weight.detach().permute(0, 2, 3, 1).contiguous()
@@ -356,8 +356,14 @@ class _Conv2d(torch.autograd.Function):
             # dX = conv4x4(dY, flipped W^T) with padding 3 - pad: the same F(3x3,4x4) kernel, channel counts swapped
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
             has_gate = ctx.in_act is not None
-            check(lib.csg_wino34_conv(_wino_desc(B, OH, OW, Cout, Cin), 3 - pad, ptr(dpre), ptr(wino_pack(weight, True, None, 34)),
-                                      None, None, ptr(x) if has_gate else None, ctx.in_act[1] if has_gate else 0.0, ptr(dx),
+            d34 = _wino_desc(B, OH, OW, Cout, Cin)
+            ws, nws = None, 0
+            if not has_gate:                     # a small tile grid is split over the input channels (slabs + ordered sum)
+                nws = lib.csg_wino34_conv_workspace(d34, 3 - pad)
+                if nws > 0:
+                    ws = torch.empty(nws // 4, device=dy.device, dtype=torch.float32)
+            check(lib.csg_wino34_conv(d34, 3 - pad, ptr(dpre), ptr(wino_pack(weight, True, None, 34)), None, None,
+                                      ptr(x) if has_gate else None, ctx.in_act[1] if has_gate else 0.0, ptr(dx), ptr(ws), nws,
                                       stream()), "wino34_conv_bwd_data")
             gated = True
         elif ctx.needs_input_grad[0]:

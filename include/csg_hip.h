@@ -262,8 +262,13 @@ int csg_wino4_conv_part(const csg_wino_desc* d, const float* x, const float* pac
 int32_t csg_wino34_supported(const csg_wino_desc* d, int32_t pad);
 int csg_wino34_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int64_t Cout, int64_t Cin,
                             int32_t backward_data, const float* sigma, float* packed, void* stream);
+/* `workspace` (csg_wino34_conv_workspace bytes, may be 0 / NULL) as csg_wino_conv's: slabs of a split over the input
+ * channels when the tile grid alone cannot fill the chip (the half-resolution scale's backward-data pass: 128 blocks)
+ * and the call has no epilogue; summed in a fixed order.                                                        */
+int64_t csg_wino34_conv_workspace(const csg_wino_desc* d, int32_t pad);
 int csg_wino34_conv(const csg_wino_desc* d, int32_t pad, const float* x, const float* packed, const float* bias,
-                    const float* residual, const float* gate, float gate_slope, float* y, void* stream);
+                    const float* residual, const float* gate, float gate_slope, float* y, float* workspace,
+                    int64_t workspace_bytes, void* stream);
 
 /* ---- K8n: stride-1 convolutions with at most four output channels (csrc/fewn.hip) --------------------------------
  * `conv_img` (generator.py:46,120-121: 64 -> 3, 3x3, pad 1, tanh behind it) and the PatchGAN prediction heads

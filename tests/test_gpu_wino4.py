@@ -186,7 +186,7 @@ def _raw_wino34(ops, x, w, pad, bias=None, res=None, act=0, slope=0.0, gate=None
     bd = bias.cuda() if bias is not None else None
     rd = ops.nhwc(res.cuda()) if res is not None else None
     gd = ops.nhwc(gate.cuda()) if gate is not None else None
-    check(lib.csg_wino34_conv(d, pad, ptr(xd), ptr(up), ptr(bd), ptr(rd), ptr(gd), gate_slope, ptr(y), stream()),
+    check(lib.csg_wino34_conv(d, pad, ptr(xd), ptr(up), ptr(bd), ptr(rd), ptr(gd), gate_slope, ptr(y), None, 0, stream()),
           "wino34_conv")
     return y
 
@@ -284,3 +284,27 @@ def _wino34_autograd_case(ops, shape):
     for name, mine, want in (("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
         e = _err(mine, want.detach())
         assert e < GATE, "%s %s: error %.2e of the gradient scale" % (name, shape, e)
+
+
+def test_wino34_split_over_input_channels(ops):
+    """The half-resolution scale's backward-data shape (512 -> 256 channels on a 17 x 17 map, 128 blocks): slabs over the
+    input channels + an ordered sum; bit-identical from run to run, the unsplit launch's values up to association."""
+    from canonicalsg2im_amd._lib import check, lib, ptr, stream
+    shape = (16, 512, 256, 17, 17)
+    B, Cin, Cout, H, W = shape
+    x, w, _ = _data44(shape)
+    ref64 = F.conv2d(x.double(), w.double(), None, padding=1)
+    d = _desc(B, H, W, Cin, Cout)
+    nws = lib.csg_wino34_conv_workspace(d, 1)
+    assert nws > 0 and nws % (B * (H - 1) * (W - 1) * Cout * 4) == 0
+    xd, up = ops.nhwc(x.cuda()), ops.wino_pack(w.cuda(), False, None, 34)
+    outs = []
+    for _ in range(2):
+        y = ops.empty_nhwc(B, Cout, H - 1, W - 1, xd.device)
+        ws = torch.full((nws // 4,), float("nan"), device="cuda")
+        check(lib.csg_wino34_conv(d, 1, ptr(xd), ptr(up), None, None, None, 0.0, ptr(y), ptr(ws), nws, stream()), "wino34 split")
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    y0 = _raw_wino34(ops, x, w, 1)
+    assert _err(outs[0], ref64) < GATE and _err(y0, ref64) < GATE
+    assert_close(outs[0], y0, 1e-4, 1e-5 * float(ref64.abs().max()) + 1e-5, "wino34 split vs unsplit")

@@ -30,7 +30,7 @@ elif variant == 34:
     up = ops.wino_pack(w, False, None, 34)
 
     def run():
-        check(lib.csg_wino34_conv(d, 2, ptr(x), ptr(up), None, None, None, 0.0, ptr(y), stream()), "conv")
+        check(lib.csg_wino34_conv(d, 2, ptr(x), ptr(up), None, None, None, 0.0, ptr(y), None, 0, stream()), "conv")
 else:
     up = ops.wino_pack(w, False, None, variant)
     fn = lib.csg_wino4_conv if variant == 4 else lib.csg_wino_conv
