@@ -373,7 +373,7 @@ def main():
         out["kernels"] = kern
         out["kernels_note"] = ("per-kernel table, roofline_wgrad, roofline_direct and hbm_kernels: %d untimed steps after the "
                                "timed region with a HIP event pair on every launch (summed durations exceed the step where "
-                               "the two PatchGAN scales overlap on their streams); `roofline`: events on the k_wino_conv and "
+                               "the two PatchGAN scales overlap on their streams); `roofline`: events on the k_wino4_conv_v (F(4x4,3x3), F(3x3,4x4)), k_wino_conv2 and "
                                "k_igemm_fwd<128> launches only, inside the timed region" % prof_all_steps)
     if gen_ms is not None:
         # algorithmic work of SPADEGenerator fwd+bwd per image (FlopCounterMode; S = 32 or 128)
