@@ -44,6 +44,7 @@ def parse():
                         "pretrained weights cannot be downloaded); 0 = --no_vgg_loss, the configuration "
                         "SURVEY.md 8(d) quotes the metric on")
     p.add_argument("--no_prof", action="store_true", help="skip the per-kernel HIP-event timing")
+    p.add_argument("--no_graphs", action="store_true", help="run every step eagerly (no HIP-graph replay)")
     p.add_argument("--no_vgg_variant", action="store_true", help="skip the short second measurement with the VGG loss on")
     p.add_argument("--no_gen_metric", action="store_true",
                    help="skip the generator-only fwd+bwd passes (use under rocprofv3 so that its per-kernel "
@@ -168,8 +169,18 @@ def main():
 
     for i in range(args.warmup):
         trainer.step(batches[i % nb])
+    graphs_on = trainer.graphs is not None and not args.no_graphs
+    if trainer.graphs is not None:
+        trainer.use_graphs = graphs_on
+    if graphs_on:
+        # the shape-static part of the step is replayed from HIP graphs (canonicalsg2im_amd/graphs.py); a key is captured
+        # the second time it is seen, so with --warmup < 2 a few more untimed steps keep the capture out of the timed region
+        for i in range(3):
+            if trainer.graphs.replays > 0:
+                break
+            trainer.step(batches[(args.warmup + i) % nb])
     sync()
-    if not args.no_prof:
+    if not args.no_prof and not graphs_on:
         # events only around the dominant kernel inside the timed region (mode 2): a pair on every one of the
         # ~1100 launches of a step would cost ~10 ms/step of queue time and distort `value`
         _lib.prof_reset()
@@ -181,6 +192,23 @@ def main():
         G, Dl = trainer.step(batches[i % nb])
     sync()
     elapsed = time.perf_counter() - t0
+    graph_stats = eager_ms = None
+    if graphs_on:
+        # kernels inside a replayed graph carry no per-dispatch events: the dominant kernel's event timing (mode 2) is
+        # taken over the SAME number of steps of the same batches run eagerly right after the timed region
+        graph_stats = {"captures": trainer.graphs.captures, "replays": trainer.graphs.replays,
+                       "eager_steps": trainer.graphs.eager_steps}
+        trainer.use_graphs = False
+        trainer.step(batches[0])
+        sync()
+        if not args.no_prof:
+            _lib.prof_reset()
+            _lib.prof_enable(2)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            trainer.step(batches[i % nb])
+        sync()
+        eager_ms = 1000.0 * (time.perf_counter() - t1) / args.steps
     comm = D.comm_report(args.steps) if world > 1 else None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -241,6 +269,8 @@ def main():
         opt_v = T.make_opt(vocab, argv_v + ["--batch_size", str(args.batch * world), "--gpu_ids",
                                             ",".join(str(i) for i in range(world))])
         del trainer
+        import gc
+        gc.collect()                                      # the graph sets hold the trainer in a reference cycle
         torch.cuda.empty_cache()
         torch.manual_seed(0)
         tv = T.Trainer(opt_v, dev)
@@ -281,6 +311,12 @@ def main():
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         "losses_finite": loss_ok,
     }
+    if graph_stats is not None:
+        out["hip_graphs"] = dict(graph_stats, eager_ms_per_step=round(eager_ms, 2),
+                                 note="timed region: generator + PatchGAN forward/backward/Adam replayed from 3 captured HIP "
+                                      "graphs per step, scene-graph encoder and object-crop discriminator enqueued eagerly "
+                                      "(canonicalsg2im_amd/graphs.py); eager_ms_per_step = the same steps without replay "
+                                      "(with the dominant kernel's events on)")
     # Winograd F(2x2,3x3) / F(3x3,2x2) issue 16 multiplications where the direct convolution needs 36: the kernels' `work`
     # is the ALGORITHMIC FLOP count (2*M*9*Cin*Cout, what FlopCounterMode counts for the layer); the matrix pipe EXECUTES
     # 4/9 of it.  Every `frac` below is executed FLOPs / time / peak (a hardware utilisation, <= 1 by construction);
@@ -328,8 +364,12 @@ def main():
                         "wino_conv": "k_wino_conv2 (3x3 convolutions forward + backward-data, Winograd F(2x2,3x3) on fp32 "
                                      "MFMA, all instantiations)"}.get(dom, "k_igemm_fwd (conv forward + backward-data, all shapes)"),
                 achieved_note="EXECUTED MFMA FLOPs (1/4 of the algorithmic 2*M*9*Cin*Cout for F(4x4,3x3), 4/9 for "
-                              "F(2x2,3x3)) / kernel time of its launches inside the timed region (start/stop events bound "
-                              "to the dispatches)",
+                              "F(2x2,3x3)) / kernel time of its launches (start/stop events bound to the dispatches) " +
+                              ("over %d eager steps of the same batches right after the timed region (kernels inside a "
+                               "replayed HIP graph carry no per-dispatch events; rocprofv3 sees them: profiles/)" % args.steps
+                               if graphs_on else "inside the timed region"),
+                peak_clock_note="peak = 256 CUs x 256 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md); under this load the shader "
+                                "clock reads ~2.0 GHz (s_memtime vs wall clock, DESIGN.md 4.1b), where the same product is 131 TFLOP/s",
                 traffic=traffic,
                 traffic_note="HBM bytes per launch (read x2-corrected FETCH_SIZE + WRITE_SIZE, two rocprofv3 --pmc passes "
                              "of this workload, profiles/pmc_traffic.json)",

@@ -1,0 +1,335 @@
+"""HIP-graph replay of the shape-static part of the training iteration (scripts/train.py:353-393 of the reference).
+
+Why.  One iteration is ~1 100 kernel launches; enqueueing them from Python costs ~29 ms of host time, which is the
+floor of every configuration whose kernels finish sooner (BASELINE configs C2 and C4: 128x128 images or 4 images per
+GPU).  Most of those launches have shapes that depend only on (batch, image size): the AttSPADE generator, the four /
+five passes of the multiscale PatchGAN, their losses, their backward passes and the PatchGAN's Adam step.  They are
+captured once per shape key into three HIP graphs and replayed:
+
+    S1  generator forward (layout pyramid -> SPADE blocks -> image), PatchGAN on fake + real, GAN_Img / GAN_Feat / VGG
+    S2  backward of S1's terms, with d(object-discriminator terms)/d(image) injected at the image
+    S3  PatchGAN discriminator step: losses on fake.detach() + real (+ the logged "wrong" pass), backward, Adam
+
+What stays eager, between the replays, is everything whose shapes follow the data: the scene-graph encoder (O objects,
+T triplets per batch; it receives no gradient from the image path because the generator consumes the ground-truth boxes,
+sg2im/meta_models.py:47 of the reference) and the object-crop discriminator (one crop per real object).  The number of
+objects enters the static part only through the layout kernels' (vecs, boxes, valid) operands: they are padded to a
+multiple of 32 objects with `__image__` rows, which the layout kernel culls (a culled object adds exact zeros, forward
+and backward), so the results do not depend on the padding.
+
+Nothing is skipped or reordered in a way the results can see: the spectral-norm power iterations of the PatchGAN passes
+happen in the reference's order (S1: fake, real; S3: fake, real, wrong); the generator's Adam step runs eagerly after S2
+over the scene-graph encoder's (eager) and the generator's (static) gradients.  Gradients of the captured parameters live
+in static buffers owned by the graph set (`.grad` is re-pointed at them whenever an eager step has replaced them).
+
+Fallback.  A batch whose key has not been captured runs `Trainer._step_eager` in the same process (a key is captured the
+second time it is seen: one-off shapes never pay for a capture; the very first iteration is always eager — it creates the
+optimisers' state, which a capture must find in place); `CSG_GRAPHS=0` turns the whole mechanism off.  Replay is
+limited to one process per node-local GPU without an initialised process group: with N > 1 ranks the SyncBN and gradient
+collectives would have to be captured by RCCL, which cannot be validated on the 1-GPU boxes — there the eager path runs.
+"""
+import os
+
+import torch
+
+from . import ops
+
+ENABLED = os.environ.get("CSG_GRAPHS", "1") != "0"
+CAPTURE_AFTER = int(os.environ.get("CSG_GRAPH_CAPTURE_AFTER", "1"))      # eager sightings of a key before it is captured
+MAX_SETS = int(os.environ.get("CSG_GRAPH_MAX_SETS", "4"))
+OBJ_PAD = 32
+TIMING = os.environ.get("CSG_GRAPH_TIMING") == "1"      # developer aid: per-segment host / device time of the replayed step
+
+
+class _Marks:
+    """Host time (perf_counter) and device time (events on the current stream) between named marks of one step."""
+
+    def __init__(self):
+        self.acc, self.steps = {}, 0
+        self.cur = None
+
+    def begin(self):
+        import time
+        self.cur = [("", time.perf_counter(), self._ev())]
+
+    def _ev(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def mark(self, name):
+        import time
+        self.cur.append((name, time.perf_counter(), self._ev()))
+
+    def end(self):
+        torch.cuda.synchronize()
+        for (_, t0, e0), (name, t1, e1) in zip(self.cur[:-1], self.cur[1:]):
+            a = self.acc.setdefault(name, [0.0, 0.0])
+            a[0] += 1000.0 * (t1 - t0)
+            a[1] += e0.elapsed_time(e1)
+        self.steps += 1
+
+    def report(self):
+        n = max(self.steps, 1)
+        return {k: {"host_ms": round(v[0] / n, 3), "device_ms": round(v[1] / n, 3)} for k, v in self.acc.items()}
+
+
+def _pad_objects(n):
+    return max(OBJ_PAD, (int(n) + OBJ_PAD - 1) // OBJ_PAD * OBJ_PAD)
+
+
+def _drop_stale_autograd(*roots):
+    """Tensors that modules keep between iterations and that still carry the previous iteration's autograd graph: torch's
+    spectral-norm hook leaves the last normalised weight on the module (`module.weight`, with its `grad_fn`), and the
+    PatchGAN caches its permuted first-layer weight.  Through them the parameters' AccumulateGrad nodes of an EAGER
+    iteration — bound to the stream they were created on — would be reused by the forward being captured, and the
+    captured backward would have to synchronise the capture stream with that other stream.  Detaching them makes the
+    capture create fresh nodes on the capture stream."""
+    from torch.nn.utils.spectral_norm import SpectralNorm
+    for root in roots:
+        for m in root.modules():
+            for hook in m._forward_pre_hooks.values():
+                if isinstance(hook, SpectralNorm):
+                    w = m.__dict__.get(hook.name)
+                    if torch.is_tensor(w) and w.grad_fn is not None:
+                        setattr(m, hook.name, w.detach())
+            if getattr(m, "_w0", None) is not None:
+                m._w0, m._w0_key = None, None
+
+
+class _GraphSet:
+    """The three captured graphs of one shape key, their static inputs / outputs and gradient buffers."""
+
+    def __init__(self, owner, key, batch):
+        self.owner, self.key = owner, key
+        self.graphs = {}                 # name -> torch.cuda.CUDAGraph
+        self.pool = None
+        self.grads = {}                  # parameter -> static gradient tensor (generator + image discriminator)
+        dev = owner.tr.device
+        imgs, objs, boxes = batch[0], batch[1], batch[2]
+        B, O, A = objs.shape
+        self.imgs = torch.empty_like(imgs)
+        self.objs = torch.zeros((B, key[2], A), device=dev, dtype=objs.dtype)
+        self.boxes = torch.full((B, key[2], 4), -1.0, device=dev, dtype=boxes.dtype)
+        self.img = self.fake = self.d_img = self.g_vals = self.d_vals = None
+        self.g_terms = self.d_terms = None
+
+    def load(self, imgs, objs, boxes):
+        O = objs.shape[1]
+        self.imgs.copy_(imgs, non_blocking=True)
+        if O < self.objs.shape[1]:
+            self.objs.zero_()                           # `__image__` rows: culled by the layout kernels
+            self.boxes.fill_(-1.0)
+        self.objs[:, :O].copy_(objs, non_blocking=True)
+        self.boxes[:, :O].copy_(boxes, non_blocking=True)
+
+    def run(self, name, fn):
+        """Replay graph `name`; the first time, capture `fn` into it (a capture executes nothing) and then replay it, so
+        the capturing iteration is an ordinary replayed iteration."""
+        g = self.graphs.get(name)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            ops.invalidate_weight_caches()              # every derived weight is recomputed INSIDE the graph that reads it
+            _drop_stale_autograd(self.owner.tr.model, self.owner.tr.discriminator)
+            with torch.cuda.graph(g, pool=self.pool):
+                fn()
+            if self.pool is None:
+                self.pool = g.pool()
+            self.graphs[name] = g
+        g.replay()
+
+    def adopt_grads(self, params):
+        for p in params:
+            if p.grad is not None:
+                self.grads[p] = p.grad
+
+    def point_grads(self):
+        for p, g in self.grads.items():
+            p.grad = g
+
+
+class StepGraphs:
+    """Owner of the graph sets of one `Trainer`; `step(batch)` returns the same (G, D) loss dictionaries as
+    `Trainer._step_eager`, or None when the batch has to run eagerly."""
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        self.sets, self.seen = {}, {}
+        self.active = None
+        self.replays = self.eager_steps = self.captures = 0
+        self.marks = _Marks() if TIMING else None
+
+    # ---- eligibility
+    @staticmethod
+    def supported(trainer):
+        opt = trainer.opt
+        from . import dist as csg_dist
+        return bool(ENABLED and torch.device(trainer.device).type == "cuda" and csg_dist.world_size() == 1
+                    and not opt.skip_generation and not opt.learned_converse and not (opt.mask_size or 0) > 0
+                    and not getattr(opt, "freeze", 0) and hasattr(trainer.model, "layout_to_image_model"))
+
+    def key_of(self, batch):
+        imgs, objs, masks = batch[0], batch[1], batch[6]
+        if masks is not None or not imgs.is_cuda:
+            return None
+        return (tuple(imgs.shape), int(objs.shape[0]), _pad_objects(objs.shape[1]), int(objs.shape[2]))
+
+    def invalidate(self):
+        """Drop every captured graph (needed when parameters are re-created or moved — `module.to()`; a checkpoint load
+        copies into the existing tensors and does not need it)."""
+        self.sets, self.seen, self.active = {}, {}, None
+
+    # ---- one iteration
+    def step(self, batch):
+        key = self.key_of(batch)
+        gs = self.sets.get(key) if key is not None else None
+        if gs is None:
+            n = self.seen.get(key, 0)
+            self.seen[key] = n + 1
+            if key is None or n < CAPTURE_AFTER or len(self.sets) >= MAX_SETS or self.tr._eager_steps == 0:
+                self.eager_steps += 1
+                return None
+            gs = _GraphSet(self, key, batch)
+            self.sets[key] = gs
+            self.captures += 1
+            try:
+                return self._run(gs, batch)
+            except Exception as e:
+                raise RuntimeError("HIP-graph capture of the training step failed for key %r (%s: %s); the step is half "
+                                   "executed, so this is not recoverable in place — rerun with CSG_GRAPHS=0 for the eager "
+                                   "path" % (key, type(e).__name__, e)) from e
+        return self._run(gs, batch)
+
+    def _object_terms_for_generator(self, img, objs, boxes):
+        """GAN_Obj / GAN_Ac on the current image and d(their sum)/d(image) (the object discriminator is frozen here)."""
+        leaf = img.detach().requires_grad_(True)
+        terms = self.tr.gans_model.generator_object_terms(leaf, objs, boxes, None, None)
+        vals = {k: v.mean() for k, v in terms.items()}
+        (d_img,) = torch.autograd.grad(list(vals.values()), [leaf])
+        return {k: v.detach() for k, v in vals.items()}, d_img
+
+    def _graph_encoder(self, batch, G):
+        """Scene-graph encoder forward, the box-regression term and its backward (eager: O and T follow the data)."""
+        tr = self.tr
+        objs, boxes, triplets, _, triplet_type = batch[1:6]
+        if not tr.model.has_graph:
+            return
+        for p in tr.sg_params:
+            p.grad = None
+        boxes_pred = tr.model.sg_to_layout(objs, triplets, triplet_type, boxes)[1]
+        out = {}
+        tr.gans_model._layout_terms(out, objs, boxes, boxes_pred, None, None)
+        G["bbox_pred_all"] = out["bbox_pred_all"].detach()
+        G["bbox_pred"] = out["bbox_pred"].detach()
+        out["bbox_pred"].backward()
+        self.boxes_pred = boxes_pred.detach()
+
+    def _run(self, gs, batch):
+        tr, opt = self.tr, self.tr.opt
+        gm, gen = tr.gans_model, tr.model.layout_to_image_model
+        imgs, objs, boxes = batch[0], batch[1], batch[2]
+        use_obj = not opt.use_img_disc
+        mk = self.marks if (self.marks is not None and len(gs.graphs) == 3) else None
+        if mk:
+            mk.begin()
+        if self.active is not gs or tr._grads_dirty:
+            gs.point_grads()
+            self.active, tr._grads_dirty = gs, False
+        if use_obj:
+            tr.discriminator.obj_discriminator.prefetch_index(objs)
+        gs.load(imgs, objs, boxes)
+        if mk:
+            mk.mark("load+prefetch")
+        G = {}
+        self.boxes_pred = None
+        self._graph_encoder(batch, G)
+        if mk:
+            mk.mark("E0 graph encoder")
+        # ---- S1: generator forward + the generator's image terms (the discriminators are frozen)
+        tr._d_requires_grad(False)
+
+        def s1():
+            gs.img = gen(gs.objs, gs.boxes, None, test_mode=False)
+            terms = gm.generator_image_terms(gs.imgs, gs.objs, gs.boxes, None, gs.img)
+            gs.g_roots = [v.mean() for v in terms.values()]
+            gs.g_terms = list(terms.keys())
+            gs.g_vals = torch.stack([v.detach() for v in gs.g_roots])
+            gs.fake = gs.img.detach()
+        gs.run("s1", s1)
+        if mk:
+            mk.mark("S1 replay")
+        # ---- eager: the object discriminator's terms and their gradient at the image
+        obj_vals = None
+        if use_obj:
+            obj_vals, d_img = self._object_terms_for_generator(gs.img, objs, boxes)
+            if gs.d_img is None:
+                gs.d_img = torch.empty_like(d_img)
+            gs.d_img.copy_(d_img)
+        if mk:
+            mk.mark("E1 object terms (G)")
+
+        # ---- S2: backward of S1's terms (+ the injected image gradient)
+        def s2():
+            for p in tr.g_params:
+                p.grad = None
+            roots, seeds = list(gs.g_roots), [None] * len(gs.g_roots)
+            if gs.d_img is not None:
+                roots.append(gs.img)
+                seeds.append(gs.d_img)
+            torch.autograd.backward(roots, seeds)
+            gs.g_roots = None
+        first = "s2" not in gs.graphs
+        gs.run("s2", s2)
+        if first:
+            gs.adopt_grads(tr.g_params)
+        if mk:
+            mk.mark("S2 replay")
+        # ---- the generator's Adam step (eager: one fused launch over the encoder's eager and the generator's static grads)
+        vals = gs.g_vals.clone()
+        for i, k in enumerate(gs.g_terms):
+            G[k] = vals[i]
+        if obj_vals is not None:
+            G.update(obj_vals)
+        G["total_loss"] = torch.stack([v for k, v in G.items() if k != "bbox_pred_all"]).sum()
+        tr.optimizer.step()
+        if mk:
+            mk.mark("G Adam")
+        # ---- S3: the image discriminator's update
+        tr._d_requires_grad(True)
+
+        def s3():
+            terms = gm.discriminator_image_terms(gs.imgs, gs.objs, gs.boxes, None, gs.fake)
+            terms = {k: v.mean() for k, v in terms.items()}
+            gs.d_terms = list(terms.keys())
+            gs.d_vals = torch.stack([v.detach() for v in terms.values()])
+            if not tr.d_frozen:
+                for p in tr.d_params:
+                    p.grad = None
+                terms["total_img_loss"].backward()
+                tr.discriminator.optimizer_d_img.step()
+        first = "s3" not in gs.graphs
+        gs.run("s3", s3)
+        if first:
+            gs.adopt_grads(tr.d_params)
+        if mk:
+            mk.mark("S3 replay")
+        vals = gs.d_vals.clone()
+        D = {k: vals[i] for i, k in enumerate(gs.d_terms)}
+        # ---- eager: the object discriminator's update
+        if use_obj:
+            terms = gm.discriminator_object_terms(imgs, objs, boxes, None, gs.fake, None)
+            terms = {k: v.mean() for k, v in terms.items()}
+            if not tr.d_frozen:
+                tr.discriminator.optimizer_d_obj.zero_grad(set_to_none=True)
+                terms["total_obj_loss"].backward()
+                tr.discriminator.optimizer_d_obj.step()
+            D.update({k: v.detach() for k, v in terms.items()})
+            tr.discriminator.obj_discriminator.release_index()
+        if mk:
+            mk.mark("E3 object D step")
+            mk.end()
+        tr.last_model_out = (gs.fake, self.boxes_pred, None)
+        ops.invalidate_weight_caches()              # S3's Adam step is replayed without torch's optimiser hooks
+        self.replays += 1
+        return G, D

@@ -58,15 +58,18 @@ class MetaDiscriminatorModel(nn.Module):
             self.mask_discriminator = spade_nets.MultiscaleMaskDiscriminator2(opt)
         self.train()
 
-    def build_optimizers(self, opt):
+    def build_optimizers(self, opt, capturable_img=False):
         """Adam with betas (beta1, 0.999); learning rates `img_learning_rate`, `learning_rate`,
-        `mask_learning_rate` for the image / object / mask discriminator (reference :67-69, :79-81, :88-90)."""
+        `mask_learning_rate` for the image / object / mask discriminator (reference :67-69, :79-81, :88-90).
+        `capturable_img`: the image discriminator's step counter lives on the device so that the step can be replayed
+        from a HIP graph (canonicalsg2im_amd/graphs.py); the arithmetic is the same fused kernel."""
         extra = {'fused': True} if next(self.parameters()).is_cuda else {}        # one multi-tensor kernel per step
         plan = [("img", opt.img_learning_rate)]
         if not opt.use_img_disc:
             plan += [("obj", opt.learning_rate), ("mask", opt.mask_learning_rate)]
         for tag, lr in plan:
             net = getattr(self, tag + "_discriminator")
+            cap = {'capturable': True} if (capturable_img and tag == "img" and extra) else {}
             setattr(self, "optimizer_d_" + tag,
-                    torch.optim.Adam(list(net.parameters()), lr=lr, betas=(opt.beta1, 0.999), **extra))
+                    torch.optim.Adam(list(net.parameters()), lr=lr, betas=(opt.beta1, 0.999), **extra, **cap))
         return self

@@ -84,6 +84,35 @@ class Pix2PixModel(torch.nn.Module):
             out["masks_pred"] = (bce * real.view(-1)).sum() / real.sum() * opt.mask_pred_loss_weight
 
     # ---------------------------------------------------------------------------------------- generator
+    # The two loss dictionaries are assembled from four term groups.  Eagerly they run back to back (the reference's
+    # order); `canonicalsg2im_amd/graphs.py` replays the image groups — whose tensor shapes depend only on the batch
+    # and image size — as captured HIP graphs and runs the object groups (one crop per real object: a data-dependent
+    # count) eagerly in between.
+    def generator_image_terms(self, imgs, objs, boxes, masks, imgs_pred):
+        """GAN_Img, GAN_Feat, VGG (reference :94-113): two passes of the (frozen) image discriminator."""
+        opt, out = self.opt, {}
+        d_args = dict(layout_masks=masks, gt_train=True, fool=False)
+        fake = self.netD_img(imgs_pred, objs, boxes, **d_args)
+        out['GAN_Img'] = self._fool(fake, opt.discriminator_img_loss_weight)
+        if not opt.no_ganFeat_loss:
+            out['GAN_Feat'] = self._feature_matching(fake, self.netD_img(imgs, objs, boxes, **d_args))
+        if not opt.no_vgg_loss:
+            out['VGG'] = self.criterionVGG(imgs_pred, imgs) * opt.lambda_vgg
+        return out
+
+    def generator_object_terms(self, imgs_pred, objs, boxes, masks, masks_pred):
+        """GAN_Obj, GAN_Ac (:115-121) and the mask discriminator's terms (:124-138)."""
+        opt, out = self.opt, {}
+        crop_scores, ac_loss, _ = self.netD_obj(imgs_pred, objs, boxes)
+        out['GAN_Obj'] = self._fool(crop_scores, opt.discriminator_obj_loss_weight)
+        out['GAN_Ac'] = ac_loss * opt.ac_loss_weight
+        if self.netD_mask is not None and opt.mask_size > 0 and masks_pred is not None:
+            m_fake = self.netD_mask(objs, masks_pred)
+            out['GAN_Mask'] = self._fool(m_fake, opt.discriminator_img_loss_weight)
+            if not opt.no_ganFeat_loss:
+                out['GAN_Mask_Feat'] = self._feature_matching(m_fake, self.netD_mask(objs, masks))
+        return out
+
     def compute_generator_loss(self, batch, model_out):
         imgs, objs, boxes, masks = batch[0], batch[1], batch[2], batch[6]
         imgs_pred, boxes_pred, masks_pred = model_out
@@ -91,47 +120,46 @@ class Pix2PixModel(torch.nn.Module):
         if not opt.skip_graph_model:
             self._layout_terms(out, objs, boxes, boxes_pred, masks, masks_pred)
         if not opt.skip_generation:
-            d_args = dict(layout_masks=masks, gt_train=True, fool=False)
-            fake = self.netD_img(imgs_pred, objs, boxes, **d_args)
-            out['GAN_Img'] = self._fool(fake, opt.discriminator_img_loss_weight)
-            if not opt.no_ganFeat_loss:
-                out['GAN_Feat'] = self._feature_matching(fake, self.netD_img(imgs, objs, boxes, **d_args))
-            if not opt.no_vgg_loss:
-                out['VGG'] = self.criterionVGG(imgs_pred, imgs) * opt.lambda_vgg
+            out.update(self.generator_image_terms(imgs, objs, boxes, masks, imgs_pred))
             if not opt.use_img_disc:
-                crop_scores, ac_loss, _ = self.netD_obj(imgs_pred, objs, boxes)                   # :115-121
-                out['GAN_Obj'] = self._fool(crop_scores, opt.discriminator_obj_loss_weight)
-                out['GAN_Ac'] = ac_loss * opt.ac_loss_weight
-                if self.netD_mask is not None and opt.mask_size > 0 and masks_pred is not None:   # :124-138
-                    m_fake = self.netD_mask(objs, masks_pred)
-                    out['GAN_Mask'] = self._fool(m_fake, opt.discriminator_img_loss_weight)
-                    if not opt.no_ganFeat_loss:
-                        out['GAN_Mask_Feat'] = self._feature_matching(m_fake, self.netD_mask(objs, masks))
+                out.update(self.generator_object_terms(imgs_pred, objs, boxes, masks, masks_pred))
         out['total_loss'] = _total(out, skip=("bbox_pred_all",))
         return out
 
     # ---------------------------------------------------------------------------------------- discriminators
-    def compute_discriminator_loss(self, batch, model_out):
-        imgs, objs, boxes, masks = batch[0], batch[1], batch[2], batch[6]
-        fake_img = model_out[0].detach()
+    def discriminator_image_terms(self, imgs, objs, boxes, masks, fake_img):
+        """D_img_fake, D_img_real, total_img_loss (:150-166) and, in the default recipe, the logged "wrong layout" pass
+        (:168-172): `fool` is ignored by the discriminator and the value is only logged, but the call advances the
+        spectral-norm vectors, so it is replayed — without autograd."""
         opt, crit = self.opt, self.criterionGAN
         d_args = dict(layout_masks=masks, gt_train=True)
         out = {"D_img_fake": crit(self.netD_img(fake_img, objs, boxes, fool=False, **d_args), False, for_discriminator=True),
                "D_img_real": crit(self.netD_img(imgs, objs, boxes, fool=False, **d_args), True, for_discriminator=True)}
         out["total_img_loss"] = _total(out)
-        if opt.use_img_disc:
-            return out
-        # "wrong layout" pass (:168-172): `fool` is ignored by the discriminator and the value is only logged,
-        # but the call advances the spectral-norm vectors, so it is replayed — without autograd
-        with torch.no_grad():
-            wrong = self.netD_img(imgs, objs, boxes, fool=True, **d_args)
-            out["D_img_wrong"] = crit(wrong, False, for_discriminator=True) * (1 / 2) * (.5)
-        s_real, out["D_ac_real"], self.d_real_crops = self.netD_obj(imgs, objs, boxes)            # :178-185
+        if not opt.use_img_disc:
+            with torch.no_grad():
+                wrong = self.netD_img(imgs, objs, boxes, fool=True, **d_args)
+                out["D_img_wrong"] = crit(wrong, False, for_discriminator=True) * (1 / 2) * (.5)
+        return out
+
+    def discriminator_object_terms(self, imgs, objs, boxes, masks, fake_img, masks_pred):
+        """D_ac_real, D_ac_fake, D_obj, total_obj_loss (:178-185) and the mask discriminator's terms (:188-196)."""
+        opt, crit, out = self.opt, self.criterionGAN, {}
+        s_real, out["D_ac_real"], self.d_real_crops = self.netD_obj(imgs, objs, boxes)
         s_fake, out["D_ac_fake"], self.d_fake_crops = self.netD_obj(fake_img, objs, boxes)
         out["D_obj"] = self.gan_d_loss(s_real, s_fake) * 0.5
         out["total_obj_loss"] = out["D_obj"] + out["D_ac_real"] + out["D_ac_fake"]
-        if opt.mask_size > 0 and model_out[2] is not None:                                        # :188-196
-            out["D_mask_fake"] = crit(self.netD_mask(objs, model_out[2].detach()), False, for_discriminator=True) * 0.5
+        if opt.mask_size > 0 and masks_pred is not None:
+            out["D_mask_fake"] = crit(self.netD_mask(objs, masks_pred.detach()), False, for_discriminator=True) * 0.5
             out["D_mask_real"] = crit(self.netD_mask(objs, masks), True, for_discriminator=True) * 0.5
             out["total_mask_loss"] = out["D_mask_fake"] + out["D_mask_real"]
+        return out
+
+    def compute_discriminator_loss(self, batch, model_out):
+        imgs, objs, boxes, masks = batch[0], batch[1], batch[2], batch[6]
+        fake_img = model_out[0].detach()
+        out = self.discriminator_image_terms(imgs, objs, boxes, masks, fake_img)
+        if self.opt.use_img_disc:
+            return out
+        out.update(self.discriminator_object_terms(imgs, objs, boxes, masks, fake_img, model_out[2]))
         return out

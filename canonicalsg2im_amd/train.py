@@ -11,6 +11,7 @@ computes and then discards are never computed; errors are raised, not swallowed 
 import torch
 
 from . import dist as csg_dist
+from . import graphs as csg_graphs
 from .scripts.args import make_opt  # noqa: F401  (re-exported)
 from .scripts.graphs_utils import calc_log_p
 from .sg2im.model import get_conv_converse
@@ -22,10 +23,13 @@ class Trainer:
     def __init__(self, opt, device):
         self.opt, self.device = opt, device
         self.model = MetaGeneratorModel(opt, device)
-        self.discriminator = MetaDiscriminatorModel(opt).to(device).build_optimizers(opt)
+        # HIP-graph replay of the shape-static part of the step (graphs.py): single process, default objective
+        self.d_frozen = False
+        use_graphs = csg_graphs.StepGraphs.supported(self)
+        # (the image discriminator's Adam step is captured: its step counter has to live on the device)
+        self.discriminator = MetaDiscriminatorModel(opt).to(device).build_optimizers(opt, capturable_img=use_graphs)
         self.gans_model = Pix2PixModel(opt, discriminator=self.discriminator).to(device)
         self.model.train()
-        self.d_frozen = False
         if getattr(opt, "freeze", 0):
             self.freeze_weights(opt.freeze_options)
         csg_dist.broadcast_module(self.model)
@@ -56,6 +60,11 @@ class Trainer:
             csg_dist.broadcast_module(self.discriminator.mask_discriminator)
             self.dmask_params = list(self.discriminator.mask_discriminator.parameters())
             self.dmask_buckets = csg_dist.GradBuckets(self.dmask_params)
+        self.sg_params = [p for p in self.model.sg_to_layout.parameters()] if self.model.has_graph else []
+        self.g_params = [p for p in self.model.layout_to_image_model.parameters()] if self.model.has_image else []
+        self._grads_dirty, self._eager_steps = False, 0
+        self.graphs = csg_graphs.StepGraphs(self) if use_graphs else None
+        self.use_graphs = True                 # False: run eagerly without dropping the captured graphs (bench.py's event legs)
 
     def freeze_weights(self, module):
         """`--freeze 1 --freeze_options generation` (scripts/train.py:104-117, 337-338): the layout-to-image model and
@@ -98,6 +107,20 @@ class Trainer:
         return loss_conv.detach()
 
     def step(self, batch):
+        """One training iteration.  Shape keys that repeat are replayed from captured HIP graphs (graphs.py); anything
+        else — a new shape, N > 1 ranks, masks, `--learned_converse` — runs the eager path below, in this process."""
+        if self.graphs is not None and self.use_graphs:
+            out = self.graphs.step(batch)
+            if out is not None:
+                return out
+        self._eager_steps += 1
+        if self.graphs is not None and not self._grads_dirty:
+            # first eager iteration after replayed ones: the modules still hold tensors of the captured autograd graph
+            csg_graphs._drop_stale_autograd(self.model, self.discriminator)
+        self._grads_dirty = True
+        return self._step_eager(batch)
+
+    def _step_eager(self, batch):
         opt = self.opt
         imgs, objs, boxes, triplets, conv_counts, triplet_type, masks, image_ids = batch
         if not opt.use_img_disc and objs.is_cuda:
@@ -158,7 +181,9 @@ class Trainer:
             self.optimizer.step()
         if not opt.use_img_disc:
             self.discriminator.obj_discriminator.release_index()        # the prefetched object list dies with its batch
-        return G, D
+        # values only: a caller that keeps the dictionaries must not keep the step's autograd graph (and with it every
+        # parameter's AccumulateGrad node, bound to the stream it was created on) alive into the next iteration
+        return {k: v.detach() for k, v in G.items()}, {k: v.detach() for k, v in D.items()}
 
 
     # ------------------------------------------------------------------ checkpoints (scripts/train.py:488-520)

@@ -1,0 +1,124 @@
+"""HIP-graph replay of the shape-static part of the step (canonicalsg2im_amd/graphs.py) against the eager path and the
+oracle: same losses, same parameters after several optimiser steps, eager fallback on a new shape in the same process."""
+import copy
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _make(cuda, argv, graphs):
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import make_vocab
+    vocab = make_vocab("tiny")
+    opt = T.make_opt(vocab, ["--image_size", "64,64", "--ngf", "8", "--ndf", "8", "--gconv_dim", "32",
+                             "--gconv_hidden_dim", "64", "--gconv_num_layers", "2", "--embedding_dim", "8",
+                             "--no_vgg_loss", "--batch_size", "4"] + argv)
+    torch.manual_seed(0)
+    tr = T.Trainer(opt, cuda)
+    if not graphs:
+        tr.graphs = None
+    return vocab, tr
+
+
+def _batches(vocab, cuda, n, B=4, lo=2, hi=6, size=64):
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch
+    return [[None if t is None else t.to(cuda) for t in make_batch(vocab, BatchConfig(B, size, lo, hi, "packed"), seed=10 + i)]
+            for i in range(n)]
+
+
+def _same_weights(src, dst):
+    dst.model.load_state_dict(copy.deepcopy(src.model.state_dict()))
+    dst.discriminator.load_state_dict(copy.deepcopy(src.discriminator.state_dict()))
+    from canonicalsg2im_amd import ops
+    ops.invalidate_weight_caches()
+
+
+@pytest.mark.parametrize("use_img_disc", [0, 1])
+def test_graph_replay_matches_eager(cuda, use_img_disc):
+    """Six iterations (eager, capture, four replays) on three alternating batches against six eager iterations from the
+    same weights.  The first captured iteration differs from the eager one only in the order in which the object
+    discriminator's image gradient joins the PatchGAN's (one fp32 addition re-associated): losses agree to 1e-6 there and
+    within the Adam sign-noise tolerance of tests/test_gpu_modules.py (STEP2) afterwards."""
+    argv = ["--use_img_disc", str(use_img_disc)]
+    vocab, eager = _make(cuda, argv, graphs=False)
+    _, graphed = _make(cuda, argv, graphs=True)
+    assert graphed.graphs is not None, "graph replay should be available on one GPU with the default objective"
+    _same_weights(eager, graphed)
+    bs = _batches(vocab, cuda, 3)
+    for it in range(6):
+        b = bs[it % 3]
+        Ge, De = eager.step(b)
+        Gg, Dg = graphed.step(b)
+        assert list(Ge.keys()) == list(Gg.keys()), (list(Ge.keys()), list(Gg.keys()))
+        assert list(De.keys()) == list(Dg.keys()), (list(De.keys()), list(Dg.keys()))
+        tol = 1e-6 if it <= 1 else 2e-3
+        for name, e, g in [("G." + k, Ge[k], Gg[k]) for k in Ge] + [("D." + k, De[k], Dg[k]) for k in De]:
+            e, g = e.detach().float().cpu(), g.detach().float().cpu()
+            assert e.shape == g.shape, name
+            assert torch.allclose(g, e, rtol=tol, atol=tol * 1e-1), \
+                "iteration %d %s: graph %s vs eager %s" % (it, name, g.flatten()[:4].tolist(), e.flatten()[:4].tolist())
+        ie, ig = eager.last_model_out[0], graphed.last_model_out[0]
+        assert torch.allclose(ig, ie, rtol=tol, atol=tol), "iteration %d image" % it
+    assert graphed.graphs.captures == 1 and graphed.graphs.replays == 5 and graphed.graphs.eager_steps == 1
+    # parameters after six Adam steps: elements whose true gradient is zero move by +-lr per step on rounding noise
+    lr = 1e-4
+    for (n, pe), (_, pg) in zip(list(eager.model.named_parameters()) + list(eager.discriminator.named_parameters()),
+                                list(graphed.model.named_parameters()) + list(graphed.discriminator.named_parameters())):
+        d = (pe.detach() - pg.detach()).abs().max().item()
+        assert d <= 2.2 * 6 * max(lr, 1e-2 if "candidates_weights" in n else lr), "%s differs by %g" % (n, d)
+
+
+def test_graph_step_vs_oracle(cuda):
+    """The captured iteration itself (S1/S2/S3 replays + the eager pieces) against the CPU oracle's step on the weights
+    the trainer held before it: every loss at rtol 1e-4."""
+    import oracle
+    from canonicalsg2im_amd import train as T
+    vocab, tr = _make(cuda, ["--use_img_disc", "0"], graphs=True)
+    bs = _batches(vocab, cuda, 2)
+    tr.step(bs[0])                                   # eager (first sighting of the key)
+    for it in range(2):                              # capture, then a replay — each checked against the oracle
+        ts = T.oracle_state_from(tr, oracle)
+        G, D = tr.step(bs[(it + 1) % 2])
+        cpu_batch = [None if t is None else t.cpu() for t in bs[(it + 1) % 2]]
+        Go, Do, img_o = oracle.train_step(ts, cpu_batch)
+        for k in Go:
+            if k == "bbox_pred_all":
+                continue
+            a, b = float(G[k]), float(Go[k].detach().mean())
+            assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, "G %s: graph %g vs oracle %g (iteration %d)" % (k, a, b, it)
+        for k in Do:
+            a, b = float(D[k]), float(Do[k].detach().mean())
+            assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, "D %s: graph %g vs oracle %g (iteration %d)" % (k, a, b, it)
+        d = (tr.last_model_out[0].cpu().double() - img_o.detach().double())
+        assert float(d.norm() / img_o.detach().double().norm()) <= 2e-5
+    assert tr.graphs.replays == 2
+
+
+def test_new_shape_runs_eagerly_in_process(cuda):
+    """A batch with another batch size (a new key) runs eagerly, the captured key keeps replaying afterwards, and the
+    gradients the optimisers read are the right buffers on both sides of the switch."""
+    vocab, tr = _make(cuda, ["--use_img_disc", "0"], graphs=True)
+    a = _batches(vocab, cuda, 2, B=4)
+    b = _batches(vocab, cuda, 1, B=2)
+    c = _batches(vocab, cuda, 1, B=4, lo=33, hi=40)          # more than 32 objects: another padded width, another key
+    for batch in (a[0], a[1], a[0], b[0], a[1], c[0], a[0]):
+        G, D = tr.step(batch)
+        assert torch.isfinite(G["total_loss"]).item() and torch.isfinite(D["total_img_loss"]).item()
+    g = tr.graphs
+    assert g.captures == 1 and g.replays == 4 and g.eager_steps == 3, (g.captures, g.replays, g.eager_steps)
+
+
+def test_graphs_can_be_switched_off(cuda, monkeypatch):
+    from canonicalsg2im_amd import graphs
+    monkeypatch.setattr(graphs, "ENABLED", False)
+    _, tr = _make(cuda, ["--use_img_disc", "0"], graphs=True)
+    assert tr.graphs is None
