@@ -40,16 +40,21 @@ def rank():
 # ---- communication audit (bench.py's "comm" object, tests): what was exchanged since the last comm_reset()
 _COMM = {"grad_allreduce_calls": 0, "grad_allreduce_bytes": 0, "syncbn_allreduce_calls": 0, "syncbn_allreduce_bytes": 0,
          "allgather_calls": 0, "allgather_bytes": 0, "grad_copy_bytes": 0, "wait_events": []}
+_AUDIT = [False]        # counters and wait events are recorded only between comm_reset() and comm_report(): a training run of
+#                         a million iterations must not accumulate six timing events per step
 
 
 def comm_reset():
+    """Start an audit window (bench.py, tests): zero the counters and start recording."""
     for k in _COMM:
         _COMM[k] = [] if k == "wait_events" else 0
+    _AUDIT[0] = True
 
 
 def comm_note(kind, nbytes):
-    _COMM[kind + "_calls"] += 1
-    _COMM[kind + "_bytes"] += int(nbytes)
+    if _AUDIT[0]:
+        _COMM[kind + "_calls"] += 1
+        _COMM[kind + "_bytes"] += int(nbytes)
 
 
 def comm_report(steps=1):
@@ -64,6 +69,8 @@ def comm_report(steps=1):
         e1.synchronize()
         ms += e0.elapsed_time(e1)
     out["blocked_ms_per_step"] = ms / max(steps, 1)
+    _COMM["wait_events"] = []
+    _AUDIT[0] = False                                  # the window is closed: nothing is recorded until the next comm_reset()
     return out
 
 
@@ -182,7 +189,8 @@ class GradBuckets:
         b, view = self.slot[id(p)]
         if p.grad is not view:
             view.copy_(p.grad)
-            _COMM["grad_copy_bytes"] += p.grad.numel() * 4
+            if _AUDIT[0]:
+                _COMM["grad_copy_bytes"] += p.grad.numel() * 4
             p.grad = view
         if view.is_cuda:
             self._streams.setdefault(b, set()).add(torch.cuda.current_stream(view.device))
@@ -233,7 +241,7 @@ class GradBuckets:
         if world_size() == 1:
             return 0
         self.flush()
-        timed = bool(self.flats) and self.flats[0].is_cuda
+        timed = _AUDIT[0] and bool(self.flats) and self.flats[0].is_cuda
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

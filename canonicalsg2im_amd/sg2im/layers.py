@@ -117,7 +117,12 @@ class Interpolate(nn.Module):
     def forward(self, x):
         if self.mode == 'nearest' and self.scale_factor == 2 and x.is_cuda:
             return ops.upsample2x(x)
-        if self.mode == 'nearest' and x.is_cuda and x.dim() == 4 and x.size(1) % 4 == 0:
+        # the device kernel samples at floor(dst * in / out) — F.interpolate's rule when a SIZE is given; with a
+        # scale_factor (and no recompute_scale_factor) torch samples at floor(dst / scale_factor), which is the same only
+        # when in * scale_factor is an integer in both dimensions
+        exact = self.size is not None or (float(x.size(2) * self.scale_factor).is_integer()
+                                          and float(x.size(3) * self.scale_factor).is_integer())
+        if self.mode == 'nearest' and x.is_cuda and x.dim() == 4 and x.size(1) % 4 == 0 and exact:
             size = self.size if self.size is not None else (int(x.size(2) * self.scale_factor), int(x.size(3) * self.scale_factor))
             size = (size, size) if isinstance(size, int) else size
             return ops.nearest_resize(x, size)

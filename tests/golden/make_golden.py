@@ -707,6 +707,86 @@ def fx_row_gaps_r3():
                          "sizes": [[32, 32], [24, 40]], "vocab": "tiny", "crop_size": 16}, **arrays)
 
 
+def _buffers_np(module, prefix):
+    return {prefix + k: npy(v) for k, v in module.state_dict().items()
+            if any(t in k for t in ("running_", "weight_u", "weight_v", "num_batches_tracked"))}
+
+
+def fx_variants():
+    """Off-recipe spellings of the builders, generated by the reference's own constructors (round 4; they were pinned to
+    torch restatements written inside the tests before): `build_mlp` activations / dropout / batch norm
+    (sg2im/layers.py:6-25), `build_cnn` grammar (sg2im/layers.py:28-112), `NLayerDiscriminator` under every `norm_D` the
+    reference's `get_nonspade_norm_layer` can build (normalization.py:16-50 — its non-spectral spellings raise
+    UnboundLocalError there, so only the four `spectral*` ones exist)."""
+    import argparse
+    from sg2im.layers import build_cnn, build_mlp
+    from spade.models.networks.discriminator import NLayerDiscriminator
+    arrays, meta = {}, {"ref": "sg2im/layers.py:6-112; spade/models/networks/normalization.py:16-50, discriminator.py:163-206",
+                        "mlp": [], "cnn": [], "nld": []}
+    # ---- build_mlp
+    mlp_cases = [dict(activation='leakyrelu-0.2', final_nonlinearity=None),
+                 dict(activation='sigmoid', final_nonlinearity='sigmoid'),
+                 dict(batch_norm='batch', activation='leakyrelu-0.3', final_nonlinearity='leakyrelu'),
+                 dict(dropout=0.5, final_nonlinearity='relu')]
+    dims = [12, 32, 24, 8]
+    for i, kw in enumerate(mlp_cases):
+        torch.manual_seed(70 + i)
+        m = build_mlp(dims, **kw)
+        m.load_state_dict(deterministic_state(m.state_dict(), seed=70 + i))
+        train = kw.get('dropout', 0) == 0                    # dropout masks of two RNGs cannot agree: eval mode there
+        m.train(train)
+        x = torch.randn(40, 12, requires_grad=True)
+        w = torch.randn(40, 8)
+        y = m(x)
+        (y * w).sum().backward()
+        tag = "mlp%d_" % i
+        arrays.update({tag + "x": npy(x), tag + "w": npy(w), tag + "y": npy(y), tag + "gx": npy(x.grad)})
+        arrays.update(grads_np(m, tag + "grad:"))
+        arrays.update(_buffers_np(m, tag + "after:"))
+        meta["mlp"].append({"kw": kw, "dims": dims, "seed": 70 + i, "train": train, "shapes": shapes_of(m),
+                            "keys": list(m.state_dict().keys()), "len": len(m)})
+    # ---- build_cnn
+    cnn_cases = [('I8,C3-16,C3-32-2,U2,C3-8,P2,C1-4', dict(normalization='instance', activation='relu'), (2, 8, 16, 16)),
+                 ('I8,C3-16,C3-32', dict(normalization='none', activation='leakyrelu-0.1'), (2, 8, 12, 12)),
+                 ('C4-16-2,C4-32-2', dict(normalization='batch', activation='sigmoid', padding='valid'), (3, 3, 22, 22)),
+                 ('I4,C3-8,U3,C3-8', dict(normalization='batch', activation='leakyrelu-0.2'), (2, 4, 8, 8))]
+    for i, (arch, kw, shape) in enumerate(cnn_cases):
+        torch.manual_seed(80 + i)
+        m, cout = build_cnn(arch, **kw)
+        m.load_state_dict(deterministic_state(m.state_dict(), seed=80 + i))
+        m.train()
+        x = torch.randn(*shape, requires_grad=True)
+        y = m(x)
+        w = torch.randn_like(y)
+        (y * w).sum().backward()
+        tag = "cnn%d_" % i
+        arrays.update({tag + "x": npy(x), tag + "w": npy(w), tag + "y": npy(y), tag + "gx": npy(x.grad)})
+        arrays.update(grads_np(m, tag + "grad:"))
+        arrays.update(_buffers_np(m, tag + "after:"))
+        meta["cnn"].append({"arch": arch, "kw": kw, "seed": 80 + i, "cout": cout, "shapes": shapes_of(m),
+                            "keys": list(m.state_dict().keys()), "len": len(m)})
+    # ---- NLayerDiscriminator under the norm_D spellings the reference can build
+    for i, norm_D in enumerate(["spectralinstance", "spectralbatch", "spectralsync_batch", "spectralnone"]):
+        opt = argparse.Namespace(ndf=8, n_layers_D=4, norm_D=norm_D, semantic_nc=5, no_ganFeat_loss=False)
+        torch.manual_seed(90 + i)
+        D = NLayerDiscriminator(opt)
+        D.load_state_dict(deterministic_state(D.state_dict(), seed=90 + i))
+        D.train()
+        x = torch.randn(2, 8, 36, 36, requires_grad=True)
+        feats = D(x)
+        w = torch.randn_like(feats[-1])
+        (feats[-1] * w).sum().backward()
+        tag = "nld%d_" % i
+        arrays.update({tag + "x": npy(x), tag + "w": npy(w), tag + "gx": npy(x.grad)})
+        for j, f in enumerate(feats):
+            arrays[tag + "feat%d" % j] = npy(f)
+        arrays.update(grads_np(D, tag + "grad:"))
+        arrays.update(_buffers_np(D, tag + "after:"))            # u / v after the power iteration, running statistics
+        meta["nld"].append({"norm_D": norm_D, "seed": 90 + i, "shapes": shapes_of(D), "keys": list(D.state_dict().keys()),
+                            "n_feats": len(feats)})
+    save("variants", meta, **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1:                      # regenerate selected fixtures: make_golden.py fx_vgg ...
@@ -728,3 +808,4 @@ if __name__ == "__main__":
     fx_converse()
     fx_row_gaps()
     fx_row_gaps_r3()
+    fx_variants()

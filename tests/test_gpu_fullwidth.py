@@ -7,7 +7,7 @@ Tolerance.  Losses, the generated image and the graph encoder's outputs: rtol 1e
 BASELINE.json (plus an absolute term scaled to the tensor's largest entry for long reductions, the rule
 tests/test_gpu_kernels.py uses for dW).  Parameter gradients of the GAN objective: the reference's own
 fp32 noise band, tests/fp64_band.py — the oracle is evaluated in fp32 AND fp64 on the host, and the HIP
-gradients must be as close to the fp64 truth as the fp32 reference arithmetic is (x5 in L2, floor 1e-4).
+gradients must be as close to the fp64 truth as the fp32 reference arithmetic is (x3 in L2, floor 1e-4).
 The per-tensor tables of the last GPU run are written to gpurun_out/ and committed under profiles/."""
 import os
 
@@ -15,7 +15,7 @@ import pytest
 import torch
 
 from conftest import ROOT, assert_close
-from fp64_band import Band, band_of, grad_rows, state_to64, step_against_oracles
+from fp64_band import Band, GateRecorder, band_of, errors, forced_gate_rows, grad_rows, state_to64, step_against_oracles
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -33,7 +33,9 @@ def scaled_close(mine, want, msg, rel_atol=1e-5, floor=1e-7):
     assert_close(mine, want, RTOL, rel_atol * float(want.abs().max()) + floor, msg)
 
 
-def _run_step(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed):
+def _run_step(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed, sg_gates=False):
+    """`sg_gates`: also record the graph encoder's ReLU decisions during the step and evaluate the fp64 oracle with them
+    (res["sg_forced"], fp64_band.forced_gate_rows)."""
     import oracle
     from canonicalsg2im_amd import train as T
     from canonicalsg2im_amd.synth import make_batch, make_vocab
@@ -43,7 +45,16 @@ def _run_step(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed):
     torch.manual_seed(seed)
     tr = T.Trainer(opt, cuda)
     batch = make_batch(vocab, batch_cfg, seed=batch_seed)
-    return tr, step_against_oracles(tr, batch, oracle, T)
+    rec = sg_state = None
+    if sg_gates:
+        rec = GateRecorder(tr.model.sg_to_layout.module)
+        sg_state = T.oracle_state_from(tr, oracle).sg
+    res = step_against_oracles(tr, batch, oracle, T)
+    if sg_gates:
+        rec.remove()
+        tr._gate_names = rec.names
+        res["sg_forced"] = forced_gate_rows(tr, batch, oracle, T, rec.gates, sg_state)
+    return tr, res
 
 
 def _check_losses_and_image(tr, G, D, Go, Do, img_o, tag):
@@ -55,8 +66,13 @@ def _check_losses_and_image(tr, G, D, Go, Do, img_o, tag):
             assert_close(G[k].reshape(()), Go[k].reshape(()), RTOL, 1e-6, "%s G %s" % (tag, k))
     for k in Do:
         assert_close(D[k].reshape(()), Do[k].reshape(()), RTOL, 1e-6, "%s D %s" % (tag, k))
-    # tanh image, |img| <= 1: absolute 1e-4 of the output scale on top of rtol
+    # tanh image, |img| <= 1: absolute 1e-4 of the output scale on top of rtol — and, because a typical |pixel| at
+    # initialisation is 0.05, the relative L2 distance as well (measured 5e-6 with Winograd F(4x4,3x3) on; a 4x regression
+    # of the convolution error trips this while staying inside the elementwise rule)
     assert_close(tr.last_model_out[0], img_o, RTOL, 1e-4, tag + " imgs_pred")
+    d = tr.last_model_out[0].detach().double().cpu() - img_o.detach().double()
+    rel_l2 = float(d.norm() / img_o.detach().double().norm())
+    assert rel_l2 <= 2e-5, "%s imgs_pred: relative L2 distance %.3e > 2e-5" % (tag, rel_l2)
 
 
 def _step_losses_image_only(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed, tag):
@@ -109,7 +125,36 @@ def _check_step(tr, res, tag, sg_band=False):
             scaled_close(mine, want, "%s SG d%s" % (tag, k))
     # dense scenes: gate-flip events are frequent and each moves every tensor upstream of it (fp64_band.Band.check);
     # sparse scenes keep the count (at most two tensors out of the band)
-    band_of(res, tr, tag, dump=os.path.join(ROOT, "gpurun_out", "r03_band_%s.txt" % tag), outliers=None if sg_band else 2)
+    if sg_band:
+        # The graph encoder's gradients on dense closure graphs, judged without the gate noise: against the fp64 oracle
+        # evaluated with the HIP path's own ReLU decisions every gradient tensor agrees to 1e-5 in relative L2 (measured
+        # 4e-7, tests/dev/debug_sg_c5.py), and the decisions that differ from the fp64 oracle's are few and sit on
+        # pre-activations within rounding distance of zero (|pre| <= 1e-5 of the layer's largest).
+        rows, stats = res["sg_forced"]
+        assert len(rows) >= 44, len(rows)
+        lines = ["%-52s %10s" % ("SG tensor vs the fp64 oracle with the HIP gates", "hip l2")]
+        worst = 0.0
+        for k, mine, want64 in rows:
+            if float(want64.abs().max()) < 1e-12:
+                continue
+            e = errors(mine, want64)[0]
+            worst = max(worst, e)
+            lines.append("%-52s %10.2e" % (k, e))
+        lines.append("ReLU decisions differing from the fp64 oracle's own: layer, units, of, max |pre| / layer max")
+        for name, n, total, rel in stats:
+            if n:
+                lines.append("  %-40s %6d %10d %10.2e" % (name, n, total, rel))
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "r04_band_%s_sg_forced.txt" % tag), "w") as f:
+            f.write("\n".join(lines) + "\n")
+        assert worst <= 1e-5, "%s SG gradients vs the gate-forced fp64 oracle: worst %.2e\n%s" % (tag, worst, "\n".join(lines))
+        flipped = sum(n for _, n, _, _ in stats)
+        units = sum(t for _, _, t, _ in stats)
+        # (measured: 25 of 2.1e8 decisions, the fp32 oracle itself 37; every one on a |pre-activation| below 4e-7)
+        assert flipped <= max(64, 1e-6 * units), "%d of %d ReLU decisions differ from the fp64 oracle" % (flipped, units)
+        assert all(rel <= 1e-5 for _, n, _, rel in stats if n), [s for s in stats if s[1]]
+        res["rows"] = {g: r for g, r in res["rows"].items() if g != "SG"}
+    band_of(res, tr, tag, dump=os.path.join(ROOT, "gpurun_out", "r04_band_%s.txt" % tag), outliers=None if sg_band else 2)
 
 
 def test_c3_full_width_step_vs_oracle(cuda):
@@ -128,6 +173,41 @@ def test_c4_full_width_step_vs_oracle(cuda):
     tr, res = _run_step(cuda, "vg", ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "2"],
                         BatchConfig(2, 256, 3, 30, "random"), seed=1, batch_seed=4)
     _check_step(tr, res, tag="C4")
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_c3_consecutive_steps_live_resync_vs_oracle(cuda, graphs):
+    """Stale derived weights.  Winograd operands, the PatchGAN's permuted first-layer weight, the joined gamma || beta
+    storage and the spectrally normalised weights are all DERIVED from parameters that the fused Adam updates in place
+    without bumping `_version` (ops.weight_epoch); a derived tensor that is one optimiser step old moves a loss by ~1e-3.
+    Four consecutive iterations at full width (C3, batch 2): before EACH one the oracle's state is rebuilt from the
+    trainer's live parameters and buffers, and that iteration's losses and image are held to rtol 1e-4 — the trajectories
+    cannot drift apart, so the tolerance stays at the contract's level at every step.  `graphs=True` runs iterations 2-4
+    through the captured HIP graphs (capture, replay, replay: canonicalsg2im_amd/graphs.py), `graphs=False` keeps all four
+    on the eager path."""
+    import oracle
+    from canonicalsg2im_amd import train as T
+    from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
+    vocab = make_vocab("coco")
+    opt = T.make_opt(vocab, ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "2"])
+    torch.manual_seed(0)
+    tr = T.Trainer(opt, cuda)
+    if graphs:
+        assert tr.graphs is not None
+    else:
+        tr.graphs = None
+    batches = [make_batch(vocab, BatchConfig(2, 256, 1, 30, "random"), seed=20 + i) for i in range(2)]
+    for it in range(4):
+        batch = batches[it % 2]
+        ts = T.oracle_state_from(tr, oracle)                      # the trainer's CURRENT weights
+        G, D = tr.step([None if t is None else t.cuda() for t in batch])
+        torch.cuda.synchronize()
+        Go, Do, img_o = oracle.train_step(ts, batch)
+        _check_losses_and_image(tr, G, D, Go, Do, img_o, "C3 iteration %d (graphs %s)" % (it, graphs))
+    if graphs:
+        assert tr.graphs.captures == 1 and tr.graphs.replays == 3, (tr.graphs.captures, tr.graphs.replays)
+    del tr
+    torch.cuda.empty_cache()
 
 
 def test_c3_batch16_step_vs_oracle(cuda):
@@ -153,7 +233,7 @@ def test_c5_full_generator_step_vs_oracle(cuda):
     from canonicalsg2im_amd.synth import BatchConfig
     tr, res = _run_step(cuda, "clevr", ["--image_size", "256,256", "--no_vgg_loss", "--use_img_disc", "1",
                                         "--batch_size", "2"],
-                        BatchConfig(2, 256, 64, 128, "closure"), seed=6, batch_seed=8)
+                        BatchConfig(2, 256, 64, 128, "closure"), seed=6, batch_seed=8, sg_gates=True)
     assert res["G"]["bbox_pred_all"].numel() == 2 and tr.opt.semantic_nc == 128
     _check_step(tr, res, tag="C5", sg_band=True)
 
@@ -229,4 +309,4 @@ def test_c5_sg2layout_default_width_vs_oracle(cuda):
     band = Band()
     for k, mine, want, want64 in rows:
         band.add("SG " + k, mine, want, want64)
-    band.check("C5sg", dump=os.path.join(ROOT, "gpurun_out", "r03_band_C5sg.txt"))
+    band.check("C5sg", dump=os.path.join(ROOT, "gpurun_out", "r04_band_C5sg.txt"))

@@ -46,7 +46,7 @@ def main():
     busy += cur_e - cur_s
     ksum = defaultdict(lambda: [0, 0])
     for s, e, n in win:
-        k = n.split("(")[0]
+        k = n.replace("(anonymous namespace)::", "").split("(")[0]
         ksum[k][0] += e - s
         ksum[k][1] += 1
     total = sum(v[0] for v in ksum.values())
