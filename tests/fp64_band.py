@@ -122,14 +122,15 @@ def grad_rows(named_params, state32, state64, skip=("repr_net", "image_encoder")
     for k, p in named_params:
         if any(s in k for s in skip) or state32 is None or k not in state32:
             continue
-        o, o64 = state32[k], state64[k]
-        if p.grad is None or not torch.is_tensor(o) or o.grad is None or o64.grad is None:
+        o = state32[k]
+        o64 = state64[k] if state64 is not None else None
+        if p.grad is None or not torch.is_tensor(o) or o.grad is None or (o64 is not None and o64.grad is None):
             continue
-        rows.append((k, p.grad, o.grad, o64.grad))
+        rows.append((k, p.grad, o.grad, o64.grad if o64 is not None else None))
     return rows
 
 
-def step_against_oracles(tr, batch, oracle_mod, train_mod):
+def step_against_oracles(tr, batch, oracle_mod, train_mod, fp64=True):
     """Run ONE `Trainer.step` on the HIP path and the same step on the oracle in fp32 and in fp64 (same weights).
 
     Generator / graph-encoder gradients: the three evaluations see identical inputs.  Discriminator gradients: the
@@ -137,18 +138,23 @@ def step_against_oracles(tr, batch, oracle_mod, train_mod):
     a 60-convolution generator is 1e-4..1e-3 relative and the discriminators' gradients are linear in their input.
     To test the discriminators' own arithmetic at the contract's level they are fed the same image on every side:
     the oracle's discriminator losses are evaluated (fp32 and fp64) on the image the HIP generator produced, after the
-    two spectral-norm iterations of the generator-loss passes, exactly as in the step."""
+    two spectral-norm iterations of the generator-loss passes, exactly as in the step.
+
+    `fp64=False` skips the two fp64 evaluations (minutes of CPU on config C5's S = 128 generator): rows then carry None in
+    the fp64 slot and the caller judges the gradients against the fp32 oracle alone."""
     opt = tr.opt
     ts = train_mod.oracle_state_from(tr, oracle_mod)
-    ts64 = trainstate_to64(ts, oracle_mod)
+    ts64 = trainstate_to64(ts, oracle_mod) if fp64 else None
     tsd = train_mod.oracle_state_from(tr, oracle_mod)
-    tsd64 = trainstate_to64(tsd, oracle_mod)
+    tsd64 = trainstate_to64(tsd, oracle_mod) if fp64 else None
     G, D = tr.step([None if t is None else t.cuda() for t in batch])
     torch.cuda.synchronize()
     Go, Do, img_o = oracle_mod.train_step(ts, batch)
-    _, _, img64 = oracle_mod.train_step(ts64, batch_to64(batch))
+    img64 = oracle_mod.train_step(ts64, batch_to64(batch))[2] if fp64 else None
     if not opt.skip_generation:
         for state, cast in ((tsd, lambda t: t), (tsd64, lambda t: t.double())):
+            if state is None:
+                continue
             mo = tuple(None if t is None else cast(t.detach().cpu().float()) for t in tr.last_model_out)
             b = batch if state is tsd else batch_to64(batch)
             with torch.no_grad():
@@ -159,14 +165,15 @@ def step_against_oracles(tr, batch, oracle_mod, train_mod):
                 Dl["total_obj_loss"].backward()
             if "total_mask_loss" in Dl:
                 Dl["total_mask_loss"].backward()
-    rows = {"SG": grad_rows(tr.model.sg_to_layout.module.named_parameters(), ts.sg, ts64.sg) if hasattr(tr.model, "sg_to_layout") else []}
+    g64 = (lambda st, name: getattr(st, name)) if fp64 else (lambda st, name: None)
+    rows = {"SG": grad_rows(tr.model.sg_to_layout.module.named_parameters(), ts.sg, g64(ts64, "sg")) if hasattr(tr.model, "sg_to_layout") else []}
     if not opt.skip_generation:
-        rows["G"] = grad_rows(tr.model.layout_to_image_model.module.named_parameters(), ts.g, ts64.g)
-        rows["D"] = grad_rows(tr.discriminator.img_discriminator.named_parameters(), tsd.d, tsd64.d)
+        rows["G"] = grad_rows(tr.model.layout_to_image_model.module.named_parameters(), ts.g, g64(ts64, "g"))
+        rows["D"] = grad_rows(tr.discriminator.img_discriminator.named_parameters(), tsd.d, g64(tsd64, "d"))
         if tsd.dobj is not None:
-            rows["Dobj"] = grad_rows(tr.discriminator.obj_discriminator.named_parameters(), tsd.dobj, tsd64.dobj)
+            rows["Dobj"] = grad_rows(tr.discriminator.obj_discriminator.named_parameters(), tsd.dobj, g64(tsd64, "dobj"))
         if tsd.dmask is not None:
-            rows["Dmask"] = grad_rows(tr.discriminator.mask_discriminator.named_parameters(), tsd.dmask, tsd64.dmask)
+            rows["Dmask"] = grad_rows(tr.discriminator.mask_discriminator.named_parameters(), tsd.dmask, g64(tsd64, "dmask"))
     return {"G": G, "D": D, "Go": Go, "Do": Do, "img_o": img_o, "img64": img64, "ts": ts, "ts64": ts64, "rows": rows}
 
 
@@ -237,9 +244,13 @@ def forced_gate_rows(tr, batch, oracle_mod, train_mod, gates, state):
     opt = copy.copy(tr.opt)
     opt.skip_generation = True
     b64 = batch_to64(batch)
-    free = state_to64(state)
-    with forced_relu() as rec:                              # the fp64 oracle's own decisions
-        _, bp, _ = oracle_mod.sg2layout_forward(free, opt.vocab, batch[1], batch[3], batch[5])
+    forced = state_to64(state)
+    # ONE fp64 pass, with the HIP gates forced: its recorded pre-activations also give the flip statistics (a unit whose
+    # forced gate disagrees with the sign of its fp64 pre-activation; upstream of it the two evaluations differ only by
+    # other such units, whose pre-activations are rounding noise themselves)
+    with forced_relu(force=gates) as rec:
+        _, bp, _ = oracle_mod.sg2layout_forward(forced, opt.vocab, batch[1], batch[3], batch[5])
+        Gl = oracle_mod.generator_losses(opt, None, b64, (None, bp, None))
     assert len(rec.seen) == len(gates), "the oracle calls F.relu %d times, the HIP encoder has %d fused ReLUs" % (
         len(rec.seen), len(gates))
     stats = []
@@ -248,10 +259,6 @@ def forced_gate_rows(tr, batch, oracle_mod, train_mod, gates, state):
         n = int(diff.sum())
         worst = float(pre[diff].abs().max() / pre.abs().max().clamp_min(1e-300)) if n else 0.0
         stats.append((name, n, theirs.numel(), worst))
-    forced = state_to64(state)
-    with forced_relu(force=gates):
-        _, bp, _ = oracle_mod.sg2layout_forward(forced, opt.vocab, batch[1], batch[3], batch[5])
-        Gl = oracle_mod.generator_losses(opt, None, b64, (None, bp, None))
     Gl["total_loss"].backward()
     rows = []
     for k, p in tr.model.sg_to_layout.module.named_parameters():
