@@ -43,6 +43,19 @@ class FewDesc(ctypes.Structure):
                 ("pad", c_i32), ("cout_real", c_i32), ("act", c_i32), ("slope", c_f32)]
 
 
+class SnFwdItem(ctypes.Structure):
+    """Mirror of `csg_sn_fwd_item` (include/csg_hip.h)."""
+    _fields_ = [("w", c_p), ("u", c_p), ("v", c_p), ("Cout", c_i64), ("K", c_i64), ("w_eff", c_p), ("cl_Cin", c_i64),
+                ("sigma", c_p), ("u_used", c_p), ("v_used", c_p), ("workspace", c_p), ("workspace_bytes", c_i64)]
+
+
+class SnBwdItem(ctypes.Structure):
+    """Mirror of `csg_sn_bwd_item` (include/csg_hip.h)."""
+    _fields_ = [("dweff", c_p), ("Cout", c_i64), ("Cin", c_i64), ("KH", c_i64), ("KW", c_i64), ("s0", c_i64), ("s1", c_i64),
+                ("s2", c_i64), ("s3", c_i64), ("w", c_p), ("u_used", c_p), ("v_used", c_p), ("sigma", c_p), ("dw", c_p),
+                ("workspace", c_p), ("workspace_bytes", c_i64)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/csg_hip.h
 SIGNATURES = {
     "csg_version": (c_i32, []),
@@ -132,6 +145,8 @@ SIGNATURES = {
                                       c_p]),
     "csg_spectral_norm_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                                       c_p, c_p, c_i64, c_p]),
+    "csg_spectral_norm_fwd_multi": (c_i32, [ctypes.POINTER(SnFwdItem), c_i32, c_i32, c_f32, c_p]),
+    "csg_spectral_norm_bwd_multi": (c_i32, [ctypes.POINTER(SnBwdItem), c_i32, c_p]),
     "csg_canon_workspace": (c_i64, [c_i64]),
     "csg_canon_build": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, ctypes.POINTER(c_i32), c_i64, c_i32, c_i32, c_p, c_i64,
                                 c_p, c_p]),

@@ -33,11 +33,11 @@ __device__ double block_sum(double v, double* sm) {
 }
 
 // part[r][k] = sum over the rows of chunk r of u[i] * W[i][k]          grid (ceil(K/1024), R)
-__global__ __launch_bounds__(256) void k_sn_wtu_partial(const float* __restrict__ w, const float* __restrict__ u,
-                                                         int Cout, int K, int R, float* __restrict__ part) {
-  const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
+__device__ __forceinline__ void d_sn_wtu_partial(const float* __restrict__ w, const float* __restrict__ u, int Cout, int K,
+                                                 int R, float* __restrict__ part, int bx, int by) {
+  const int k = (bx * 256 + threadIdx.x) * 4;
   if (k >= K) return;
-  const int r = blockIdx.y;
+  const int r = by;
   const int per = (Cout + R - 1) / R;
   const int i0 = r * per, i1 = min(Cout, i0 + per);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -59,9 +59,14 @@ __global__ __launch_bounds__(256) void k_sn_wtu_partial(const float* __restrict_
   *(float4*)(part + (int64_t)r * K + k) = a;
 }
 
+__global__ __launch_bounds__(256) void k_sn_wtu_partial(const float* __restrict__ w, const float* __restrict__ u,
+                                                         int Cout, int K, int R, float* __restrict__ part) {
+  d_sn_wtu_partial(w, u, Cout, K, R, part, blockIdx.x, blockIdx.y);
+}
+
 // t[k] = sum_r part[r][k]
-__global__ void k_sn_wtu_reduce(const float* __restrict__ part, int K, int R, float* __restrict__ t) {
-  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+__device__ __forceinline__ void d_sn_wtu_reduce(const float* __restrict__ part, int K, int R, float* __restrict__ t, int bx) {
+  const int k = (bx * blockDim.x + threadIdx.x) * 4;
   if (k >= K) return;
   float4 a = ld4(part + k);
 #pragma unroll 8
@@ -72,15 +77,18 @@ __global__ void k_sn_wtu_reduce(const float* __restrict__ part, int K, int R, fl
   *(float4*)(t + k) = a;
 }
 
+__global__ void k_sn_wtu_reduce(const float* __restrict__ part, int K, int R, float* __restrict__ t) {
+  d_sn_wtu_reduce(part, K, R, t, blockIdx.x);
+}
+
 // s[i] = W[i] . v with v = t / max(||t||, eps) formed on the fly (training) or v = the stored buffer (eval).
 // One block per row (all of a thread's loads are independent: one HBM round trip per row); every block
 // recomputes ||t|| in the same order (t is K floats, L2 resident), which saves a single-block
 // normalisation launch.  Block 0 publishes v.
-__global__ __launch_bounds__(256) void k_sn_rowdot(const float* __restrict__ w, const float* __restrict__ t,
-                                                    int Cout, int K, float eps, int iterate, float* __restrict__ v,
-                                                    float* __restrict__ v_used, float* __restrict__ s) {
-  __shared__ double sm[16];
-  const int row = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void d_sn_rowdot(const float* __restrict__ w, const float* __restrict__ t, int Cout, int K,
+                                            float eps, int iterate, float* __restrict__ v, float* __restrict__ v_used,
+                                            float* __restrict__ s, int row, double* sm) {
+  const int tid = threadIdx.x;
   const float* vin = iterate ? t : v;
   float nrm = 1.f;
   if (iterate) {
@@ -110,13 +118,19 @@ __global__ __launch_bounds__(256) void k_sn_rowdot(const float* __restrict__ w, 
   if (tid == 0) s[row] = (float)tot;
 }
 
+__global__ __launch_bounds__(256) void k_sn_rowdot(const float* __restrict__ w, const float* __restrict__ t,
+                                                    int Cout, int K, float eps, int iterate, float* __restrict__ v,
+                                                    float* __restrict__ v_used, float* __restrict__ s) {
+  __shared__ double sm[16];
+  d_sn_rowdot(w, t, Cout, K, eps, iterate, v, v_used, s, blockIdx.x, sm);
+}
+
 // W_eff = W / sigma.  Every block derives sigma from s (Cout floats) in the same order:
 // training: u = s / max(||s||, eps), sigma = u . s;  eval: sigma = u_stored . s.  Block 0 publishes u, sigma.
-__global__ __launch_bounds__(256) void k_sn_scale(const float* __restrict__ w, const float* __restrict__ s, int Cout,
-                                                   float eps, int iterate, float* __restrict__ u,
-                                                   float* __restrict__ u_used, float* __restrict__ sigma, int64_t n4,
-                                                   float* __restrict__ w_eff, int Cin, int khw) {
-  __shared__ double sm[16];
+__device__ __forceinline__ void d_sn_scale(const float* __restrict__ w, const float* __restrict__ s, int Cout, float eps,
+                                           int iterate, float* __restrict__ u, float* __restrict__ u_used,
+                                           float* __restrict__ sigma, int64_t n4, float* __restrict__ w_eff, int Cin, int khw,
+                                           int bx, int gx, double* sm, float* row) {
   float nrm = 1.f;
   if (iterate) {
     double acc = 0.0;
@@ -126,16 +140,16 @@ __global__ __launch_bounds__(256) void k_sn_scale(const float* __restrict__ w, c
   double dot = 0.0;
   for (int i = threadIdx.x; i < Cout; i += 256) {
     const float ui = iterate ? s[i] / nrm : u[i];
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
       if (iterate) u[i] = ui;
       u_used[i] = ui;
     }
     dot += (double)ui * (double)s[i];
   }
   const float sg = (float)block_sum(dot, sm);
-  if (blockIdx.x == 0 && threadIdx.x == 0) sigma[0] = sg;
+  if (bx == 0 && threadIdx.x == 0) sigma[0] = sg;
   if (Cin == 0) {                        // W_eff in the memory order of W
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+    for (int64_t e = (int64_t)bx * 256 + threadIdx.x; e < n4; e += (int64_t)gx * 256) {
       const float4 a = ld4(w + e * 4);
       *(float4*)(w_eff + e * 4) = make_float4(a.x / sg, a.y / sg, a.z / sg, a.w / sg);     // `weight / sigma`
     }
@@ -144,9 +158,8 @@ __global__ __launch_bounds__(256) void k_sn_scale(const float* __restrict__ w, c
   // W is (Cout, Cin, KH, KW) row-major; W_eff is written in channels-last memory [Cout][KH][KW][Cin] — the
   // convolution kernels' forward operand.  One block per output channel: its row is read as it lies, transposed
   // (cin, tap) -> (tap, cin) through LDS and written as it will lie (both sides coalesced).
-  extern __shared__ __attribute__((aligned(16))) float row[];          // [khw][Cin + 4]
   const int K = Cin * khw, LD = Cin + 4;
-  for (int co = blockIdx.x; co < Cout; co += gridDim.x) {
+  for (int co = bx; co < Cout; co += gx) {
     __syncthreads();
     for (int e = threadIdx.x; e < (K >> 2); e += 256) {
       const float4 a = ld4(w + (int64_t)co * K + e * 4);
@@ -166,6 +179,15 @@ __global__ __launch_bounds__(256) void k_sn_scale(const float* __restrict__ w, c
   }
 }
 
+__global__ __launch_bounds__(256) void k_sn_scale(const float* __restrict__ w, const float* __restrict__ s, int Cout,
+                                                   float eps, int iterate, float* __restrict__ u,
+                                                   float* __restrict__ u_used, float* __restrict__ sigma, int64_t n4,
+                                                   float* __restrict__ w_eff, int Cin, int khw) {
+  __shared__ double sm[16];
+  extern __shared__ __attribute__((aligned(16))) float row[];          // [khw][Cin + 4]
+  d_sn_scale(w, s, Cout, eps, iterate, u, u_used, sigma, n4, w_eff, Cin, khw, blockIdx.x, gridDim.x, sm, row);
+}
+
 struct SnGeom {
   int Cout, Cin, KH, KW;
   int64_t s0, s1, s2, s3;   // element strides of dW_eff along (Cout, Cin, KH, KW)
@@ -183,12 +205,8 @@ __device__ __forceinline__ int row_off(const SnGeom& g, int k) {
 // [Cout][KH][KW][Cin] while W is [Cout][Cin][KH][KW]: the row is staged in LDS in its own memory order
 // (coalesced) and read back permuted, so both global streams stay coalesced.
 // partial[row] = sum_k dW_eff[row][k] * W[row][k]
-__global__ __launch_bounds__(256) void k_sn_bwd_dot(SnGeom g, const float* __restrict__ dweff,
-                                                     const float* __restrict__ w, int K,
-                                                     double* __restrict__ partial) {
-  extern __shared__ float row[];
-  __shared__ double sm[16];
-  const int co = blockIdx.x;
+__device__ __forceinline__ void d_sn_bwd_dot(const SnGeom& g, const float* __restrict__ dweff, const float* __restrict__ w,
+                                             int K, double* __restrict__ partial, int co, double* sm, float* row) {
   const float* src = dweff + (int64_t)co * g.s0;
   for (int j = threadIdx.x * 4; j < K; j += 256 * 4) *(float4*)(row + j) = ld4(src + j);
   __syncthreads();
@@ -199,14 +217,19 @@ __global__ __launch_bounds__(256) void k_sn_bwd_dot(SnGeom g, const float* __res
   if (threadIdx.x == 0) partial[co] = acc;
 }
 
-// dW = (dW_eff - c u v^T) / sigma,  c = sum dW_eff . W_eff = (sum dW_eff . W) / sigma
-__global__ __launch_bounds__(256) void k_sn_bwd_dw(SnGeom g, const float* __restrict__ dweff,
-                                                    const float* __restrict__ u, const float* __restrict__ v,
-                                                    const float* __restrict__ sigma, const double* __restrict__ partial,
-                                                    int K, float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void k_sn_bwd_dot(SnGeom g, const float* __restrict__ dweff,
+                                                     const float* __restrict__ w, int K,
+                                                     double* __restrict__ partial) {
   extern __shared__ float row[];
   __shared__ double sm[16];
-  const int co = blockIdx.x;
+  d_sn_bwd_dot(g, dweff, w, K, partial, blockIdx.x, sm, row);
+}
+
+// dW = (dW_eff - c u v^T) / sigma,  c = sum dW_eff . W_eff = (sum dW_eff . W) / sigma
+__device__ __forceinline__ void d_sn_bwd_dw(const SnGeom& g, const float* __restrict__ dweff, const float* __restrict__ u,
+                                            const float* __restrict__ v, const float* __restrict__ sigma,
+                                            const double* __restrict__ partial, int K, float* __restrict__ dw, int co,
+                                            double* sm, float* row) {
   const float* src = dweff + (int64_t)co * g.s0;
   for (int j = threadIdx.x * 4; j < K; j += 256 * 4) *(float4*)(row + j) = ld4(src + j);
   double tot = 0.0;
@@ -216,6 +239,77 @@ __global__ __launch_bounds__(256) void k_sn_bwd_dw(SnGeom g, const float* __rest
   const float cu = (float)(tot / (double)sg) * u[co];
   float* dr = dw + (int64_t)co * K;
   for (int k = threadIdx.x; k < K; k += 256) dr[k] = (row[row_off(g, k)] - cu * v[k]) / sg;
+}
+
+__global__ __launch_bounds__(256) void k_sn_bwd_dw(SnGeom g, const float* __restrict__ dweff,
+                                                    const float* __restrict__ u, const float* __restrict__ v,
+                                                    const float* __restrict__ sigma, const double* __restrict__ partial,
+                                                    int K, float* __restrict__ dw) {
+  extern __shared__ float row[];
+  __shared__ double sm[16];
+  d_sn_bwd_dw(g, dweff, u, v, sigma, partial, K, dw, blockIdx.x, sm, row);
+}
+
+// ---- multi-tensor forms: every spectrally normalised weight of a network in ONE launch per stage (blockIdx.z = tensor).
+// A generator forward calls the hook on 18 convolutions and a PatchGAN pass on 3 per scale; one by one that is 4 launches
+// of a few microseconds each per weight — ~200 launches per training step that individually cannot fill the chip.
+#define SN_MAXT 12
+struct SnFwdItem {
+  const float* w;
+  float *u, *v, *w_eff, *sigma, *u_used, *v_used, *part, *t, *sv;
+  int Cout, K, R, cl_Cin, khw, scale_grid;
+  long long n4;
+};
+struct SnFwdMulti {
+  SnFwdItem it[SN_MAXT];
+};
+struct SnBwdItem {
+  SnGeom g;
+  const float *dweff, *w, *u, *v, *sigma;
+  double* partial;
+  float* dw;
+  int K;
+};
+struct SnBwdMulti {
+  SnBwdItem it[SN_MAXT];
+};
+
+__global__ __launch_bounds__(256) void k_sn_wtu_partial_m(SnFwdMulti m) {
+  const SnFwdItem& a = m.it[blockIdx.z];
+  if ((int)blockIdx.y >= a.R) return;
+  d_sn_wtu_partial(a.w, a.u, a.Cout, a.K, a.R, a.part, blockIdx.x, blockIdx.y);
+}
+__global__ void k_sn_wtu_reduce_m(SnFwdMulti m) {
+  const SnFwdItem& a = m.it[blockIdx.z];
+  d_sn_wtu_reduce(a.part, a.K, a.R, a.t, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_sn_rowdot_m(SnFwdMulti m, float eps, int iterate) {
+  __shared__ double sm[16];
+  const SnFwdItem& a = m.it[blockIdx.z];
+  if ((int)blockIdx.x >= a.Cout) return;
+  d_sn_rowdot(a.w, a.t, a.Cout, a.K, eps, iterate, a.v, a.v_used, a.sv, blockIdx.x, sm);
+}
+__global__ __launch_bounds__(256) void k_sn_scale_m(SnFwdMulti m, float eps, int iterate) {
+  __shared__ double sm[16];
+  extern __shared__ __attribute__((aligned(16))) float row[];
+  const SnFwdItem& a = m.it[blockIdx.z];
+  if ((int)blockIdx.x >= a.scale_grid) return;
+  d_sn_scale(a.w, a.sv, a.Cout, eps, iterate, a.u, a.u_used, a.sigma, a.n4, a.w_eff, a.cl_Cin, a.khw, blockIdx.x, a.scale_grid,
+             sm, row);
+}
+__global__ __launch_bounds__(256) void k_sn_bwd_dot_m(SnBwdMulti m) {
+  extern __shared__ float row[];
+  __shared__ double sm[16];
+  const SnBwdItem& a = m.it[blockIdx.z];
+  if ((int)blockIdx.x >= a.g.Cout) return;
+  d_sn_bwd_dot(a.g, a.dweff, a.w, a.K, a.partial, blockIdx.x, sm, row);
+}
+__global__ __launch_bounds__(256) void k_sn_bwd_dw_m(SnBwdMulti m) {
+  extern __shared__ float row[];
+  __shared__ double sm[16];
+  const SnBwdItem& a = m.it[blockIdx.z];
+  if ((int)blockIdx.x >= a.g.Cout) return;
+  d_sn_bwd_dw(a.g, a.dweff, a.u, a.v, a.sigma, a.partial, a.K, a.dw, blockIdx.x, sm, row);
 }
 
 inline int sn_R(int64_t Cout, int64_t K) {
@@ -313,6 +407,118 @@ int csg_spectral_norm_bwd(const float* dweff, int64_t Cout, int64_t Cin, int64_t
   CSG_LAUNCH(k_sn_bwd_dw, dim3((unsigned)Cout), dim3(256), shm, s, g, dweff, u_used, v_used, sigma,
                      (const double*)workspace, (int)K, dw);
   return check_launch("csg_spectral_norm_bwd");
+}
+
+// ---- multi-tensor entry points (see SnFwdMulti above): the same arithmetic, kernel by kernel, for up to SN_MAXT weights
+// per launch (longer lists go out in chunks); every weight's results are bit-identical to the single-tensor calls.
+int csg_spectral_norm_fwd_multi(const csg_sn_fwd_item* items, int32_t n, int32_t iterate, float eps, void* stream) {
+  CSG_REQUIRE(items != nullptr && n > 0, CSG_E_BADSHAPE, "csg_spectral_norm_fwd_multi: empty list");
+  hipStream_t s = (hipStream_t)stream;
+  for (int base = 0; base < n; base += SN_MAXT) {
+    const int cnt = n - base < SN_MAXT ? n - base : SN_MAXT;
+    SnFwdMulti m;
+    unsigned g_part_x = 1, g_part_y = 1, g_red = 1, g_row = 1, g_scale = 1;
+    size_t shm = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < cnt; ++i) {
+      const csg_sn_fwd_item& a = items[base + i];
+      CSG_REQUIRE(a.cl_Cin == 0 || (a.cl_Cin % 4 == 0 && a.K % a.cl_Cin == 0), CSG_E_BADSHAPE,
+                  "csg_spectral_norm_fwd_multi: channels-last output needs Cin %% 4 == 0 dividing K");
+      CSG_REQUIRE(a.Cout > 0 && a.K > 0 && a.K % 4 == 0, CSG_E_BADSHAPE,
+                  "csg_spectral_norm_fwd_multi: bad shape Cout=%ld K=%ld (K must be a multiple of 4)", (long)a.Cout, (long)a.K);
+      CSG_REQUIRE(a.workspace && a.workspace_bytes >= csg_spectral_norm_workspace(a.Cout, a.K), CSG_E_BADSHAPE,
+                  "csg_spectral_norm_fwd_multi: workspace too small");
+      SnFwdItem& t = m.it[i];
+      t.w = a.w; t.u = a.u; t.v = a.v; t.w_eff = a.w_eff; t.sigma = a.sigma; t.u_used = a.u_used; t.v_used = a.v_used;
+      t.Cout = (int)a.Cout; t.K = (int)a.K; t.R = sn_R(a.Cout, a.K);
+      t.part = (float*)a.workspace;
+      t.t = t.part + (int64_t)t.R * a.K;
+      t.sv = t.t + a.K;
+      t.cl_Cin = (int)a.cl_Cin;
+      t.khw = a.cl_Cin ? (int)(a.K / a.cl_Cin) : 1;
+      t.n4 = a.Cout * a.K / 4;
+      int64_t grid = cdiv(t.n4, 256 * 4);
+      if (grid > 2048) grid = 2048;
+      if (grid < 1) grid = 1;
+      if (a.cl_Cin) {
+        const size_t need = (size_t)t.khw * (a.cl_Cin + 4) * sizeof(float);
+        CSG_REQUIRE(need <= 64 * 1024, CSG_E_UNSUPPORTED,
+                    "csg_spectral_norm_fwd_multi: a %ld-element row does not fit the transpose buffer", (long)a.K);
+        if (need > shm) shm = need;
+        grid = a.Cout < 2048 ? a.Cout : 2048;
+      }
+      t.scale_grid = (int)grid;
+      if ((unsigned)cdiv(a.K, 1024) > g_part_x) g_part_x = (unsigned)cdiv(a.K, 1024);
+      if ((unsigned)t.R > g_part_y) g_part_y = (unsigned)t.R;
+      if ((unsigned)cdiv(a.K, 256) > g_red) g_red = (unsigned)cdiv(a.K, 256);
+      if ((unsigned)a.Cout > g_row) g_row = (unsigned)a.Cout;
+      if ((unsigned)grid > g_scale) g_scale = (unsigned)grid;
+      bytes += (double)a.Cout * a.K * 4 * (iterate ? 4 : 3);
+    }
+    ProfScope p(K_SPECTRAL_FWD, bytes, s);
+    if (iterate) {
+      CSG_LAUNCH(k_sn_wtu_partial_m, dim3(g_part_x, g_part_y, (unsigned)cnt), dim3(256), 0, s, m);
+      CSG_LAUNCH(k_sn_wtu_reduce_m, dim3(g_red, 1, (unsigned)cnt), dim3(64), 0, s, m);
+    }
+    CSG_LAUNCH(k_sn_rowdot_m, dim3(g_row, 1, (unsigned)cnt), dim3(256), 0, s, m, eps, (int)iterate);
+    CSG_LAUNCH(k_sn_scale_m, dim3(g_scale, 1, (unsigned)cnt), dim3(256), shm, s, m, eps, (int)iterate);
+    const int rc = check_launch("csg_spectral_norm_fwd_multi");
+    if (rc != CSG_OK) return rc;
+  }
+  return CSG_OK;
+}
+
+int csg_spectral_norm_bwd_multi(const csg_sn_bwd_item* items, int32_t n, void* stream) {
+  CSG_REQUIRE(items != nullptr && n > 0, CSG_E_BADSHAPE, "csg_spectral_norm_bwd_multi: empty list");
+  hipStream_t s = (hipStream_t)stream;
+  for (int base = 0; base < n; base += SN_MAXT) {
+    const int cnt = n - base < SN_MAXT ? n - base : SN_MAXT;
+    SnBwdMulti m;
+    unsigned g_row = 1;
+    size_t shm = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < cnt; ++i) {
+      const csg_sn_bwd_item& a = items[base + i];
+      CSG_REQUIRE(a.Cout > 0 && a.Cin > 0 && a.KH > 0 && a.KW > 0, CSG_E_BADSHAPE, "csg_spectral_norm_bwd_multi: bad shape");
+      const int64_t K = a.Cin * a.KH * a.KW;
+      CSG_REQUIRE(K % 4 == 0 && K <= 15360, CSG_E_UNSUPPORTED,
+                  "csg_spectral_norm_bwd_multi: K=%ld must be a multiple of 4 and at most 15360 (one LDS row)", (long)K);
+      {
+        int64_t d[3] = {a.Cin, a.KH, a.KW}, st[3] = {a.s1, a.s2, a.s3};
+        for (int x = 0; x < 3; ++x)
+          for (int c = x + 1; c < 3; ++c)
+            if (st[c] < st[x]) {
+              int64_t t = st[x]; st[x] = st[c]; st[c] = t;
+              t = d[x]; d[x] = d[c]; d[c] = t;
+            }
+        int64_t run = 1;
+        bool dense = a.s0 == K;
+        for (int x = 0; x < 3; ++x) {
+          if (d[x] > 1 && st[x] != run) dense = false;
+          run *= d[x];
+        }
+        CSG_REQUIRE(dense, CSG_E_BADSHAPE, "csg_spectral_norm_bwd_multi: dW_eff rows must be dense (strides %ld %ld %ld %ld)",
+                    (long)a.s0, (long)a.s1, (long)a.s2, (long)a.s3);
+      }
+      CSG_REQUIRE(a.workspace && a.workspace_bytes >= a.Cout * (int64_t)sizeof(double), CSG_E_BADSHAPE,
+                  "csg_spectral_norm_bwd_multi: workspace too small");
+      SnBwdItem& t = m.it[i];
+      t.g = SnGeom{(int)a.Cout, (int)a.Cin, (int)a.KH, (int)a.KW, a.s0, a.s1, a.s2, a.s3};
+      t.dweff = a.dweff; t.w = a.w; t.u = a.u_used; t.v = a.v_used; t.sigma = a.sigma;
+      t.partial = (double*)a.workspace;
+      t.dw = a.dw;
+      t.K = (int)K;
+      if ((unsigned)a.Cout > g_row) g_row = (unsigned)a.Cout;
+      if ((size_t)K * sizeof(float) > shm) shm = (size_t)K * sizeof(float);
+      bytes += (double)a.Cout * K * 4 * 4;
+    }
+    ProfScope p(K_SPECTRAL_BWD, bytes, s);
+    CSG_LAUNCH(k_sn_bwd_dot_m, dim3(g_row, 1, (unsigned)cnt), dim3(256), shm, s, m);
+    CSG_LAUNCH(k_sn_bwd_dw_m, dim3(g_row, 1, (unsigned)cnt), dim3(256), shm, s, m);
+    const int rc = check_launch("csg_spectral_norm_bwd_multi");
+    if (rc != CSG_OK) return rc;
+  }
+  return CSG_OK;
 }
 
 }  // extern "C"

@@ -104,13 +104,18 @@ class GradBuckets:
 
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large messages beat many small ones, so buckets are
     ~64 MB (the generator's 375 MB of gradients travel in 6 collectives).  Buckets are filled in reverse registration
-    order, which is the order gradients become ready.  Which parameters take part is discovered at the first
-    synchronisation: those that received a gradient — the never-used `repr_net` / `image_encoder` of G and D
-     stay out instead of tripping a DDP 'unused parameter' error; a parameter that receives its
-    first gradient on a LATER step (a branch that was inactive before) makes the buckets rebuild at that step's
-    flush() — the set is a function of the model and the step, hence identical on every rank.  In steady state nothing
-    is allocated: a hook copies the fresh gradient into its slot (the only extra pass over the gradients — there is no
-    `torch.cat`, no copy back) and re-points `.grad` at the slot, which is what the optimiser then reads.
+    order, which is the order gradients become ready.  Which parameters take part is AGREED at the first
+    synchronisation: the union over ranks of the parameters that received a gradient (one blocking all-reduce of a
+    has-gradient bitmask, once) — the never-used `repr_net` / `image_encoder` of G and D stay
+    out instead of tripping a DDP 'unused parameter' error, and a rank whose shard left a branch empty (no real object
+    for the crop discriminator) still holds the same buckets as the others.  From then on every rank issues the same
+    collectives in the same order by construction: a member without a local gradient contributes zeros and RECEIVES
+    the average of the others (its `.grad` becomes the slot view like everybody's — the replicas cannot part).  A
+    parameter outside the agreed set that receives a gradient later (a branch inactive at the first step) cannot be
+    exchanged without the other ranks knowing: flush() raises — loudly, instead of issuing a collective the others may
+    not issue (a hang) — and `rebuild()`, a collective call, re-agrees the set.  In steady state nothing is allocated:
+    a hook copies the fresh gradient into its slot (the only extra pass over the gradients — there is no `torch.cat`,
+    no copy back) and re-points `.grad` at the slot, which is what the optimiser then reads.
 
     Usage per backward:  begin(); loss.backward(); [independent work]; finish()  — or all_reduce_mean() alone after the
     backward (the one-shot form: the hooks were not armed, so every gradient is moved into its slot then).
@@ -130,14 +135,19 @@ class GradBuckets:
         self._pending, self._fired, self._works, self._next, self._streams = [], set(), [], 0, {}
         self.allocations = 0                                    # flat buffers ever allocated (tests: steady state adds none)
         self.rebuilds = 0
-        self._late, self._late_flat = [], None
 
     # ---- construction (first synchronisation, or a parameter's first gradient)
     def _build(self):
         for h in self._hooks:
             h.remove()
         self._hooks, self.flats, self.members, self.slot = [], [], [], {}
-        live = [p for p in self.params if p.grad is not None]
+        # the live set is the UNION over ranks (blocking, but only here): every rank builds identical buckets even if
+        # its own shard left a branch without a gradient
+        has = torch.tensor([1 if p.grad is not None else 0 for p in self.params], dtype=torch.int32,
+                           device=self.params[0].device if (self.params and dist.get_backend() == "nccl") else "cpu")
+        if has.numel():
+            dist.all_reduce(has, op=dist.ReduceOp.MAX)
+        live = [p for p, h in zip(self.params, has.tolist()) if h]
         cur, size, groups = [], 0, []
         for p in reversed(live):                                 # reverse registration order ~ order of readiness
             n = p.numel() * 4
@@ -227,17 +237,20 @@ class GradBuckets:
                     if p.grad is not None:
                         self._hook(p)
         self._launch_ready(force=True)
-        # parameters outside the buckets that hold a gradient now (first gradient on a later step): one extra
-        # collective for them this time, and the buckets are rebuilt around the new set at the end of finish()
-        self._late = [p for p in self.params if p.grad is not None and id(p) not in self.slot]
-        if self._late:
-            self._late_flat = torch.cat([p.grad.reshape(-1) for p in self._late])
-            self._works.append(dist.all_reduce(self._late_flat, op=_avg_op(), async_op=True))
-            comm_note("grad_allreduce", self._late_flat.numel() * 4)
+        late = [p for p in self.params if p.grad is not None and id(p) not in self.slot]
+        if late:
+            # the collectives above are already in flight on every rank; nothing rank-dependent has been issued
+            self._state = "flushed"
+            raise RuntimeError(
+                "GradBuckets: %d parameter(s) outside the agreed set received a gradient (first gradient after the "
+                "buckets were built: shapes %s).  The other ranks may not hold one, so it cannot be exchanged here; call "
+                "rebuild() on EVERY rank (a collective) after this step, or activate the branch from the first step."
+                % (len(late), [tuple(p.shape) for p in late[:4]]))
         self._state = "flushed"
 
     def finish(self):
-        """Wait for the collectives; gradients are then the mean over ranks.  Returns the bytes exchanged."""
+        """Wait for the collectives; gradients are then the mean over ranks — on EVERY member, also those this rank's
+        backward left without a gradient.  Returns the bytes exchanged."""
         if world_size() == 1:
             return 0
         self.flush()
@@ -254,27 +267,28 @@ class GradBuckets:
             n = world_size()
             for flat in self.flats:
                 flat.div_(n)
-            if self._late:
-                self._late_flat.div_(n)
+        for group in self.members:
+            for p in group:
+                if id(p) not in self._fired:             # no local gradient: the others' average is this rank's gradient too
+                    p.grad = self.slot[id(p)][1]
         self._works = []
         self._state = "idle"
-        nbytes = sum(f.numel() * 4 for f in self.flats)
-        if self._late:
-            off = 0
-            for p in self._late:
-                p.grad.copy_(self._late_flat[off:off + p.numel()].view(p.shape))
-                off += p.numel()
-            nbytes += off * 4
-            held = {id(p): p.grad.clone() for p in self.params if p.grad is not None}     # out of the old slots
-            self._build()
-            for q in self.params:
-                if id(q) in held:
-                    view = self.slot[id(q)][1]
-                    view.copy_(held[id(q)])
-                    q.grad = view
-            self._late, self._late_flat = [], None
-            self.rebuilds += 1
-        return nbytes
+        return sum(f.numel() * 4 for f in self.flats)
+
+    def rebuild(self):
+        """COLLECTIVE: re-agree the live set (every rank must call it at the same point, between two steps) — after
+        flush() reported a parameter outside the set, or when a branch is switched on.  Gradients currently held are kept."""
+        if world_size() == 1:
+            return
+        held = {id(p): p.grad.clone() for p in self.params if p.grad is not None}
+        self._build()
+        for q in self.params:
+            if id(q) in held and id(q) in self.slot:
+                view = self.slot[id(q)][1]
+                view.copy_(held[id(q)])
+                q.grad = view
+        self._state = "idle"
+        self.rebuilds += 1
 
     def all_reduce_mean(self):
         """grad <- mean over ranks.  With begin() before the backward the buckets were filled (and partly sent) by the

@@ -95,6 +95,7 @@ def _drop_stale_autograd(*roots):
                         setattr(m, hook.name, w.detach())
             if getattr(m, "_w0", None) is not None:
                 m._w0, m._w0_key = None, None
+            m.__dict__.pop("_sn_prepared", None)
 
 
 class _GraphSet:

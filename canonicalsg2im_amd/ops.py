@@ -20,7 +20,7 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, WinoDesc, ch
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "nearest_resize", "avgpool3s2", "embed", "real_object_mask",
     "norm_act_pair", "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "l1_mean",
-    "invalidate_weight_caches", "pack_conv_weight", "wino_pack", "wino_eligible", "wino_variant", "spectral_weight", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
+    "invalidate_weight_caches", "pack_conv_weight", "wino_pack", "wino_eligible", "wino_variant", "spectral_weight", "spectral_weights", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
 
 
@@ -533,6 +533,86 @@ class _SpectralWeight(torch.autograd.Function):
                                         ptr(v_used), ptr(sigma), ptr(dw), ptr(ws), nbytes, stream()),
               "spectral_norm_bwd")
         return dw, None, None, None, None
+
+
+class _SpectralWeightMulti(torch.autograd.Function):
+    """`_SpectralWeight` for every spectrally normalised weight of a network pass at once (csg_spectral_norm_*_multi): one
+    launch per stage instead of one per weight and stage — a generator forward has 18 such weights, a PatchGAN pass 3 per
+    scale, ~200 launches of a few microseconds each per training step.  Same arithmetic, bit-identical per weight."""
+
+    @staticmethod
+    def forward(ctx, iterate, eps, *wuv):
+        n = len(wuv) // 3
+        ws = [_f32(wuv[3 * i]).contiguous() for i in range(n)]
+        items = (_lib.SnFwdItem * n)()
+        outs, smalls, keep = [], [], []
+        for i, w in enumerate(ws):
+            u, v = wuv[3 * i + 1], wuv[3 * i + 2]
+            Cout = w.shape[0]
+            K = w.numel() // Cout
+            nbytes = lib.csg_spectral_norm_workspace(Cout, K)
+            if nbytes < 0:
+                raise RuntimeError("spectral_weight: weight (%d x %d) needs K %% 4 == 0" % (Cout, K))
+            wsb = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+            cl = w.shape[1] if (w.dim() == 4 and w.shape[1] % 4 == 0 and w.shape[2] * w.shape[3] > 1
+                               and w.shape[2] * w.shape[3] * (w.shape[1] + 4) * 4 <= 65536) else 0
+            w_eff = torch.empty_like(w, memory_format=torch.channels_last) if cl else torch.empty_like(w)
+            small = torch.empty(1 + Cout + K, device=w.device, dtype=torch.float32)      # sigma | u_used | v_used
+            it = items[i]
+            it.w, it.u, it.v, it.Cout, it.K = w.data_ptr(), u.data_ptr(), v.data_ptr(), Cout, K
+            it.w_eff, it.cl_Cin = w_eff.data_ptr(), cl
+            it.sigma, it.u_used, it.v_used = small.data_ptr(), small.data_ptr() + 4, small.data_ptr() + 4 * (1 + Cout)
+            it.workspace, it.workspace_bytes = wsb.data_ptr(), nbytes
+            outs.append(w_eff)
+            smalls.append(small)
+            keep.append(wsb)
+        check(lib.csg_spectral_norm_fwd_multi(items, n, 1 if iterate else 0, eps, stream()), "spectral_norm_fwd_multi")
+        ctx.n = n
+        ctx.save_for_backward(*ws, *smalls)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dweffs):
+        n = ctx.n
+        ws, smalls = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        idx = [i for i in range(n) if dweffs[i] is not None and ctx.needs_input_grad[2 + 3 * i]]
+        grads = [None] * (2 + 3 * n)
+        if not idx:
+            return tuple(grads)
+        items = (_lib.SnBwdItem * len(idx))()
+        keep = []
+        for j, i in enumerate(idx):
+            w, small = ws[i], smalls[i]
+            Cout = w.shape[0]
+            K = w.numel() // Cout
+            Cin, KH, KW = (w.shape[1], w.shape[2], w.shape[3]) if w.dim() == 4 else (K, 1, 1)
+            dweff = _f32(dweffs[i])
+            st = dweff.stride() if dweff.dim() == 4 else (K, 1, 1, 1)
+            if not _rows_dense(st, (Cin, KH, KW), K):
+                dweff = dweff.contiguous()
+                st = dweff.stride() if dweff.dim() == 4 else (K, 1, 1, 1)
+            nbytes = lib.csg_spectral_norm_workspace(Cout, K)
+            wsb = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+            dw = torch.empty_like(w)
+            it = items[j]
+            it.dweff, it.Cout, it.Cin, it.KH, it.KW = dweff.data_ptr(), Cout, Cin, KH, KW
+            it.s0, it.s1, it.s2, it.s3 = st[0], st[1], st[2], st[3]
+            it.w, it.sigma = w.data_ptr(), small.data_ptr()
+            it.u_used, it.v_used = small.data_ptr() + 4, small.data_ptr() + 4 * (1 + Cout)
+            it.dw, it.workspace, it.workspace_bytes = dw.data_ptr(), wsb.data_ptr(), nbytes
+            keep += [dweff, wsb]
+            grads[2 + 3 * i] = dw
+        check(lib.csg_spectral_norm_bwd_multi(items, len(idx), stream()), "spectral_norm_bwd_multi")
+        return tuple(grads)
+
+
+def spectral_weights(wuv, iterate, eps=1e-12):
+    """[(weight_orig, u, v), ...] -> [W / sigma, ...] (see _SpectralWeightMulti)."""
+    flat = [t for triple in wuv for t in triple]
+    for t in flat:
+        if not t.is_cuda:
+            raise RuntimeError("canonicalsg2im_amd ops need HIP (cuda) tensors; there is no CPU path")
+    return list(_SpectralWeightMulti.apply(bool(iterate), float(eps), *flat))
 
 
 def _rows_dense(st, dims, K):

@@ -8,6 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
+from .... import spectral_norm as csg_spectral_norm
 from ....sg2im.attribute_embed import AttributeEmbeddings
 from ....sg2im.layers import Conv2d, GlobalAvgPool, Linear, _FusedActivation, build_hot_cnn, build_mlp
 from ....sg2im.utils import real_object_mask
@@ -103,6 +104,7 @@ class MultiscaleDiscriminator(BaseNetwork):
 
     def forward(self, img, objs, layout_boxes, layout_masks=None, gt_train=True, fool=False):
         """`fool` is accepted and ignored, as in the reference."""
+        csg_spectral_norm.prepare(self)              # the spectrally normalised weights of every scale, one launch per stage
         obj_vecs = self.attribute_embedding(objs)
         valid = real_object_mask(objs, self.opt.vocab)
         S = obj_vecs.size(-1)

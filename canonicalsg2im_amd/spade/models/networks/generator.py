@@ -3,6 +3,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
+from .... import spectral_norm as csg_spectral_norm
 from ....sg2im.attribute_embed import AttributeEmbeddings
 from ....sg2im.layers import Conv2d, GlobalAvgPool, build_cnn, build_mlp
 from ....sg2im.utils import real_object_mask
@@ -72,6 +73,7 @@ class SPADEGenerator(BaseNetwork):
     def forward(self, objs, layout_boxes, layout_masks, test_mode=False):
         if self.sw != self.sh:
             raise NotImplementedError("aspect_ratio != 1 is not on the hot path")
+        csg_spectral_norm.prepare(self)              # all 18 spectrally normalised weights in one launch per stage
         H = self.opt.image_size[0]
         levels = [self.sw << k for k in range(H.bit_length()) if (self.sw << k) <= H]
         valid = real_object_mask(objs, self.opt.vocab)

@@ -4,14 +4,53 @@ state_dict hooks) whose per-call arithmetic runs on the HIP kernels of csrc/spec
 
 Registration is torch's own (`SpectralNorm.apply`), so checkpoints, `remove_spectral_norm` and the
 state-dict version hooks behave exactly as in the reference; only `compute_weight` is replaced."""
+import os
+
 from torch.nn.utils.spectral_norm import SpectralNorm
 from torch.nn.utils.spectral_norm import spectral_norm as _torch_spectral_norm
 
 from . import ops
 
 
+BATCHED = os.environ.get("CSG_SN_BATCHED", "1") != "0"
+
+
+def prepare(root):
+    """Run the hooks of EVERY spectrally normalised sub-module of `root` now, as one multi-tensor launch per stage
+    (ops.spectral_weights), and park each result on its module; the module's own pre-hook, firing a moment later in the same
+    forward, picks it up instead of computing.  Call at the top of a network's forward whose spectrally normalised layers
+    are each called exactly once per forward (the generator, a PatchGAN scale): the power iterations, u / v updates and
+    W / sigma are then exactly those of the per-module calls, in one launch per stage instead of one per weight."""
+    if not BATCHED:
+        return
+    plan = root.__dict__.get("_sn_plan")
+    if plan is None:
+        plan = []
+        for m in root.modules():
+            for hook in m._forward_pre_hooks.values():
+                if isinstance(hook, HipSpectralNorm):
+                    plan.append((m, hook))
+        root.__dict__["_sn_plan"] = plan
+    if len(plan) < 2:
+        return
+    groups = {}
+    for m, hook in plan:
+        w = getattr(m, hook.name + "_orig")
+        if not w.is_cuda or hook.dim != 0 or hook.n_power_iterations != 1:
+            return                                   # the per-module hook reports what is wrong
+        groups.setdefault((bool(m.training), float(hook.eps)), []).append((m, hook, w))
+    for (training, eps), items in groups.items():
+        outs = ops.spectral_weights([(w, getattr(m, h.name + "_u"), getattr(m, h.name + "_v")) for m, h, w in items],
+                                    training, eps)
+        for (m, h, _), w_eff in zip(items, outs):
+            m.__dict__["_sn_prepared"] = (h.name, w_eff)
+
+
 class HipSpectralNorm(SpectralNorm):
     def compute_weight(self, module, do_power_iteration):
+        ready = module.__dict__.pop("_sn_prepared", None)
+        if ready is not None and ready[0] == self.name:
+            return ready[1]
         weight = getattr(module, self.name + "_orig")
         if not weight.is_cuda:
             raise RuntimeError("canonicalsg2im_amd ops need HIP (cuda) tensors; got a %s tensor — there is no CPU path"

@@ -426,6 +426,36 @@ int csg_spectral_norm_bwd(const float* dweff, int64_t Cout, int64_t Cin, int64_t
                           const float* v_used, const float* sigma, float* dw, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* Multi-tensor forms: every spectrally normalised weight of a network pass in ONE launch per stage (a generator forward
+ * calls the hook of architecture.py:35-39 on 18 convolutions, a PatchGAN pass on 3 per scale).  Same arithmetic and
+ * bit-identical results per weight as the single-tensor calls; `workspace` per item as csg_spectral_norm_workspace. */
+typedef struct csg_sn_fwd_item {
+  const float* w;
+  float* u;
+  float* v;
+  int64_t Cout, K;
+  float* w_eff;
+  int64_t cl_Cin;
+  float* sigma;
+  float* u_used;
+  float* v_used;
+  void* workspace;
+  int64_t workspace_bytes;
+} csg_sn_fwd_item;
+int csg_spectral_norm_fwd_multi(const csg_sn_fwd_item* items, int32_t n, int32_t iterate, float eps, void* stream);
+typedef struct csg_sn_bwd_item {
+  const float* dweff;
+  int64_t Cout, Cin, KH, KW, s0, s1, s2, s3;
+  const float* w;
+  const float* u_used;
+  const float* v_used;
+  const float* sigma;
+  float* dw;
+  void* workspace;
+  int64_t workspace_bytes;
+} csg_sn_bwd_item;
+int csg_spectral_norm_bwd_multi(const csg_sn_bwd_item* items, int32_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,8 +35,8 @@ def _worker(rank, world, port, out):
     mine = shard_batch(full, rank, world)
     x = mine[2].reshape(mine[2].shape[0], -1)[:, :6]    # boxes as features
     buckets = D.GradBuckets(list(net.parameters()) + list(unused.parameters()), bucket_bytes=256)
-    # first backward: buckets do not exist yet — they are built at the first synchronisation from the parameters
-    # that received a gradient (the unused module stays out)
+    # first backward: buckets do not exist yet — they are built at the first synchronisation from the UNION over ranks
+    # of the parameters that received a gradient (the unused module stays out)
     buckets.begin()
     loss = net(x).pow(2).mean()
     loss.backward()
@@ -59,13 +59,21 @@ def _worker(rank, world, port, out):
     for p, g in zip(net.parameters(), averaged):
         assert torch.equal(p.grad, g)
         assert p.grad.data_ptr() == buckets.slot[id(p)][1].data_ptr()
-    # a backward in which one parameter gets no gradient: its slot contributes zeros, the others still average
+    # a backward in which a member gets no LOCAL gradient on one rank (a shard that left a branch empty): that rank
+    # contributes zeros and receives the other rank's average — same collectives on both ranks, same `.grad` afterwards
     for p in net.parameters():
         p.grad = None
     buckets.begin()
-    (net[0](x).pow(2).mean()).backward()                      # only the first Linear
+    if rank == 0:
+        (net[0](x).pow(2).mean()).backward()                  # rank 0: only the first Linear
+    else:
+        net(x).pow(2).mean().backward()
+    second_local = net[2].weight.grad.clone() if rank == 1 else torch.zeros_like(net[2].weight)
     buckets.finish()
-    assert net[2].weight.grad is None and net[0].weight.grad is not None
+    both2 = [torch.empty_like(second_local) for _ in range(world)]
+    dist.all_gather(both2, second_local)
+    assert net[2].weight.grad is not None and torch.allclose(net[2].weight.grad, sum(both2) / world, rtol=1e-6, atol=1e-9)
+    assert net[2].weight.grad.data_ptr() == buckets.slot[id(net[2].weight)][1].data_ptr()
     for p, g in zip(net.parameters(), local):                 # restore the first result for the checks below
         p.grad = None
     buckets.begin()
@@ -86,31 +94,46 @@ def _worker(rank, world, port, out):
     assert rep["world_size"] == world and rep["backend"] == "gloo"
     assert rep["grad_allreduce_calls_per_step"] == len(buckets.flats) and rep["grad_allreduce_bytes_per_step"] == nbytes
     assert rep["grad_copy_bytes_per_step"] == nbytes
-    # a parameter that receives its FIRST gradient on a later step (a branch inactive until now): exchanged by an
-    # extra collective in that step, then the buckets are rebuilt around the new set
+    # a parameter outside the agreed set that receives a gradient on a later step (a branch inactive until now): the
+    # exchange refuses loudly — it cannot know whether the other ranks hold one — and the COLLECTIVE rebuild() re-agrees
+    # the set; the buckets then work in steady state around the new set
     for p in list(net.parameters()) + list(unused.parameters()):
         p.grad = None
     buckets.begin()
     x4 = x[:, :4]
     (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
     lw = unused.weight.grad.clone()
-    buckets.finish()
+    try:
+        buckets.finish()
+        raise AssertionError("a late parameter must make the exchange raise")
+    except RuntimeError as e:
+        assert "rebuild()" in str(e)
+    buckets.finish()                                          # the members' collectives were issued before the refusal
+    buckets.rebuild()
     assert buckets.rebuilds == 1 and all(id(p) in buckets.slot for p in unused.parameters())
+    for p in list(net.parameters()) + list(unused.parameters()):
+        p.grad = None
+    buckets.begin()
+    (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
+    buckets.finish()
     both = [torch.empty_like(lw) for _ in range(world)]
     dist.all_gather(both, lw)
     assert torch.allclose(unused.weight.grad, sum(both) / world, rtol=1e-6, atol=1e-8)
     for p, g in zip(net.parameters(), averaged):
         assert torch.equal(p.grad, g)
     assert unused.weight.grad.data_ptr() == buckets.slot[id(unused.weight)][1].data_ptr()
-    late_avg = unused.weight.grad.clone()
-    for p in list(net.parameters()) + list(unused.parameters()):     # and the rebuilt buckets work in steady state
-        p.grad = None
-    buckets.begin()
-    (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
-    buckets.finish()
-    assert torch.allclose(unused.weight.grad, late_avg, rtol=1e-6, atol=1e-8) and buckets.rebuilds == 1
-    for p, g in zip(net.parameters(), averaged):
-        assert torch.equal(p.grad, g)
+    # a rank-local first step: rank 1's shard leaves the second Linear without a gradient BEFORE any bucket exists —
+    # the union still puts it into the buckets of both ranks
+    net2 = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    D.broadcast_module(net2)
+    b2 = D.GradBuckets(list(net2.parameters()), bucket_bytes=1 << 20)
+    b2.begin()
+    if rank == 0:
+        net2(x).pow(2).mean().backward()
+    else:
+        net2[0](x).pow(2).mean().backward()
+    b2.finish()
+    assert all(id(p) in b2.slot for p in net2.parameters()) and net2[2].weight.grad is not None
     # SyncBN message
     xs = torch.randn(2, 5, 4, 4, generator=torch.Generator().manual_seed(7 + rank)) * (1 + rank) + rank
     C = 5

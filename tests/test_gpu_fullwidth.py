@@ -160,7 +160,8 @@ def _check_step(tr, res, tag, sg_band=False):
         errs = []
         for group in ("G", "D"):
             for k, mine, want, _ in res["rows"][group]:
-                if float(want.abs().max()) < 1e-12:
+                if float(want.abs().max()) < 1e-5:          # analytically zero (a bias in front of a normalisation): noise
+                    assert float(mine.abs().max()) < 1e-4, group + " " + k + " should vanish"
                     continue
                 errs.append((errors(mine, want)[0], group + " " + k))
         errs.sort()

@@ -547,6 +547,38 @@ def test_spectral_norm_vs_torch(ops, shape):
     assert torch.equal(mine.weight_u, u_before)               # no power iteration in eval mode
 
 
+def test_spectral_norm_multi_is_bit_identical_to_single(ops):
+    """The multi-tensor spectral normalisation (csg_spectral_norm_*_multi: every weight of a network pass in one launch
+    per stage) against the per-weight calls: W / sigma, the updated u / v buffers and d weight_orig bit for bit — 14
+    weights (more than one chunk of 12) of mixed shapes, two training-mode calls and an eval call."""
+    shapes = [(64, 32, 3, 3), (128, 64, 4, 4), (256, 128, 4, 4), (20, 12, 1, 1), (512, 256, 3, 3), (1024, 1024, 3, 3),
+              (64, 64, 3, 3), (32, 16, 1, 1), (128, 128, 3, 3), (512, 256, 4, 4), (96, 48, 3, 3), (256, 256, 1, 1),
+              (40, 8, 3, 3), (128, 32, 3, 3)]
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(sh, generator=g).cuda() for sh in shapes]
+
+    def fresh():
+        gg = torch.Generator().manual_seed(6)
+        us = [torch.nn.functional.normalize(torch.randn(sh[0], generator=gg), dim=0).cuda() for sh in shapes]
+        vs = [torch.nn.functional.normalize(torch.randn(sh[1] * sh[2] * sh[3], generator=gg), dim=0).cuda() for sh in shapes]
+        return us, vs
+    us1, vs1 = fresh()
+    us2, vs2 = fresh()
+    for call, iterate in enumerate([True, True, False]):
+        w1 = [w.clone().requires_grad_(True) for w in ws]
+        w2 = [w.clone().requires_grad_(True) for w in ws]
+        single = [ops.spectral_weight(w, u, v, iterate) for w, u, v in zip(w1, us1, vs1)]
+        multi = ops.spectral_weights(list(zip(w2, us2, vs2)), iterate)
+        cots = [torch.randn(sh[0], sh[2], sh[3], sh[1], generator=g).cuda().permute(0, 3, 1, 2) for sh in shapes]
+        torch.autograd.backward(single, cots)
+        torch.autograd.backward(multi, cots)
+        for i, sh in enumerate(shapes):
+            assert single[i].stride() == multi[i].stride(), sh
+            assert torch.equal(single[i], multi[i]), "W_eff %s call %d" % (sh, call)
+            assert torch.equal(us1[i], us2[i]) and torch.equal(vs1[i], vs2[i]), "u / v %s call %d" % (sh, call)
+            assert torch.equal(w1[i].grad, w2[i].grad), "dW_orig %s call %d" % (sh, call)
+
+
 def test_object_crops_golden(ops):
     """crop_bbox_batch of the reference (expand + grid_sample) vs the gather kernel, fwd + d(image)."""
     from canonicalsg2im_amd.synth import make_vocab
