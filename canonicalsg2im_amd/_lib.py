@@ -27,7 +27,7 @@ class ConvDesc(ctypes.Structure):
         ("Cout", c_i32), ("y_cs", c_i32),
         ("istride", c_i32), ("ntaps", c_i32), ("wtaps", c_i32),
         ("tap_dy", c_i32 * MAX_TAPS), ("tap_dx", c_i32 * MAX_TAPS), ("tap_w", c_i32 * MAX_TAPS),
-        ("act", c_i32), ("slope", c_f32), ("accumulate", c_i32),
+        ("act", c_i32), ("slope", c_f32), ("accumulate", c_i32), ("res_gate", c_i32),
     ]
 
 
@@ -75,7 +75,7 @@ SIGNATURES = {
     "csg_segment_avg_fwd_workspace": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "csg_segment_avg_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                                     c_i64, c_p]),
-    "csg_segment_avg_bwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64,
+    "csg_segment_avg_bwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32,
                                     c_p, c_p, c_p, c_p]),
     "csg_layout_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64,
                                c_i64, c_p]),

@@ -514,8 +514,8 @@ __global__ __launch_bounds__(64) void k_segment_avg_bwd(const float* __restrict_
                                                          const uint8_t* __restrict__ valid,
                                                          const int64_t* __restrict__ triplets,
                                                          const float* __restrict__ cnt, const float* __restrict__ dcnt,
-                                                         int O, int T, int H, int Dp, float* __restrict__ dh,
-                                                         float* __restrict__ dconf) {
+                                                         int O, int T, int H, int Dp, int gate_relu,
+                                                         float* __restrict__ dh, float* __restrict__ dconf) {
   const int64_t bt = blockIdx.x;
   const int64_t b = bt / T;
   const int Dh = 2 * H + Dp;
@@ -534,13 +534,14 @@ __global__ __launch_bounds__(64) void k_segment_avg_bwd(const float* __restrict_
   for (int d = threadIdx.x; d < H; d += 64) {
     float gs = dps[d] * sc_s;
     float go = dpo[d] * sc_o;
-    dhp[d] = gs * c;
-    dhp[H + Dp + d] = go * c;
+    // gate_relu: h is the output of a ReLU and dh goes to that ReLU's producer as the gradient of its PRE-activation
+    dhp[d] = (gate_relu && !(hp[d] > 0.f)) ? 0.f : gs * c;
+    dhp[H + Dp + d] = (gate_relu && !(hp[H + Dp + d] > 0.f)) ? 0.f : go * c;
     acc += gs * hp[d] + go * hp[H + Dp + d];
   }
   for (int d = threadIdx.x; d < Dp; d += 64) {
     float gp = dnew_p ? dnew_p[bt * Dp + d] : 0.f;
-    dhp[H + d] = gp * c;
+    dhp[H + d] = (gate_relu && !(hp[H + d] > 0.f)) ? 0.f : gp * c;
     acc += gp * hp[H + d];
   }
   acc = wave_sum(acc);
@@ -711,8 +712,8 @@ int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid,
 
 int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* h, const float* conf,
                         const uint8_t* valid, const int64_t* triplets, const float* pooled, const float* cnt,
-                        int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, float* dh, float* dconf,
-                        float* dcnt_scratch, void* stream) {
+                        int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, int32_t gate_relu, float* dh,
+                        float* dconf, float* dcnt_scratch, void* stream) {
   CSG_REQUIRE(B > 0 && O > 0 && T >= 0 && H > 0 && Dp >= 0, CSG_E_BADSHAPE, "csg_segment_avg_bwd: bad shape");
   if (T == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -720,7 +721,7 @@ int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* 
   CSG_LAUNCH(k_segavg_dcnt, dim3((unsigned)(B * O)), dim3(64), 0, s, dpooled, pooled, cnt, (int)H,
                      dcnt_scratch);
   CSG_LAUNCH(k_segment_avg_bwd, dim3((unsigned)(B * T)), dim3(64), 0, s, dpooled, dnew_p, h, conf, valid,
-                     triplets, cnt, dcnt_scratch, (int)O, (int)T, (int)H, (int)Dp, dh, dconf);
+                     triplets, cnt, dcnt_scratch, (int)O, (int)T, (int)H, (int)Dp, (int)gate_relu, dh, dconf);
   return check_launch("csg_segment_avg_bwd");
 }
 

@@ -408,7 +408,12 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(typename std::conditional<
           }
           if (rrow != nullptr) {
             const float4 rv = *(const float4*)(rrow + n);
-            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+            if (d.res_gate) {
+              v[0] *= rv.x > 0.f ? 1.f : d.slope; v[1] *= rv.y > 0.f ? 1.f : d.slope;
+              v[2] *= rv.z > 0.f ? 1.f : d.slope; v[3] *= rv.w > 0.f ? 1.f : d.slope;
+            } else {
+              v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+            }
           }
           if (d.accumulate) {
             const float4 ov = *(const float4*)(yrow + n);
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm_fwd(typename std::conditional<
                 t = t > 0.f ? t : t * d.slope;
               else if (d.act == CSG_ACT_TANH)
                 t = tanhf(t);
-              if (rrow != nullptr) t += rrow[n + j];
+              if (rrow != nullptr) t = d.res_gate ? t * (rrow[n + j] > 0.f ? 1.f : d.slope) : t + rrow[n + j];
               if (d.accumulate) t += yrow[n + j];
               yrow[n + j] = t;
             }
@@ -482,7 +487,10 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(typename std::condition
         t = t > 0.f ? t : t * d.slope;
       else if (d.act == CSG_ACT_TANH)
         t = tanhf(t);
-      if (res != nullptr) t += res[pix * d.y_cs + n + j];
+      if (res != nullptr) {
+        const float rv = res[pix * d.y_cs + n + j];
+        t = d.res_gate ? t * (rv > 0.f ? 1.f : d.slope) : t + rv;
+      }
       if (d.accumulate) t += dst[j];
       dst[j] = t;
     }
@@ -947,6 +955,8 @@ int csg_conv_fwd(const csg_conv_desc* d, const float* x, const float* w, const f
   if (rc) return rc;
   CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, CSG_E_UNSUPPORTED,
               "csg_conv_fwd: x and w must be 16-byte aligned");
+  CSG_REQUIRE(!d->res_gate || (d->act == CSG_ACT_NONE && residual != nullptr && !d->accumulate), CSG_E_UNSUPPORTED,
+              "csg_conv_fwd: res_gate needs act == NONE, a residual (the gating tensor) and no accumulation");
   IgemmParams p;
   fill(p, d);
   fwd_plan(p);

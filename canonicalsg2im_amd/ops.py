@@ -370,8 +370,15 @@ class _Conv2d(torch.autograd.Function):
             wt = ctx.packs[1] if ctx.packs is not None else \
                 weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
-            _conv_launch_classes(_descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW), dpre, wt, ptr(dx),
-                                 dy.device, "conv_bwd_data")
+            descs = _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW)
+            if ctx.in_act is not None and len(descs) == 1:
+                # the producer's (Leaky)ReLU derivative in the epilogue: x (its output) rides in the residual slot as a gate
+                d = descs[0]
+                d.res_gate, d.slope = 1, ctx.in_act[1]
+                _conv_launch(d, dpre, wt, None, x, dx, "conv_bwd_data")
+                gated = True
+            else:
+                _conv_launch_classes(descs, dpre, wt, ptr(dx), dy.device, "conv_bwd_data")
         if dx is not None and not gated:              # the producer's activation derivative as a separate pass
             check(lib.csg_act_bwd(ptr(dx), ptr(x), dx.numel(), ctx.in_act[0], ctx.in_act[1], ptr(dx), stream()), "act_bwd")
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
@@ -476,15 +483,17 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, r
     return y[:, :Cout] if po else y
 
 
-def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
-    """F.linear (+ReLU) as a 1x1 implicit GEMM: rows of x are 'pixels'."""
+def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0, in_act=None, grad_is_pre=False):
+    """F.linear (+ReLU) as a 1x1 implicit GEMM: rows of x are 'pixels'.  `in_act` / `grad_is_pre`: as conv2d's (a Linear ->
+    ReLU -> Linear chain: the second Linear's backward-data pass applies the ReLU derivative in its epilogue and the first
+    receives the gradient of its pre-activation directly)."""
     lead = x.shape[:-1]
     K = x.shape[-1]
     N = weight.shape[0]
     x2 = x.reshape(-1, K)
     if not x2.is_contiguous():
         x2 = x2.contiguous()
-    y = conv2d(x2.view(-1, K, 1, 1), weight.view(N, K, 1, 1), bias, 1, 0, act, slope)
+    y = conv2d(x2.view(-1, K, 1, 1), weight.view(N, K, 1, 1), bias, 1, 0, act, slope, in_act=in_act, grad_is_pre=grad_is_pre)
     return y.reshape(*lead, N)
 
 
@@ -1145,7 +1154,9 @@ class _SegmentAvg(torch.autograd.Function):
     """(pooled (B,O,H), new_p (B,T,Dp)) from net1's output h (B,T,2H+Dp) and confidences (B,T)."""
 
     @staticmethod
-    def forward(ctx, h, conf, valid, triplets, row_ptr, col, H, Dp):
+    def forward(ctx, h, conf, valid, triplets, row_ptr, col, H, Dp, h_is_relu=False):
+        """`h_is_relu`: h is the output of a ReLU whose only consumer is this call; the backward then returns the gradient of
+        the ReLU's pre-activation (the producer runs with grad_is_pre) — no activation-derivative pass over (B,T,2H+Dp)."""
         h, conf = _f32(h).contiguous(), _f32(conf).contiguous()
         B, T, _ = h.shape
         O = row_ptr.shape[1] - 1
@@ -1158,6 +1169,7 @@ class _SegmentAvg(torch.autograd.Function):
                                       ptr(pooled), ptr(cnt), ptr(new_p), ptr(ws), nbytes, stream()), "segment_avg_fwd")
         ctx.save_for_backward(h, conf, valid, triplets, pooled, cnt)
         ctx.dims = (B, O, T, H, Dp)
+        ctx.h_is_relu = bool(h_is_relu)
         return pooled, new_p
 
     @staticmethod
@@ -1170,13 +1182,13 @@ class _SegmentAvg(torch.autograd.Function):
         dconf = torch.empty_like(conf)
         scratch = torch.empty((B, O), device=h.device, dtype=torch.float32)
         check(lib.csg_segment_avg_bwd(ptr(dpooled), ptr(dnew_p), ptr(h), ptr(conf), ptr(valid), ptr(triplets),
-                                      ptr(pooled), ptr(cnt), B, O, T, H, Dp, ptr(dh), ptr(dconf), ptr(scratch),
-                                      stream()), "segment_avg_bwd")
-        return dh, dconf, None, None, None, None, None, None
+                                      ptr(pooled), ptr(cnt), B, O, T, H, Dp, 1 if ctx.h_is_relu else 0, ptr(dh), ptr(dconf),
+                                      ptr(scratch), stream()), "segment_avg_bwd")
+        return dh, dconf, None, None, None, None, None, None, None
 
 
-def segment_avg(h, conf, valid, triplets, row_ptr, col, H, Dp):
-    return _SegmentAvg.apply(h, conf, valid, triplets, row_ptr, col, int(H), int(Dp))
+def segment_avg(h, conf, valid, triplets, row_ptr, col, H, Dp, h_is_relu=False):
+    return _SegmentAvg.apply(h, conf, valid, triplets, row_ptr, col, int(H), int(Dp), bool(h_is_relu))
 
 
 # ------------------------------------------------------------------------------------ layout

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .layers import build_mlp
+from .layers import Linear, _FusedActivation, build_mlp
 
 ORIGINAL_EDGE, TRANSITIVE_EDGE, SYMMETRIC_EDGE, ANTI_SYMMETRIC_EDGE = 0, 1, 2, 3   # sg2im/data/base_dataset.py:7-10
 
@@ -53,13 +53,24 @@ class GraphTripleConv(nn.Module):
             topology = GraphTopology(triplets, pred_indicators, obj_vecs.size(1))
         t = topology
         cur_t = ops.gather_concat(obj_vecs, pred_vecs, t.triplets, t.row_ptr, t.col)      # graph.py:63-66
-        h = self.net1(cur_t)                                                              # :67
+        # net1 (:67).  Its final ReLU feeds ONLY the segment average below, whose backward then returns the gradient of
+        # the pre-activation (h_is_relu): no activation-derivative pass over the (B, T, 2H + Dp) tensor
+        last = self.net1[-2] if len(self.net1) >= 2 else None
+        relu_tail = (isinstance(last, Linear) and last.fused_slope == 0.0 and isinstance(self.net1[-1], _FusedActivation)
+                     and last.out_features % 4 == 0)
+        if relu_tail:
+            h = cur_t
+            for m in list(self.net1)[:-2]:
+                h = m(h)
+            h = last(h, grad_is_pre=True)
+        else:
+            h = self.net1(cur_t)
         # confidence gate (:69-74): P-sized sigmoid stays a torch op so autograd reaches the weights
         tt = triplet_type
         sig = torch.sigmoid(self.predicates_transitive_weights)
         conf = (tt == ORIGINAL_EDGE).to(h.dtype) + (tt == TRANSITIVE_EDGE).to(h.dtype) * sig[predicate_ids]
         pooled, new_p = ops.segment_avg(h, conf, t.valid, t.triplets, t.row_ptr, t.col, self.hidden_dim,
-                                        self.predicate_output_dim)                        # :76-109
+                                        self.predicate_output_dim, h_is_relu=relu_tail)   # :76-109
         new_obj = self.net2(pooled)                                                       # :110
         if not self.return_new_p_vecs:
             new_p = pred_vecs

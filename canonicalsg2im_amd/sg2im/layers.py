@@ -15,11 +15,21 @@ class Linear(nn.Linear):
         super().__init__(din, dout, bias=bias)
         self.fused_relu = fused_relu
         self.fused_slope = 0.0 if (fused_relu and fused_slope is None) else fused_slope
+        # set by build_mlp for a Linear -> (Leaky)ReLU -> Linear chain with nothing in between: the second Linear's
+        # backward-data pass applies the activation derivative in its epilogue (`in_slope`: the slope of the activation
+        # that produced its input), the first receives the gradient of its pre-activation (`grad_is_pre`) — no separate
+        # activation-derivative pass over the hidden tensor
+        self.in_slope = None
+        self.grad_is_pre = False
 
-    def forward(self, x):
+    def forward(self, x, grad_is_pre=None):
+        """`grad_is_pre=True` (per call): the caller's consumer of this layer's fused activation returns the gradient of the
+        pre-activation itself (GraphTripleConv: ops.segment_avg(h_is_relu=True))."""
+        pre = self.grad_is_pre if grad_is_pre is None else bool(grad_is_pre)
+        in_act = (ops.ACT_LEAKY, float(self.in_slope)) if (self.in_slope is not None and x.requires_grad) else None
         if self.fused_slope is None:
-            return ops.linear(x, self.weight, self.bias, ops.ACT_NONE, 0.0)
-        return ops.linear(x, self.weight, self.bias, ops.ACT_LEAKY, float(self.fused_slope))
+            return ops.linear(x, self.weight, self.bias, ops.ACT_NONE, 0.0, in_act=in_act)
+        return ops.linear(x, self.weight, self.bias, ops.ACT_LEAKY, float(self.fused_slope), in_act=in_act, grad_is_pre=pre)
 
 
 class Conv2d(nn.Conv2d):
@@ -101,6 +111,12 @@ def build_mlp(dim_list, activation='relu', batch_norm='none', dropout=0, final_n
         if last and final_nonlinearity is not None:
             fused = tail is not None and slope is not None
             layers.append(_FusedActivation() if fused else get_activation(final_nonlinearity))
+    # Linear -> fused (Leaky)ReLU -> Linear with nothing in between: hand the activation derivative to the consumer
+    linears = [m for m in layers if isinstance(m, Linear)]
+    if batch_norm == 'none' and dropout == 0:
+        for a, b in zip(linears[:-1], linears[1:]):
+            if a.fused_slope is not None and a.out_features % 4 == 0:
+                a.grad_is_pre, b.in_slope = True, a.fused_slope
     return nn.Sequential(*layers)
 
 

@@ -98,11 +98,13 @@ int64_t csg_segment_avg_fwd_workspace(int64_t B, int64_t O, int64_t T, int64_t H
 int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid, const int32_t* row_ptr,
                         const int32_t* col, int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, float* pooled,
                         float* cnt, float* new_p, void* workspace, int64_t workspace_bytes, void* stream);
-/* dcnt_scratch (B,O) float workspace */
+/* dcnt_scratch (B,O) float workspace.  gate_relu = 1: h is the output of a ReLU (the final non-linearity of net1,
+ * sg2im/graph.py:67) and dh is written as the gradient of its PRE-activation (zero where h <= 0): the producing Linear
+ * needs no activation-derivative pass. */
 int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* h, const float* conf,
                         const uint8_t* valid, const int64_t* triplets, const float* pooled, const float* cnt,
-                        int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, float* dh, float* dconf,
-                        float* dcnt_scratch, void* stream);
+                        int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, int32_t gate_relu, float* dh,
+                        float* dconf, float* dcnt_scratch, void* stream);
 
 /* ---- K6: boxes_to_layout (sg2im/layout.py:12-45) and masks_to_layout (:48-77, train mode), batched
  * out[b, y, x, out_off + d] = sum_o valid[b,o] * vecs[b,o,d] * cov(y_src) * cov(x_src)
@@ -153,7 +155,11 @@ int csg_layout_paint(const float* vecs, const float* boxes, const float* masks, 
  *   iy = gy*istride + tap_dy[t], ix = gx*istride + tap_dx[t]; outside [0,IHv)x[0,IWv) reads 0;
  *   the physical source pixel is (iy >> in_up, ix >> in_up) (nearest 2x upsample folded in).
  * Packed weights: w[n][tap_w[t]][c], c fastest, row length wtaps*Cin.
- * Output pixel of grid point: (gy*os + ooy, gx*os + oox) in an (OHf,OWf) image.                */
+ * Output pixel of grid point: (gy*os + ooy, gx*os + oox) in an (OHf,OWf) image.
+ * res_gate = 1: `residual` is not added but GATES the result, y = result * (residual > 0 ? 1 : slope) — the derivative
+ * of the (Leaky)ReLU whose output `residual` is: a backward-data pass hands the producer of its input the gradient of the
+ * PRE-activation and no separate activation-derivative pass runs.  Requires act == CSG_ACT_NONE (slope is then the
+ * gate's negative slope).                                                                                            */
 typedef struct csg_conv_desc {
   int32_t B, IHp, IWp, Cin, x_cs;
   int32_t IHv, IWv, in_up;
@@ -164,6 +170,7 @@ typedef struct csg_conv_desc {
   int32_t act;
   float slope;
   int32_t accumulate; /* y += result (after bias/act) instead of y = */
+  int32_t res_gate; /* 1: the residual gates the result instead of being added (see above) */
 } csg_conv_desc;
 
 /* y = act(conv(x, w) + bias) [+ residual];  bias and residual may be NULL; residual has y's layout.

@@ -36,7 +36,7 @@ def test_conv_descriptor_struct_matches_header(built):
     body = hdr[hdr.index("typedef struct csg_conv_desc {"):hdr.index("} csg_conv_desc;")]
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)(?:\[CSG_MAX_TAPS\])?\s*[,;]", body.split("{", 1)[1])
     assert names == [f[0] for f in built.ConvDesc._fields_]
-    assert ctypes.sizeof(built.ConvDesc) == 4 * (20 + 3 * 16 + 3)
+    assert ctypes.sizeof(built.ConvDesc) == 4 * (20 + 3 * 16 + 4)
 
 
 def test_product_never_imports_the_oracle():
