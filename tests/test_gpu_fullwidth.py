@@ -99,7 +99,22 @@ def _step_losses_image_only(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed,
     torch.cuda.empty_cache()
 
 
-def _check_step(tr, res, tag, sg_band=False):
+def _check_gd_against_fp32(res, tag):
+    """Generator / PatchGAN gradients against the fp32 oracle alone (no fp64 evaluation: minutes of CPU).  Gate flips are
+    drawn on BOTH sides (profiles/r04_band_C5.txt, taken with the fp64 leg on: HIP up to 3.9e-3 from fp64, the fp32 oracle
+    up to 2.4e-3), so two fp32 evaluations may differ by their sum: cap 1.5e-2 per tensor, median 3e-3."""
+    errs = []
+    for group in ("G", "D"):
+        for k, mine, want, _ in res["rows"][group]:
+            if float(want.abs().max()) < 1e-5:              # analytically zero (a bias in front of a normalisation): noise
+                assert float(mine.abs().max()) < 1e-4, group + " " + k + " should vanish"
+                continue
+            errs.append((errors(mine, want)[0], group + " " + k))
+    errs.sort()
+    assert errs[-1][0] <= 1.5e-2 and errs[len(errs) // 2][0] <= 3e-3, (tag, errs[-1], errs[len(errs) // 2])
+
+
+def _check_step(tr, res, tag, sg_band=False, fp64=True):
     G, D, Go, Do, img_o = res["G"], res["D"], res["Go"], res["Do"], res["img_o"]
     _check_losses_and_image(tr, G, D, Go, Do, img_o, tag)
 
@@ -153,19 +168,10 @@ def _check_step(tr, res, tag, sg_band=False):
         # (measured: 25 of 2.1e8 decisions, the fp32 oracle itself 37; every one on a |pre-activation| below 4e-7)
         assert flipped <= max(64, 1e-6 * units), "%d of %d ReLU decisions differ from the fp64 oracle" % (flipped, units)
         assert all(rel <= 1e-5 for _, n, _, rel in stats if n), [s for s in stats if s[1]]
-        # generator / PatchGAN gradients of this configuration: against the fp32 oracle alone (the fp64 evaluation of the
-        # S = 128 generator costs minutes of CPU; C3 and C4 put the same kernels through the fp64 band).  Dense scenes draw
-        # gate flips on BOTH sides (profiles/r04_band_C5.txt, taken with the fp64 leg on: HIP up to 3.9e-3 from fp64, the
-        # fp32 oracle up to 2.4e-3), so the two fp32 evaluations may differ by their sum: cap 1.5e-2, median 3e-3.
-        errs = []
-        for group in ("G", "D"):
-            for k, mine, want, _ in res["rows"][group]:
-                if float(want.abs().max()) < 1e-5:          # analytically zero (a bias in front of a normalisation): noise
-                    assert float(mine.abs().max()) < 1e-4, group + " " + k + " should vanish"
-                    continue
-                errs.append((errors(mine, want)[0], group + " " + k))
-        errs.sort()
-        assert errs[-1][0] <= 1.5e-2 and errs[len(errs) // 2][0] <= 3e-3, (errs[-1], errs[len(errs) // 2])
+        _check_gd_against_fp32(res, tag)     # (C3 puts the same kernels through the fp64 band)
+        return
+    if not fp64:
+        _check_gd_against_fp32(res, tag)
         return
     band_of(res, tr, tag, dump=os.path.join(ROOT, "gpurun_out", "r04_band_%s.txt" % tag), outliers=2)
 
@@ -184,8 +190,11 @@ def test_c4_full_width_step_vs_oracle(cuda):
     256x256, 3-30 objects, default recipe, batch 2."""
     from canonicalsg2im_amd.synth import BatchConfig
     tr, res = _run_step(cuda, "vg", ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "2"],
-                        BatchConfig(2, 256, 3, 30, "random"), seed=1, batch_seed=4)
-    _check_step(tr, res, tag="C4")
+                        BatchConfig(2, 256, 3, 30, "random"), seed=1, batch_seed=4, fp64=False)
+    # what C4 changes against C3 is the vocabulary (179 classes, 46 predicates: embedding tables, transitive weights);
+    # the graph encoder's gradients meet the plain contract, the GAN gradients are held to the fp32 oracle (the fp64 band
+    # of the same kernels is C3's test; profiles/r04_band_C4.txt is this test's last run WITH the fp64 leg)
+    _check_step(tr, res, tag="C4", fp64=False)
 
 
 @pytest.mark.parametrize("graphs", [False, True])
