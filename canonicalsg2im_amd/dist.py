@@ -148,8 +148,21 @@ class GradBuckets:
         if has.numel():
             dist.all_reduce(has, op=dist.ReduceOp.MAX)
         live = [p for p, h in zip(self.params, has.tolist()) if h]
-        cur, size, groups = [], 0, []
+        # parameters that are pieces of ONE allocation (SPADE's gamma / beta convolution weights: one joined tensor, one
+        # weight-gradient launch) stay adjacent, in memory order, so that the joined gradient has one contiguous slot
+        by_storage = {}
+        for p in live:
+            by_storage.setdefault(p.untyped_storage().data_ptr(), []).append(p)
+        order, seen = [], set()
         for p in reversed(live):                                 # reverse registration order ~ order of readiness
+            if id(p) in seen:
+                continue
+            fam = sorted(by_storage[p.untyped_storage().data_ptr()], key=lambda q: q.data_ptr())
+            for q in fam:
+                seen.add(id(q))
+                order.append(q)
+        cur, size, groups = [], 0, []
+        for p in order:
             n = p.numel() * 4
             if cur and size + n > self.bucket_bytes:
                 groups.append(cur)
@@ -172,6 +185,24 @@ class GradBuckets:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._hook))
             self.flats.append(flat)
             self.members.append(group)
+        # where the weight-gradient producers write (ops.set_grad_destinations): each parameter's slot, and for runs of
+        # parameters that are adjacent in memory AND in their bucket the joined slot as well
+        self._dests = {}
+        for b, group in enumerate(self.members):
+            off, run = 0, None                                   # run: [first data_ptr, numel so far, flat offset]
+            for p in group:
+                n = p.numel()
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                if dense:
+                    self._dests[(p.data_ptr(), n)] = self.flats[b][off:off + n]
+                    if run is not None and run[0] + run[1] * 4 == p.data_ptr():
+                        run[1] += n
+                        self._dests[(run[0], run[1])] = self.flats[b][run[2]:run[2] + run[1]]
+                    else:
+                        run = [p.data_ptr(), n, off]
+                else:
+                    run = None
+                off += n
         self.built = True
 
     def _launch_ready(self, force=False):
@@ -198,9 +229,10 @@ class GradBuckets:
             return
         b, view = self.slot[id(p)]
         if p.grad is not view:
-            view.copy_(p.grad)
-            if _AUDIT[0]:
-                _COMM["grad_copy_bytes"] += p.grad.numel() * 4
+            if p.grad.data_ptr() != view.data_ptr() or p.grad.stride() != view.stride():
+                view.copy_(p.grad)                               # (producers without a destination: biases, embeddings, ...)
+                if _AUDIT[0]:
+                    _COMM["grad_copy_bytes"] += p.grad.numel() * 4
             p.grad = view
         if view.is_cuda:
             self._streams.setdefault(b, set()).add(torch.cuda.current_stream(view.device))
@@ -214,6 +246,9 @@ class GradBuckets:
         self._fired, self._works, self._next = set(), [], 0
         self._streams = {}
         self._state = "armed"
+        if self.flats and self.flats[0].is_cuda:
+            from . import ops                                    # the producers of this backward write into the slots
+            ops.set_grad_destinations(self._dests)
 
     # ---- per-backward protocol
     def begin(self):
@@ -273,6 +308,9 @@ class GradBuckets:
                     p.grad = self.slot[id(p)][1]
         self._works = []
         self._state = "idle"
+        if self.flats and self.flats[0].is_cuda:
+            from . import ops
+            ops.clear_grad_destinations()
         return sum(f.numel() * 4 for f in self.flats)
 
     def rebuild(self):

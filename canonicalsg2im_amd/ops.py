@@ -224,6 +224,46 @@ def invalidate_weight_caches():
     _bump_weight_epoch()
 
 
+# ---- gradient destinations (N > 1 ranks): `dist.GradBuckets` registers, for the backward that is about to run, where each
+# parameter's gradient has to end up — its slot in a flat all-reduce bucket, laid out like the parameter's own memory.
+# The weight-gradient producers below (convolution / linear, spectral normalisation, the joined gamma || beta convolution)
+# then write there directly and hand autograd an alias of the slot, so `.grad` IS the bucket slot without a copy.  Only the
+# FIRST contribution of a backward takes the slot (a discriminator weight used by two passes accumulates its second
+# contribution into it through autograd's in-place add).  Empty on a single rank.
+_GRAD_DEST = {}
+
+
+def set_grad_destinations(mapping):
+    """mapping: (data_ptr, numel) of a weight tensor as its producer sees it -> 1-D slot of that many floats."""
+    global _GRAD_DEST
+    _GRAD_DEST = {k: [v, False] for k, v in mapping.items()}
+
+
+def clear_grad_destinations():
+    global _GRAD_DEST
+    _GRAD_DEST = {}
+
+
+def _grad_dest(weight, shape):
+    """A fresh tensor of `shape` (row-major) aliasing the registered slot of `weight`, once per registration; else None."""
+    if not _GRAD_DEST:
+        return None
+    e = _GRAD_DEST.get((weight.data_ptr(), weight.numel()))
+    if e is None or e[1]:
+        return None
+    e[1] = True
+    return e[0].view(shape)
+
+
+def _ohwi_dense(w):
+    """True if the memory of the (Cout, Cin, KH, KW) tensor `w` is [Cout][KH][KW][Cin] dense — what the weight-gradient
+    kernels write (channels-last parameters, 1 x 1 kernels, linears)."""
+    Cout, Cin, KH, KW = w.shape
+    if KH * KW == 1:
+        return w.stride(0) == Cin and (Cin == 1 or w.stride(1) == 1)
+    return w.stride() == (KH * KW * Cin, 1, KW * Cin, Cin)
+
+
 def _few_desc(B, IH, IW, Cin, KH, KW, stride, pad, cout_real, act, slope):
     """Descriptor of csrc/fewn.hip if this convolution is one it serves (<= 4 outputs, stride 1, 3x3 or 4x4), else None."""
     if not FEW_ENABLED or cout_real is None or stride != 1 or KH != KW:
@@ -391,7 +431,9 @@ class _Conv2d(torch.autograd.Function):
             # Winograd F(3x3,2x2) weight gradient (csrc/wino.hip), same output layout as the direct kernel
             nbytes = wino_wg
             ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
-            dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
+            dwp = _grad_dest(weight, (Cout, KH, KW, Cin)) if _ohwi_dense(weight) else None
+            if dwp is None:
+                dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
             if want_db:
                 db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
             check(lib.csg_wino_bwd_weight(d, ptr(x), ptr(dpre), ptr(dwp), ptr(db), ptr(ws), nbytes, stream()),
@@ -403,7 +445,9 @@ class _Conv2d(torch.autograd.Function):
             if nbytes < 0:
                 raise RuntimeError("conv_bwd_weight_workspace: " + _lib.last_error())
             ws = torch.empty(max(nbytes // 4, 4), device=dy.device, dtype=torch.float32)
-            dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
+            dwp = _grad_dest(weight, (Cout, KH, KW, Cin)) if _ohwi_dense(weight) else None
+            if dwp is None:
+                dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
             if want_db:                                   # column sums of dY ride along in the same kernel
                 db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
             check(lib.csg_conv_bwd_weight(d, ptr(x), ptr(dpre), ptr(dwp), ptr(db), ptr(ws), nbytes, stream()),
@@ -537,7 +581,9 @@ class _SpectralWeight(torch.autograd.Function):
         sigma, u_used, v_used = small[:1], small[1:1 + Cout], small[1 + Cout:]
         nbytes = lib.csg_spectral_norm_workspace(Cout, K)
         ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-        dw = torch.empty_like(w)
+        dw = _grad_dest(w, tuple(w.shape))           # w is contiguous (rows of W.view(Cout, -1)): the slot has its order
+        if dw is None:
+            dw = torch.empty_like(w)
         check(lib.csg_spectral_norm_bwd(ptr(dweff), Cout, Cin, KH, KW, st[0], st[1], st[2], st[3], ptr(w), ptr(u_used),
                                         ptr(v_used), ptr(sigma), ptr(dw), ptr(ws), nbytes, stream()),
               "spectral_norm_bwd")
@@ -602,7 +648,9 @@ class _SpectralWeightMulti(torch.autograd.Function):
                 st = dweff.stride() if dweff.dim() == 4 else (K, 1, 1, 1)
             nbytes = lib.csg_spectral_norm_workspace(Cout, K)
             wsb = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-            dw = torch.empty_like(w)
+            dw = _grad_dest(w, tuple(w.shape))
+            if dw is None:
+                dw = torch.empty_like(w)
             it = items[j]
             it.dweff, it.Cout, it.Cin, it.KH, it.KW = dweff.data_ptr(), Cout, Cin, KH, KW
             it.s0, it.s1, it.s2, it.s3 = st[0], st[1], st[2], st[3]
