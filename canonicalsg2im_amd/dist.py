@@ -171,16 +171,19 @@ class GradBuckets:
             size += n
         if cur:
             groups.append(cur)
+        al = lambda n: (n + 3) // 4 * 4                          # every slot starts on a 16-byte boundary (kernels write there)
+        self._offs = {}
         for b, group in enumerate(groups):
-            flat = torch.zeros(sum(p.numel() for p in group), device=group[0].device, dtype=torch.float32)
+            flat = torch.zeros(sum(al(p.numel()) for p in group), device=group[0].device, dtype=torch.float32)
             self.allocations += 1
             off = 0
             for p in group:
+                self._offs[id(p)] = off
                 view = flat[off:off + p.numel()]
                 # the slot mirrors the parameter's own (dense) memory layout — conv weights are channels-last — so that
                 # the fused optimiser walks parameter, gradient and moments in the same element order
                 view = view.view(p.shape) if p.is_contiguous() else view.as_strided(p.shape, p.stride())
-                off += p.numel()
+                off += al(p.numel())
                 self.slot[id(p)] = (b, view)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._hook))
             self.flats.append(flat)
@@ -189,20 +192,19 @@ class GradBuckets:
         # parameters that are adjacent in memory AND in their bucket the joined slot as well
         self._dests = {}
         for b, group in enumerate(self.members):
-            off, run = 0, None                                   # run: [first data_ptr, numel so far, flat offset]
+            run = None                                           # [first data_ptr, numel so far, flat offset]
             for p in group:
-                n = p.numel()
+                n, off = p.numel(), self._offs[id(p)]
                 dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
                 if dense:
                     self._dests[(p.data_ptr(), n)] = self.flats[b][off:off + n]
-                    if run is not None and run[0] + run[1] * 4 == p.data_ptr():
+                    if run is not None and run[0] + run[1] * 4 == p.data_ptr() and run[2] + run[1] == off:
                         run[1] += n
                         self._dests[(run[0], run[1])] = self.flats[b][run[2]:run[2] + run[1]]
                     else:
                         run = [p.data_ptr(), n, off]
                 else:
                     run = None
-                off += n
         self.built = True
 
     def _launch_ready(self, force=False):

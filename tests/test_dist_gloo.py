@@ -42,7 +42,10 @@ def _worker(rank, world, port, out):
     loss.backward()
     local = [p.grad.clone() for p in net.parameters()]
     nbytes = buckets.all_reduce_mean()
-    assert buckets.built and len(buckets.flats) >= 2 and nbytes == sum(p.numel() for p in net.parameters()) * 4
+    raw = sum(p.numel() for p in net.parameters()) * 4
+    # (every slot starts on a 16-byte boundary — the weight-gradient kernels write into the slots — so a bucket may carry
+    # up to 12 bytes of zero padding per parameter)
+    assert buckets.built and len(buckets.flats) >= 2 and nbytes == sum((p.numel() + 3) // 4 * 4 for p in net.parameters()) * 4
     assert all(id(p) not in buckets.slot for p in unused.parameters())
     averaged = [p.grad.clone() for p in net.parameters()]
     allocs = buckets.allocations
@@ -93,7 +96,7 @@ def _worker(rank, world, port, out):
     rep = D.comm_report(steps=1)
     assert rep["world_size"] == world and rep["backend"] == "gloo"
     assert rep["grad_allreduce_calls_per_step"] == len(buckets.flats) and rep["grad_allreduce_bytes_per_step"] == nbytes
-    assert rep["grad_copy_bytes_per_step"] == nbytes
+    assert rep["grad_copy_bytes_per_step"] == raw
     # a parameter outside the agreed set that receives a gradient on a later step (a branch inactive until now): the
     # exchange refuses loudly — it cannot know whether the other ranks hold one — and the COLLECTIVE rebuild() re-agrees
     # the set; the buckets then work in steady state around the new set

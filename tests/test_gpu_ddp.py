@@ -119,7 +119,9 @@ def test_bench_contract_with_two_ranks():
     # 7 SPADE resnet blocks (4 with a learned shortcut: norm_0/norm_s share their statistics) + ... : one all-reduce
     # per norm in the forward and one in the backward
     assert c["syncbn_allreduce_calls_per_step"] >= 2 * 14 and c["syncbn_allreduce_bytes_per_step"] > 0
-    assert c["blocked_ms_per_step"] >= 0.0 and c["grad_copy_bytes_per_step"] <= c["grad_allreduce_bytes_per_step"]
+    # weight gradients are written straight into their bucket slots (ops.set_grad_destinations): only biases, embeddings and the
+    # few-output / permuted-weight layers are still copied (10.7 % of the bytes at ngf = ndf = 8, where small tensors weigh most)
+    assert c["blocked_ms_per_step"] >= 0.0 and c["grad_copy_bytes_per_step"] <= 0.25 * c["grad_allreduce_bytes_per_step"]
     assert "parity_b16" not in d
 
 
