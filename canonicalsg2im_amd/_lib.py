@@ -40,7 +40,7 @@ class WinoDesc(ctypes.Structure):
 class FewDesc(ctypes.Structure):
     """Mirror of `csg_few_desc` (include/csg_hip.h)."""
     _fields_ = [("B", c_i32), ("IH", c_i32), ("IW", c_i32), ("Cin", c_i32), ("x_cs", c_i32), ("KH", c_i32), ("KW", c_i32),
-                ("pad", c_i32), ("cout_real", c_i32), ("act", c_i32), ("slope", c_f32)]
+                ("pad", c_i32), ("cout_real", c_i32), ("act", c_i32), ("slope", c_f32), ("in_act", c_i32), ("in_slope", c_f32)]
 
 
 class SnFwdItem(ctypes.Structure):

@@ -18,7 +18,13 @@ using namespace csg;
 struct FewParams {
   int B, IH, IW, Cin, x_cs, OH, OW, pad, nreal, act;
   float slope;
+  int in_act;         // 1: the convolution sees leaky(x, in_slope) — the activation in front of it applied in the loaders
+  float in_slope;
 };
+
+__device__ __forceinline__ float4 few_in_act(float4 v, float s) {
+  return make_float4(v.x > 0.f ? v.x : v.x * s, v.y > 0.f ? v.y : v.y * s, v.z > 0.f ? v.z : v.z * s, v.w > 0.f ? v.w : v.w * s);
+}
 
 #define FW_CK 16
 #define FW_LD 20
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void k_few_fwd(FewParams p, const float* __res
 #pragma unroll
     for (int it = 0; it < 7; ++it) {
       const int e = tid + 256 * it;
-      if (e < PH * PW * (FW_CK / 4)) *(float4*)(patch + (e >> 2) * FW_LD + (e & 3) * 4) = st[it];
+      if (e < PH * PW * (FW_CK / 4)) *(float4*)(patch + (e >> 2) * FW_LD + (e & 3) * 4) = p.in_act ? few_in_act(st[it], p.in_slope) : st[it];
     }
     __syncthreads();
     // one tap at a time: 4 * NR scalar weight quads live at once (fully unrolled, the compiler hoists every weight of
@@ -224,7 +230,8 @@ __global__ __launch_bounds__(256) void k_few_bwd_weight(FewParams p, const float
   PixWalk pw;
   pw.start(q0 + pl < npix ? q0 + pl : 0, p.IH, p.IW);
   for (int64_t q = q0 + pl; q < q1; q += PL) {
-    const float4 xv = *(const float4*)(x + q * p.x_cs + c4 * 4);
+    float4 xv = *(const float4*)(x + q * p.x_cs + c4 * 4);
+    if (p.in_act) xv = few_in_act(xv, p.in_slope);
     const float* dyb = dy + (int64_t)pw.b * p.OH * p.OW * 4;
 #pragma unroll
     for (int kh = 0; kh < KH; ++kh) {
@@ -306,6 +313,7 @@ static int few_plan(const csg_few_desc* d, FewParams& p, const char* who) {
   p.OW = d->IW + 2 * d->pad - d->KW + 1;
   CSG_REQUIRE(p.OH > 0 && p.OW > 0, CSG_E_BADSHAPE, "%s: empty output", who);
   p.nreal = d->cout_real; p.act = d->act; p.slope = d->slope;
+  p.in_act = d->in_act; p.in_slope = d->in_slope;
   CSG_REQUIRE((int64_t)d->B * d->IH * d->IW * d->x_cs < (1ll << 40), CSG_E_UNSUPPORTED, "%s: tensor too large", who);
   return CSG_OK;
 }

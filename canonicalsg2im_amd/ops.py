@@ -280,7 +280,7 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, stride, pad, act, slope, packs=None, dx_range=None, in_act=None,
-                grad_is_pre=False, cout_real=None):
+                grad_is_pre=False, cout_real=None, pre_slope=None):
         """`in_act=(act, slope)`: x is the output of that activation and THIS call is its only consumer — the
         backward returns dx already multiplied by act'(x), i.e. the gradient of the producer's pre-activation (folded
         into the Winograd backward-data epilogue).  `grad_is_pre=True` is the producer's half of the pair: its incoming
@@ -299,6 +299,13 @@ class _Conv2d(torch.autograd.Function):
         if (Cout == 4 or (cout_real is not None and Cout == cout_real and Cout < 4)) and res is None and dx_range is None \
                 and packs is None and in_act is None:
             ctx.few = _few_desc(B, IH, IW, Cin, KH, KW, stride, pad, cout_real, act, slope)
+        ctx.pre_slope = pre_slope
+        if pre_slope is not None:
+            # `pre_slope`: the convolution sees leaky(x, pre_slope) — applied in the few-output kernels' loaders (conv_img)
+            if ctx.few is None:
+                raise RuntimeError("conv2d: pre_slope is served by the few-output kernels only (the caller applies the "
+                                   "activation itself otherwise)")
+            ctx.few.in_act, ctx.few.in_slope = 1, float(pre_slope)
         if ctx.few is None and Cout % 4:
             raise RuntimeError("conv2d: an output-channel count that is not a multiple of 4 reached the kernels")
         if ctx.few is not None:
@@ -351,6 +358,8 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = dres = None
         if ctx.few is not None:
             if ctx.needs_input_grad[0] and Cin >= 256:
+                if ctx.pre_slope is not None:
+                    raise RuntimeError("conv2d: pre_slope with >= 256 input channels is not served")
                 wp = weight.detach().permute(0, 2, 3, 1).contiguous()
                 dx = empty_nhwc(B, Cin, IH, IW, dy.device)
                 check(lib.csg_conv_few_bwd_data(ctx.few, ptr(dpre), ptr(wp), ptr(dx), stream()), "conv_few_bwd_data")
@@ -360,7 +369,11 @@ class _Conv2d(torch.autograd.Function):
                 wt = w4.permute(1, 2, 3, 0).contiguous()                    # [Cin][KH][KW][Cout]
                 dx = empty_nhwc(B, Cin, IH, IW, dy.device)
                 for d in _descs_backward_data(B, IH, IW, Cin, Cout, KH, KW, stride, pad, OH, OW):
-                    _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
+                    if ctx.pre_slope is not None:            # d leaky(x) / dx in the epilogue: x gates through the residual slot
+                        d.res_gate, d.slope = 1, ctx.pre_slope
+                        _conv_launch(d, dpre, wt, None, x, dx, "conv_bwd_data")
+                    else:
+                        _conv_launch(d, dpre, wt, None, None, dx, "conv_bwd_data")
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
                 nbytes = lib.csg_conv_few_bwd_weight_workspace(ctx.few)
                 ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
@@ -370,7 +383,7 @@ class _Conv2d(torch.autograd.Function):
                       "conv_few_bwd_weight")
                 dw = dwp[:ctx.cout_w].permute(0, 3, 1, 2)
                 db = db[:ctx.cout_w] if db is not None else None
-            return dx, dw, db, None, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0] and ctx.dx_range is not None:
             # only input channels [lo, hi) are wanted by the consumer of dx (the discriminator's packed
             # [layout | img | pad] input: the image part in the generator pass, the layout part in the
@@ -461,7 +474,7 @@ class _Conv2d(torch.autograd.Function):
             check(lib.csg_colsum(ptr(dpre), rows, Cout, Cout, ptr(db), ptr(part), nch, stream()), "colsum")
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy                            # the residual is added AFTER the activation (igemm.hip epilogue)
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None
 
 
 def pack_conv_weight(weight):
@@ -490,7 +503,7 @@ def _frozen_pack(packs, backward_data, variant):
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, residual=None, packs=None,
-           dx_range=None, in_act=None, grad_is_pre=False):
+           dx_range=None, in_act=None, grad_is_pre=False, pre_slope=None):
     """Channel counts that are not multiples of 4 (conv_img: 3 outputs, the PatchGAN head: 1) are
     zero-padded to 16-byte pixel rows; the result is a channel-slice view of the padded output."""
     Cout, Cin = weight.shape[0], weight.shape[1]
@@ -512,6 +525,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, r
         # csrc/fewn.hip takes the 1..3 real output channels as they are (no zero-padded copies of weight and bias)
         few_raw = _few_desc(x.shape[0], x.shape[2], x.shape[3], Cin, weight.shape[2], weight.shape[3], int(stride),
                             int(padding), Cout, int(act), float(slope)) is not None
+    if pre_slope is not None and not (few_raw and x.shape[1] < 256):
+        x, pre_slope = F.leaky_relu(x, float(pre_slope)), None      # no loader to fold it into: a pass of its own
     if po and not few_raw:
         weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, po))
         bias = F.pad(bias, (0, po)) if bias is not None else None
@@ -523,7 +538,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, r
     if grad_is_pre and po:
         raise RuntimeError("conv2d: grad_is_pre needs an unpadded output")
     y = _Conv2d.apply(x, weight, bias, residual, int(stride), int(padding), int(act), float(slope), packs, dx_range,
-                      in_act, bool(grad_is_pre), Cout if Cout + po == 4 else None)
+                      in_act, bool(grad_is_pre), Cout if Cout + po == 4 else None,
+                      None if pre_slope is None else float(pre_slope))
     return y[:, :Cout] if po else y
 
 
@@ -926,7 +942,8 @@ class _SpadeFused(torch.autograd.Function):
             fake = types.SimpleNamespace(
                 saved_tensors=(actv, w, None), geom=(B, H, W, nh, 2 * C, 3, 3, 1, 1, H, W, ACT_NONE, 0.0),
                 in_act=(ACT_LEAKY, in_slope) if in_slope is not None else None, grad_is_pre=False, few=None, dx_range=None,
-                packs=None, needs_input_grad=(need[0], need[1], need[2], False), has_bias=True, has_res=False, cout_w=2 * C)
+                packs=None, needs_input_grad=(need[0], need[1], need[2], False), has_bias=True, has_res=False, cout_w=2 * C,
+                pre_slope=None)
             r = _Conv2d.backward(fake, dgbs[k])
             grads += [r[0], r[1], r[2], None, None, None, None]
         if ctx.needs_input_grad[0]:

@@ -47,8 +47,10 @@ class Conv2d(nn.Conv2d):
         # state_dict; `spectral_norm` puts its `weight_orig` back to row-major, the order of its u / v vectors)
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def forward(self, x, residual=None):
-        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.act, self.slope, residual)
+    def forward(self, x, residual=None, pre_slope=None):
+        """`pre_slope`: the layer sees leaky_relu(x, pre_slope) (folded into the kernel's loaders where there is one)."""
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.act, self.slope, residual,
+                          pre_slope=pre_slope)
 
 
 class _FusedActivation(nn.Identity):

@@ -1,6 +1,5 @@
 """AttSPADE generator (reference: spade/models/networks/generator.py:13-147)."""
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .... import ops
 from .... import spectral_norm as csg_spectral_norm
@@ -89,4 +88,4 @@ class SPADEGenerator(BaseNetwork):
             if name not in no_upsample:
                 x = ops.upsample2x(x)
             x = getattr(self, name)(x, seg)
-        return self.conv_img(F.leaky_relu(x, 2e-1))
+        return self.conv_img(x, pre_slope=2e-1)          # LeakyReLU(0.2) of generator.py:123 rides in conv_img's loaders

@@ -291,6 +291,10 @@ typedef struct csg_few_desc {
   int32_t cout_real;
   int32_t act;
   float slope;
+  int32_t in_act; /* 1: the convolution sees leaky(x, in_slope): the LeakyReLU in front of conv_img (generator.py:123-124) is
+                   * applied in the forward and weight-gradient loaders instead of a pass of its own; backward-data callers
+                   * multiply by its derivative themselves (csg_conv_desc.res_gate) */
+  float in_slope;
 } csg_few_desc;
 int csg_conv_few_supported(const csg_few_desc* d);      /* 1 / 0 */
 /* forward `workspace` (csg_conv_few_fwd_workspace bytes, may be 0): slabs of a split over the input channels for maps

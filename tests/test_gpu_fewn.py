@@ -80,3 +80,35 @@ def test_unsupported_shapes_are_declined(ops):
     assert lib.csg_conv_few_supported(d) == 0                       # 16 taps x 3 outputs: registers
     d.cout_real, d.Cin, d.x_cs = 1, 48, 48
     assert lib.csg_conv_few_supported(d) == 0                       # Cin not a power-of-two multiple of 32
+
+
+def test_conv_img_with_the_leaky_relu_in_its_loaders():
+    """`conv_img(leaky_relu(x, 0.2))` of the generator (reference generator.py:123-124) with the activation folded into
+    the few-output kernels' forward / weight-gradient loaders and its derivative into the backward-data epilogue
+    (csg_conv_desc.res_gate): output, d x, d weight, d bias against torch on the CPU, and bit-equal to the unfolded form."""
+    import torch.nn.functional as F
+    from canonicalsg2im_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 40, 48)
+    w = torch.randn(3, 64, 3, 3) * 0.05
+    b = torch.randn(3) * 0.1
+    g = torch.randn(2, 3, 40, 48)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.tanh(F.conv2d(F.leaky_relu(xr, 0.2), wr, br, padding=1))
+    yr.backward(g)
+    outs = []
+    for folded in (True, False):
+        xd = ops.nhwc(x.cuda()).requires_grad_(True)
+        wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        if folded:
+            y = ops.conv2d(xd, wd, bd, 1, 1, act=ops.ACT_TANH, pre_slope=0.2)
+        else:
+            y = ops.conv2d(F.leaky_relu(xd, 0.2), wd, bd, 1, 1, act=ops.ACT_TANH)
+        y.backward(g.cuda())
+        outs.append((y.detach(), xd.grad, wd.grad, bd.grad))
+        assert torch.allclose(y.cpu(), yr.detach(), rtol=1e-4, atol=1e-5)
+        assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5 * float(xr.grad.abs().max()))
+        assert torch.allclose(wd.grad.cpu(), wr.grad, rtol=1e-4, atol=1e-5 * float(wr.grad.abs().max()))
+        assert torch.allclose(bd.grad.cpu(), br.grad, rtol=1e-4, atol=1e-5 * float(br.grad.abs().max()))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c), "folding the activation into the loaders must not change a bit"
