@@ -132,14 +132,19 @@ def _conv_launch_classes(descs, x, w, y_ptr, dev, what):
 
 # ---- Winograd F(2x2,3x3) path (csrc/wino.hip): 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip
 FEW_ENABLED = os.environ.get("CSG_FEW_OUTPUT_KERNELS", "1") != "0"   # csrc/fewn.hip for convolutions with <= 4 outputs
-WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "4096"))     # B*H*W below which the direct kernel stays
+WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "1024"))     # B*H*W below which the direct kernel stays
 WINO_ENABLED = os.environ.get("CSG_WINOGRAD", "1") != "0"
 WINO_WGRAD = os.environ.get("CSG_WINOGRAD_WGRAD", "1") != "0"
 
 
 def wino_eligible(B, H, W, Cin, Cout, KH, KW, stride, pad):
+    """At least 1 024 output pixels (round 4; 4 096 before).  Launches that small are split over the input channels into
+    slabs and still beat the direct kernel's split-K launch on K = 9 216: the 16 x 16 maps at batch 4 gain 1.0 ms/step
+    (config C4), the 8 x 8 maps at batch 16 0.8 ms (C2) and 0.2 ms (C3), C5 1.5 ms (tools/sweep_knobs.sh).  Round 2's
+    measurement that 8 x 8 maps lose 1.4 ms on Winograd predates the split of under-filled grids."""
+    enough = B * H * W >= WINO_MIN_PIXELS
     return (WINO_ENABLED and KH == 3 and KW == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 and W >= 8
-            and Cin % 16 == 0 and Cout % 4 == 0 and Cout >= 32 and B * H * W >= WINO_MIN_PIXELS)
+            and Cin % 16 == 0 and Cout % 4 == 0 and Cout >= 32 and enough)
 
 
 def _wino_desc(B, H, W, Cin, Cout, act=ACT_NONE, slope=0.0):
