@@ -152,6 +152,8 @@ SIGNATURES = {
                                 c_p, c_p]),
     "csg_canon_emit": (c_i32, [c_p, c_p, c_i64, c_i64, ctypes.POINTER(c_i32), c_i64, c_i32, c_i32, c_p, c_p, c_i64, c_p,
                                c_p, c_p]),
+    "csg_canon_converse": (c_i32, [c_p, c_p, c_i64, c_i64, ctypes.POINTER(c_i32), c_i64, c_i32, c_i32, c_p, c_p, c_p, c_p,
+                                   c_i64, c_p, c_p, c_p]),
 }
 
 

@@ -4,7 +4,8 @@
 //   BaseDataset.add_location_triplets   sg2im/data/base_dataset.py:35-87
 //   triplets_to_minimal / path / hsu    scripts/graphs_utils.py:15-71
 //   BaseDataset.add_dummy_triplets      sg2im/data/base_dataset.py:141-151
-//   BaseDataset.add_learnt_triplets     sg2im/data/base_dataset.py:89-139 (learned_converse = 0)
+//   BaseDataset.add_learnt_triplets     sg2im/data/base_dataset.py:89-139
+//   get_edge_converse_triplets          scripts/graphs_utils.py:126-152 (learned_converse = 1: k_canon_converse)
 //   get_current_and_transitive_triplets scripts/graphs_utils.py:96-100
 //   triplet padding of the collate      sg2im/data/packed_clevr_dialog.py:309-315
 //
@@ -278,6 +279,152 @@ __global__ __launch_bounds__(256) void k_canon_emit(CanonParams P, const int64_t
     put(trip, tt, t, 0, P.pid_padding, 0, 0);
 }
 
+
+// ---- learned_converse = 1 (base_dataset.py:104-107, graphs_utils.py:126-152).  For every original triplet (s, rel, o) of
+// the six location relations — in the reference's order: relations by ascending predicate id, triplets by (s, o) — ONE
+// uniform number u decides through the relation's cumulative distribution whether a converse edge (o, r, s) is added and
+// for which other relation r.  The distribution (scipy softmax over the five candidate weights and a zero for "none",
+// numpy's cumsum / normalisation in float64) is computed on the host exactly as numpy.random.choice does and arrives as
+// `cdf` (6 relations x 6 thresholds); the uniforms are the host's np.random stream (the reference's global RNG), one per
+// triplet, `u_off[b]` = the number of triplets of the samples before b.  The choice is searchsorted(cdf, u, 'right'): the
+// number of thresholds <= u.  Converse edges join their relation BEFORE the transitive closure is taken (:109-120), so the
+// closure, the "current" graph and every count are recomputed here: R <- minimal + converse, X <- closure(R) - R (the
+// diagonal included: converse edges can close cycles, and `path` then marks i -> i), conv_counts[rel][r] += 1 per draw.
+__global__ __launch_bounds__(256) void k_canon_converse(CanonParams P, const int64_t* __restrict__ objs0,
+                                                         const int64_t* __restrict__ n_objs, void* __restrict__ ws,
+                                                         const double* __restrict__ cdf, const double* __restrict__ uniforms,
+                                                         const int64_t* __restrict__ u_off, int npred,
+                                                         float* __restrict__ conv_counts, int64_t* __restrict__ counts) {
+  __shared__ uint64_t adj[NREL][MAXN][W];      // converse edges first, then R | converse, then its closure
+  __shared__ int scan[256];
+  __shared__ int hist[NREL][NREL];             // [relation slot][choice 0..4 = candidate, 5 = none]
+  __shared__ int cand[NREL][NREL - 1];         // candidate relation slots of a slot, ascending predicate id
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int n = (int)n_objs[b];
+  if (n > P.O) n = P.O;
+  if (n > MAXN) n = MAXN;
+  const int nw = (n + 63) >> 6;
+  uint64_t* R = ws_R(ws, b);
+  uint64_t* X = ws_X(ws, b);
+  for (int i = tid; i < NREL * MAXN * W; i += 256) (&adj[0][0][0])[i] = 0;
+  if (tid < NREL * NREL) (&hist[0][0])[tid] = 0;
+  if (tid < NREL) {
+    int k = 0;
+    for (int q = 0; q < NREL + 1; ++q) {
+      const int r = P.order[q];
+      if (r < NREL && r != tid) cand[tid][k++] = r;
+    }
+  }
+  __syncthreads();
+  // ---- one draw per original triplet, numbered in (relation by ascending id, s, o) order
+  int base = 0;
+  for (int q = 0; q < NREL + 1; ++q) {
+    const int r = P.order[q];
+    if (r >= NREL) continue;
+    int c = 0;
+    if (tid < n)
+      for (int w = 0; w < nw; ++w) c += __popcll(R[((int64_t)r * MAXN + tid) * W + w]);
+    int tot = 0;
+    int k = base + block_exscan(c, scan, &tot);
+    if (tid < n) {
+      const int s = tid;
+      const double* cd = cdf + r * NREL;
+      for (int w = 0; w < nw; ++w) {
+        uint64_t m = R[((int64_t)r * MAXN + s) * W + w];
+        while (m) {
+          const int o = w * 64 + (__ffsll((long long)m) - 1);
+          m &= m - 1;
+          const double u = uniforms[u_off[b] + k];
+          ++k;
+          int j = 0;
+          while (j < NREL - 1 && cd[j] <= u) ++j;            // searchsorted(cdf, u, side='right'); the last threshold is 1
+          atomicAdd(&hist[r][j], 1);
+          if (j < NREL - 1)                                    // converse edge (o, cand, s)
+            atomicOr((unsigned long long*)&adj[cand[r][j]][o][s >> 6], 1ull << (s & 63));
+        }
+      }
+    }
+    base += tot;
+  }
+  __syncthreads();
+  // ---- R <- minimal | converse (np.unique removes a converse edge that repeats an original one)
+  const int tasks = NREL * n;
+  for (int t = tid; t < tasks * W; t += 256) {
+    const int w = t % W, rj = t / W;
+    const int r = rj / n, j = rj - r * n;
+    const int64_t at = ((int64_t)r * MAXN + j) * W + w;
+    const uint64_t v = adj[r][j][w] | R[at];
+    adj[r][j][w] = v;
+    R[at] = v;
+  }
+  // ---- closure of the new graphs (path(): graphs_utils.py:15-27), X <- closure - current
+  if (P.learned_transitivity) {
+    for (int i = 0; i < n; ++i) {
+      __syncthreads();
+      for (int t = tid; t < tasks; t += 256) {
+        const int r = t / n, j = t - r * n;
+        if (j != i && ((adj[r][j][i >> 6] >> (i & 63)) & 1ull)) {
+          for (int w = 0; w < nw; ++w) adj[r][j][w] |= adj[r][i][w];
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < tasks * W; t += 256) {
+      const int w = t % W, rj = t / W;
+      const int r = rj / n, j = rj - r * n;
+      const int64_t at = ((int64_t)r * MAXN + j) * W + w;
+      X[at] = adj[r][j][w] & ~R[at];
+    }
+  }
+  __syncthreads();
+  // ---- counts and offsets (as k_canon_build)
+  int img = -1;
+  if (P.include_dummies) {
+    scan[tid] = (tid < n && objs0[(int64_t)b * P.O + tid] == (int64_t)P.image_id) ? tid : MAXN;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) scan[tid] = min(scan[tid], scan[tid + o]);
+      __syncthreads();
+    }
+    img = scan[0] < MAXN ? scan[0] : -1;
+  }
+  int c = 0;
+  if (tid < n) {
+    for (int r = 0; r < NREL; ++r)
+      for (int w = 0; w < nw; ++w) c += __popcll(R[((int64_t)r * MAXN + tid) * W + w]);
+    if (img >= 0 && tid != img) c += 1;
+  }
+  int* off = ws_off(ws, b);
+  int total = 0;
+  int ex = block_exscan(c, scan, &total);
+  off[tid] = ex;
+  const int n_orig = total;
+  int n_trans = 0;
+  if (P.learned_transitivity) {
+    for (int q = 0; q < NREL + 1; ++q) {
+      const int r = P.order[q];
+      if (r >= NREL) continue;
+      int cx = 0;
+      if (tid < n)
+        for (int w = 0; w < nw; ++w) cx += __popcll(X[((int64_t)r * MAXN + tid) * W + w]);
+      int tot = 0;
+      int e = block_exscan(cx, scan, &tot);
+      off[MAXN + r * MAXN + tid] = n_trans + e;
+      n_trans += tot;
+    }
+  }
+  if (tid == 0) {
+    counts[b * 2 + 0] = n_orig;
+    counts[b * 2 + 1] = n_trans;
+  }
+  // ---- conv_counts[b][rel][r] (base_dataset.py:93, graphs_utils.py:146): r = a relation id, or npred for "none"
+  if (tid < NREL * NREL) {
+    const int r = tid / NREL, j = tid - r * NREL;
+    const int col = j < NREL - 1 ? P.pid[cand[r][j]] : npred;
+    conv_counts[((int64_t)b * npred + P.pid[r]) * (npred + 1) + col] = (float)hist[r][j];
+  }
+}
+
 int fill_params(CanonParams* P, int64_t O, const int32_t* pred_ids, int64_t image_id, int include_dummies,
                 int learned_transitivity) {
   P->O = (int)O;
@@ -342,6 +489,26 @@ int csg_canon_emit(const int64_t* objs0, const int64_t* n_objs, int64_t B, int64
   CSG_LAUNCH(k_canon_emit, dim3((unsigned)B), dim3(256), 0, s, P, objs0, n_objs, workspace, counts, T,
                      triplets, triplet_type);
   return check_launch("csg_canon_emit");
+}
+
+int csg_canon_converse(const int64_t* objs0, const int64_t* n_objs, int64_t B, int64_t O, const int32_t* pred_ids,
+                       int64_t image_id, int include_dummies, int learned_transitivity, void* workspace,
+                       const double* cdf, const double* uniforms, const int64_t* u_off, int64_t num_preds,
+                       float* conv_counts, int64_t* counts, void* stream) {
+  CSG_REQUIRE(B > 0 && O > 0 && O <= MAXN && num_preds >= 8, CSG_E_BADSHAPE, "csg_canon_converse: bad shape B=%ld O=%ld P=%ld",
+              (long)B, (long)O, (long)num_preds);
+  CSG_REQUIRE(workspace && cdf && uniforms && u_off && conv_counts && counts, CSG_E_BADSHAPE, "csg_canon_converse: null argument");
+  CanonParams P;
+  CSG_REQUIRE(fill_params(&P, O, pred_ids, image_id, include_dummies, learned_transitivity), CSG_E_BADSHAPE,
+              "csg_canon_converse: the eight predicate ids must be distinct");
+  for (int r = 0; r < NREL; ++r)
+    CSG_REQUIRE(P.pid[r] >= 0 && P.pid[r] < num_preds, CSG_E_BADSHAPE, "csg_canon_converse: predicate id %d outside [0, %ld)",
+                P.pid[r], (long)num_preds);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_CANON_BUILD, (double)B * O * O, s);
+  CSG_LAUNCH(k_canon_converse, dim3((unsigned)B), dim3(256), 0, s, P, objs0, n_objs, workspace, cdf, uniforms, u_off,
+             (int)num_preds, conv_counts, counts);
+  return check_launch("csg_canon_converse");
 }
 
 }  // extern "C"

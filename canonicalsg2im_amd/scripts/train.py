@@ -62,8 +62,14 @@ def main(argv=None):
             boxes = torch.cat([boxes, boxes.new_full((boxes.shape[0], 1, 4), -1.0)], 1)
             centers = boxes[..., :2] + 0.5 * boxes[..., 2:]
             batch[1], batch[2] = objs, boxes
+            conv_w = None
+            if args.learned_converse:    # the data loader reads the model's converse weights back (scripts/train.py:274-276)
+                from ..sg2im.model import get_conv_converse
+                conv_w = get_conv_converse(trainer.model).detach().cpu().numpy()
             batch[3], batch[4], batch[5] = canonical_triplets(objs, boxes, centers, n, args.vocab,
-                                                              learned_transitivity=bool(args.learned_transitivity))
+                                                              learned_transitivity=bool(args.learned_transitivity),
+                                                              learned_converse=bool(args.learned_converse),
+                                                              converse_weights=conv_w)
             assert batch[3].shape[1] > 0 and objs.shape[1] == O
         G, D = trainer.step(batch)
         if rank == 0 and (t % args.print_every == 0 or t == args.num_iterations):

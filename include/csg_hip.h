@@ -415,6 +415,19 @@ int csg_canon_build(const int64_t* objs0, const float* boxes, const float* cente
 int csg_canon_emit(const int64_t* objs0, const int64_t* n_objs, int64_t B, int64_t O, const int32_t* pred_ids,
                    int64_t image_id, int include_dummies, int learned_transitivity, const void* workspace,
                    const int64_t* counts, int64_t T, int64_t* triplets, int64_t* triplet_type, void* stream);
+/* learned_converse = 1 (base_dataset.py:104-107; get_edge_converse_triplets, scripts/graphs_utils.py:126-152), between
+ * csg_canon_build and csg_canon_emit: one uniform number per original triplet of the six location relations (the order of
+ * the reference's loops: relations by ascending predicate id, triplets by (s, o); counts[b][0] minus the __in_image__
+ * dummies of sample b) picks, through `cdf` (6 x 6 float64: per relation — in the order __below__ __above__ __left of__
+ * __right of__ __inside__ __surrounding__ — the cumulative distribution numpy.random.choice forms from the softmax of the
+ * five candidate weights, candidates by ascending predicate id, and a zero for "none"), whether a converse edge (o, r, s)
+ * joins relation r.  `uniforms` is the host's random stream, `u_off[b]` the first number of sample b.  The workspace is
+ * updated in place (current graph, transitive extras, offsets), `counts` rewritten, conv_counts (B, P, P + 1) float32 —
+ * zero-initialised by the caller — receives the draw counts with column P = "none".                                    */
+int csg_canon_converse(const int64_t* objs0, const int64_t* n_objs, int64_t B, int64_t O, const int32_t* pred_ids,
+                       int64_t image_id, int include_dummies, int learned_transitivity, void* workspace,
+                       const double* cdf, const double* uniforms, const int64_t* u_off, int64_t num_preds,
+                       float* conv_counts, int64_t* counts, void* stream);
 
 /* ---- spectral normalisation of a conv weight (a13) ----------------------------------------------
  * torch.nn.utils.spectral_norm's forward pre-hook (reference call sites architecture.py:35-39,

@@ -453,6 +453,57 @@ def fx_canon_graph():
          **arrays)
 
 
+def fx_canon_converse():
+    """Canonical graphs with `--learned_converse 1`: BaseDataset.add_learnt_triplets drawing converse edges through
+    get_edge_converse_triplets (scripts/graphs_utils.py:126-152) from numpy's GLOBAL random stream, seeded here; the
+    data loader's weights are numpy float32 (scripts/train.py:276).  Stored: the collated batch, conv_counts, the seed and
+    the number of draws (the oracle and the HIP path replay the stream with np.random.seed(seed); random_sample(n))."""
+    from sg2im.data.base_dataset import BaseDataset
+    from sg2im.data.packed_clevr_dialog import packed_clevr_collate_fn
+    vocab = make_vocab("clevr")
+    rng = np.random.default_rng(77)
+    arrays, cases = {}, []
+    for ci, (sizes, trans, seed, scale) in enumerate((((2, 3, 5, 8, 13), 1, 11, 1.0), ((4, 9, 21, 34), 0, 12, 3.0),
+                                                      ((30, 6, 18), 1, 13, 0.2))):
+        ds = BaseDataset()
+        ds.vocab, ds.include_dummies = vocab, True
+        ds.learned_transitivity, ds.learned_converse, ds.learned_symmetry = bool(trans), True, False
+        P = len(vocab["pred_name_to_idx"])
+        w = torch.from_numpy(rng.normal(size=(P, P)).astype(np.float32) * scale)
+        up = torch.triu(w, diagonal=0)
+        ds.converse_candidates_weights = (up + up.t()).detach().cpu().numpy()          # model.py:10-13, train.py:276
+        np.random.seed(seed)
+        batch = []
+        for n in sizes:
+            wh = rng.uniform(0.05, 0.6, size=(n, 2))
+            xy = rng.uniform(0.0, 1.0, size=(n, 2)) * (1.0 - wh)
+            bx = [tuple(float(v) for v in r) for r in np.concatenate([xy, wh], axis=1)]
+            centers = torch.FloatTensor([[x0 + 0.5 * ww, y0 + 0.5 * h] for x0, y0, ww, h in bx])
+            boxes = torch.FloatTensor(bx + [[-1, -1, -1, -1]])
+            objs = {a: torch.LongTensor(list(rng.integers(1, max(vocab["attributes"][a].values()) + 1, size=n)) + [0])
+                    for a in vocab["attributes"]}
+            triplets = []
+            ds.add_location_triplets(boxes, centers, objs["shape"], triplets)
+            ds.add_dummy_triplets(objs["shape"], triplets)
+            triplets, conv_counts, ttype = ds.add_learnt_triplets(triplets, boxes.size(0))
+            batch.append((torch.zeros(3, 4, 4), objs, boxes, torch.LongTensor(triplets), torch.FloatTensor(conv_counts),
+                          torch.LongTensor(ttype), None, len(batch), centers))
+        draws = int(sum(float(b[4].sum()) for b in batch))
+        out = packed_clevr_collate_fn(vocab, [b[:8] for b in batch])
+        _, all_objs, all_boxes, all_triplets, all_conv, all_tt, _, _ = out
+        O = all_boxes.shape[1]
+        cen = torch.zeros(len(sizes), O, 2)
+        for b, n in enumerate(sizes):
+            cen[b, :n] = batch[b][8]
+        arrays.update({"c%d_objs" % ci: npy(all_objs), "c%d_boxes" % ci: npy(all_boxes), "c%d_triplets" % ci: npy(all_triplets),
+                       "c%d_tt" % ci: npy(all_tt), "c%d_n" % ci: np.asarray([n + 1 for n in sizes], np.int64),
+                       "c%d_counts" % ci: np.asarray([len(b[3]) for b in batch], np.int64), "c%d_centers" % ci: npy(cen),
+                       "c%d_conv" % ci: npy(all_conv), "c%d_weights" % ci: ds.converse_candidates_weights.copy()})
+        cases.append({"sizes": list(sizes), "learned_transitivity": trans, "seed": seed, "draws": draws})
+    save("canon_converse", {"ref": "sg2im/data/base_dataset.py:89-139; scripts/graphs_utils.py:126-152; scripts/train.py:276",
+                            "vocab": "clevr", "cases": cases}, **arrays)
+
+
 def fx_converse():
     """REINFORCE signal of --learned_converse (scripts/train.py:343-345,370-378) from the reference's own
     calc_log_p / get_conv_converse on seeded inputs."""
@@ -805,6 +856,7 @@ if __name__ == "__main__":
     fx_vgg()
     fx_step_masks()
     fx_canon_graph()
+    fx_canon_converse()
     fx_converse()
     fx_row_gaps()
     fx_row_gaps_r3()

@@ -44,3 +44,23 @@ def test_closure_and_reduction_properties():
         r = canon.hsu(t)
         assert not (r & ~t).any() and np.array_equal(canon.path(r), t)
         assert not (r & (t.astype(int) @ t.astype(int) > 0)).any()       # no edge of the reduction is implied
+
+
+def test_canonical_graph_with_converse_edges_matches_reference():
+    """`--learned_converse 1`: the reference drew its converse edges from numpy's global stream (seeded by the fixture
+    script); the oracle replays the same stream — np.random.seed(seed); random_sample(draws) — through the cumulative
+    distribution np.random.choice would search.  Triplets, types and conv_counts bit for bit."""
+    meta, a = load_golden("canon_converse")
+    vocab = make_vocab(meta["vocab"])
+    for ci, case in enumerate(meta["cases"]):
+        g = {k[len("c%d_" % ci):]: v.numpy() for k, v in a.items() if k.startswith("c%d_" % ci)}
+        np.random.seed(case["seed"])
+        u = np.random.random_sample(case["draws"])
+        trip, tt, counts, conv = canon.canonical_batch(g["objs"][:, :, 0], g["boxes"], g["centers"], g["n"], vocab,
+                                                       learned_transitivity=bool(case["learned_transitivity"]),
+                                                       learned_converse=True, converse_weights=g["weights"], uniforms=u)
+        assert np.array_equal(counts, g["counts"]), (ci, counts, g["counts"])
+        assert np.array_equal(trip, g["triplets"]), ci
+        assert np.array_equal(tt, g["tt"]), ci
+        assert np.array_equal(conv, g["conv"]), ci
+        assert conv.sum() == case["draws"] and conv[:, :-1].sum() > 0          # some converse edges were drawn

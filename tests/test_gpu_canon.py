@@ -67,6 +67,54 @@ def test_canonical_triplets_vs_oracle(trans, dummies):
     assert np.array_equal(t, to) and np.array_equal(tt, tto)
 
 
+def test_converse_edges_vs_reference_golden():
+    """`--learned_converse 1` on the device against the reference's own draws (tests/golden/canon_converse.npz): the
+    fixture's seed replayed through numpy's GLOBAL stream — what `canonical_triplets` reads when no numbers are passed —
+    triplets, types and conv_counts bit for bit."""
+    meta, a = load_golden("canon_converse")
+    vocab = make_vocab(meta["vocab"])
+    for ci, case in enumerate(meta["cases"]):
+        g = {k[len("c%d_" % ci):]: v.numpy() for k, v in a.items() if k.startswith("c%d_" % ci)}
+        np.random.seed(case["seed"])
+        t, cc, tt = _run(g["objs"], g["boxes"], g["centers"], g["n"], vocab,
+                         learned_transitivity=bool(case["learned_transitivity"]), learned_converse=True,
+                         converse_weights=g["weights"])
+        assert t.shape == g["triplets"].shape, (ci, t.shape, g["triplets"].shape)
+        assert np.array_equal(t, g["triplets"]), ci
+        assert np.array_equal(tt, g["tt"]), ci
+        assert np.array_equal(cc.cpu().numpy(), g["conv"].astype(np.float32)), ci
+        # the stream was advanced by exactly the reference's number of draws
+        np.random.seed(case["seed"])
+        np.random.random_sample(case["draws"])
+        expect_next = np.random.random_sample()
+        np.random.seed(case["seed"])
+        _run(g["objs"], g["boxes"], g["centers"], g["n"], vocab, learned_transitivity=bool(case["learned_transitivity"]),
+             learned_converse=True, converse_weights=g["weights"])
+        assert np.random.random_sample() == expect_next
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_converse_edges_vs_oracle_dense_scenes(trans):
+    """Dense scenes (up to 130 objects: thousands of draws per sample, converse edges closing cycles) against the oracle
+    with the same explicit uniform numbers."""
+    from oracle import canon
+    rng = np.random.default_rng(21 + trans)
+    vocab = make_vocab("clevr")
+    objs, boxes, cen, n = _scene(rng, (1, 2, 7, 40, 64, 65, 130), vocab)
+    P = len(vocab["pred_name_to_idx"])
+    w = rng.normal(size=(P, P)).astype(np.float32)
+    w = np.triu(w) + np.triu(w).T
+    u = rng.random(200000)
+    t, cc, tt = _run(objs, boxes, cen, n, vocab, learned_transitivity=trans, learned_converse=True, converse_weights=w,
+                     uniforms=u)
+    to, tto, _, conv = canon.canonical_batch(objs[:, :, 0], boxes, cen, n, vocab, trans, True, True, w, u)
+    assert t.shape == to.shape and np.array_equal(t, to) and np.array_equal(tt, tto)
+    assert np.array_equal(cc.cpu().numpy(), conv.astype(np.float32)) and conv[:, :, :-1].sum() > 100
+    if trans:
+        loops = t[(tt == 1) & (t[..., 0] == t[..., 2])]
+        assert len(loops) > 0                      # converse edges closed cycles: `path` marks i -> i, as the reference's
+
+
 def test_permuted_predicate_ids():
     """The (s, p, o) sort and the transitive order follow the NUMERIC predicate ids, whatever they are."""
     from oracle import canon
