@@ -137,6 +137,8 @@ SIGNATURES = {
                                    c_p]),
     "csg_maxpool2_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_maxpool2_bwd": (c_i32, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_avgpool2_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_avgpool2_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_l1_mean_workspace": (c_i64, [c_i64]),
     "csg_l1_mean_fwd": (c_i32, [c_p, c_p, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_l1_mean_bwd": (c_i32, [c_p, c_p, c_p, c_i64, c_p, c_p]),

@@ -127,6 +127,48 @@ static inline unsigned ew_grid(int64_t n) {
   return (unsigned)g;
 }
 
+// ---- AvgPool2d(2,2), floor mode (sg2im/layers.py:88-90, `build_cnn(pooling='avg')`): mean of the 2 x 2 window; backward
+// hands each covered input pixel a quarter of its window's gradient, rows / columns no window covers get 0
+__global__ void k_avgpool2_fwd(const float* __restrict__ x, int H, int W, int OH, int OW, int Q, int64_t n4,
+                               float* __restrict__ y) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t pix = e / Q;
+    int q = (int)(e - pix * Q);
+    int ox = (int)(pix % OW);
+    int64_t t = pix / OW;
+    int oy = (int)(t % OH);
+    int64_t b = t / OH;
+    const float* p = x + (((b * H + 2 * oy) * W + 2 * ox) * (int64_t)Q + q) * 4;
+    const int64_t row = (int64_t)W * Q * 4;
+    const float4 a = ld4(p), c = ld4(p + Q * 4), d = ld4(p + row), f = ld4(p + row + Q * 4);
+    float4 r;                                  // ATen's order: the window summed row by row, then divided by its size
+    r.x = (((a.x + c.x) + d.x) + f.x) / 4.f;
+    r.y = (((a.y + c.y) + d.y) + f.y) / 4.f;
+    r.z = (((a.z + c.z) + d.z) + f.z) / 4.f;
+    r.w = (((a.w + c.w) + d.w) + f.w) / 4.f;
+    st4(y + e * 4, r);
+  }
+}
+
+__global__ void k_avgpool2_bwd(const float* __restrict__ dy, int H, int W, int OH, int OW, int Q, int64_t n4,
+                               float* __restrict__ dx) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t pix = e / Q;
+    int q = (int)(e - pix * Q);
+    int w = (int)(pix % W);
+    int64_t t = pix / W;
+    int h = (int)(t % H);
+    int64_t b = t / H;
+    const int oy = h >> 1, ox = w >> 1;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (oy < OH && ox < OW) {
+      const float4 g = ld4(dy + (((b * OH + oy) * OW + ox) * (int64_t)Q + q) * 4);
+      r = make_float4(g.x / 4.f, g.y / 4.f, g.z / 4.f, g.w / 4.f);
+    }
+    st4(dx + e * 4, r);
+  }
+}
+
 extern "C" {
 
 int csg_maxpool2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream) {
@@ -152,6 +194,28 @@ int csg_maxpool2_bwd(const float* dy, const float* x, int64_t B, int64_t H, int6
   CSG_LAUNCH(k_maxpool2_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, (int)H, (int)W, (int)OH, (int)OW,
                      (int)(C / 4), n4, dx);
   return check_launch("csg_maxpool2_bwd");
+}
+
+int csg_avgpool2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream) {
+  CSG_REQUIRE(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE,
+              "csg_avgpool2_fwd: bad shape B=%ld H=%ld W=%ld C=%ld", (long)B, (long)H, (long)W, (long)C);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t OH = H / 2, OW = W / 2;
+  const int64_t n4 = B * OH * OW * C / 4;
+  ProfScope p(K_AVGPOOL_FWD, (double)(B * OH * OW * C) * 5 * 4, s);
+  CSG_LAUNCH(k_avgpool2_fwd, dim3(ew_grid(n4)), dim3(256), 0, s, x, (int)H, (int)W, (int)OH, (int)OW, (int)(C / 4), n4, y);
+  return check_launch("csg_avgpool2_fwd");
+}
+
+int csg_avgpool2_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream) {
+  CSG_REQUIRE(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE,
+              "csg_avgpool2_bwd: bad shape B=%ld H=%ld W=%ld C=%ld", (long)B, (long)H, (long)W, (long)C);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t OH = H / 2, OW = W / 2;
+  const int64_t n4 = B * H * W * C / 4;
+  ProfScope p(K_AVGPOOL_BWD, (double)(B * H * W * C) * 1.25 * 4, s);
+  CSG_LAUNCH(k_avgpool2_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, (int)H, (int)W, (int)OH, (int)OW, (int)(C / 4), n4, dx);
+  return check_launch("csg_avgpool2_bwd");
 }
 
 int64_t csg_l1_mean_workspace(int64_t n) {

@@ -19,7 +19,7 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, WinoDesc, ch
 
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "nearest_resize", "avgpool3s2", "embed", "real_object_mask",
-    "norm_act_pair", "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "l1_mean",
+    "norm_act_pair", "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "avgpool2", "l1_mean",
     "invalidate_weight_caches", "pack_conv_weight", "wino_pack", "wino_eligible", "wino_variant", "spectral_weight", "spectral_weights", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
 
@@ -1083,6 +1083,31 @@ class _MaxPool2(torch.autograd.Function):
 
 def maxpool2(x):
     return _MaxPool2.apply(x)
+
+
+class _AvgPool2(torch.autograd.Function):
+    """nn.AvgPool2d(2, 2) (reference sg2im/layers.py:88-90, `build_cnn(pooling='avg')`)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(_f32(x))
+        B, C, H, W = x.shape
+        y = empty_nhwc(B, C, H // 2, W // 2, x.device)
+        check(lib.csg_avgpool2_fwd(ptr(x), B, H, W, C, ptr(y), stream()), "avgpool2_fwd")
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = nhwc(dy)
+        dx = empty_nhwc(B, C, H, W, dy.device)
+        check(lib.csg_avgpool2_bwd(ptr(dy), B, H, W, C, ptr(dx), stream()), "avgpool2_bwd")
+        return dx
+
+
+def avgpool2(x):
+    return _AvgPool2.apply(x)
 
 
 class _L1Mean(torch.autograd.Function):

@@ -216,14 +216,78 @@ class MaxPool2(nn.Module):
         return ops.maxpool2(x)
 
 
+class AvgPool2(nn.Module):
+    """nn.AvgPool2d(kernel_size=2, stride=2) on csrc/perceptual.hip (`build_cnn(pooling='avg')`)."""
+
+    def forward(self, x):
+        return ops.avgpool2(x)
+
+
+class Flatten(nn.Module):
+    """`x.view(N, -1)` of the reference (sg2im/layers.py:160-165): the values in (C, H, W) order, whatever the memory
+    format of the activation is here."""
+
+    def forward(self, x):
+        return x.reshape(x.size(0), -1)
+
+    def __repr__(self):
+        return 'Flatten()'
+
+
+class ResidualBlock(nn.Module):
+    """sg2im/layers.py:190-217: [norm, act, conv, norm, act, conv] (the norms absent with normalization='none') and
+    `shortcut + self.net(x)`.  Two properties of the reference are kept on purpose: `self.net(x)` is evaluated TWICE per
+    call (:214-215; the first result is dropped, but in training mode the BatchNorm running statistics advance twice), and
+    padding='valid' slices an empty shortcut (`x[:, :, 0:-0, 0:-0]`) — it fails there, so it is refused here.  The skip
+    addition rides in the last convolution's epilogue.  Same nn.Sequential indices, hence the same state_dict keys."""
+
+    def __init__(self, channels, normalization='batch', activation='relu', padding='same', kernel_size=3, init='default'):
+        super().__init__()
+        if padding != 'same':
+            raise NotImplementedError("ResidualBlock: padding='valid' slices an empty shortcut in the reference "
+                                      "(sg2im/layers.py:211-213) and cannot run there either")
+        K, C = kernel_size, channels
+        assert K % 2 == 1, 'Invalid kernel size %d for "same" padding' % K
+        self.padding = (K - 1) // 2
+        slope = _fusable_slope(activation)
+        layers = []
+        for _ in range(2):
+            if normalization == 'batch':
+                layers.append(BatchNormAct(C, fused_slope=1.0 if slope is None else slope))
+            elif normalization == 'instance':
+                layers.append(InstanceNorm2dAct(C, fused_slope=1.0 if slope is None else slope))
+            elif normalization != 'none':
+                raise ValueError('Unrecognized normalization type "%s"' % normalization)
+            fused = slope is not None and normalization != 'none'
+            layers.append(_FusedActivation() if fused else get_activation(activation))
+            conv = Conv2d(C, C, kernel_size=K, padding=self.padding)
+            if init == 'kaiming-normal':
+                nn.init.kaiming_normal_(conv.weight)
+            elif init == 'kaiming-uniform':
+                nn.init.kaiming_uniform_(conv.weight)
+            layers.append(conv)
+        # the reference filters absent norms out BEFORE building the Sequential: indices 0..3 then, 0..5 with norms
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, x):
+        mods = list(self.net)
+        for rep in range(2):                       # (:214-215) the block runs its net twice; the first result is dropped
+            h = x
+            for m in mods[:-1]:
+                h = m(h)
+            if rep == 1:
+                return mods[-1](h, residual=x)
+            mods[-1](h)
+
+
 def build_cnn(arch, normalization='batch', activation='relu', padding='same', pooling='max', init='default'):
     """Arch-string CNN (reference sg2im/layers.py:28-112) with the same nn.Sequential indices and state_dict keys as the
     reference builder, executed on the HIP kernels: IX (input channels), CK-X[-S] (Conv2d on the implicit GEMM /
     Winograd kernels; every convolution except the first is preceded by normalisation and non-linearity — BatchNorm2d
     or InstanceNorm2d with ReLU / LeakyReLU-x fused into its apply pass, or, with normalization='none', the activation
-    fused into the previous convolution's epilogue), UX (nearest-neighbour upsampling), P2 with max pooling.  Residual
-    blocks, FC layers, average pooling and pooling factors other than 2 are used by no call site of the reference
-    (`AcCropDiscriminator`: 'C4-64-2,C4-128-2,C4-256-2', `AppearanceEncoder` likewise) and raise."""
+    fused into the previous convolution's epilogue), R (ResidualBlock), UX (nearest-neighbour upsampling), P2 with max
+    or average pooling, FC-X-Y (Flatten + Linear, activated unless it closes the network).  Pooling factors other than 2
+    are used by no call site of the reference and raise."""
     if isinstance(arch, str):
         arch = arch.split(',')
     if normalization not in ('batch', 'instance', 'none'):
@@ -234,8 +298,8 @@ def build_cnn(arch, normalization='batch', activation='relu', padding='same', po
     if len(arch) > 0 and arch[0][0] == 'I':
         cur = int(arch[0][1:])
         arch = arch[1:]
-    first, layers, prev_conv = True, [], None
-    for s in arch:
+    first, layers, prev_conv, flat = True, [], None, False
+    for idx, s in enumerate(arch):
         if s[0] == 'C':
             if not first:
                 if normalization == 'batch':
@@ -262,11 +326,30 @@ def build_cnn(arch, normalization='batch', activation='relu', padding='same', po
             cur = nxt
         elif s[0] == 'U':
             layers.append(Interpolate(scale_factor=int(s[1:]), mode='nearest'))
-        elif s[0] == 'P' and int(s[1:]) == 2 and pooling == 'max':
-            layers.append(MaxPool2())
-        elif s[0] in ('R', 'P') or s[:2] == 'FC':
-            raise NotImplementedError('build_cnn: layer "%s" (pooling=%s) is used by no call site of the reference and is '
-                                      'not built on the HIP kernels' % (s, pooling))
+        elif s[0] == 'R':
+            # (normalization is dropped for a block that opens the network, as in the reference)
+            layers.append(ResidualBlock(cur, normalization='none' if first else normalization, activation=activation,
+                                        padding=padding, init=init))
+            first = False
+            prev_conv = None
+        elif s[0] == 'P' and int(s[1:]) == 2 and pooling in ('max', 'avg'):
+            layers.append(MaxPool2() if pooling == 'max' else AvgPool2())
+        elif s[:2] == 'FC':
+            _, din, dout = s.split('-')
+            din, dout = int(din), int(dout)
+            if not flat:
+                layers.append(Flatten())
+            flat = True
+            more = idx + 1 < len(arch)                       # every FC except the network's last layer is activated
+            lin = Linear(din, dout, fused_slope=slope if more else None)
+            layers.append(lin)
+            if more:
+                layers.append(_FusedActivation() if slope is not None else get_activation(activation))
+            cur = dout
+            prev_conv = None
+        elif s[0] == 'P':
+            raise NotImplementedError('build_cnn: pooling layer "%s" (pooling=%s): only factor 2, max or avg, is built on the '
+                                      'HIP kernels (no call site of the reference uses another)' % (s, pooling))
         else:
             raise ValueError('Invalid layer "%s"' % s)
     return nn.Sequential(*layers), cur

@@ -386,6 +386,9 @@ int csg_crop_bwd_boxes(const float* dout, const float* img, int64_t B, int64_t H
 int csg_maxpool2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
 int csg_maxpool2_bwd(const float* dy, const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* dx,
                      void* stream);
+/* nn.AvgPool2d(2, 2) of `build_cnn(pooling='avg')` (sg2im/layers.py:88-90): mean of each 2 x 2 window, floor mode */
+int csg_avgpool2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
+int csg_avgpool2_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream);
 int64_t csg_l1_mean_workspace(int64_t n);
 int csg_l1_mean_fwd(const float* a, const float* b, int64_t n, float* out, void* workspace, int64_t workspace_bytes,
                     void* stream);

@@ -800,7 +800,11 @@ def fx_variants():
     cnn_cases = [('I8,C3-16,C3-32-2,U2,C3-8,P2,C1-4', dict(normalization='instance', activation='relu'), (2, 8, 16, 16)),
                  ('I8,C3-16,C3-32', dict(normalization='none', activation='leakyrelu-0.1'), (2, 8, 12, 12)),
                  ('C4-16-2,C4-32-2', dict(normalization='batch', activation='sigmoid', padding='valid'), (3, 3, 22, 22)),
-                 ('I4,C3-8,U3,C3-8', dict(normalization='batch', activation='leakyrelu-0.2'), (2, 4, 8, 8))]
+                 ('I4,C3-8,U3,C3-8', dict(normalization='batch', activation='leakyrelu-0.2'), (2, 4, 8, 8)),
+                 # round 4: residual blocks (the reference evaluates their net twice per call), average pooling, FC layers
+                 ('I8,C3-16,R,P2,C3-8', dict(normalization='batch', activation='relu', pooling='avg'), (3, 8, 12, 12)),
+                 ('I4,R,C3-8-2,R,FC-128-12,FC-12-4', dict(normalization='instance', activation='leakyrelu-0.2'), (2, 4, 8, 8)),
+                 ('I8,R,P2,FC-128-8', dict(normalization='none', activation='relu', pooling='avg'), (3, 8, 8, 8))]
     for i, (arch, kw, shape) in enumerate(cnn_cases):
         torch.manual_seed(80 + i)
         m, cout = build_cnn(arch, **kw)

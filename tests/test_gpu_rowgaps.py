@@ -275,14 +275,18 @@ def _load_variant(mine, entry, seed_key="seed"):
 
 
 def _check_grads_and_buffers(mine, a, tag, what, zero_grad_keys=()):
+    """Parameter gradients and buffers against the fixture.  A gradient that is analytically zero (a bias whose output
+    reaches a normalisation through nothing but resampling, pooling or a residual skip) holds rounding noise on both sides:
+    recognised by its size in the FIXTURE (< 1e-5 of the largest gradient entry of the network) and held to that size."""
+    gmax = max(float(a[k].abs().max()) for k in a if k.startswith(tag + "grad:"))
     n = 0
     for k, p in mine.named_parameters():
         key = tag + "grad:" + k
         if key not in a:
             continue
         want = a[key]
-        if k in zero_grad_keys:            # analytically zero (a bias in front of a normalisation): rounding noise on both sides
-            assert float(p.grad.abs().max()) < 1e-4 and float(want.abs().max()) < 1e-4, (what, k)
+        if k in zero_grad_keys or float(want.abs().max()) < 1e-5 * gmax:
+            assert float(p.grad.abs().max()) < 1e-4 * gmax + 1e-7, (what, k, float(p.grad.abs().max()), gmax)
             continue
         assert_close(p.grad, want, RTOL, 1e-5 * float(want.abs().max()) + 1e-6, "%s d%s" % (what, k))
         n += 1
@@ -316,10 +320,11 @@ def test_build_mlp_variants_vs_reference(idx):
     _check_grads_and_buffers(mine, a, tag, "mlp %s" % (e["kw"],))
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5, 6])
 def test_build_cnn_grammar_vs_reference(idx):
-    """build_cnn's I / C / U / P grammar on the HIP layers against the REFERENCE's builder (sg2im/layers.py:28-112,
-    fixture tests/golden/variants.npz): same Sequential indices and state_dict keys, outputs, gradients, running stats."""
+    """build_cnn's whole grammar — I / C / R / U / P (max, avg) / FC — on the HIP layers against the REFERENCE's builder
+    (sg2im/layers.py:28-112,190-217, fixture tests/golden/variants.npz): same Sequential indices and state_dict keys,
+    outputs, gradients, running statistics (a residual block's advance TWICE per call, as the reference's do)."""
     import torch.nn as nn
     from canonicalsg2im_amd import ops
     from canonicalsg2im_amd.sg2im.layers import build_cnn
@@ -333,6 +338,7 @@ def test_build_cnn_grammar_vs_reference(idx):
     y = mine(x)
     (y * a[tag + "w"].cuda()).sum().backward()
     want = a[tag + "y"]
+    assert y.shape == want.shape, (y.shape, want.shape)
     assert_close(y, want, RTOL, 1e-5 * float(want.abs().max()) + 1e-6, "cnn out %s" % e["arch"])
     assert_close(x.grad, a[tag + "gx"], RTOL, 1e-5 * float(a[tag + "gx"].abs().max()) + 1e-6, "cnn dx %s" % e["arch"])
     # a conv bias whose output reaches a normalisation through nothing but resampling has an analytically zero gradient
