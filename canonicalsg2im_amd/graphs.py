@@ -177,8 +177,10 @@ class StepGraphs:
         return (tuple(imgs.shape), int(objs.shape[0]), _pad_objects(objs.shape[1]), int(objs.shape[2]))
 
     def invalidate(self):
-        """Drop every captured graph (needed when parameters are re-created or moved — `module.to()`; a checkpoint load
-        copies into the existing tensors and does not need it)."""
+        """Drop every captured graph: needed whenever a tensor a graph reads or writes by ADDRESS is replaced — parameters
+        re-created or moved (`module.to()`), optimiser state reloaded (`load_state_dict` replaces the moment tensors the
+        captured Adam step updates; `Trainer.load_checkpoint` calls this), a learning rate of `optimizer_d_img` edited (it
+        is baked into the captured step)."""
         self.sets, self.seen, self.active = {}, {}, None
 
     # ---- one iteration

@@ -225,16 +225,38 @@ class Trainer:
             if 'd_mask_state' in ckpt:                  # absent from the reference's own save_checkpoint (:488-520)
                 d.mask_discriminator.load_state_dict(ckpt['d_mask_state'])
         if optimizers:
-            self.optimizer.load_state_dict(ckpt['optim_state'])
-            d.optimizer_d_img.load_state_dict(ckpt['d_img_optim_state'])
+            _load_optimizer(self.optimizer, ckpt['optim_state'])
+            _load_optimizer(d.optimizer_d_img, ckpt['d_img_optim_state'])
             if not self.opt.use_img_disc and 'd_obj_optim_state' in ckpt:
-                d.optimizer_d_obj.load_state_dict(ckpt['d_obj_optim_state'])
+                _load_optimizer(d.optimizer_d_obj, ckpt['d_obj_optim_state'])
                 if 'd_mask_optim_state' in ckpt:
-                    d.optimizer_d_mask.load_state_dict(ckpt['d_mask_optim_state'])
+                    _load_optimizer(d.optimizer_d_mask, ckpt['d_mask_optim_state'])
         from . import ops
         ops.invalidate_weight_caches()
+        if self.graphs is not None:
+            # optimizer.load_state_dict REPLACES the moment tensors the captured Adam step updates in place: the graphs
+            # would keep stepping the old ones.  Drop them; the next repeated shape is captured afresh.
+            self.graphs.invalidate()
+            self._grads_dirty = True
         c = ckpt.get('counters', {})
         return c.get('t', 0), c.get('epoch', 0)
+
+
+def _load_optimizer(optimizer, state):
+    """`optimizer.load_state_dict(state)` keeping THIS optimiser's implementation flags.  `load_state_dict` takes every
+    entry of the saved param_groups — learning rate and betas (wanted: the reference restores them the same way,
+    scripts/train.py:40-60), but also `fused` / `capturable` / `foreach`, and it leaves the step counters on the host when
+    the saved optimiser was not fused.  A checkpoint written by the reference (plain Adam) would so turn the one-kernel
+    fused step off and make the image discriminator's step un-capturable."""
+    keep = [{k: g[k] for k in ('fused', 'capturable', 'foreach') if k in g} for g in optimizer.param_groups]
+    optimizer.load_state_dict(state)
+    for g, flags in zip(optimizer.param_groups, keep):
+        g.update(flags)
+        if g.get('fused') or g.get('capturable'):
+            for p in g['params']:
+                st = optimizer.state.get(p)
+                if st and 'step' in st:
+                    st['step'] = torch.as_tensor(st['step'], dtype=torch.float32).to(p.device)
 
 
 # ------------------------------------------------------------------ test / smoke helpers
