@@ -321,9 +321,10 @@ def main():
             torch.cuda.synchronize()
             pg = _lib.prof_read()
             _lib.prof_enable(0)
-            alg = sum(pg.get(k, (0.0, 0, 0.0))[2] for k in ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad", "wino4_conv"))
+            mk = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "gemm_nt", "gemm_tn", "wino_conv", "wino_wgrad", "wino4_conv")
+            alg = sum(pg.get(k, (0.0, 0, 0.0))[2] for k in mk)
             exe = sum(pg.get(k, (0.0, 0, 0.0))[2] * {"wino_conv": 4.0 / 9.0, "wino_wgrad": 4.0 / 9.0, "wino4_conv": 0.25}.get(k, 1.0)
-                      for k in ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad", "wino4_conv"))
+                      for k in mk)
             gen_exec_ratio = exe / alg if alg > 0 else None
 
     # the reference's DEFAULT recipe keeps the VGG perceptual term (scripts/args.py:153-154); the headline above is
@@ -390,7 +391,7 @@ def main():
     # the algorithmic rate is reported beside it as `algorithmic` / `algorithmic_over_peak` (it may exceed 1).
     # (F(4x4,3x3): 36 multiplications per 16 outputs where the direct sum needs 144 -> 1/4)
     EXEC = {"wino_conv": 4.0 / 9.0, "wino_wgrad": 4.0 / 9.0, "wino4_conv": 0.25}
-    mfma_kernels = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "wino_conv", "wino_wgrad", "wino4_conv")
+    mfma_kernels = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "gemm_nt", "gemm_tn", "wino_conv", "wino_wgrad", "wino4_conv")
 
     def mfma_rates(table, names, seconds):
         """(algorithmic TFLOP/s, executed TFLOP/s) of the launches `names` in a prof table over `seconds`."""

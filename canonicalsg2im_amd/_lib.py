@@ -57,6 +57,13 @@ class SnBwdItem(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol declared in include/csg_hip.h
+class GemmDesc(ctypes.Structure):
+    """csg_gemm_desc (include/csg_hip.h)."""
+    _fields_ = [("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64),
+                ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldy", ctypes.c_int64), ("ldg", ctypes.c_int64),
+                ("act", ctypes.c_int32), ("slope", ctypes.c_float), ("gate_slope", ctypes.c_float)]
+
+
 SIGNATURES = {
     "csg_version": (c_i32, []),
     "csg_last_error": (ctypes.c_char_p, []),
@@ -95,6 +102,10 @@ SIGNATURES = {
     "csg_wino_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
     "csg_conv_fwd_multi_workspace": (c_i64, [ctypes.POINTER(ConvDesc), c_i32]),
     "csg_conv_fwd_multi": (c_i32, [ctypes.POINTER(ConvDesc), c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_gemm_supported": (c_i32, [ctypes.POINTER(GemmDesc)]),
+    "csg_gemm_nt": (c_i32, [ctypes.POINTER(GemmDesc), c_p, c_p, c_p, c_p, c_p, c_p]),
+    "csg_gemm_tn_workspace": (c_i64, [c_i64, c_i64, c_i64]),
+    "csg_gemm_tn": (c_i32, [c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p]),
     "csg_conv_few_supported": (c_i32, [ctypes.POINTER(FewDesc)]),
     "csg_conv_few_fwd_workspace": (c_i64, [ctypes.POINTER(FewDesc)]),
     "csg_conv_few_fwd": (c_i32, [ctypes.POINTER(FewDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
@@ -122,9 +133,9 @@ SIGNATURES = {
     "csg_norm_finalize": (c_i32, [c_p, c_i64, c_i64, c_f64, c_f32, c_i32, c_p, c_p, c_p, c_p, c_f32, c_p]),
     "csg_norm_apply_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_f32, c_p, c_p]),
     "csg_norm_apply_bwd_reduce": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64,
-                                          c_p]),
+                                          c_i64, c_p]),
     "csg_norm_apply_bwd_dx": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_f64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_f32,
-                                      c_p, c_p, c_p]),
+                                      c_p, c_p, c_i64, c_p]),
     "csg_nearest_resize_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_nearest_resize_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_upsample2x_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),

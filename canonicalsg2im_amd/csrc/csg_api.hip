@@ -124,7 +124,8 @@ static const char* kNames[K_COUNT] = {
     "canon_build",    "canon_emit",     "spectral_norm_fwd", "spectral_norm_bwd",
     "wino_conv",      "wino_pack",      "wino_wgrad",
     "few_fwd",        "few_bwd_data",   "few_bwd_weight",
-    "wino4_conv",     "wino4_wgrad"};
+    "wino4_conv",     "wino4_wgrad",
+    "gemm_nt",        "gemm_tn"};
 
 }  // namespace csg
 

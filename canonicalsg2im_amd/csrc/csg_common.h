@@ -58,6 +58,8 @@ enum KernelId {
   K_FEW_BWD_WEIGHT,
   K_WINO4_CONV,
   K_WINO4_WGRAD,
+  K_GEMM_NT,
+  K_GEMM_TN,
   K_COUNT
 };
 

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const float* __restrict
                                                           const float* __restrict__ gb,
                                                           const float* __restrict__ yact, float slope, int64_t P, int C,
                                                           int nchunk, float* __restrict__ dgb,
-                                                          double* __restrict__ partial) {
+                                                          double* __restrict__ partial, int gcs) {
+  // gcs: floats per pixel of gb — 2C for a [gamma | beta] map, C for a gamma-only map (fused forward; needs yact)
   // yact (nullable): the activated output y of the forward.  With it the LeakyReLU gate is read off y's sign (y > 0 iff
   // the pre-activation was) and the beta half of gb is never touched — the fused forward (csg_wino4_conv_part) does not
   // write beta.
@@ -206,13 +207,13 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const float* __restrict
         float4 xh = make_float4((xv.x - m.x) * r.x, (xv.y - m.y) * r.y, (xv.z - m.z) * r.z, (xv.w - m.w) * r.w);
         float4 dn = d;
         if (gb != nullptr) {
-          const float4 ga = ld4(gb + pix * 2 * C + co);
+          const float4 ga = ld4(gb + pix * gcs + co);
           if (slope != 1.0f) {
             if (yact != nullptr) {
               const float4 yv = ld4(yact + pix * C + co);
               d.x *= lrelu_g(yv.x, slope); d.y *= lrelu_g(yv.y, slope); d.z *= lrelu_g(yv.z, slope); d.w *= lrelu_g(yv.w, slope);
             } else {
-              const float4 be = ld4(gb + pix * 2 * C + C + co);
+              const float4 be = ld4(gb + pix * gcs + C + co);
               d.x *= lrelu_g(xh.x * (1.f + ga.x) + be.x, slope); d.y *= lrelu_g(xh.y * (1.f + ga.y) + be.y, slope);
               d.z *= lrelu_g(xh.z * (1.f + ga.z) + be.z, slope); d.w *= lrelu_g(xh.w * (1.f + ga.w) + be.w, slope);
             }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_dx(const float* __restrict__ d
                                                       int C, int64_t n4, float* __restrict__ dx,
                                                       const float* __restrict__ dy2, const float* __restrict__ gb2,
                                                       float slope2, const float* __restrict__ dgb,
-                                                      const float* __restrict__ dgb2) {
+                                                      const float* __restrict__ dgb2, int gcs) {
   const int Q = C >> 2;
 #pragma unroll 2
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
@@ -272,13 +273,13 @@ __global__ __launch_bounds__(256) void k_norm_bwd_dx(const float* __restrict__ d
     float4 dn = d;
     if (gb != nullptr && dgb != nullptr) {
       // pass 1 already wrote d(beta) = dy * activation gate: read it instead of dy and beta (one map less)
-      const float4 ga = ld4(gb + pix * 2 * C + co);
+      const float4 ga = ld4(gb + pix * gcs + co);
       d = ld4(dgb + pix * 2 * C + C + co);
       dn = make_float4(d.x * (1.f + ga.x), d.y * (1.f + ga.y), d.z * (1.f + ga.z), d.w * (1.f + ga.w));
     } else if (gb != nullptr) {
-      const float4 ga = ld4(gb + pix * 2 * C + co);
+      const float4 ga = ld4(gb + pix * gcs + co);
       if (slope != 1.0f) {
-        const float4 be = ld4(gb + pix * 2 * C + C + co);
+        const float4 be = ld4(gb + pix * gcs + C + co);
         d.x *= lrelu_g(xh.x * (1.f + ga.x) + be.x, slope); d.y *= lrelu_g(xh.y * (1.f + ga.y) + be.y, slope);
         d.z *= lrelu_g(xh.z * (1.f + ga.z) + be.z, slope); d.w *= lrelu_g(xh.w * (1.f + ga.w) + be.w, slope);
       }
@@ -287,10 +288,10 @@ __global__ __launch_bounds__(256) void k_norm_bwd_dx(const float* __restrict__ d
       dn.x *= lrelu_g(xh.x, slope); dn.y *= lrelu_g(xh.y, slope); dn.z *= lrelu_g(xh.z, slope); dn.w *= lrelu_g(xh.w, slope);
     }
     if (dy2 != nullptr) {                 // second modulation (gb2 is required with it)
-      const float4 ga = ld4(gb2 + pix * 2 * C + co);
+      const float4 ga = ld4(gb2 + pix * gcs + co);
       float4 d2 = dgb2 != nullptr ? ld4(dgb2 + pix * 2 * C + C + co) : ld4(dy2 + e * 4);
       if (slope2 != 1.0f && dgb2 == nullptr) {
-        const float4 be = ld4(gb2 + pix * 2 * C + C + co);
+        const float4 be = ld4(gb2 + pix * gcs + C + co);
         d2.x *= lrelu_g(xh.x * (1.f + ga.x) + be.x, slope2); d2.y *= lrelu_g(xh.y * (1.f + ga.y) + be.y, slope2);
         d2.z *= lrelu_g(xh.z * (1.f + ga.z) + be.z, slope2); d2.w *= lrelu_g(xh.w * (1.f + ga.w) + be.w, slope2);
       }
@@ -503,8 +504,10 @@ int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, c
 
 int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
                               const float* gb, const float* yact, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
-                              double* dsums, double* partial, int64_t nchunk, void* stream) {
+                              double* dsums, double* partial, int64_t nchunk, int64_t gb_cs, void* stream) {
   CSG_REQUIRE(yact == nullptr || gb != nullptr, CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: yact goes with a modulation");
+  CSG_REQUIRE(gb == nullptr || gb_cs == 2 * C || (gb_cs == C && yact != nullptr), CSG_E_BADSHAPE,
+              "csg_norm_apply_bwd_reduce: gb_cs is 2C ([gamma | beta]) or, with yact, C (gamma only)");
   CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: bad shape");
   CSG_REQUIRE((gb == nullptr) == (dgb == nullptr), CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: gb/dgb mismatch");
   CSG_REQUIRE(nchunk >= 1 && nchunk <= 65535 && G <= 65535, CSG_E_BADSHAPE, "csg_norm_apply_bwd_reduce: bad nchunk");
@@ -512,7 +515,7 @@ int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean
   {
     ProfScope p(K_NORM_BWD_REDUCE, (double)G * P * C * 4 * (gb ? 6 : 2), s);
     CSG_LAUNCH(k_norm_bwd_reduce, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 8, s, dy, x, mean,
-                       invstd, gb, yact, slope, P, (int)C, (int)nchunk, dgb, partial);
+                       invstd, gb, yact, slope, P, (int)C, (int)nchunk, dgb, partial, (int)gb_cs);
   }
   CSG_LAUNCH(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
                      (int)(2 * C), (int)nchunk, (int)(2 * C), dsums);
@@ -522,14 +525,16 @@ int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean
 int csg_norm_apply_bwd_dx(const float* dy, const float* x, const float* mean, const float* invstd, const float* gb,
                           float slope, const double* dsums, double count, int64_t G, int64_t P, int64_t C, float* dx,
                           const float* dy2, const float* gb2, float slope2, const float* dgb, const float* dgb2,
-                          void* stream) {
+                          int64_t gb_cs, void* stream) {
   CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0 && count > 0, CSG_E_BADSHAPE, "csg_norm_apply_bwd_dx: bad shape");
+  CSG_REQUIRE(gb == nullptr || gb_cs == 2 * C || (gb_cs == C && dgb != nullptr && (gb2 == nullptr || dgb2 != nullptr)),
+              CSG_E_BADSHAPE, "csg_norm_apply_bwd_dx: gb_cs is 2C ([gamma | beta]) or, with dgb (and dgb2), C (gamma only)");
   CSG_REQUIRE((dy2 == nullptr) == (gb2 == nullptr), CSG_E_BADSHAPE, "csg_norm_apply_bwd_dx: dy2 and gb2 come together");
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = G * P * C / 4;
   ProfScope p(K_NORM_BWD_DX, (double)G * P * C * 4 * ((gb ? (dgb ? 4 : 5) : 3) + (dy2 ? (dgb2 ? 2 : 3) : 0)), s);
   CSG_LAUNCH(k_norm_bwd_dx, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, mean, invstd, gb, slope, dsums,
-                     1.0 / count, P, (int)C, n4, dx, dy2, gb2, slope2, dgb, dgb2);
+                     1.0 / count, P, (int)C, n4, dx, dy2, gb2, slope2, dgb, dgb2, (int)gb_cs);
   return check_launch("csg_norm_apply_bwd_dx");
 }
 

@@ -15,7 +15,7 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _register
 
 from . import _lib
 from . import dist as csg_dist
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, WinoDesc, check, lib, ptr, stream
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, GemmDesc, WinoDesc, check, lib, ptr, stream
 
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "nearest_resize", "avgpool3s2", "embed", "real_object_mask",
@@ -135,6 +135,41 @@ FEW_ENABLED = os.environ.get("CSG_FEW_OUTPUT_KERNELS", "1") != "0"   # csrc/fewn
 WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "1024"))     # B*H*W below which the direct kernel stays
 WINO_ENABLED = os.environ.get("CSG_WINOGRAD", "1") != "0"
 WINO_WGRAD = os.environ.get("CSG_WINOGRAD_WGRAD", "1") != "0"
+
+# ---- plain GEMM kernels (csrc/gemm.hip) for the 1x1 convolutions / linears they are measured faster on
+GEMM_MODE = os.environ.get("CSG_GEMM", "auto")        # "auto": the measured rule below; "all": every shape the kernels fill the
+#                                                        chip with (tests, tools/gemm_bench.py); "off" / "0": never
+GEMM_MIN_TILES = int(os.environ.get("CSG_GEMM_MIN_TILES", "256"))       # 128 x 128 output tiles of the forward product
+_GEMM_CALLS = [0]
+
+
+def gemm_calls():
+    """Launches of csrc/gemm.hip so far (tests: which path served a layer)."""
+    return _GEMM_CALLS[0]
+
+
+def gemm_eligible(M, N, K):
+    """A (M rows) x (K -> N) linear map goes to csrc/gemm.hip when its forward product has at least one 128 x 128 tile per CU
+    and — mode "auto" — N <= 256 <= K: the shapes on which the dedicated kernels beat the implicit-GEMM kernel in all three
+    directions (tools/gemm_bench.py on MI355X, forward / backward pair, TFLOP/s: M 96 000, 512 -> 128: 115 / 47 against
+    93 / 39; M 262 144, 256 -> 128: 96 / 43 against 89 / 29; M 65 536, 512 -> 256: 116 / 51 against 109 / 51).  On the graph
+    encoder's wide layers (384 -> 512 -> 1152 at 96 000 rows) the two tie — both run the same 128 x 128 x 32 MFMA tile loop at
+    ~0.8 of the matrix pipe — and the implicit-GEMM kernel keeps them."""
+    if GEMM_MODE in ("off", "0") or K % 4 or N % 4 or K < 32:
+        return False
+    if ((M + 127) // 128) * ((N + 127) // 128) < GEMM_MIN_TILES:
+        return False
+    return GEMM_MODE == "all" or (N <= 256 <= K)
+
+
+def _gemm_nt(a, M, K, w2, N, bias, act, slope, gate, gate_slope, y):
+    """y (M, N) = epi(a (M, K) . w2 (N, K)^T + bias), all dense row-major (csg_gemm_nt)."""
+    d = GemmDesc()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldy, d.ldg = M, N, K, K, K, N, N
+    d.act, d.slope, d.gate_slope = act, slope, gate_slope
+    check(lib.csg_gemm_nt(d, ptr(a), ptr(w2), ptr(bias), ptr(gate), ptr(y), stream()), "gemm_nt")
+    _GEMM_CALLS[0] += 1
+
 
 
 def wino_eligible(B, H, W, Cin, Cout, KH, KW, stride, pad):
@@ -300,6 +335,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.packs, ctx.dx_range, ctx.in_act, ctx.grad_is_pre = packs, dx_range, in_act, grad_is_pre
         res = nhwc(residual) if residual is not None else None
         ctx.few = None
+        ctx.gemm = False
         ctx.cout_w = Cout                       # rows of the weight as given (1..3 when the few-output path takes it raw)
         if (Cout == 4 or (cout_real is not None and Cout == cout_real and Cout < 4)) and res is None and dx_range is None \
                 and packs is None and in_act is None:
@@ -338,6 +374,15 @@ class _Conv2d(torch.autograd.Function):
             check(lib.csg_wino34_conv(_wino_desc(B, IH, IW, Cin, Cout, act, slope), pad, ptr(x),
                                       ptr(wino_pack(weight, False, None, 34)), ptr(bias.detach() if bias is not None else None),
                                       ptr(res), None, 0.0, ptr(y), None, 0, stream()), "wino34_conv_fwd")
+        elif (KH == 1 and KW == 1 and stride == 1 and pad == 0 and res is None and packs is None and dx_range is None
+              and act in (ACT_NONE, ACT_LEAKY) and gemm_eligible(B * IH * IW, Cout, Cin)):
+            # a matrix product: rows = pixels (or the rows of a Linear), csrc/gemm.hip
+            OH, OW = IH, IW
+            y = empty_nhwc(B, Cout, OH, OW, x.device)
+            w2 = weight.detach().reshape(Cout, Cin)
+            _gemm_nt(x, B * IH * IW, Cin, w2 if w2.is_contiguous() else w2.contiguous(), Cout,
+                     bias.detach() if bias is not None else None, act, slope, None, 0.0, y)
+            ctx.gemm = True
         else:
             # [Cout][KH][KW][Cin]: free for channels-last parameters (sg2im.layers.Conv2d keeps them that way)
             wp = packs[0] if packs is not None else weight.detach().permute(0, 2, 3, 1).contiguous()
@@ -424,6 +469,15 @@ class _Conv2d(torch.autograd.Function):
                                       ptr(x) if has_gate else None, ctx.in_act[1] if has_gate else 0.0, ptr(dx), ptr(ws), nws,
                                       stream()), "wino34_conv_bwd_data")
             gated = True
+        elif ctx.needs_input_grad[0] and getattr(ctx, "gemm", False):
+            # dX (M, Cin) = dY (M, Cout) . W^T stored [Cin][Cout] (the reduction index contiguous), the producer's
+            # activation derivative as the epilogue's gate
+            wt = weight.detach().reshape(Cout, Cin).t().contiguous()
+            dx = empty_nhwc(B, Cin, IH, IW, dy.device)
+            has_gate = ctx.in_act is not None
+            _gemm_nt(dpre, B * IH * IW, Cout, wt, Cin, None, ACT_NONE, 0.0, x if has_gate else None,
+                     ctx.in_act[1] if has_gate else 0.0, dx)
+            gated = True
         elif ctx.needs_input_grad[0]:
             wt = ctx.packs[1] if ctx.packs is not None else \
                 weight.detach().permute(1, 2, 3, 0).contiguous()       # [Cin][KH][KW][Cout]
@@ -445,7 +499,23 @@ class _Conv2d(torch.autograd.Function):
             d = WinoDesc()
             d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, IH, IW, Cin, Cin, Cout, Cout, ACT_NONE, 0.0
             wino_wg = lib.csg_wino_bwd_weight_workspace(d)      # < 0: the 16-tile stages do not tile this image exactly
-        if wino_wg >= 0:
+        if ctx.needs_input_grad[1] and getattr(ctx, "gemm", False):
+            # dW (Cout, Cin) = dY^T . X over the rows, the bias gradient from the same staged tiles (csg_gemm_tn)
+            M = B * IH * IW
+            nbytes = lib.csg_gemm_tn_workspace(M, Cout, Cin)
+            if nbytes < 0:
+                raise RuntimeError("gemm_tn_workspace: (%d, %d, %d) not served" % (M, Cout, Cin))
+            ws = torch.empty(max(nbytes // 4, 4), device=dy.device, dtype=torch.float32)
+            dwp = _grad_dest(weight, (Cout, KH, KW, Cin)) if _ohwi_dense(weight) else None
+            if dwp is None:
+                dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
+            if want_db:
+                db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
+            check(lib.csg_gemm_tn(M, Cout, Cin, ptr(dpre), Cout, ptr(x), Cin, ptr(dwp), ptr(db), ptr(ws), nbytes, stream()),
+                  "gemm_tn")
+            _GEMM_CALLS[0] += 1
+            dw = dwp.permute(0, 3, 1, 2)
+        elif wino_wg >= 0:
             # Winograd F(3x3,2x2) weight gradient (csrc/wino.hip), same output layout as the direct kernel
             nbytes = wino_wg
             ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
@@ -766,7 +836,7 @@ class _NormAct(torch.autograd.Function):
         part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float64)
         dsums = torch.empty(G * 2 * C, device=dev, dtype=torch.float64)
         check(lib.csg_norm_apply_bwd_reduce(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), None, slope, G, P, C, ptr(dgb),
-                                            ptr(dsums), ptr(part), nch, stream()), "norm_bwd_reduce")
+                                            ptr(dsums), ptr(part), nch, 2 * C, stream()), "norm_bwd_reduce")
         dx = None
         if ctx.needs_input_grad[0]:
             if not use_batch_stats:
@@ -775,7 +845,7 @@ class _NormAct(torch.autograd.Function):
                 csg_dist.all_reduce_stats(dsums)
             dx = torch.empty_like(x)
             check(lib.csg_norm_apply_bwd_dx(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, ptr(dsums), count,
-                                            G, P, C, ptr(dx), None, None, 1.0, ptr(dgb), None, stream()), "norm_bwd_dx")
+                                            G, P, C, ptr(dx), None, None, 1.0, ptr(dgb), None, 2 * C, stream()), "norm_bwd_dx")
         return dx, dgb, None, None, None, None, None, None, None, None
 
 
@@ -823,9 +893,9 @@ class _NormActPair(torch.autograd.Function):
         dsums = torch.empty(2, 2 * C, device=dev, dtype=torch.float64)
         dgb0, dgb1 = torch.empty_like(gb0), torch.empty_like(gb1)
         check(lib.csg_norm_apply_bwd_reduce(ptr(dy0), ptr(x), ptr(mean), ptr(invstd), ptr(gb0), None, slope0, 1, P, C, ptr(dgb0),
-                                            ptr(dsums[0]), ptr(part), nch, stream()), "norm_bwd_reduce")
+                                            ptr(dsums[0]), ptr(part), nch, 2 * C, stream()), "norm_bwd_reduce")
         check(lib.csg_norm_apply_bwd_reduce(ptr(dy1), ptr(x), ptr(mean), ptr(invstd), ptr(gb1), None, slope1, 1, P, C, ptr(dgb1),
-                                            ptr(dsums[1]), ptr(part), nch, stream()), "norm_bwd_reduce")
+                                            ptr(dsums[1]), ptr(part), nch, 2 * C, stream()), "norm_bwd_reduce")
         dx = None
         if ctx.needs_input_grad[0]:
             both = dsums[0] + dsums[1]                    # the reductions are linear in dn: 4C doubles
@@ -833,7 +903,7 @@ class _NormActPair(torch.autograd.Function):
                 csg_dist.all_reduce_stats(both)
             dx = torch.empty_like(x)
             check(lib.csg_norm_apply_bwd_dx(ptr(dy0), ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, ptr(both), count,
-                                            1, P, C, ptr(dx), ptr(dy1), ptr(gb1), slope1, ptr(dgb0), ptr(dgb1), stream()),
+                                            1, P, C, ptr(dx), ptr(dy1), ptr(gb1), slope1, ptr(dgb0), ptr(dgb1), 2 * C, stream()),
                   "norm_bwd_dx")
         return dx, dgb0, dgb1, None, None, None, None, None, None, None, None, None
 
@@ -855,8 +925,8 @@ def spade_fused_eligible(x, nhidden, C, ks, training):
 class _SpadeFused(torch.autograd.Function):
     """K = 1 or 2 SPADE modulations of ONE batch-normalised x (reference normalization.py:96-110; K = 2: norm_s and norm_0
     of a residual block, architecture.py:37-47), each `leaky(xhat (1 + gamma_k) + beta_k, slope_k)` with gamma_k || beta_k =
-    conv3x3(actv_k, w_k) + b_k.  Forward per modulation: the gamma half of the convolution into a (B,H,W,2C) buffer (its
-    beta half is never written), then the beta half with the modulation as its epilogue.  Backward: the two norm passes of
+    conv3x3(actv_k, w_k) + b_k.  Forward per modulation: the gamma half of the convolution into a (B,H,W,C) buffer, then
+    the beta half with the modulation as its epilogue (beta itself is never materialised).  Backward: the two norm passes of
     _NormAct / _NormActPair (the LeakyReLU gate read off y's sign), then the joined convolution's backward-data and
     weight-gradient passes on d(gamma || beta)."""
 
@@ -889,9 +959,9 @@ class _SpadeFused(torch.autograd.Function):
                                                                                          tuple(x.shape)))
             up = wino_pack(w, False, None, 4)
             bd = b.detach().contiguous()
-            gbuf = empty_nhwc(B, 2 * C, H, W, dev)            # [gamma | (beta: never written, never read)]
+            gbuf = empty_nhwc(B, C, H, W, dev)                # gamma only: beta is consumed in the epilogue that forms it
             d = _wino_desc(B, H, W, nh, C)
-            d.y_cs = 2 * C
+            d.y_cs = C
             check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), 0, 2 * C // 32, ptr(bd), None, None, 0, None, None, 1.0,
                                           ptr(gbuf), stream()), "wino4_conv_part(gamma)")
             launches.append((actv, w, up, bd, gbuf, nh, slope, in_slope))
@@ -905,7 +975,7 @@ class _SpadeFused(torch.autograd.Function):
             y = torch.empty_like(x)
             d = _wino_desc(B, H, W, nh, C)
             d.y_cs = C
-            check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), C // 32, 2 * C // 32, ptr(bd[C:]), ptr(x), ptr(gbuf), 2 * C,
+            check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), C // 32, 2 * C // 32, ptr(bd[C:]), ptr(x), ptr(gbuf), C,
                                           ptr(mean), ptr(invstd), slope, ptr(y), stream()), "wino4_conv_part(beta)")
             saved += [actv, w, gbuf, y]
             outs.append(y)
@@ -928,9 +998,9 @@ class _SpadeFused(torch.autograd.Function):
         dgbs = []
         for k in range(K):
             actv, w, gbuf, y = sv[3 + 4 * k:7 + 4 * k]
-            dgb = torch.empty_like(gbuf)
+            dgb = empty_nhwc(B, 2 * C, H, W, dev)             # d(gamma || beta): the joined convolution's incoming gradient
             check(lib.csg_norm_apply_bwd_reduce(ptr(dys[k]), ptr(x), ptr(mean), ptr(invstd), ptr(gbuf), ptr(y), cfg[k][0], 1, P,
-                                                C, ptr(dgb), ptr(dsums[k]), ptr(part), nch, stream()), "norm_bwd_reduce")
+                                                C, ptr(dgb), ptr(dsums[k]), ptr(part), nch, C, stream()), "norm_bwd_reduce")
             dgbs.append(dgb)
         dx, both, pending = None, None, None
         if ctx.needs_input_grad[0]:
@@ -958,7 +1028,7 @@ class _SpadeFused(torch.autograd.Function):
             two = K == 2
             check(lib.csg_norm_apply_bwd_dx(ptr(dys[0]), ptr(x), ptr(mean), ptr(invstd), ptr(sv[5]), cfg[0][0], ptr(both), count,
                                             1, P, C, ptr(dx), ptr(dys[1]) if two else None, ptr(sv[9]) if two else None,
-                                            cfg[1][0] if two else 1.0, ptr(dgbs[0]), ptr(dgbs[1]) if two else None, stream()),
+                                            cfg[1][0] if two else 1.0, ptr(dgbs[0]), ptr(dgbs[1]) if two else None, C, stream()),
                   "norm_bwd_dx")
             grads[0] = dx
         return tuple(grads)

@@ -307,6 +307,32 @@ int64_t csg_conv_few_bwd_weight_workspace(const csg_few_desc* d);
 int csg_conv_few_bwd_weight(const csg_few_desc* d, const float* x, const float* dy, float* dw, float* db,
                             float* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- plain fp32 GEMMs (csrc/gemm.hip) ------------------------------------------------------------
+ * The layers of the path that ARE matrix products: nn.Linear of the graph encoder (sg2im/graph.py:63-77 through
+ * sg2im/layers.py:114-140 build_mlp; rows = triplets or objects) and 1x1 convolutions on NHWC maps (SPADEResnetBlock.conv_s,
+ * spade/models/networks/architecture.py:37-39; rows = pixels).  csg_conv_fwd / csg_conv_bwd_weight serve them as well (the
+ * small ones stay there); these kernels drop the convolution's tap table and stage both operands by LDS-DMA.
+ *   csg_gemm_nt:  y[m][n] = epi(sum_k a[m][k] * bw[n][k] + bias[n]);  epi = act, then `gate` (nullable, rows of ldg
+ *                 floats): y *= (gate[m][n] > 0 ? 1 : gate_slope) — the derivative of the (Leaky)ReLU that produced this
+ *                 layer's input, for the backward-data pass (a = dy, bw = W^T stored [K_layer][N_layer]).
+ *   csg_gemm_tn:  dw[n][k] = sum_m dy[m][n] * x[m][k]  ([Cout][Cin] = the layout of csg_conv_bwd_weight for a 1x1
+ *                 filter), db[n] = sum_m dy[m][n] (nullable).  Rows are cut into slices with one slab each in `workspace`
+ *                 (csg_gemm_tn_workspace bytes, 0 = none needed), summed in a fixed order: bit-reproducible.
+ * K, N (tn), every row stride: multiples of 4 floats; pointers 16-byte aligned.                                       */
+typedef struct csg_gemm_desc {
+  int64_t M, N, K;
+  int64_t lda, ldb, ldy, ldg; /* floats per row of a, bw, y, gate */
+  int32_t act;                /* CSG_ACT_NONE / CSG_ACT_LEAKY (ReLU = slope 0) */
+  float slope;
+  float gate_slope;
+} csg_gemm_desc;
+int csg_gemm_supported(const csg_gemm_desc* d);
+int csg_gemm_nt(const csg_gemm_desc* d, const float* a, const float* bw, const float* bias, const float* gate, float* y,
+                void* stream);
+int64_t csg_gemm_tn_workspace(int64_t M, int64_t N, int64_t K);
+int csg_gemm_tn(int64_t M, int64_t N, int64_t K, const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dw,
+                float* db, float* workspace, int64_t workspace_bytes, void* stream);
+
 /* dpre = dy * act'(.) evaluated from the OUTPUT y (leaky: y>0 ? 1 : slope; tanh: 1-y^2)          */
 int csg_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float slope, float* dpre, void* stream);
 /* out[c] = sum_rows x[r, c] over (rows, C) with row stride x_cs — bias gradients; partial (nchunk,2C) fp64 */
@@ -332,21 +358,23 @@ int csg_norm_finalize(const double* sums, int64_t G, int64_t C, double count, fl
 int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gb, float slope,
                        int64_t G, int64_t P, int64_t C, float* y, const float* gb2, float slope2, float* y2,
                        void* stream);
-/* pass 1: dgb (if gb) and dsums (G,2C) double = [sum dn | sum dn*xhat].  `yact` (nullable, with gb): the activated
- * output y of the forward — the LeakyReLU gate is then read off y's sign and the beta half of gb is never read (the
- * fused forward csg_wino4_conv_part does not write it).                                                        */
+/* pass 1: dgb (if gb; always (G*P, 2C) = [d gamma | d beta]) and dsums (G,2C) double = [sum dn | sum dn*xhat].  `yact`
+ * (nullable, with gb): the activated output y of the forward — the LeakyReLU gate is then read off y's sign and beta is
+ * never read; gb may then be a gamma-only map.  `gb_cs`: floats per pixel of gb — 2C ([gamma | beta]) or, with yact, C
+ * (what the fused forward csg_wino4_conv_part keeps: it never materialises beta).                                  */
 int csg_norm_apply_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
                               const float* gb, const float* yact, float slope, int64_t G, int64_t P, int64_t C, float* dgb,
-                              double* dsums, double* partial, int64_t nchunk, void* stream);
+                              double* dsums, double* partial, int64_t nchunk, int64_t gb_cs, void* stream);
 /* pass 2: dx = invstd*(dn - dsum0/count - xhat*dsum1/count).  (dy2, gb2, slope2), nullable: a second SPADE modulation
  * of the SAME normalised x (norm_0 and norm_s of a residual block with a learned shortcut, architecture.py:37-47, see
  * the same batch statistics): dn = dn_1 + dn_2 and `dsums` holds the sum of both pass-1 reductions — one pass and one
  * dx instead of two passes and an addition.  `dgb` / `dgb2` (nullable): pass 1's output for the same modulation — its
- * d(beta) half IS dy times the activation gate, so pass 2 reads it instead of dy and beta (one map less, same bits). */
+ * d(beta) half IS dy times the activation gate, so pass 2 reads it instead of dy and beta (one map less, same bits).
+ * `gb_cs`: floats per pixel of gb and gb2 — 2C, or C for gamma-only maps (then dgb / dgb2 are required).             */
 int csg_norm_apply_bwd_dx(const float* dy, const float* x, const float* mean, const float* invstd, const float* gb,
                           float slope, const double* dsums, double count, int64_t G, int64_t P, int64_t C, float* dx,
                           const float* dy2, const float* gb2, float slope2, const float* dgb, const float* dgb2,
-                          void* stream);
+                          int64_t gb_cs, void* stream);
 
 /* ---- K7 / pooling ------------------------------------------------------------------------------
  * nearest 2x upsample (generator.py:48,102-121) and its adjoint */

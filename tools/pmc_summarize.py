@@ -3,10 +3,10 @@ files = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for f in files:
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:40]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:40]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
 for k, d in acc.items():
-    if "wino" not in k and "igemm" not in k: continue
+    if "wino" not in k and "gemm" not in k: continue
     print(k, {c: "%.3e" % v for c, v in d.items()})
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
         print("   mfma busy per SIMD / elapsed = %.3f" % ((d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (d["GRBM_GUI_ACTIVE"] / 8)))
