@@ -1034,6 +1034,85 @@ class _SpadeFused(torch.autograd.Function):
         return tuple(grads)
 
 
+class _SpadeJoined(torch.autograd.Function):
+    """One SPADE modulation of a batch-normalised x whose gamma || beta convolution is NOT one the fused epilogue serves (the
+    8 x 8 and 16 x 16 maps of `head_0` / `G_middle_*`): the same kernels as conv2d + norm_act in the same arithmetic, but
+    ordered inside one Function so that on N > 1 ranks both SyncBN messages travel under a convolution, as in _SpadeFused —
+    forward: statistics, asynchronous all-reduce, gamma || beta convolution (needs no statistics), wait, finalise, modulate;
+    backward: pass 1 (d gamma || beta and the two reductions), asynchronous all-reduce, the convolution's backward passes
+    (they need only d gamma || beta), wait, pass 2 (dx).  On one rank the launches are those of the unfused path."""
+
+    @staticmethod
+    def forward(ctx, x, actv, w, b, running_mean, running_var, pad, slope, in_slope, eps, momentum, sync):
+        import types
+        x = nhwc(_f32(x))
+        B, C, H, W = x.shape
+        P = B * H * W
+        dev = x.device
+        world = _sync_world() if sync else 1
+        count = float(P * world)
+        mean = torch.empty(C, device=dev, dtype=torch.float32)
+        invstd = torch.empty(C, device=dev, dtype=torch.float32)
+        nch = _chunks(P, 1)
+        part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
+        sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+        check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
+        pending = csg_dist.all_reduce_stats_async(sums) if world > 1 else None
+        # the joined convolution through _Conv2d's own forward on a stand-in context (its saved tensors are kept for the
+        # backward below)
+        fake = types.SimpleNamespace(needs_input_grad=(True, True, True, False))
+        fake.save_for_backward = lambda *t: setattr(fake, "saved_tensors", t)
+        in_act = (ACT_LEAKY, float(in_slope)) if in_slope is not None else None
+        gb = _Conv2d.forward(fake, actv, w, b, None, 1, int(pad), ACT_NONE, 0.0, None, None, in_act, False, None, None)
+        if pending is not None:
+            pending.wait()
+        check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if world > 1 else 0, ptr(mean), ptr(invstd),
+                                    ptr(running_mean), ptr(running_var if running_mean is not None else None), momentum,
+                                    stream()), "norm_finalize")
+        y = torch.empty_like(x)
+        check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, 1, P, C, ptr(y), None, 1.0, None, stream()),
+              "norm_apply_fwd")
+        cx, cw, cy = fake.saved_tensors
+        ctx.save_for_backward(x, gb, mean, invstd, cx, cw)
+        fake.save_for_backward = None
+        fake.saved_tensors = None
+        ctx.conv = fake
+        ctx.cfg = (P, C, slope, world, count)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gb, mean, invstd, cx, cw = ctx.saved_tensors
+        P, C, slope, world, count = ctx.cfg
+        dy = nhwc(dy)
+        dev = x.device
+        nch = _chunks(P, 1)
+        part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
+        dsums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+        dgb = torch.empty_like(gb)
+        check(lib.csg_norm_apply_bwd_reduce(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), None, slope, 1, P, C, ptr(dgb),
+                                            ptr(dsums), ptr(part), nch, 2 * C, stream()), "norm_bwd_reduce")
+        pending = csg_dist.all_reduce_stats_async(dsums) if (world > 1 and ctx.needs_input_grad[0]) else None
+        fake = ctx.conv
+        fake.saved_tensors = (cx, cw, None)
+        fake.needs_input_grad = (ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3], False)
+        r = _Conv2d.backward(fake, dgb)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if pending is not None:
+                pending.wait()
+            dx = torch.empty_like(x)
+            check(lib.csg_norm_apply_bwd_dx(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, ptr(dsums), count,
+                                            1, P, C, ptr(dx), None, None, 1.0, ptr(dgb), None, 2 * C, stream()), "norm_bwd_dx")
+        return dx, r[0], r[1], r[2], None, None, None, None, None, None, None, None
+
+
+def spade_joined(x, actv, w, b, running_mean, running_var, pad, slope, in_slope, eps=1e-5, momentum=0.1, sync=True):
+    """leaky(batchnorm(x) (1 + gamma) + beta, slope) with gamma || beta = conv(actv, w) + b — see _SpadeJoined."""
+    return _SpadeJoined.apply(x, actv, w, b, running_mean, running_var, int(pad), float(slope),
+                              None if in_slope is None else float(in_slope), float(eps), float(momentum), bool(sync))
+
+
 def spade_fused(x, mods, eps=1e-5, momentum=0.1, sync=True):
     """mods: one or two tuples (actv, w, b, running_mean, running_var, slope, in_slope) — see _SpadeFused.  Returns the
     list of modulated maps."""

@@ -144,7 +144,20 @@ class SPADE(nn.Module):
         if self.fusable(x):
             return ops.spade_fused(x, [self.fused_operands(x, segmap, fused_slope)], self.param_free_norm.eps,
                                    self.param_free_norm.momentum, getattr(self.param_free_norm, "sync", True))[0]
-        return self.param_free_norm(x, gb=self.modulation(x, segmap), fused_slope=fused_slope)
+        pn = self.param_free_norm
+        if self.joinable(x):
+            actv, w, b, rm, rv, slope, in_slope = self.fused_operands(x, segmap, fused_slope)
+            return ops.spade_joined(x, actv, w, b, rm, rv, self.pw, slope, in_slope, pn.eps, pn.momentum,
+                                    getattr(pn, "sync", True))
+        return pn(x, gb=self.modulation(x, segmap), fused_slope=fused_slope)
+
+    def joinable(self, x):
+        """Training-mode param-free BatchNorm on a map the fused epilogue does not serve (8 x 8, 16 x 16): statistics,
+        convolution and modulation ordered inside one Function (ops._SpadeJoined) so that the SyncBN messages of N > 1 ranks
+        travel under the gamma || beta convolution; the kernels are those of the plain path."""
+        pn = self.param_free_norm
+        return (isinstance(pn, (SynchronizedBatchNorm2d, LocalBatchNorm2d)) and not pn.affine and pn.training
+                and x.dim() == 4 and x.is_cuda and self.mlp_gamma.weight.shape[0] % 4 == 0)
 
     def fusable(self, x):
         """The modulation can ride in the epilogue of the gamma || beta convolution (ops._SpadeFused): a param-free
