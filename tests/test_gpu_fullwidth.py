@@ -202,11 +202,11 @@ def test_c3_consecutive_steps_live_resync_vs_oracle(cuda, graphs):
     """Stale derived weights.  Winograd operands, the PatchGAN's permuted first-layer weight, the joined gamma || beta
     storage and the spectrally normalised weights are all DERIVED from parameters that the fused Adam updates in place
     without bumping `_version` (ops.weight_epoch); a derived tensor that is one optimiser step old moves a loss by ~1e-3.
-    Four (eager: three) consecutive iterations at full width (C3, batch 2): before EACH one the oracle's state is rebuilt from the
+    Four (eager: two) consecutive iterations at full width (C3, batch 2): before EACH one the oracle's state is rebuilt from the
     trainer's live parameters and buffers, and that iteration's losses and image are held to rtol 1e-4 — the trajectories
     cannot drift apart, so the tolerance stays at the contract's level at every step.  `graphs=True` runs iterations 2-4
-    through the captured HIP graphs (capture, replay, replay: canonicalsg2im_amd/graphs.py), `graphs=False` keeps all four
-    on the eager path."""
+    through the captured HIP graphs (capture, replay, replay: canonicalsg2im_amd/graphs.py), `graphs=False` runs two on the
+    eager path (the second already sees every derived tensor one optimiser step after it was formed)."""
     import oracle
     from canonicalsg2im_amd import train as T
     from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
@@ -219,7 +219,7 @@ def test_c3_consecutive_steps_live_resync_vs_oracle(cuda, graphs):
     else:
         tr.graphs = None
     batches = [make_batch(vocab, BatchConfig(2, 256, 1, 30, "random"), seed=20 + i) for i in range(2)]
-    for it in range(4 if graphs else 3):
+    for it in range(4 if graphs else 2):
         batch = batches[it % 2]
         ts = T.oracle_state_from(tr, oracle)                      # the trainer's CURRENT weights
         G, D = tr.step([None if t is None else t.cuda() for t in batch])
