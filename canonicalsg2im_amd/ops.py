@@ -911,6 +911,7 @@ class _NormActPair(torch.autograd.Function):
 # ------------------------------------------------------------------------------------ SPADE with the modulation in the
 # gamma || beta convolution's epilogue
 SPADE_FUSED = os.environ.get("CSG_SPADE_FUSED", "1") != "0"
+SPADE_JOINED = os.environ.get("CSG_SPADE_JOINED", "1") != "0"     # _SpadeJoined for the maps the fused epilogue does not serve
 
 
 def spade_fused_eligible(x, nhidden, C, ks, training):

@@ -156,8 +156,8 @@ class SPADE(nn.Module):
         convolution and modulation ordered inside one Function (ops._SpadeJoined) so that the SyncBN messages of N > 1 ranks
         travel under the gamma || beta convolution; the kernels are those of the plain path."""
         pn = self.param_free_norm
-        return (isinstance(pn, (SynchronizedBatchNorm2d, LocalBatchNorm2d)) and not pn.affine and pn.training
-                and x.dim() == 4 and x.is_cuda and self.mlp_gamma.weight.shape[0] % 4 == 0)
+        return (ops.SPADE_JOINED and isinstance(pn, (SynchronizedBatchNorm2d, LocalBatchNorm2d)) and not pn.affine
+                and pn.training and x.dim() == 4 and x.is_cuda and self.mlp_gamma.weight.shape[0] % 4 == 0)
 
     def fusable(self, x):
         """The modulation can ride in the epilogue of the gamma || beta convolution (ops._SpadeFused): a param-free

@@ -98,3 +98,37 @@ def test_fused_spade_vs_torch():
     assert_close(sd.grad, sr.grad.float(), RTOL, 2e-5 * float(sr.grad.abs().max()), "dseg")
     for k, p in sp.named_parameters():
         assert_close(p.grad, P[k].grad.float(), RTOL, 2e-5 * float(P[k].grad.abs().max()) + 1e-5, "d" + k)
+
+
+@pytest.mark.parametrize("shape", [(4, 256, 16, 16, 8), (2, 64, 8, 8, 8)])
+def test_joined_spade_is_the_plain_path_bit_for_bit(shape):
+    """ops._SpadeJoined (maps below 32 pixels: head_0, G_middle_*) only ORDERS the plain path's kernels inside one autograd
+    Function (so that the SyncBN messages of N > 1 ranks travel under the gamma || beta convolution): on one rank output,
+    every gradient and the running statistics are those of conv2d + norm_act, bit for bit."""
+    from canonicalsg2im_amd import ops
+    from canonicalsg2im_amd.spade.models.networks.normalization import SPADE
+    B, C, H, W, S = shape
+    torch.manual_seed(4)
+    sp_a = SPADE("spadesyncbatch3x3", C, S).cuda().train()
+    sp_b = copy.deepcopy(sp_a)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+    seg = torch.randn(B, S, H, W, generator=g)
+    w = torch.randn(B, C, H, W, generator=g)
+    assert not sp_a.fusable(ops.nhwc(x.cuda())) and sp_a.joinable(ops.nhwc(x.cuda()))
+    out = []
+    for sp, joined in ((sp_a, True), (sp_b, False)):
+        saved, ops.SPADE_JOINED = ops.SPADE_JOINED, joined
+        try:
+            xd, sd = x.clone().cuda().requires_grad_(True), seg.clone().cuda().requires_grad_(True)
+            y = sp(xd, sd, fused_slope=0.2)
+            assert (y.grad_fn.__class__.__name__ == "_SpadeJoinedBackward") == joined, y.grad_fn
+            (y * w.cuda()).sum().backward()
+        finally:
+            ops.SPADE_JOINED = saved
+        out.append((y.detach(), xd.grad, sd.grad, {k: p.grad.clone() for k, p in sp.named_parameters()},
+                    {k: v.clone() for k, v in sp.state_dict().items()}))
+    (ya, gxa, gsa, ga, sa), (yb, gxb, gsb, gb, sb) = out
+    assert torch.equal(ya, yb) and torch.equal(gxa, gxb) and torch.equal(gsa, gsb)
+    assert set(ga) == set(gb) and all(torch.equal(ga[k], gb[k]) for k in gb), [k for k in gb if not torch.equal(ga[k], gb[k])]
+    assert all(torch.equal(sa[k], sb[k]) for k in sb)
