@@ -15,7 +15,8 @@ import pytest
 import torch
 
 from conftest import ROOT, assert_close
-from fp64_band import Band, GateRecorder, band_of, errors, forced_gate_rows, grad_rows, state_to64, step_against_oracles
+from fp64_band import (Band, GateRecorder, band_of, batch_to64, errors, forced_gate_rows, grad_rows, state_to64,
+                       step_against_oracles, trainstate_to64)
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -75,12 +76,14 @@ def _check_losses_and_image(tr, G, D, Go, Do, img_o, tag):
     assert rel_l2 <= 2e-5, "%s imgs_pred: relative L2 distance %.3e > 2e-5" % (tag, rel_l2)
 
 
-def _step_losses_image_only(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed, tag):
+def _step_losses_image_only(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed, tag, image_vs_fp64=False):
     """One step at the BENCHMARK's batch size: loss dictionaries and the generated image against the fp32 oracle (no
-    fp64 leg — at batch 16 the gradient band would cost minutes of CPU; the per-image networks are the ones the
-    batch-2 tests put through it).  What batch size changes is decided per launch — Winograd tile/slab plans, split-K
-    factors and tail splits, grids above the 512 resident blocks, >1 GB tensors next to the 32-bit offset guards —
-    and every one of those decisions shows in the losses and in the image."""
+    gradient band — the per-image networks are the ones the batch-2 tests put through it).  What batch size changes is
+    decided per launch — Winograd tile/slab plans, split-K factors and tail splits, grids above the 512 resident blocks,
+    >1 GB tensors next to the 32-bit offset guards — and every one of those decisions shows in the losses and in the image.
+    `image_vs_fp64`: the image is held to the fp64 oracle instead (config C5: 128 layout channels and up to 128
+    overlapping objects put the mean |pixel| at 0.2, and the fp32 ORACLE is then itself up to 1.7e-4 away from fp64 on a
+    few pixels — profiles/r04_c5_image_vs_fp64.txt: HIP 7.1e-5 / 4.4e-6 in relative L2, the fp32 oracle 1.7e-4 / 7.4e-6)."""
     import oracle
     from canonicalsg2im_amd import train as T
     from canonicalsg2im_amd.synth import make_batch, make_vocab
@@ -90,10 +93,23 @@ def _step_losses_image_only(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed,
     torch.manual_seed(seed)
     tr = T.Trainer(opt, cuda)
     ts = T.oracle_state_from(tr, oracle)
+    ts64 = trainstate_to64(ts, oracle) if image_vs_fp64 else None
     batch = make_batch(vocab, batch_cfg, seed=batch_seed)
     G, D = tr.step([None if t is None else t.cuda() for t in batch])
     torch.cuda.synchronize()
     Go, Do, img_o = oracle.train_step(ts, batch)
+    if image_vs_fp64:
+        b64 = batch_to64(batch)
+        with torch.no_grad():                                  # the forward half of oracle.train_step, in fp64
+            from oracle import functional as OF
+            _, _, masks_pred = OF.sg2layout_forward(ts64.sg, opt.vocab, b64[1], b64[3], b64[5], mask_noise=ts64.mask_noise)
+            img64 = OF.generator_forward(ts64.g, opt.vocab, opt.image_size[0], b64[1], b64[2], True,
+                                         num_upsampling_layers=opt.num_upsampling_layers,
+                                         layout_masks=masks_pred if b64[6] is None else b64[6]).detach()
+        d32 = (img_o.detach().double() - img64).abs()
+        # the yardstick's own distance from fp64 is recorded, and bounded: a broken oracle must not pass as "fp32 noise"
+        assert float(d32.max()) <= 5e-4 and float(d32.norm() / img64.norm()) <= 2e-5, (float(d32.max()), float(d32.norm() / img64.norm()))
+        img_o = img64.float()
     _check_losses_and_image(tr, G, D, Go, Do, img_o, tag)
     del tr
     torch.cuda.empty_cache()
@@ -244,6 +260,24 @@ def test_c2_full_width_batch16_step_vs_oracle(cuda):
     from canonicalsg2im_amd.synth import BatchConfig
     _step_losses_image_only(cuda, "coco", ["--image_size", "128,128", "--no_vgg_loss", "--batch_size", "16"],
                             BatchConfig(16, 128, 3, 8, "random"), seed=2, batch_seed=5, tag="C2/B16")
+
+
+def test_c4_batch4_step_vs_oracle(cuda):
+    """BASELINE config C4 exactly as `bench.py --config C4 --batch 4` runs it (32 images over 8 GPUs): Visual-Genome
+    vocabulary, 256x256, 3-30 objects, default recipe, 4 images per GPU — the small-batch launch plans (split-K, slabs,
+    Winograd from 1 024 pixels on) decide differently from batch 16."""
+    from canonicalsg2im_amd.synth import BatchConfig
+    _step_losses_image_only(cuda, "vg", ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "4"],
+                            BatchConfig(4, 256, 3, 30, "random"), seed=3, batch_seed=6, tag="C4/B4")
+
+
+def test_c5_batch6_step_vs_oracle(cuda):
+    """BASELINE config C5 exactly as `bench.py --config C5 --batch 6` runs it (48 images over 8 GPUs): CLEVR vocabulary,
+    64-128 objects per scene with closure graphs, the default recipe (object-crop discriminator on ~570 crops), 6 images
+    per GPU: losses against the fp32 oracle, the image against the fp64 oracle."""
+    from canonicalsg2im_amd.synth import BatchConfig
+    _step_losses_image_only(cuda, "clevr", ["--image_size", "256,256", "--no_vgg_loss", "--batch_size", "6"],
+                            BatchConfig(6, 256, 64, 128, "closure"), seed=4, batch_seed=7, tag="C5/B6", image_vs_fp64=True)
 
 
 def test_c5_full_generator_step_vs_oracle(cuda):
