@@ -100,7 +100,7 @@ def _parity(gpu_step, Go, Do, img_o, note, rel_l2_limit=2e-5, img_atol=1e-4):
             "losses": rows, "imgs_pred": img, "bbox_pred_all_ok": bb_ok, "note": note}
 
 
-def cpu_baseline(snapshot, batch0, gpu_step0, image_size, snapshot_k=None, gpu_stepk=None, k=None):
+def cpu_baseline(snapshot, batch0, gpu_step0, image_size, snapshot_k=None, gpu_stepk=None, k=None, dense=False):
     """The oracle (CPU restatement of the reference path) on the bench's own per-GPU batch, timed as the CPU baseline
     (one warm-up + three repetitions of one full G+D step) — and the checker of the benchmarked
     workload itself: the warm-up replays step 0 of the GPU trainer (`snapshot`: its weights before that step), the first
@@ -123,14 +123,14 @@ def cpu_baseline(snapshot, batch0, gpu_step0, image_size, snapshot_k=None, gpu_s
     # every physical core, the first repetition on 32 threads, the remaining two on whichever was faster
     small = min(phys, 32)
     t_phys, (Go, Do, img_o) = one(snapshot, phys)
-    # dense scenes (config C5: 128 layout channels, up to 128 overlapping objects) put the mean |pixel| at 0.2 instead of 0.05,
-    # and the fp32 ORACLE is then itself 1.7e-4 away from fp64 on a few pixels (profiles/r04_c5_image_vs_fp64.txt; the HIP path
-    # 7e-5): the per-pixel floor follows the image's scale there, the relative-L2 bound stays
-    big = float(img_o.detach().abs().mean()) > 0.1
+    # `dense` (config C5: 128 layout channels, up to 128 overlapping objects per scene): the fp32 ORACLE is itself 1.7e-4 away
+    # from fp64 on a few pixels there (profiles/r04_c5_image_vs_fp64.txt; the HIP path 7e-5), so the per-pixel floor is 2.5e-4
+    # for that configuration; the relative-L2 bound stays
+    big = bool(dense)
     parity0 = _parity(gpu_step0, Go, Do, img_o,
                       "step 0 of the GPU trainer (taken before warm-up) vs oracle.train_step on the same weights and batch: "
                       "every loss at rtol 1e-4 (+1e-6), the whole generated image at rtol 1e-4 + %s absolute and 2e-5 in "
-                      "relative L2" % ("2.5e-4 (mean |pixel| > 0.1)" if big else "1e-4"), img_atol=2.5e-4 if big else 1e-4)
+                      "relative L2" % ("2.5e-4 (dense scenes)" if big else "1e-4"), img_atol=2.5e-4 if big else 1e-4)
     times, parityk = {phys: [t_phys]}, None
     if snapshot_k is not None:
         t_small, (Gk, Dk, img_k) = one(snapshot_k, small)
@@ -516,7 +516,7 @@ def main():
     parity_ok = True
     if check:                                             # the CPU leg runs at N = 1 only
         out["cpu_baseline"], out["parity_b16"], pk = cpu_baseline(snapshot, batch0_cpu, gpu_step0, H, snapshot_k, gpu_stepk,
-                                                                    k_index)
+                                                                    k_index, dense=cfg.graph == "closure")
         parity_ok = out["parity_b16"]["ok"]
         if pk is not None:
             out["parity_step%d" % k_index] = pk
