@@ -502,6 +502,8 @@ int csg_gemm_tn(int64_t M, int64_t N, int64_t K, const float* dy, int64_t ldy, c
   CSG_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldy >= N && ldx >= K,
               CSG_E_UNSUPPORTED, "csg_gemm_tn: needs N, K, ldy, ldx multiples of 4 (M %lld N %lld K %lld)", (long long)M,
               (long long)N, (long long)K);
+  CSG_REQUIRE(M < (1ll << 31) && N < (1ll << 31) - 128 && K < (1ll << 31) - 128, CSG_E_UNSUPPORTED,
+              "csg_gemm_tn: extents beyond 32-bit indexing (M %lld N %lld K %lld)", (long long)M, (long long)N, (long long)K);
   CSG_REQUIRE((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw) & 15) == 0, CSG_E_BADSHAPE, "csg_gemm_tn: pointers must be 16-byte aligned");
   int ns, per;
   tn_plan(M, N, K, &ns, &per);
