@@ -235,8 +235,9 @@ def main():
     if graphs_on:
         # the shape-static part of the step is replayed from HIP graphs (canonicalsg2im_amd/graphs.py); a key is captured
         # the second time it is seen, so with --warmup < 2 a few more untimed steps keep the capture out of the timed region
-        for i in range(3):
-            if trainer.graphs.replays > 0:
+        # (the scene-graph encoder's graph follows one sighting later: bucket of triplet counts seen once with the set in place)
+        for i in range(6):
+            if trainer.graphs.replays > 0 and (trainer.graphs.sg_replays > 0 or not trainer.model.has_graph):
                 break
             trainer.step(batches[(args.warmup + i) % nb])
     sync()
@@ -268,7 +269,8 @@ def main():
         # kernels inside a replayed graph carry no per-dispatch events: the dominant kernel's event timing (mode 2) is
         # taken over the SAME number of steps of the same batches run eagerly right after the timed region
         graph_stats = {"captures": trainer.graphs.captures, "replays": trainer.graphs.replays,
-                       "eager_steps": trainer.graphs.eager_steps}
+                       "eager_steps": trainer.graphs.eager_steps, "encoder_captures": trainer.graphs.sg_captures,
+                       "encoder_replays": trainer.graphs.sg_replays}
         trainer.use_graphs = False
         trainer.step(batches[0])
         sync()

@@ -10,9 +10,14 @@ captured once per shape key into three HIP graphs and replayed:
     S2  backward of S1's terms, with d(object-discriminator terms)/d(image) injected at the image
     S3  PatchGAN discriminator step: losses on fake.detach() + real (+ the logged "wrong" pass), backward, Adam
 
-What stays eager, between the replays, is everything whose shapes follow the data: the scene-graph encoder (O objects,
-T triplets per batch; it receives no gradient from the image path because the generator consumes the ground-truth boxes,
-sg2im/meta_models.py:47 of the reference) and the object-crop discriminator (one crop per real object).  The number of
+    S0  (round 4, late) the scene-graph encoder: forward, box-regression term, backward — one small graph per bucket of the
+        batch's triplet count (rows padded to a multiple of 64 with the `__padding__` triplets every batch already carries),
+        in its own memory pool; it receives no gradient from the image path because the generator consumes the
+        ground-truth boxes (sg2im/meta_models.py:47 of the reference).  It takes 3.8 ms of enqueue off the host (13.4 ->
+        9.6 ms per step) and nothing off the step: the host was already ahead of the device (tools/graph_timing.py)
+
+What stays eager, between the replays, is what follows the data: the object-crop discriminator (one crop per real object),
+and the encoder on graphs of more than 2 048 triplets per sample (config C5) or in a bucket seen for the first time.  The number of
 objects enters the static part only through the layout kernels' (vecs, boxes, valid) operands: they are padded to a
 multiple of 32 objects with `__image__` rows, which the layout kernel culls (a culled object adds exact zeros, forward
 and backward), so the results do not depend on the padding.
@@ -38,6 +43,10 @@ ENABLED = os.environ.get("CSG_GRAPHS", "1") != "0"
 CAPTURE_AFTER = int(os.environ.get("CSG_GRAPH_CAPTURE_AFTER", "1"))      # eager sightings of a key before it is captured
 MAX_SETS = int(os.environ.get("CSG_GRAPH_MAX_SETS", "4"))
 OBJ_PAD = 32
+TRIPLET_PAD = int(os.environ.get("CSG_GRAPH_TRIPLET_PAD", "64"))         # the encoder's graph: triplet rows padded to a multiple of this
+MAX_SG_GRAPHS = int(os.environ.get("CSG_GRAPH_MAX_SG", "8"))             # triplet-count buckets captured per shape key; 0: encoder eager
+SG_MAX_TRIPLETS = int(os.environ.get("CSG_GRAPH_SG_MAX_T", "2048"))      # larger graphs (config C5: thousands of triplets per scene) are
+#                                                                          GPU-bound in the encoder and rarely repeat a bucket: eager
 TIMING = os.environ.get("CSG_GRAPH_TIMING") == "1"      # developer aid: per-segment host / device time of the replayed step
 
 
@@ -78,6 +87,10 @@ def _pad_objects(n):
     return max(OBJ_PAD, (int(n) + OBJ_PAD - 1) // OBJ_PAD * OBJ_PAD)
 
 
+def _pad_triplets(n):
+    return max(TRIPLET_PAD, (int(n) + TRIPLET_PAD - 1) // TRIPLET_PAD * TRIPLET_PAD)
+
+
 def _drop_stale_autograd(*roots):
     """Tensors that modules keep between iterations and that still carry the previous iteration's autograd graph: torch's
     spectral-norm hook leaves the last normalised weight on the module (`module.weight`, with its `grad_fn`), and the
@@ -98,6 +111,60 @@ def _drop_stale_autograd(*roots):
             m.__dict__.pop("_sn_prepared", None)
 
 
+class _SgGraph:
+    """S0: the scene-graph encoder's forward, the box-regression term and its backward for ONE triplet-count bucket of a
+    shape key (objects padded like the rest of the set, triplet rows padded to a multiple of TRIPLET_PAD with
+    `[0, __padding__, 0]` rows — the rows every batch already carries for its shorter samples: `is_edge` masks them out of
+    every message, their own outputs feed nothing, their gradients are exact zeros).  Its own memory pool: it is captured
+    whenever its bucket is first seen again — after S1-S3 — and replayed BEFORE them, so it must not share blocks with their
+    temporaries."""
+
+    def __init__(self, gs, tpad, pad_pred, batch):
+        dev = gs.objs.device
+        B = gs.objs.shape[0]
+        self.gs, self.tpad = gs, tpad
+        self.triplets = torch.zeros((B, tpad, 3), device=dev, dtype=batch[3].dtype)
+        self.triplets[:, :, 1] = pad_pred
+        self.ttype = torch.zeros((B, tpad), device=dev, dtype=batch[5].dtype)
+        self.pad_pred = pad_pred
+        self.graph = None
+        self.grads = {}
+        self.boxes_pred = self.vals = self.bbox_all = None
+
+    def load(self, triplets, triplet_type):
+        T = triplets.shape[1]
+        if T < self.tpad:
+            self.triplets[:, T:, 0] = 0
+            self.triplets[:, T:, 1] = self.pad_pred
+            self.triplets[:, T:, 2] = 0
+            self.ttype[:, T:] = 0
+        self.triplets[:, :T].copy_(triplets, non_blocking=True)
+        self.ttype[:, :T].copy_(triplet_type, non_blocking=True)
+
+    def run(self, tr):
+        gs = self.gs
+        if self.graph is None:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            ops.invalidate_weight_caches()
+            _drop_stale_autograd(tr.model)
+            with torch.cuda.graph(g):
+                for p in tr.sg_params:
+                    p.grad = None
+                self.boxes_pred = tr.model.sg_to_layout(gs.objs, self.triplets, self.ttype, gs.boxes)[1]
+                out = {}
+                tr.gans_model._layout_terms(out, gs.objs, gs.boxes, self.boxes_pred, None, None)
+                self.bbox_all = out["bbox_pred_all"].detach()
+                self.vals = out["bbox_pred"].detach()
+                out["bbox_pred"].backward()
+                self.boxes_pred = self.boxes_pred.detach()
+            self.graph = g
+            self.grads = {p: p.grad for p in tr.sg_params if p.grad is not None}
+        self.graph.replay()
+        for p, gr in self.grads.items():             # (another bucket's buffers, or an eager step's tensors, may be in place)
+            p.grad = gr
+
+
 class _GraphSet:
     """The three captured graphs of one shape key, their static inputs / outputs and gradient buffers."""
 
@@ -114,6 +181,8 @@ class _GraphSet:
         self.boxes = torch.full((B, key[2], 4), -1.0, device=dev, dtype=boxes.dtype)
         self.img = self.fake = self.d_img = self.g_vals = self.d_vals = None
         self.g_terms = self.d_terms = None
+        self.sg = {}                     # padded triplet count -> _SgGraph
+        self.sg_seen = {}
 
     def load(self, imgs, objs, boxes):
         O = objs.shape[1]
@@ -159,6 +228,7 @@ class StepGraphs:
         self.sets, self.seen = {}, {}
         self.active = None
         self.replays = self.eager_steps = self.captures = 0
+        self.sg_replays = self.sg_captures = 0
         self.marks = _Marks() if TIMING else None
 
     # ---- eligibility
@@ -212,11 +282,31 @@ class StepGraphs:
         (d_img,) = torch.autograd.grad(list(vals.values()), [leaf])
         return {k: v.detach() for k, v in vals.items()}, d_img
 
-    def _graph_encoder(self, batch, G):
-        """Scene-graph encoder forward, the box-regression term and its backward (eager: O and T follow the data)."""
+    def _graph_encoder(self, gs, batch, G):
+        """Scene-graph encoder forward, the box-regression term and its backward: replayed from the graph of the batch's
+        triplet-count bucket (S0, `_SgGraph`; a bucket is captured the second time it is seen), else eager."""
         tr = self.tr
         objs, boxes, triplets, _, triplet_type = batch[1:6]
         if not tr.model.has_graph:
+            return
+        sg = None
+        tpad = _pad_triplets(triplets.shape[1])
+        if MAX_SG_GRAPHS > 0 and tpad <= SG_MAX_TRIPLETS and "s1" in gs.graphs:      # (the set's first iteration: eager encoder)
+            sg = gs.sg.get(tpad)
+            if sg is None:
+                seen = gs.sg_seen.get(tpad, 0)
+                gs.sg_seen[tpad] = seen + 1
+                if seen >= 1 and len(gs.sg) < MAX_SG_GRAPHS:
+                    sg = gs.sg[tpad] = _SgGraph(gs, tpad, tr.model.sg_to_layout.module.vocab["pred_name_to_idx"]["__padding__"],
+                                                batch)
+                    self.sg_captures += 1
+        if sg is not None:
+            sg.load(triplets, triplet_type)
+            sg.run(tr)
+            G["bbox_pred_all"] = sg.bbox_all.clone()
+            G["bbox_pred"] = sg.vals.clone()
+            self.boxes_pred = sg.boxes_pred[:, :objs.shape[1]]
+            self.sg_replays += 1
             return
         for p in tr.sg_params:
             p.grad = None
@@ -246,7 +336,7 @@ class StepGraphs:
             mk.mark("load+prefetch")
         G = {}
         self.boxes_pred = None
-        self._graph_encoder(batch, G)
+        self._graph_encoder(gs, batch, G)
         if mk:
             mk.mark("E0 graph encoder")
         # ---- S1: generator forward + the generator's image terms (the discriminators are frozen)

@@ -243,6 +243,8 @@ def test_c3_consecutive_steps_live_resync_vs_oracle(cuda, graphs):
         _check_losses_and_image(tr, G, D, Go, Do, img_o, "C3 iteration %d (graphs %s)" % (it, graphs))
     if graphs:
         assert tr.graphs.captures == 1 and tr.graphs.replays == 3, (tr.graphs.captures, tr.graphs.replays)
+        # the last iteration also replayed the scene-graph encoder's own graph (S0: captured on its bucket's second sighting)
+        assert tr.graphs.sg_captures == 1 and tr.graphs.sg_replays == 1, (tr.graphs.sg_captures, tr.graphs.sg_replays)
     del tr
     torch.cuda.empty_cache()
 

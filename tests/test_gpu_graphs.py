@@ -177,3 +177,32 @@ def test_checkpoint_load_drops_the_captured_graphs(cuda):
         ma, mb = sa["exp_avg"].float().cpu(), sb["exp_avg"].float().cpu()
         assert float((ma - mb).norm()) <= 5e-2 * float(mb.norm()) + 1e-7, float((ma - mb).norm() / mb.norm())
     assert checked >= 10
+
+
+def test_encoder_graph_matches_the_eager_encoder(cuda, monkeypatch):
+    """S0: the scene-graph encoder replayed from its own graph (triplet rows padded to the bucket with `__padding__`
+    triplets) against the same iterations with the encoder enqueued eagerly between the replays: box-regression losses to
+    1e-6 at every iteration, the encoder's parameters after six optimiser steps within Adam's sign noise."""
+    from canonicalsg2im_amd import graphs
+    argv = ["--use_img_disc", "1"]
+    vocab, a = _make(cuda, argv, graphs=True)
+    _, b = _make(cuda, argv, graphs=True)
+    _same_weights(a, b)
+    bs = _batches(vocab, cuda, 2)
+    out = []
+    for tr, max_sg in ((a, 8), (b, 0)):
+        monkeypatch.setattr(graphs, "MAX_SG_GRAPHS", max_sg)
+        rows = []
+        for it in range(6):
+            G, _ = tr.step(bs[it % 2])
+            rows.append((G["bbox_pred"].detach().float().cpu(), G["bbox_pred_all"].detach().float().cpu()))
+        out.append(rows)
+    assert a.graphs.sg_captures >= 1 and a.graphs.sg_replays >= 2 and b.graphs.sg_replays == 0
+    for it, ((la, alla), (lb, allb)) in enumerate(zip(*out)):
+        tol = 1e-6 if it < 4 else 2e-3                  # (after the first replayed encoder step the two runs are two fp32 trajectories)
+        assert torch.allclose(la, lb, rtol=tol, atol=tol * 1e-1), (it, la, lb)
+        assert torch.allclose(alla, allb, rtol=tol, atol=tol * 1e-1), (it, alla, allb)
+    lr = 1e-4
+    for (n, pa), (_, pb) in zip(a.model.sg_to_layout.named_parameters(), b.model.sg_to_layout.named_parameters()):
+        d = (pa.detach() - pb.detach()).abs().max().item()
+        assert d <= 2.2 * 6 * max(lr, 1e-2 if "candidates_weights" in n else lr), "%s differs by %g" % (n, d)

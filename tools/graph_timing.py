@@ -25,9 +25,10 @@ tr = T.Trainer(opt, dev)
 cfg = base["cfg"]
 bs = [[None if t is None else t.to(dev) for t in make_batch(vocab, BatchConfig(B, H, cfg.min_objects, cfg.max_objects, cfg.graph), seed=i)]
       for i in range(4)]
-for i in range(4):
+for i in range(8):                       # eager, capture, the encoder's bucket seen once, its capture, replays
     tr.step(bs[i % 4])
 torch.cuda.synchronize()
+print(cfg_name, "graphs:", tr.graphs.captures, "sets,", tr.graphs.sg_captures, "encoder graphs,", tr.graphs.sg_replays, "encoder replays so far")
 # untimed-by-marks wall clock first (marks add a device sync per step)
 marks, tr.graphs.marks = tr.graphs.marks, None
 t0 = time.perf_counter()
