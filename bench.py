@@ -388,7 +388,8 @@ def main():
     if graph_stats is not None:
         out["hip_graphs"] = dict(graph_stats, eager_ms_per_step=round(eager_ms, 2),
                                  note="timed region: generator + PatchGAN forward/backward/Adam replayed from 3 captured HIP "
-                                      "graphs per step, scene-graph encoder and object-crop discriminator enqueued eagerly "
+                                      "graphs per step and the scene-graph encoder from its own (encoder_*: one per bucket of "
+                                      "the batch's triplet count), object-crop discriminator enqueued eagerly "
                                       "(canonicalsg2im_amd/graphs.py); eager_ms_per_step = the same steps without replay "
                                       "(with the dominant kernel's events on)")
     # Winograd F(2x2,3x3) / F(3x3,2x2) issue 16 multiplications where the direct convolution needs 36: the kernels' `work`
