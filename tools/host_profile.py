@@ -1,5 +1,5 @@
-"""cProfile of the host side of one training step (small workloads — C2, C4 — are bound by it: ~37 ms of enqueue per
-step against 25-30 ms of GPU time)."""
+"""cProfile of the host side of one training step at config C2 (round 3: ~29 ms of enqueue per step; round 4, with the
+HIP-graph replay of canonicalsg2im_amd/graphs.py on: ~10 ms)."""
 import cProfile
 import os
 import pstats
@@ -23,7 +23,7 @@ def main():
     torch.manual_seed(0)
     tr = T.Trainer(opt, dev)
     batch = [None if t is None else t.to(dev) for t in make_batch(vocab, BatchConfig(16, 128, cfg.min_objects, cfg.max_objects, cfg.graph), seed=1)]
-    for _ in range(3):
+    for _ in range(6):                  # eager, capture of the set, the encoder's bucket seen once, its capture, replays
         tr.step(batch)
     torch.cuda.synchronize()
     pr = cProfile.Profile()
