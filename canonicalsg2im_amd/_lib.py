@@ -73,7 +73,8 @@ SIGNATURES = {
     "csg_prof_kernel_name": (ctypes.c_char_p, [c_i32]),
     "csg_prof_read": (c_i32, [c_i32, ctypes.POINTER(c_f64), ctypes.POINTER(c_i64), ctypes.POINTER(c_f64)]),
     "csg_embed_fwd": (c_i32, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p]),
-    "csg_embed_bwd": (c_i32, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_embed_bwd_workspace": (c_i64, [c_i64, c_i64, c_i64]),
+    "csg_embed_bwd": (c_i32, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_real_object_mask": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_graph_csr_build": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "csg_gather_concat_fwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),

@@ -3,9 +3,9 @@
 //
 // The reference expands the image once per object ((sum O, C, H, W) tensor) and calls
 // F.grid_sample; here each output pixel of each crop gathers its 4 source pixels directly from the
-// object's own image (NHWC), so the traffic is the crops themselves.  Backward scatters with float
-// atomics (crops of different objects overlap in the image): ~3 M atomics per step, far below the
-// chip's atomic rate; the summation order, hence the last bits of d(image), can vary run to run.
+// object's own image (NHWC), so the traffic is the crops themselves.  Backward is a GATHER as well
+// (crops of different objects overlap in the image): every image pixel sums the taps that touch it over
+// the crops of its image in crop order, crop rows, then crop columns — no atomics, the same bits every run.
 #include "csg_common.h"
 
 using namespace csg;
@@ -76,24 +76,72 @@ __global__ void k_crop_fwd(const float* __restrict__ img, int H, int W, int cs, 
   }
 }
 
-__global__ void k_crop_bwd(const float* __restrict__ dout, int H, int W, int cs, int C, const float* __restrict__ boxes,
-                           const int64_t* __restrict__ img_idx, int64_t total, int HH, int WW, int out_cs,
-                           float* __restrict__ dimg) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int x = (int)(e % WW);
-    const int64_t t1 = e / WW;
-    const int y = (int)(t1 % HH);
-    const int64_t n = t1 / HH;
-    const CropTaps t = crop_taps(boxes + n * 4, x, y, WW, HH, W, H);
-    float* base = dimg + (int64_t)img_idx[n] * H * W * cs;
-    const float* g = dout + e * out_cs;
-    for (int c = 0; c < C; ++c) {
-      const float v = g[c];
-      if (t.w00 != 0.f) atomicAdd(&base[((int64_t)t.iy0 * W + t.ix0) * cs + c], t.w00 * v);
-      if (t.w01 != 0.f) atomicAdd(&base[((int64_t)t.iy0 * W + t.ix0 + 1) * cs + c], t.w01 * v);
-      if (t.w10 != 0.f) atomicAdd(&base[((int64_t)(t.iy0 + 1) * W + t.ix0) * cs + c], t.w10 * v);
-      if (t.w11 != 0.f) atomicAdd(&base[((int64_t)(t.iy0 + 1) * W + t.ix0 + 1) * cs + c], t.w11 * v);
+// d(image) as a gather.  The sampling grid of a crop is separable (fx depends on the crop column only, fy on the crop
+// row only), so the taps of crop n are two tables of HH / WW entries: (first source row / column, fraction).  A block owns
+// a 16 x 16 pixel tile of one image and walks the crops in order; for each crop of ITS image whose footprint meets the
+// tile it stages the two tables in LDS, and every thread sums, over the crop rows and columns whose taps land on its
+// pixel, weight * dout — rows outer, columns inner, crops outermost: a fixed order.  (The scatter form this replaces
+// issued ~3 M float atomics per step; their arrival order decided the last bits of d(image).)
+#define CROP_MAXHW 64
+__global__ __launch_bounds__(256) void k_crop_bwd(const float* __restrict__ dout, int H, int W, int cs, int C,
+                                                   const float* __restrict__ boxes, const int64_t* __restrict__ img_idx,
+                                                   int N, int HH, int WW, int out_cs, int tiles_x, int tiles_per_img,
+                                                   float* __restrict__ dimg) {
+  __shared__ int s_i0[2][CROP_MAXHW];              // [axis: 0 = x, 1 = y][crop column / row]: first source index
+  __shared__ float s_t[2][CROP_MAXHW];             // fraction towards the second one
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / tiles_per_img, tile = blockIdx.x - b * tiles_per_img;
+  const int x = (tile % tiles_x) * 16 + (tid & 15), y = (tile / tiles_x) * 16 + (tid >> 4);
+  const int tx0 = (tile % tiles_x) * 16, ty0 = (tile / tiles_x) * 16;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < N; ++n) {
+    if (img_idx[n] != b) continue;                 // block-uniform
+    const float* box = boxes + (int64_t)n * 4;
+    {
+      // conservative footprint from the two ends of each axis (the grid is a monotone interpolation between them; one
+      // pixel of slack for its rounding) — block-uniform, so crops that miss the tile cost no barrier
+      const float fx0 = ((2.0f * box[0] - 1.0f + 1.0f) * (float)W - 1.0f) / 2.0f;
+      const float fx1 = ((2.0f * (box[0] + box[2]) - 1.0f + 1.0f) * (float)W - 1.0f) / 2.0f;
+      const float fy0 = ((2.0f * box[1] - 1.0f + 1.0f) * (float)H - 1.0f) / 2.0f;
+      const float fy1 = ((2.0f * (box[1] + box[3]) - 1.0f + 1.0f) * (float)H - 1.0f) / 2.0f;
+      if (!(fminf(fx0, fx1) - 2.0f <= (float)(tx0 + 15) && fmaxf(fx0, fx1) + 2.0f >= (float)tx0 &&
+            fminf(fy0, fy1) - 2.0f <= (float)(ty0 + 15) && fmaxf(fy0, fy1) + 2.0f >= (float)ty0))
+        continue;
     }
+    __syncthreads();
+    if (tid < WW + HH) {
+      const bool isx = tid < WW;
+      const int i = isx ? tid : tid - WW, nn = isx ? WW : HH, L = isx ? W : H;
+      const float lo = isx ? box[0] : box[1], sz = isx ? box[2] : box[3];
+      const float b0 = 2.0f * lo - 1.0f, b1 = 2.0f * (lo + sz) - 1.0f;
+      const float g = lin_down(i, nn) * b0 + lin_up(i, nn) * b1;
+      const float f = ((g + 1.0f) * (float)L - 1.0f) / 2.0f;
+      s_i0[isx ? 0 : 1][i] = (int)fminf(fmaxf(floorf(f), -2.0f), (float)L);
+      s_t[isx ? 0 : 1][i] = f - floorf(f);
+    }
+    __syncthreads();
+    const float* g = dout + (int64_t)n * HH * WW * out_cs;
+    for (int cy = 0; cy < HH && x < W && y < H; ++cy) {
+      const int iy0 = s_i0[1][cy];
+      if (iy0 != y && iy0 + 1 != y) continue;
+      const float ty = s_t[1][cy];
+      const float wy = iy0 == y ? 1.f - ty : ty;   // (y itself is inside the image: the tap is a valid one)
+      for (int cx = 0; cx < WW; ++cx) {
+        const int ix0 = s_i0[0][cx];
+        if (ix0 != x && ix0 + 1 != x) continue;
+        const float tx = s_t[0][cx];
+        // the four weights exactly as crop_taps forms them: (1-tx)(1-ty), tx(1-ty), (1-tx)ty, tx ty
+        const float wx = ix0 == x ? 1.f - tx : tx;
+        const float w = wx * wy;
+        if (w == 0.f) continue;
+        const float* gp = g + ((int64_t)cy * WW + cx) * out_cs;
+        for (int c = 0; c < C; ++c) acc[c] += w * gp[c];
+      }
+    }
+  }
+  if (x < W && y < H) {
+    float* o = dimg + (((int64_t)b * H + y) * W + x) * cs;
+    for (int c = 0; c < C; ++c) o[c] += acc[c];
   }
 }
 
@@ -187,12 +235,13 @@ int csg_crop_bwd(const float* dout, int64_t B, int64_t H, int64_t W, int64_t img
               CSG_E_BADSHAPE, "csg_crop_bwd: bad shape");
   if (N == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
+  CSG_REQUIRE(C <= 4 && HH <= CROP_MAXHW && WW <= CROP_MAXHW && HH + WW <= 256, CSG_E_UNSUPPORTED,
+              "csg_crop_bwd: at most 4 channels and %d x %d crops", CROP_MAXHW, CROP_MAXHW);
   const int64_t total = N * HH * WW;
   ProfScope p(K_CROP_BWD, (double)total * (C * 4 + out_cs) * 4, s);
-  int64_t g = cdiv(total, 256);
-  if (g > 4096) g = 4096;
-  CSG_LAUNCH(k_crop_bwd, dim3((unsigned)g), dim3(256), 0, s, dout, (int)H, (int)W, (int)img_cs, (int)C, boxes,
-                     img_idx, total, (int)HH, (int)WW, (int)out_cs, dimg);
+  const int tiles_x = (int)cdiv(W, 16), tiles_per_img = tiles_x * (int)cdiv(H, 16);
+  CSG_LAUNCH(k_crop_bwd, dim3((unsigned)(B * tiles_per_img)), dim3(256), 0, s, dout, (int)H, (int)W, (int)img_cs, (int)C, boxes,
+             img_idx, (int)N, (int)HH, (int)WW, (int)out_cs, tiles_x, tiles_per_img, dimg);
   return check_launch("csg_crop_bwd");
 }
 

@@ -470,6 +470,8 @@ int csg_gemm_nt(const csg_gemm_desc* d, const float* a, const float* bw, const f
   // deeper ring — (16, 3) three blocks, (16, 4) two blocks — equals the two-buffer form at the same occupancy: the DMA latency
   // is not what is exposed.  The 64-wide tiles of N <= 64 prefer the long stages (84 vs 72 TFLOP/s at K = 128).
   const int cfg = cfg_env ? cfg_env : (narrow ? 322 : 162);
+  // only these two (BK, NBUF) pairs are instantiated; any other value would size the LDS for a kernel that is not launched
+  CSG_REQUIRE(cfg == 162 || cfg == 322, CSG_E_UNSUPPORTED, "csg_gemm_nt: CSG_GEMM_CFG=%d (only 162 and 322 are built)", cfg);
   const int bk = cfg / 10, nbuf = cfg % 10;
   p.nstage = (int)cdiv(d->K, bk);
   const size_t shm = (size_t)nbuf * (128 + (narrow ? 64 : 128)) * bk * 4;
@@ -530,6 +532,7 @@ int csg_gemm_tn(int64_t M, int64_t N, int64_t K, const float* dy, int64_t ldy, c
   ProfScope ps(K_GEMM_TN, 2.0 * (double)M * (double)N * (double)K, s);
   // rows per stage: 16 (four 32 KB blocks per CU) measured 2-4 % ahead of 32 (two 64 KB blocks); developer knob
   static const int rs = getenv("CSG_GEMM_TN_ROWS") ? atoi(getenv("CSG_GEMM_TN_ROWS")) : 16;
+  CSG_REQUIRE(rs == 16 || rs == 32, CSG_E_UNSUPPORTED, "csg_gemm_tn: CSG_GEMM_TN_ROWS=%d (only 16 and 32 are built)", rs);
   if (rs == 16)
     CSG_LAUNCH(k_gemm_tn<16>, dim3((unsigned)(p.nnb * p.nkb * ns)), dim3(256), GM_LDS_BYTES / 2, s, p, dy, x, slabs, dbs);
   else

@@ -3,7 +3,7 @@
 // GraphTripleConv (reference: sg2im/graph.py:44-113, sg2im/attribute_embed.py:31-48).
 //
 // All of these are HBM/latency-bound index kernels: wave64, one row segment per wave, no
-// atomics on the forward path, fixed summation order (subject entries in t order, then object
+// atomics (forward or backward), fixed summation order (subject entries in t order, then object
 // entries in t order) so results are reproducible run to run.
 #include "csg_common.h"
 
@@ -21,40 +21,42 @@ __global__ void k_embed_fwd(const int64_t* __restrict__ idx, int64_t rows, int64
   out[r * out_stride + out_off + d] = v;
 }
 
-__global__ void k_embed_bwd(const int64_t* __restrict__ idx, int64_t rows, int64_t idx_stride,
-                            const float* __restrict__ dout, int64_t out_stride, int64_t out_off, int64_t num_emb,
-                            int64_t dim, float* __restrict__ dtable) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= rows * dim) return;
-  int64_t r = e / dim, d = e - r * dim;
-  int64_t i = idx[r * idx_stride];
-  if (i >= 0 && i < num_emb) atomicAdd(&dtable[i * dim + d], dout[r * out_stride + out_off + d]);
+// d(table)[i] = sum over the rows r with idx[r] == i of dout[r], in row order: no atomics, the same bits every run.
+// A block owns EMB_CHUNK consecutive rows (their indices staged in LDS) x 256 consecutive table entries e = i * dim + d;
+// a thread walks the chunk in order and adds the rows that name its table row (the 32..128 threads of one table row read
+// one coalesced piece of dout).  One chunk: the sums go straight onto dtable; more: per-chunk partials in the caller's
+// workspace + k_embed_bwd_sum adding them in chunk order.  (Dense graphs send 2e5 predicate rows to an 8-row table: 196
+// chunks of 1 024 compare-and-add steps.)
+#define EMB_CHUNK 1024
+__global__ __launch_bounds__(256) void k_embed_bwd(const int64_t* __restrict__ idx, int64_t rows, int64_t idx_stride,
+                                                    const float* __restrict__ dout, int64_t out_stride, int64_t out_off,
+                                                    int num_emb, int dim, float* __restrict__ dst, int64_t dst_chunk_stride,
+                                                    int accumulate) {
+  __shared__ int s_idx[EMB_CHUNK];
+  const int64_t r0 = (int64_t)blockIdx.x * EMB_CHUNK;
+  const int n = (int)min((int64_t)EMB_CHUNK, rows - r0);
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const int64_t v = idx[(r0 + j) * idx_stride];
+    s_idx[j] = (v >= 0 && v < num_emb) ? (int)v : -1;
+  }
+  __syncthreads();
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  if (e >= num_emb * dim) return;
+  const int i = e / dim, d = e - i * dim;
+  const float* src = dout + r0 * out_stride + out_off + d;
+  float acc = 0.f;
+  for (int j = 0; j < n; ++j)
+    if (s_idx[j] == i) acc += src[(int64_t)j * out_stride];
+  float* o = dst + (int64_t)blockIdx.x * dst_chunk_stride + e;
+  *o = accumulate ? *o + acc : acc;
 }
 
-// Small tables (predicate / attribute embeddings: <= 8192 floats) receive hundreds of thousands of rows on
-// dense graphs; per-block accumulation in LDS first cuts the global atomics by the rows-per-block factor.
-#define EMB_ROWS_PER_BLOCK 2048
-__global__ __launch_bounds__(256) void k_embed_bwd_lds(const int64_t* __restrict__ idx, int64_t rows,
-                                                        int64_t idx_stride, const float* __restrict__ dout,
-                                                        int64_t out_stride, int64_t out_off, int num_emb, int dim,
-                                                        float* __restrict__ dtable) {
-  extern __shared__ float acc[];                               // [num_emb * dim]
-  const int n = num_emb * dim;
-  for (int i = threadIdx.x; i < n; i += 256) acc[i] = 0.f;
-  __syncthreads();
-  const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS_PER_BLOCK;
-  const int64_t r1 = min(rows, r0 + EMB_ROWS_PER_BLOCK);
-  for (int64_t e = r0 * dim + threadIdx.x; e < r1 * dim; e += 256) {
-    const int64_t r = e / dim;
-    const int d = (int)(e - r * dim);
-    const int64_t i = idx[r * idx_stride];
-    if (i >= 0 && i < num_emb) atomicAdd(&acc[i * dim + d], dout[r * out_stride + out_off + d]);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = acc[i];
-    if (v != 0.f) atomicAdd(&dtable[i], v);
-  }
+__global__ void k_embed_bwd_sum(const float* __restrict__ part, int nchunks, int n, float* __restrict__ dtable) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float v = dtable[e];
+  for (int c = 0; c < nchunks; ++c) v += part[(int64_t)c * n + e];
+  dtable[e] = v;
 }
 
 __global__ void k_obj_mask(const int64_t* __restrict__ objs, int64_t n, int64_t A, int64_t image_id,
@@ -568,22 +570,34 @@ int csg_embed_fwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const fl
   return check_launch("csg_embed_fwd");
 }
 
+int64_t csg_embed_bwd_workspace(int64_t rows, int64_t num_emb, int64_t dim) {
+  const int64_t chunks = cdiv(rows, EMB_CHUNK);
+  return chunks > 1 ? chunks * num_emb * dim * (int64_t)sizeof(float) : 0;
+}
+
 int csg_embed_bwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const float* dout, int64_t out_stride,
-                  int64_t out_off, int64_t num_emb, int64_t dim, float* dtable, void* stream) {
-  CSG_REQUIRE(rows >= 0 && dim > 0 && num_emb > 0, CSG_E_BADSHAPE, "csg_embed_bwd: bad shape");
+                  int64_t out_off, int64_t num_emb, int64_t dim, float* dtable, float* workspace, int64_t workspace_bytes,
+                  void* stream) {
+  CSG_REQUIRE(rows >= 0 && dim > 0 && num_emb > 0 && num_emb * dim < (1ll << 30), CSG_E_BADSHAPE, "csg_embed_bwd: bad shape");
   if (rows == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_EMBED_BWD, (double)rows * dim * 8, s);
-  int64_t n = rows * dim;
-  if (num_emb * dim <= 8192 && rows >= 4 * EMB_ROWS_PER_BLOCK) {
-    CSG_LAUNCH(k_embed_bwd_lds, dim3((unsigned)cdiv(rows, EMB_ROWS_PER_BLOCK)), dim3(256),
-                       (size_t)(num_emb * dim) * sizeof(float), s, idx, rows, idx_stride, dout, out_stride, out_off,
-                       (int)num_emb, (int)dim, dtable);
-  } else {
-    CSG_LAUNCH(k_embed_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, idx, rows, idx_stride, dout,
-                       out_stride, out_off, num_emb, dim, dtable);
+  const int64_t chunks = cdiv(rows, EMB_CHUNK), n = num_emb * dim;
+  CSG_REQUIRE(chunks < 65536 * 32, CSG_E_UNSUPPORTED, "csg_embed_bwd: too many rows");
+  const dim3 grid((unsigned)chunks, (unsigned)cdiv(n, 256));
+  if (chunks == 1) {
+    CSG_LAUNCH(k_embed_bwd, grid, dim3(256), 0, s, idx, rows, idx_stride, dout, out_stride, out_off, (int)num_emb, (int)dim,
+               dtable, (int64_t)0, 1);
+    return check_launch("csg_embed_bwd");
   }
-  return check_launch("csg_embed_bwd");
+  CSG_REQUIRE(workspace != nullptr && workspace_bytes >= chunks * n * (int64_t)sizeof(float), CSG_E_WORKSPACE,
+              "csg_embed_bwd: workspace %ld < %ld bytes", (long)workspace_bytes, (long)(chunks * n * sizeof(float)));
+  CSG_LAUNCH(k_embed_bwd, grid, dim3(256), 0, s, idx, rows, idx_stride, dout, out_stride, out_off, (int)num_emb, (int)dim,
+             workspace, n, 0);
+  int rc = check_launch("csg_embed_bwd");
+  if (rc) return rc;
+  CSG_LAUNCH(k_embed_bwd_sum, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, workspace, (int)chunks, (int)n, dtable);
+  return check_launch("csg_embed_bwd(sum)");
 }
 
 int csg_real_object_mask(const int64_t* objs, int64_t B, int64_t O, int64_t A, int64_t image_id, uint8_t* mask,

@@ -112,8 +112,13 @@ class GradBuckets:
     collectives in the same order by construction: a member without a local gradient contributes zeros and RECEIVES
     the average of the others (its `.grad` becomes the slot view like everybody's — the replicas cannot part).  A
     parameter outside the agreed set that receives a gradient later (a branch inactive at the first step) cannot be
-    exchanged without the other ranks knowing: flush() raises — loudly, instead of issuing a collective the others may
-    not issue (a hang) — and `rebuild()`, a collective call, re-agrees the set.  In steady state nothing is allocated:
+    exchanged without the other ranks knowing, and a rank that raised on its own would leave the others blocked in their
+    next collective.  So the DETECTION is collective and costs nothing: the last bucket carries one extra float, "this
+    rank saw a late gradient", which travels with that bucket's all-reduce (the bucket of the first-registered parameters —
+    it is held back until flush(), when the backward is over and the flag is known; its gradients are the last to be
+    ready anyway).  The late gradient itself is DROPPED for this step on the ranks that hold one (`.grad = None`: the
+    optimiser skips the parameter, so the replicas stay identical), and at the next begin() / flush() every rank reads
+    the same averaged flag and calls `rebuild()` — a collective — together.  In steady state nothing is allocated:
     a hook copies the fresh gradient into its slot (the only extra pass over the gradients — there is no `torch.cat`,
     no copy back) and re-points `.grad` at the slot, which is what the optimiser then reads.
 
@@ -135,15 +140,21 @@ class GradBuckets:
         self._pending, self._fired, self._works, self._next, self._streams = [], set(), [], 0, {}
         self.allocations = 0                                    # flat buffers ever allocated (tests: steady state adds none)
         self.rebuilds = 0
+        self.late_dropped = 0                                   # late gradients dropped (one step each) before a rebuild
+        self._flag = self._flag_host = self._flag_event = None  # the "late gradient seen" float riding in the last bucket
+        self._flag_pending = False
+        self._late_ids = set()                                  # parameters whose late gradient this rank dropped
 
     # ---- construction (first synchronisation, or a parameter's first gradient)
     def _build(self):
         for h in self._hooks:
             h.remove()
+        wanted = set(self.slot) | self._late_ids                # a rebuild keeps the members and adds the late arrivals
+        self._late_ids = set()
         self._hooks, self.flats, self.members, self.slot = [], [], [], {}
         # the live set is the UNION over ranks (blocking, but only here): every rank builds identical buckets even if
         # its own shard left a branch without a gradient
-        has = torch.tensor([1 if p.grad is not None else 0 for p in self.params], dtype=torch.int32,
+        has = torch.tensor([1 if (p.grad is not None or id(p) in wanted) else 0 for p in self.params], dtype=torch.int32,
                            device=self.params[0].device if (self.params and dist.get_backend() == "nccl") else "cpu")
         if has.numel():
             dist.all_reduce(has, op=dist.ReduceOp.MAX)
@@ -174,7 +185,8 @@ class GradBuckets:
         al = lambda n: (n + 3) // 4 * 4                          # every slot starts on a 16-byte boundary (kernels write there)
         self._offs = {}
         for b, group in enumerate(groups):
-            flat = torch.zeros(sum(al(p.numel()) for p in group), device=group[0].device, dtype=torch.float32)
+            extra = 4 if b == len(groups) - 1 else 0             # the late-gradient flag (+ padding to 16 bytes)
+            flat = torch.zeros(sum(al(p.numel()) for p in group) + extra, device=group[0].device, dtype=torch.float32)
             self.allocations += 1
             off = 0
             for p in group:
@@ -205,12 +217,39 @@ class GradBuckets:
                         run = [p.data_ptr(), n, off]
                 else:
                     run = None
+        self._flag = self.flats[-1][-4:-3] if self.flats else None
+        self._flag_pending = False
+        if self._flag is not None and self._flag.is_cuda:
+            self._flag_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._flag_event = torch.cuda.Event()
+        else:
+            self._flag_host = self._flag_event = None
         self.built = True
+
+    def _resolve_flag(self):
+        """COLLECTIVE when it fires: the flag of the previous exchange says some rank saw a gradient outside the agreed
+        set — every rank reads the same value at the same point (the start of its next backward) and rebuilds."""
+        if not self._flag_pending:
+            return
+        self._flag_pending = False
+        if self._flag_event is not None:
+            self._flag_event.synchronize()                       # (recorded a whole step ago)
+            seen = float(self._flag_host[0]) > 0.0
+        else:
+            seen = float(self._flag_host) > 0.0
+        if seen:
+            import warnings
+            warnings.warn("GradBuckets: a parameter outside the agreed set received a gradient on some rank during the last "
+                          "step (it was dropped for that step on every rank); re-agreeing the set now (rebuild #%d)"
+                          % (self.rebuilds + 1))
+            self.rebuild()
 
     def _launch_ready(self, force=False):
         """Launch, in bucket order (identical on every rank), the all-reduces of the buckets that are complete."""
         while self._next < len(self.flats) and (force or self._pending[self._next] == 0):
             b = self._next
+            if b == len(self.flats) - 1 and not force:           # carries the late-gradient flag: known at flush() only
+                break
             if self._pending[b]:                                 # parameters that got no gradient this time contribute 0
                 for p in self.members[b]:
                     if id(p) not in self._fired:
@@ -257,6 +296,7 @@ class GradBuckets:
         """Call right before `backward()` (after zero_grad): arms the hooks for this backward."""
         if world_size() == 1 or not self.built:
             return
+        self._resolve_flag()
         self._arm()
 
     def flush(self):
@@ -268,21 +308,27 @@ class GradBuckets:
             # nothing): every gradient is an ordinary tensor, or a slot view autograd accumulated into
             if not self.built:
                 self._build()
+            else:
+                self._resolve_flag()
             self._arm()
             for group in self.members:
                 for p in group:
                     if p.grad is not None:
                         self._hook(p)
-        self._launch_ready(force=True)
         late = [p for p in self.params if p.grad is not None and id(p) not in self.slot]
-        if late:
-            # the collectives above are already in flight on every rank; nothing rank-dependent has been issued
+        if late and self._flag is None:
+            # no bucket exists to carry the flag (nothing had a gradient when the set was agreed): nothing has been issued
             self._state = "flushed"
             raise RuntimeError(
-                "GradBuckets: %d parameter(s) outside the agreed set received a gradient (first gradient after the "
-                "buckets were built: shapes %s).  The other ranks may not hold one, so it cannot be exchanged here; call "
-                "rebuild() on EVERY rank (a collective) after this step, or activate the branch from the first step."
-                % (len(late), [tuple(p.shape) for p in late[:4]]))
+                "GradBuckets: %d parameter(s) received their first gradient after an EMPTY set was agreed (shapes %s); call "
+                "rebuild() on EVERY rank (a collective)" % (len(late), [tuple(p.shape) for p in late[:4]]))
+        if self._flag is not None:
+            self._flag.fill_(1.0 if late else 0.0)
+        for p in late:                                           # not exchanged this step -> not applied on any rank
+            p.grad = None
+            self._late_ids.add(id(p))
+        self.late_dropped += len(late)
+        self._launch_ready(force=True)
         self._state = "flushed"
 
     def finish(self):
@@ -304,6 +350,13 @@ class GradBuckets:
             n = world_size()
             for flat in self.flats:
                 flat.div_(n)
+        if self._flag is not None:                               # read at the start of the next backward (_resolve_flag)
+            if self._flag_event is not None:
+                self._flag_host.copy_(self._flag, non_blocking=True)
+                self._flag_event.record()
+            else:
+                self._flag_host = self._flag.clone()
+            self._flag_pending = True
         for group in self.members:
             for p in group:
                 if id(p) not in self._fired:             # no local gradient: the others' average is this rank's gradient too

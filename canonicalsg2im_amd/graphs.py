@@ -130,6 +130,7 @@ class _SgGraph:
         self.graph = None
         self.grads = {}
         self.boxes_pred = self.vals = self.bbox_all = None
+        self.last_used = 0
 
     def load(self, triplets, triplet_type):
         T = triplets.shape[1]
@@ -148,8 +149,8 @@ class _SgGraph:
             torch.cuda.synchronize()
             ops.invalidate_weight_caches()
             _drop_stale_autograd(tr.model)
-            with torch.cuda.graph(g):
-                for p in tr.sg_params:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):    # (another host thread's HIP calls — a pinned-memory
+                for p in tr.sg_params:                                       #  loader, an async checkpoint — do not break the capture)
                     p.grad = None
                 self.boxes_pred = tr.model.sg_to_layout(gs.objs, self.triplets, self.ttype, gs.boxes)[1]
                 out = {}
@@ -202,7 +203,7 @@ class _GraphSet:
             torch.cuda.synchronize()
             ops.invalidate_weight_caches()              # every derived weight is recomputed INSIDE the graph that reads it
             _drop_stale_autograd(self.owner.tr.model, self.owner.tr.discriminator)
-            with torch.cuda.graph(g, pool=self.pool):
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
                 fn()
             if self.pool is None:
                 self.pool = g.pool()
@@ -296,13 +297,18 @@ class StepGraphs:
             if sg is None:
                 seen = gs.sg_seen.get(tpad, 0)
                 gs.sg_seen[tpad] = seen + 1
-                if seen >= 1 and len(gs.sg) < MAX_SG_GRAPHS:
+                if seen >= 1:
+                    if len(gs.sg) >= MAX_SG_GRAPHS:                     # least recently replayed bucket makes room
+                        old = min(gs.sg, key=lambda t: gs.sg[t].last_used)
+                        del gs.sg[old]
+                        gs.sg_seen.pop(old, None)
                     sg = gs.sg[tpad] = _SgGraph(gs, tpad, tr.model.sg_to_layout.module.vocab["pred_name_to_idx"]["__padding__"],
                                                 batch)
                     self.sg_captures += 1
         if sg is not None:
             sg.load(triplets, triplet_type)
             sg.run(tr)
+            sg.last_used = self.replays + self.eager_steps
             G["bbox_pred_all"] = sg.bbox_all.clone()
             G["bbox_pred"] = sg.vals.clone()
             self.boxes_pred = sg.boxes_pred[:, :objs.shape[1]]
@@ -422,7 +428,9 @@ class StepGraphs:
         if mk:
             mk.mark("E3 object D step")
             mk.end()
-        tr.last_model_out = (gs.fake, self.boxes_pred, None)
+        # copies: gs.fake / the encoder's boxes are static buffers the next replay overwrites in place, and a caller may keep
+        # last_model_out across steps (image logging every N iterations) as it may on the eager path
+        tr.last_model_out = (gs.fake.clone(), None if self.boxes_pred is None else self.boxes_pred.clone(), None)
         ops.invalidate_weight_caches()              # S3's Adam step is replayed without torch's optimiser hooks
         self.replays += 1
         return G, D

@@ -1326,8 +1326,10 @@ class _Embed(torch.autograd.Function):
         grads, off = [], 0
         for k in range(A):
             g = torch.zeros((sizes[k], dims[k]), device=dout.device, dtype=torch.float32)
+            wb = lib.csg_embed_bwd_workspace(rows, sizes[k], dims[k])
+            ws = torch.empty((wb // 4,), device=dout.device, dtype=torch.float32) if wb > 0 else None
             check(lib.csg_embed_bwd(ctypes_ptr_off(idx2, k), rows, A, ptr(dout), D, off, sizes[k], dims[k], ptr(g),
-                                    stream()), "embed_bwd")
+                                    ptr(ws) if ws is not None else None, wb, stream()), "embed_bwd")
             grads.append(g)
             off += dims[k]
         return (None, *grads)

@@ -58,14 +58,32 @@ class LocalBatchNorm2d(_SynchronizedBatchNorm):
 
 class DataParallelWithCallback(nn.Module):
     """Same constructor as the reference (`replicate.py:50-67`); no replication happens here —
-    the process owns exactly one GPU and data parallelism is across processes."""
+    the process owns exactly one GPU and data parallelism is across processes (`torchrun`, one rank per
+    GPU: canonicalsg2im_amd/dist.py).  The reference's single-process form of `--gpu_ids 0,1,2,3` would
+    silently run the whole batch on one device here, so the first forward refuses it: several device ids
+    need a process group of that many ranks (scripts/train.py sets `--gpu_ids` from WORLD_SIZE itself)."""
 
     def __init__(self, module, device_ids=None, output_device=None, dim=0):
         super().__init__()
         self.module = module
         self.device_ids = list(device_ids) if device_ids else []
+        self._checked = False
+
+    def _check_world(self):
+        self._checked = True
+        n = len(self.device_ids)
+        if n > 1:
+            import torch.distributed as dist
+            world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+            if world != n:
+                raise RuntimeError(
+                    "DataParallelWithCallback(device_ids=%r): this implementation is one process per GPU — launch %d ranks "
+                    "(python -m torch.distributed.run --nproc-per-node %d ...) instead of one process with %d device ids; "
+                    "the current process group has %d rank(s), so the batch would run on ONE device" % (self.device_ids, n, n, n, world))
 
     def forward(self, *inputs, **kwargs):
+        if not self._checked:
+            self._check_world()
         return self.module(*inputs, **kwargs)
 
 

@@ -62,9 +62,13 @@ int csg_prof_read(int kernel_id, double* ms, int64_t* launches, double* work);
  * out[r, out_off + 0..dim) = table[idx[r*idx_stride], :]                                       */
 int csg_embed_fwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const float* table, int64_t num_emb,
                   int64_t dim, float* out, int64_t out_stride, int64_t out_off, void* stream);
-/* dtable[idx[r], :] += dout[r, out_off..]   (dtable must be zero-initialised by the caller)    */
+/* dtable[idx[r], :] += dout[r, out_off..] — replaces the backward of nn.Embedding (attribute_embed.py:40-45): rows added in
+ * row order (no atomics, bit-reproducible).  More than 1 024 rows need a workspace of csg_embed_bwd_workspace(...) bytes for
+ * the per-chunk partial tables (0 = none needed).                                                */
+int64_t csg_embed_bwd_workspace(int64_t rows, int64_t num_emb, int64_t dim);
 int csg_embed_bwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const float* dout, int64_t out_stride,
-                  int64_t out_off, int64_t num_emb, int64_t dim, float* dtable, void* stream);
+                  int64_t out_off, int64_t num_emb, int64_t dim, float* dtable, float* workspace, int64_t workspace_bytes,
+                  void* stream);
 
 /* ---- real-object mask: sg2im/utils.py:56-63 (remove_dummy_objects), batched, bit-exact ------ */
 int csg_real_object_mask(const int64_t* objs, int64_t B, int64_t O, int64_t A, int64_t image_id, uint8_t* mask,

@@ -14,30 +14,7 @@ contract where that error is negligible — the graph encoder's gradients, whose
 import torch
 
 
-def state_to64(state, memo=None):
-    """fp64 leaf copy of an oracle state dict; aliased tensors (the six names of the transitive weights) stay aliased."""
-    if state is None:
-        return None
-    memo = {} if memo is None else memo
-    out = {}
-    for k, v in state.items():
-        if torch.is_tensor(v) and v.is_floating_point():
-            if id(v) not in memo:
-                memo[id(v)] = v.detach().double().clone().requires_grad_(v.requires_grad)
-            out[k] = memo[id(v)]
-        else:
-            out[k] = v
-    return out
-
-
-def trainstate_to64(ts, oracle_mod):
-    noise = None if ts.mask_noise is None else ts.mask_noise.double()
-    return oracle_mod.TrainState(ts.opt, state_to64(ts.sg), state_to64(ts.g), state_to64(ts.d), state_to64(ts.dobj),
-                                 state_to64(ts.vgg), state_to64(ts.dmask), noise)
-
-
-def batch_to64(batch):
-    return tuple(t.double() if (torch.is_tensor(t) and t.is_floating_point()) else t for t in batch)
+from oracle.fp64 import batch_to64, state_to64, trainstate_to64  # noqa: F401,E402  (re-exported: the tests import them from here)
 
 
 def errors(x, ref64):

@@ -271,3 +271,18 @@ def test_spade_gamma_beta_parameters_share_one_allocation(built):
     m.double()                                            # separates the parameters; the next call re-joins them
     w3 = N._joined(m, "_jw", m.a, m.b)
     assert w3.dtype == torch.float64 and m.a.data_ptr() == w3.data_ptr() and torch.equal(w3[3:], m.b.detach())
+
+
+def test_data_parallel_wrapper_refuses_several_devices_without_a_process_group():
+    """The reference's `--gpu_ids 0,1,2,3` in ONE process (replicate.py:50-67) would run the whole batch on one device here:
+    the wrapper refuses at its first forward instead of doing so silently; one device id (or none) is the normal form."""
+    import pytest
+    from canonicalsg2im_amd.spade.models.networks.sync_batchnorm import DataParallelWithCallback
+    lin = torch.nn.Linear(3, 2)
+    x = torch.randn(4, 3)
+    for ids in (None, [], [0]):
+        assert torch.equal(DataParallelWithCallback(lin, device_ids=ids)(x), lin(x))
+    dp = DataParallelWithCallback(lin, device_ids=[0, 1, 2, 3])
+    assert dp.module is lin and dp.device_ids == [0, 1, 2, 3]          # constructing is fine (checkpoint tools do it)
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        dp(x)

@@ -45,7 +45,7 @@ def _worker(rank, world, port, out):
     raw = sum(p.numel() for p in net.parameters()) * 4
     # (every slot starts on a 16-byte boundary — the weight-gradient kernels write into the slots — so a bucket may carry
     # up to 12 bytes of zero padding per parameter)
-    assert buckets.built and len(buckets.flats) >= 2 and nbytes == sum((p.numel() + 3) // 4 * 4 for p in net.parameters()) * 4
+    assert buckets.built and len(buckets.flats) >= 2 and nbytes == sum((p.numel() + 3) // 4 * 4 for p in net.parameters()) * 4 + 16      # (+ the late-gradient flag's 16 bytes in the last bucket)
     assert all(id(p) not in buckets.slot for p in unused.parameters())
     averaged = [p.grad.clone() for p in net.parameters()]
     allocs = buckets.allocations
@@ -57,7 +57,8 @@ def _worker(rank, world, port, out):
     net(x).pow(2).mean().backward()
     launched_in_backward = len(buckets._works)
     buckets.flush()
-    assert launched_in_backward == len(buckets.flats)         # every bucket was complete before flush()
+    assert launched_in_backward == len(buckets.flats) - 1     # every bucket was complete before flush(); the last one — it carries
+    #                                                           the "late gradient seen" flag — is launched by flush()
     assert buckets.finish() == nbytes and buckets.allocations == allocs
     for p, g in zip(net.parameters(), averaged):
         assert torch.equal(p.grad, g)
@@ -97,27 +98,38 @@ def _worker(rank, world, port, out):
     assert rep["world_size"] == world and rep["backend"] == "gloo"
     assert rep["grad_allreduce_calls_per_step"] == len(buckets.flats) and rep["grad_allreduce_bytes_per_step"] == nbytes
     assert rep["grad_copy_bytes_per_step"] == raw
-    # a parameter outside the agreed set that receives a gradient on a later step (a branch inactive until now): the
-    # exchange refuses loudly — it cannot know whether the other ranks hold one — and the COLLECTIVE rebuild() re-agrees
-    # the set; the buckets then work in steady state around the new set
+    # a parameter outside the agreed set that receives a gradient on a later step, ON ONE RANK ONLY (a branch inactive until
+    # now): no rank may raise or issue a collective on its own (the others would block in their next one).  The "late
+    # gradient seen" flag rides in the last bucket; the gradient is dropped for this step where it exists (the optimiser
+    # must not apply what was not exchanged), and at the next begin() BOTH ranks re-agree the set (rebuild, collective).
     for p in list(net.parameters()) + list(unused.parameters()):
         p.grad = None
     buckets.begin()
     x4 = x[:, :4]
-    (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
-    lw = unused.weight.grad.clone()
-    try:
-        buckets.finish()
-        raise AssertionError("a late parameter must make the exchange raise")
-    except RuntimeError as e:
-        assert "rebuild()" in str(e)
-    buckets.finish()                                          # the members' collectives were issued before the refusal
-    buckets.rebuild()
-    assert buckets.rebuilds == 1 and all(id(p) in buckets.slot for p in unused.parameters())
+    if rank == 1:
+        (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
+    else:
+        net(x).pow(2).mean().backward()
+    assert len(buckets._works) == len(buckets.flats) - 1      # the flag's bucket waits for flush()
+    buckets.finish()                                          # no exception, no hang: same collectives on both ranks
+    assert unused.weight.grad is None and unused.bias.grad is None
+    assert buckets.late_dropped == (2 if rank == 1 else 0) and buckets.rebuilds == 0
+    for p, g in zip(net.parameters(), averaged):
+        assert torch.equal(p.grad, g)
     for p in list(net.parameters()) + list(unused.parameters()):
         p.grad = None
-    buckets.begin()
-    (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        buckets.begin()                                       # both ranks read the averaged flag (0.5) and rebuild together
+    assert buckets.rebuilds == 1 and all(id(p) in buckets.slot for p in unused.parameters())
+    assert any("re-agreeing" in str(c.message) for c in caught)
+    if rank == 1:
+        (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
+        lw = unused.weight.grad.clone()
+    else:
+        net(x).pow(2).mean().backward()
+        lw = torch.zeros_like(unused.weight)
     buckets.finish()
     both = [torch.empty_like(lw) for _ in range(world)]
     dist.all_gather(both, lw)
@@ -125,6 +137,13 @@ def _worker(rank, world, port, out):
     for p, g in zip(net.parameters(), averaged):
         assert torch.equal(p.grad, g)
     assert unused.weight.grad.data_ptr() == buckets.slot[id(unused.weight)][1].data_ptr()
+    # steady state after the rebuild: no further rebuild, the flag reads zero
+    for p in list(net.parameters()) + list(unused.parameters()):
+        p.grad = None
+    buckets.begin()
+    (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
+    buckets.finish()
+    assert buckets.rebuilds == 1
     # a rank-local first step: rank 1's shard leaves the second Linear without a gradient BEFORE any bucket exists —
     # the union still puts it into the buckets of both ranks
     net2 = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))

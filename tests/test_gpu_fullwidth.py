@@ -93,19 +93,14 @@ def _step_losses_image_only(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed,
     torch.manual_seed(seed)
     tr = T.Trainer(opt, cuda)
     ts = T.oracle_state_from(tr, oracle)
-    ts64 = trainstate_to64(ts, oracle) if image_vs_fp64 else None
+    ts_before = T.oracle_state_from(tr, oracle) if image_vs_fp64 else None   # (oracle.train_step below updates `ts` in place)
     batch = make_batch(vocab, batch_cfg, seed=batch_seed)
     G, D = tr.step([None if t is None else t.cuda() for t in batch])
     torch.cuda.synchronize()
     Go, Do, img_o = oracle.train_step(ts, batch)
     if image_vs_fp64:
-        b64 = batch_to64(batch)
-        with torch.no_grad():                                  # the forward half of oracle.train_step, in fp64
-            from oracle import functional as OF
-            _, _, masks_pred = OF.sg2layout_forward(ts64.sg, opt.vocab, b64[1], b64[3], b64[5], mask_noise=ts64.mask_noise)
-            img64 = OF.generator_forward(ts64.g, opt.vocab, opt.image_size[0], b64[1], b64[2], True,
-                                         num_upsampling_layers=opt.num_upsampling_layers,
-                                         layout_masks=masks_pred if b64[6] is None else b64[6]).detach()
+        from oracle.fp64 import generated_image64
+        img64 = generated_image64(ts_before, batch)            # the forward half of oracle.train_step, in fp64
         d32 = (img_o.detach().double() - img64).abs()
         # the yardstick's own distance from fp64 is recorded, and bounded: a broken oracle must not pass as "fp32 noise"
         assert float(d32.max()) <= 5e-4 and float(d32.norm() / img64.norm()) <= 2e-5, (float(d32.max()), float(d32.norm() / img64.norm()))
@@ -176,7 +171,7 @@ def _check_step(tr, res, tag, sg_band=False, fp64=True):
             if n:
                 lines.append("  %-40s %6d %10d %10.2e" % (name, n, total, rel))
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "r04_band_%s_sg_forced.txt" % tag), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "r05_band_%s_sg_forced.txt" % tag), "w") as f:
             f.write("\n".join(lines) + "\n")
         assert worst <= 1e-5, "%s SG gradients vs the gate-forced fp64 oracle: worst %.2e\n%s" % (tag, worst, "\n".join(lines))
         flipped = sum(n for _, n, _, _ in stats)
@@ -184,12 +179,18 @@ def _check_step(tr, res, tag, sg_band=False, fp64=True):
         # (measured: 25 of 2.1e8 decisions, the fp32 oracle itself 37; every one on a |pre-activation| below 4e-7)
         assert flipped <= max(64, 1e-6 * units), "%d of %d ReLU decisions differ from the fp64 oracle" % (flipped, units)
         assert all(rel <= 1e-5 for _, n, _, rel in stats if n), [s for s in stats if s[1]]
-        _check_gd_against_fp32(res, tag)     # (C3 puts the same kernels through the fp64 band)
+        if fp64:
+            # generator / PatchGAN gradients inside the fp64 noise band (dense scenes: no tensor beyond 1e-2, median ratio
+            # <= 1.5 — fp64_band.Band.check, `outliers=None`); the encoder's rows were judged gate-forced above
+            gd = dict(res, rows={k: v for k, v in res["rows"].items() if k != "SG"})
+            band_of(gd, tr, tag, dump=os.path.join(ROOT, "gpurun_out", "r05_band_%s.txt" % tag), outliers=None)
+        else:
+            _check_gd_against_fp32(res, tag)
         return
     if not fp64:
         _check_gd_against_fp32(res, tag)
         return
-    band_of(res, tr, tag, dump=os.path.join(ROOT, "gpurun_out", "r04_band_%s.txt" % tag), outliers=2)
+    band_of(res, tr, tag, dump=os.path.join(ROOT, "gpurun_out", "r05_band_%s.txt" % tag), outliers=2)
 
 
 def test_c3_full_width_step_vs_oracle(cuda):
@@ -290,7 +291,7 @@ def test_c5_full_generator_step_vs_oracle(cuda):
     from canonicalsg2im_amd.synth import BatchConfig
     tr, res = _run_step(cuda, "clevr", ["--image_size", "256,256", "--no_vgg_loss", "--use_img_disc", "1",
                                         "--batch_size", "2"],
-                        BatchConfig(2, 256, 64, 128, "closure"), seed=6, batch_seed=8, sg_gates=True, fp64=False)
+                        BatchConfig(2, 256, 64, 128, "closure"), seed=6, batch_seed=8, sg_gates=True, fp64=True)
     assert res["G"]["bbox_pred_all"].numel() == 2 and tr.opt.semantic_nc == 128
     _check_step(tr, res, tag="C5", sg_band=True)
 

@@ -418,6 +418,26 @@ def test_embed(ops):
     assert_close(out, ref, 0, 0, "embedding, many rows")
     out.backward(gy.cuda())
     assert_close(t_dev.grad, t_ref.grad, RTOL, 2e-4 * float(t_ref.grad.abs().max()), "dtable, many rows")
+    # rows are added in row order (chunk partials in chunk order): the same bits on every run, and the bits of a plain
+    # sequential fp32 sum per 1 024-row chunk
+    first = t_dev.grad.clone()
+    for _ in range(3):
+        t_dev.grad = None
+        ops.embed(idx.cuda(), [t_dev]).backward(gy.cuda())
+        assert torch.equal(t_dev.grad, first), "embedding backward is not bit-reproducible"
+    flat_idx, flat_gy = idx.reshape(-1), gy.reshape(-1, 32)
+    want = torch.zeros(8, 32)
+    for c0 in range(0, flat_idx.numel(), 1024):
+        part = torch.zeros(8, 32)
+        ii, gg = flat_idx[c0:c0 + 1024], flat_gy[c0:c0 + 1024]
+        for i in range(8):
+            rows = gg[ii == i]
+            acc = torch.zeros(32)
+            for r in rows:                                   # sequential fp32 adds, row order
+                acc = acc + r
+            part[i] = acc
+        want = want + part
+    assert torch.equal(first.cpu(), want), "embedding backward: not the ordered sum"
 
 
 def test_gather_concat_and_segment_avg_vs_golden(ops):
@@ -593,6 +613,13 @@ def test_object_crops_golden(ops):
     assert_close(crops[:, :3], a["crops"], RTOL, 2e-6, "crops")
     (crops[:, :3] * a["w"].cuda()).sum().backward()
     assert_close(imgs.grad, a["gimgs"], RTOL, 1e-5, "d imgs")
+    # d(image) is a gather in a fixed order (crops, crop rows, crop columns): identical bits on every run
+    first = imgs.grad.clone()
+    for _ in range(3):
+        imgs.grad = None
+        crops = ops.crop_objects(imgs, boxes[nz[:, 0], nz[:, 1]], nz[:, 0].contiguous(), meta["size"])
+        (crops[:, :3] * a["w"].cuda()).sum().backward()
+        assert torch.equal(imgs.grad, first), "crop backward is not bit-reproducible"
 
 
 def test_cpu_tensor_is_refused(ops):
