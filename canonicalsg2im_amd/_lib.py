@@ -117,6 +117,8 @@ SIGNATURES = {
     "csg_wino_conv": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_i64, c_p]),
     "csg_wino_bwd_weight_workspace": (c_i64, [ctypes.POINTER(WinoDesc)]),
     "csg_wino_bwd_weight": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "csg_wino4_bwd_weight_workspace": (c_i64, [ctypes.POINTER(WinoDesc)]),
+    "csg_wino4_bwd_weight": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_wino4_supported": (c_i32, [ctypes.POINTER(WinoDesc)]),
     "csg_wino4_pack_bytes": (c_i64, [c_i64, c_i64]),
     "csg_wino4_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),

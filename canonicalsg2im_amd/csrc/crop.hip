@@ -78,68 +78,114 @@ __global__ void k_crop_fwd(const float* __restrict__ img, int H, int W, int cs, 
 
 // d(image) as a gather.  The sampling grid of a crop is separable (fx depends on the crop column only, fy on the crop
 // row only), so the taps of crop n are two tables of HH / WW entries: (first source row / column, fraction).  A block owns
-// a 16 x 16 pixel tile of one image and walks the crops in order; for each crop of ITS image whose footprint meets the
-// tile it stages the two tables in LDS, and every thread sums, over the crop rows and columns whose taps land on its
-// pixel, weight * dout — rows outer, columns inner, crops outermost: a fixed order.  (The scatter form this replaces
-// issued ~3 M float atomics per step; their arrival order decided the last bits of d(image).)
+// a 16 x 16 pixel tile of one image:
+//   1. the crops of ITS image whose footprint (conservatively, from the box corners) meets the tile are compacted, in crop
+//      order, into an LDS list — 256 candidates per pass, one per thread, wave ballots + a prefix over the four waves
+//      (walking the crop list with dependent scalar loads cost a memory latency per crop: 300 - 700 us per launch);
+//   2. eight listed crops at a time get their tap tables staged in LDS;
+//   3. every thread sums, over the crop rows and columns whose taps land on its pixel, weight * dout — crops outermost,
+//      rows, then columns: a fixed order.  The rows / columns worth testing come from the linear form of the grid
+//      (f(i) ~ f0 + sl i, widened by one entry each side); the test itself reads the exact staged tables.
+// (The scatter form this replaces issued ~3 M float atomics per step; their arrival order decided the last bits of d(image).)
 #define CROP_MAXHW 64
+#define CROP_K 8
 __global__ __launch_bounds__(256) void k_crop_bwd(const float* __restrict__ dout, int H, int W, int cs, int C,
                                                    const float* __restrict__ boxes, const int64_t* __restrict__ img_idx,
                                                    int N, int HH, int WW, int out_cs, int tiles_x, int tiles_per_img,
                                                    float* __restrict__ dimg) {
-  __shared__ int s_i0[2][CROP_MAXHW];              // [axis: 0 = x, 1 = y][crop column / row]: first source index
-  __shared__ float s_t[2][CROP_MAXHW];             // fraction towards the second one
-  const int tid = threadIdx.x;
+  __shared__ int s_i0[CROP_K][2][CROP_MAXHW];      // [crop of the group][axis: 0 = x, 1 = y][crop column / row]: first source index
+  __shared__ float s_t[CROP_K][2][CROP_MAXHW];     // fraction towards the second one
+  __shared__ float s_lin[CROP_K][2][2];            // [axis]: f0, sl of the linear form
+  __shared__ int s_list[256];
+  __shared__ int s_cnt[5];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.x / tiles_per_img, tile = blockIdx.x - b * tiles_per_img;
-  const int x = (tile % tiles_x) * 16 + (tid & 15), y = (tile / tiles_x) * 16 + (tid >> 4);
   const int tx0 = (tile % tiles_x) * 16, ty0 = (tile / tiles_x) * 16;
+  const int x = tx0 + (tid & 15), y = ty0 + (tid >> 4);
+  const bool inside = x < W && y < H;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int n = 0; n < N; ++n) {
-    if (img_idx[n] != b) continue;                 // block-uniform
-    const float* box = boxes + (int64_t)n * 4;
-    {
-      // conservative footprint from the two ends of each axis (the grid is a monotone interpolation between them; one
-      // pixel of slack for its rounding) — block-uniform, so crops that miss the tile cost no barrier
-      const float fx0 = ((2.0f * box[0] - 1.0f + 1.0f) * (float)W - 1.0f) / 2.0f;
-      const float fx1 = ((2.0f * (box[0] + box[2]) - 1.0f + 1.0f) * (float)W - 1.0f) / 2.0f;
-      const float fy0 = ((2.0f * box[1] - 1.0f + 1.0f) * (float)H - 1.0f) / 2.0f;
-      const float fy1 = ((2.0f * (box[1] + box[3]) - 1.0f + 1.0f) * (float)H - 1.0f) / 2.0f;
-      if (!(fminf(fx0, fx1) - 2.0f <= (float)(tx0 + 15) && fmaxf(fx0, fx1) + 2.0f >= (float)tx0 &&
-            fminf(fy0, fy1) - 2.0f <= (float)(ty0 + 15) && fmaxf(fy0, fy1) + 2.0f >= (float)ty0))
-        continue;
+  for (int c0 = 0; c0 < N; c0 += 256) {
+    // ---- 1. ordered compaction of the candidates c0 .. c0 + 255
+    const int n = c0 + tid;
+    bool take = false;
+    if (n < N && img_idx[n] == b) {
+      const float4 bx = *(const float4*)(boxes + (int64_t)n * 4);
+      // conservative footprint from the two ends of each axis (the grid is a monotone interpolation between them; two
+      // pixels of slack for its rounding and the second tap)
+      const float fx0 = ((2.0f * bx.x - 1.0f + 1.0f) * (float)W - 1.0f) / 2.0f;
+      const float fx1 = ((2.0f * (bx.x + bx.z) - 1.0f + 1.0f) * (float)W - 1.0f) / 2.0f;
+      const float fy0 = ((2.0f * bx.y - 1.0f + 1.0f) * (float)H - 1.0f) / 2.0f;
+      const float fy1 = ((2.0f * (bx.y + bx.w) - 1.0f + 1.0f) * (float)H - 1.0f) / 2.0f;
+      take = fminf(fx0, fx1) - 2.0f <= (float)(tx0 + 15) && fmaxf(fx0, fx1) + 2.0f >= (float)tx0 &&
+             fminf(fy0, fy1) - 2.0f <= (float)(ty0 + 15) && fmaxf(fy0, fy1) + 2.0f >= (float)ty0;
     }
+    const unsigned long long m = __ballot(take);
+    __syncthreads();                               // the previous pass is done with s_list / s_cnt
+    if (lane == 0) s_cnt[wv] = __popcll(m);
     __syncthreads();
-    if (tid < WW + HH) {
-      const bool isx = tid < WW;
-      const int i = isx ? tid : tid - WW, nn = isx ? WW : HH, L = isx ? W : H;
-      const float lo = isx ? box[0] : box[1], sz = isx ? box[2] : box[3];
-      const float b0 = 2.0f * lo - 1.0f, b1 = 2.0f * (lo + sz) - 1.0f;
-      const float g = lin_down(i, nn) * b0 + lin_up(i, nn) * b1;
-      const float f = ((g + 1.0f) * (float)L - 1.0f) / 2.0f;
-      s_i0[isx ? 0 : 1][i] = (int)fminf(fmaxf(floorf(f), -2.0f), (float)L);
-      s_t[isx ? 0 : 1][i] = f - floorf(f);
+    if (take) {
+      int pos = __popcll(m & ((1ull << lane) - 1ull));
+      for (int w2 = 0; w2 < wv; ++w2) pos += s_cnt[w2];
+      s_list[pos] = n;
     }
-    __syncthreads();
-    const float* g = dout + (int64_t)n * HH * WW * out_cs;
-    for (int cy = 0; cy < HH && x < W && y < H; ++cy) {
-      const int iy0 = s_i0[1][cy];
-      if (iy0 != y && iy0 + 1 != y) continue;
-      const float ty = s_t[1][cy];
-      const float wy = iy0 == y ? 1.f - ty : ty;   // (y itself is inside the image: the tap is a valid one)
-      for (int cx = 0; cx < WW; ++cx) {
-        const int ix0 = s_i0[0][cx];
-        if (ix0 != x && ix0 + 1 != x) continue;
-        const float tx = s_t[0][cx];
-        // the four weights exactly as crop_taps forms them: (1-tx)(1-ty), tx(1-ty), (1-tx)ty, tx ty
-        const float wx = ix0 == x ? 1.f - tx : tx;
-        const float w = wx * wy;
-        if (w == 0.f) continue;
-        const float* gp = g + ((int64_t)cy * WW + cx) * out_cs;
-        for (int c = 0; c < C; ++c) acc[c] += w * gp[c];
+    const int L = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    // ---- 2. / 3. groups of CROP_K listed crops
+    for (int k0 = 0; k0 < L; k0 += CROP_K) {
+      __syncthreads();                             // s_list complete / the previous group's tables are no longer read
+      const int kn = min(CROP_K, L - k0);
+      for (int e = tid; e < kn * (WW + HH); e += 256) {
+        const int k = e / (WW + HH), r = e - k * (WW + HH);
+        const bool isx = r < WW;
+        const int i = isx ? r : r - WW, nn = isx ? WW : HH, Ld = isx ? W : H;
+        const float* box = boxes + (int64_t)s_list[k0 + k] * 4;
+        const float lo = isx ? box[0] : box[1], sz = isx ? box[2] : box[3];
+        const float b0 = 2.0f * lo - 1.0f, b1 = 2.0f * (lo + sz) - 1.0f;
+        const float g = lin_down(i, nn) * b0 + lin_up(i, nn) * b1;
+        const float f = ((g + 1.0f) * (float)Ld - 1.0f) / 2.0f;
+        s_i0[k][isx ? 0 : 1][i] = (int)fminf(fmaxf(floorf(f), -2.0f), (float)Ld);
+        s_t[k][isx ? 0 : 1][i] = f - floorf(f);
+        if (i == 0) {
+          s_lin[k][isx ? 0 : 1][0] = ((b0 + 1.0f) * (float)Ld - 1.0f) / 2.0f;
+          s_lin[k][isx ? 0 : 1][1] = nn > 1 ? (b1 - b0) * (float)Ld / (2.0f * (float)(nn - 1)) : 0.0f;
+        }
+      }
+      __syncthreads();
+      if (inside) {
+        for (int k = 0; k < kn; ++k) {
+          // candidate rows / columns: f(i) in [p - 1, p + 1)  ->  i in [(p - 1 - f0) / sl, (p + 1 - f0) / sl), widened;
+          // a flat or reversed grid (sl <= 0: degenerate box) scans everything
+          int ylo = 0, yhi = HH - 1, xlo = 0, xhi = WW - 1;
+          const float fy0 = s_lin[k][1][0], sly = s_lin[k][1][1], fx0 = s_lin[k][0][0], slx = s_lin[k][0][1];
+          if (sly > 1e-3f) {
+            ylo = max(0, (int)fminf(floorf(((float)(y - 1) - fy0) / sly), 1e6f) - 1);
+            yhi = min(HH - 1, (int)fmaxf(ceilf(((float)(y + 1) - fy0) / sly), -1e6f) + 1);
+          }
+          if (slx > 1e-3f) {
+            xlo = max(0, (int)fminf(floorf(((float)(x - 1) - fx0) / slx), 1e6f) - 1);
+            xhi = min(WW - 1, (int)fmaxf(ceilf(((float)(x + 1) - fx0) / slx), -1e6f) + 1);
+          }
+          const float* g = dout + (int64_t)s_list[k0 + k] * HH * WW * out_cs;
+          for (int cy = ylo; cy <= yhi; ++cy) {
+            const int iy0 = s_i0[k][1][cy];
+            if (iy0 != y && iy0 + 1 != y) continue;
+            const float ty = s_t[k][1][cy];
+            const float wy = iy0 == y ? 1.f - ty : ty;         // (y itself is inside the image: the tap is a valid one)
+            for (int cx = xlo; cx <= xhi; ++cx) {
+              const int ix0 = s_i0[k][0][cx];
+              if (ix0 != x && ix0 + 1 != x) continue;
+              const float tx = s_t[k][0][cx];
+              // the four weights exactly as crop_taps forms them: (1-tx)(1-ty), tx(1-ty), (1-tx)ty, tx ty
+              const float w = (ix0 == x ? 1.f - tx : tx) * wy;
+              if (w == 0.f) continue;
+              const float* gp = g + ((int64_t)cy * WW + cx) * out_cs;
+              for (int c = 0; c < C; ++c) acc[c] += w * gp[c];
+            }
+          }
+        }
       }
     }
   }
-  if (x < W && y < H) {
+  if (inside) {
     float* o = dimg + (((int64_t)b * H + y) * W + x) * cs;
     for (int c = 0; c < C; ++c) o[c] += acc[c];
   }
@@ -235,8 +281,9 @@ int csg_crop_bwd(const float* dout, int64_t B, int64_t H, int64_t W, int64_t img
               CSG_E_BADSHAPE, "csg_crop_bwd: bad shape");
   if (N == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
-  CSG_REQUIRE(C <= 4 && HH <= CROP_MAXHW && WW <= CROP_MAXHW && HH + WW <= 256, CSG_E_UNSUPPORTED,
+  CSG_REQUIRE(C <= 4 && HH <= CROP_MAXHW && WW <= CROP_MAXHW, CSG_E_UNSUPPORTED,
               "csg_crop_bwd: at most 4 channels and %d x %d crops", CROP_MAXHW, CROP_MAXHW);
+  CSG_REQUIRE(((uintptr_t)boxes % 16) == 0, CSG_E_UNSUPPORTED, "csg_crop_bwd: boxes must be 16-byte aligned");
   const int64_t total = N * HH * WW;
   ProfScope p(K_CROP_BWD, (double)total * (C * 4 + out_cs) * 4, s);
   const int tiles_x = (int)cdiv(W, 16), tiles_per_img = tiles_x * (int)cdiv(H, 16);

@@ -22,31 +22,39 @@ __global__ void k_embed_fwd(const int64_t* __restrict__ idx, int64_t rows, int64
 }
 
 // d(table)[i] = sum over the rows r with idx[r] == i of dout[r], in row order: no atomics, the same bits every run.
-// A block owns EMB_CHUNK consecutive rows (their indices staged in LDS) x 256 consecutive table entries e = i * dim + d;
-// a thread walks the chunk in order and adds the rows that name its table row (the 32..128 threads of one table row read
-// one coalesced piece of dout).  One chunk: the sums go straight onto dtable; more: per-chunk partials in the caller's
-// workspace + k_embed_bwd_sum adding them in chunk order.  (Dense graphs send 2e5 predicate rows to an 8-row table: 196
-// chunks of 1 024 compare-and-add steps.)
-#define EMB_CHUNK 1024
+// A block owns a chunk of consecutive rows — their indices AND their dout rows staged in LDS with independent, coalesced
+// loads (a conditional global load per matching row serialises one memory latency per match: 154 us per launch on dense
+// graphs) — x 256 consecutive table entries e = i * dim + d; a thread walks the chunk in order and adds the rows that
+// name its table row (a select, so the LDS reads pipeline).  One chunk: the sums go straight onto dtable; more: per-chunk
+// partials in the caller's workspace + k_embed_bwd_sum adding them in chunk order.  (Dense graphs send 1e5 predicate
+// rows to an 8-row table: 370 chunks of 256 rows.)
+#define EMB_TILE_FLOATS 8192
+__host__ __device__ inline int emb_chunk_rows(int64_t dim) {
+  int64_t r = EMB_TILE_FLOATS / dim;
+  return (int)(r > 1024 ? 1024 : (r < 32 ? 32 : r));
+}
 __global__ __launch_bounds__(256) void k_embed_bwd(const int64_t* __restrict__ idx, int64_t rows, int64_t idx_stride,
                                                     const float* __restrict__ dout, int64_t out_stride, int64_t out_off,
-                                                    int num_emb, int dim, float* __restrict__ dst, int64_t dst_chunk_stride,
-                                                    int accumulate) {
-  __shared__ int s_idx[EMB_CHUNK];
-  const int64_t r0 = (int64_t)blockIdx.x * EMB_CHUNK;
-  const int n = (int)min((int64_t)EMB_CHUNK, rows - r0);
+                                                    int num_emb, int dim, int chunk, float* __restrict__ dst,
+                                                    int64_t dst_chunk_stride, int accumulate) {
+  extern __shared__ float s_d[];                   // [chunk][dim] dout rows, then [chunk] indices
+  int* s_idx = (int*)(s_d + (size_t)chunk * dim);
+  const int64_t r0 = (int64_t)blockIdx.x * chunk;
+  const int n = (int)min((int64_t)chunk, rows - r0);
   for (int j = threadIdx.x; j < n; j += 256) {
     const int64_t v = idx[(r0 + j) * idx_stride];
     s_idx[j] = (v >= 0 && v < num_emb) ? (int)v : -1;
+  }
+  for (int t = threadIdx.x; t < n * dim; t += 256) {
+    const int j = t / dim, d = t - j * dim;
+    s_d[t] = dout[(r0 + j) * out_stride + out_off + d];
   }
   __syncthreads();
   const int e = blockIdx.y * 256 + threadIdx.x;
   if (e >= num_emb * dim) return;
   const int i = e / dim, d = e - i * dim;
-  const float* src = dout + r0 * out_stride + out_off + d;
   float acc = 0.f;
-  for (int j = 0; j < n; ++j)
-    if (s_idx[j] == i) acc += src[(int64_t)j * out_stride];
+  for (int j = 0; j < n; ++j) acc += s_idx[j] == i ? s_d[j * dim + d] : 0.f;
   float* o = dst + (int64_t)blockIdx.x * dst_chunk_stride + e;
   *o = accumulate ? *o + acc : acc;
 }
@@ -571,29 +579,33 @@ int csg_embed_fwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const fl
 }
 
 int64_t csg_embed_bwd_workspace(int64_t rows, int64_t num_emb, int64_t dim) {
-  const int64_t chunks = cdiv(rows, EMB_CHUNK);
+  if (rows <= 0 || num_emb <= 0 || dim <= 0) return 0;
+  const int64_t chunks = cdiv(rows, emb_chunk_rows(dim));
   return chunks > 1 ? chunks * num_emb * dim * (int64_t)sizeof(float) : 0;
 }
 
 int csg_embed_bwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const float* dout, int64_t out_stride,
                   int64_t out_off, int64_t num_emb, int64_t dim, float* dtable, float* workspace, int64_t workspace_bytes,
                   void* stream) {
-  CSG_REQUIRE(rows >= 0 && dim > 0 && num_emb > 0 && num_emb * dim < (1ll << 30), CSG_E_BADSHAPE, "csg_embed_bwd: bad shape");
+  CSG_REQUIRE(rows >= 0 && dim > 0 && dim <= 256 && num_emb > 0 && num_emb * dim < (1ll << 30), CSG_E_BADSHAPE,
+              "csg_embed_bwd: bad shape");
   if (rows == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_EMBED_BWD, (double)rows * dim * 8, s);
-  const int64_t chunks = cdiv(rows, EMB_CHUNK), n = num_emb * dim;
-  CSG_REQUIRE(chunks < 65536 * 32, CSG_E_UNSUPPORTED, "csg_embed_bwd: too many rows");
+  const int chunk = emb_chunk_rows(dim);
+  const int64_t chunks = cdiv(rows, chunk), n = num_emb * dim;
+  CSG_REQUIRE(chunks < (1ll << 31) && cdiv(n, 256) < 65536, CSG_E_UNSUPPORTED, "csg_embed_bwd: too many rows / entries");
   const dim3 grid((unsigned)chunks, (unsigned)cdiv(n, 256));
+  const size_t shm = ((size_t)chunk * dim + chunk) * sizeof(float);
   if (chunks == 1) {
-    CSG_LAUNCH(k_embed_bwd, grid, dim3(256), 0, s, idx, rows, idx_stride, dout, out_stride, out_off, (int)num_emb, (int)dim,
-               dtable, (int64_t)0, 1);
+    CSG_LAUNCH(k_embed_bwd, grid, dim3(256), shm, s, idx, rows, idx_stride, dout, out_stride, out_off, (int)num_emb, (int)dim,
+               chunk, dtable, (int64_t)0, 1);
     return check_launch("csg_embed_bwd");
   }
   CSG_REQUIRE(workspace != nullptr && workspace_bytes >= chunks * n * (int64_t)sizeof(float), CSG_E_WORKSPACE,
               "csg_embed_bwd: workspace %ld < %ld bytes", (long)workspace_bytes, (long)(chunks * n * sizeof(float)));
-  CSG_LAUNCH(k_embed_bwd, grid, dim3(256), 0, s, idx, rows, idx_stride, dout, out_stride, out_off, (int)num_emb, (int)dim,
-             workspace, n, 0);
+  CSG_LAUNCH(k_embed_bwd, grid, dim3(256), shm, s, idx, rows, idx_stride, dout, out_stride, out_off, (int)num_emb, (int)dim,
+             chunk, workspace, n, 0);
   int rc = check_launch("csg_embed_bwd");
   if (rc) return rc;
   CSG_LAUNCH(k_embed_bwd_sum, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, workspace, (int)chunks, (int)n, dtable);

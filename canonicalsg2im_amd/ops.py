@@ -135,6 +135,10 @@ FEW_ENABLED = os.environ.get("CSG_FEW_OUTPUT_KERNELS", "1") != "0"   # csrc/fewn
 WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "1024"))     # B*H*W below which the direct kernel stays
 WINO_ENABLED = os.environ.get("CSG_WINOGRAD", "1") != "0"
 WINO_WGRAD = os.environ.get("CSG_WINOGRAD_WGRAD", "1") != "0"
+# F(3x3,4x4) weight gradient (csrc/wino4w.hip) where it pays: maps of at least WINO4_WGRAD_MIN_PIXELS pixels per image with H, W
+# multiples of 8 and at least 64 input and output channels (a block owns 64 x 64 channels); 0 turns it off
+WINO4_WGRAD = os.environ.get("CSG_WINO4_WGRAD", "1") != "0"
+WINO4_WGRAD_MIN_PIXELS = int(os.environ.get("CSG_WINO4_WGRAD_MIN_PIXELS", "1024"))
 
 # ---- plain GEMM kernels (csrc/gemm.hip) for the 1x1 convolutions / linears they are measured faster on
 GEMM_MODE = os.environ.get("CSG_GEMM", "auto")        # "auto": the measured rule below; "all": every shape the kernels fill the
@@ -494,11 +498,14 @@ class _Conv2d(torch.autograd.Function):
         if dx is not None and not gated:              # the producer's activation derivative as a separate pass
             check(lib.csg_act_bwd(ptr(dx), ptr(x), dx.numel(), ctx.in_act[0], ctx.in_act[1], ptr(dx), stream()), "act_bwd")
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        wino_wg = -1
+        wino_wg = wino4_wg = -1
         if ctx.needs_input_grad[1] and WINO_WGRAD and wino_eligible(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
             d = WinoDesc()
             d.B, d.H, d.W, d.Cin, d.x_cs, d.Cout, d.y_cs, d.act, d.slope = B, IH, IW, Cin, Cin, Cout, Cout, ACT_NONE, 0.0
             wino_wg = lib.csg_wino_bwd_weight_workspace(d)      # < 0: the 16-tile stages do not tile this image exactly
+            if (WINO4_WGRAD and Cin >= 64 and Cout >= 64 and IH % 8 == 0 and IW % 8 == 0
+                    and IH * IW >= WINO4_WGRAD_MIN_PIXELS):
+                wino4_wg = lib.csg_wino4_bwd_weight_workspace(d)
         if ctx.needs_input_grad[1] and getattr(ctx, "gemm", False):
             # dW (Cout, Cin) = dY^T . X over the rows, the bias gradient from the same staged tiles (csg_gemm_tn)
             M = B * IH * IW
@@ -514,6 +521,18 @@ class _Conv2d(torch.autograd.Function):
             check(lib.csg_gemm_tn(M, Cout, Cin, ptr(dpre), Cout, ptr(x), Cin, ptr(dwp), ptr(db), ptr(ws), nbytes, stream()),
                   "gemm_tn")
             _GEMM_CALLS[0] += 1
+            dw = dwp.permute(0, 3, 1, 2)
+        elif wino4_wg >= 0:
+            # Winograd F(3x3,4x4) weight gradient (csrc/wino4w.hip), same output layout as the direct kernel
+            nbytes = wino4_wg
+            ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
+            dwp = _grad_dest(weight, (Cout, KH, KW, Cin)) if _ohwi_dense(weight) else None
+            if dwp is None:
+                dwp = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
+            if want_db:
+                db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
+            check(lib.csg_wino4_bwd_weight(d, ptr(x), ptr(dpre), ptr(dwp), ptr(db), ptr(ws), nbytes, stream()),
+                  "wino4_bwd_weight")
             dw = dwp.permute(0, 3, 1, 2)
         elif wino_wg >= 0:
             # Winograd F(3x3,2x2) weight gradient (csrc/wino.hip), same output layout as the direct kernel

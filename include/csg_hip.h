@@ -63,7 +63,7 @@ int csg_prof_read(int kernel_id, double* ms, int64_t* launches, double* work);
 int csg_embed_fwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const float* table, int64_t num_emb,
                   int64_t dim, float* out, int64_t out_stride, int64_t out_off, void* stream);
 /* dtable[idx[r], :] += dout[r, out_off..] — replaces the backward of nn.Embedding (attribute_embed.py:40-45): rows added in
- * row order (no atomics, bit-reproducible).  More than 1 024 rows need a workspace of csg_embed_bwd_workspace(...) bytes for
+ * row order (no atomics, bit-reproducible).  More than one chunk of 8192 / dim rows needs a workspace of csg_embed_bwd_workspace(...) bytes for
  * the per-chunk partial tables (0 = none needed).                                                */
 int64_t csg_embed_bwd_workspace(int64_t rows, int64_t num_emb, int64_t dim);
 int csg_embed_bwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const float* dout, int64_t out_stride,
@@ -237,6 +237,14 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
 int64_t csg_wino_bwd_weight_workspace(const csg_wino_desc* d);
 int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy, float* dw, float* db, float* workspace,
                         int64_t workspace_bytes, void* stream);
+
+/* Weight gradient of the same layers by Winograd F(3x3,4x4) (csrc/wino4w.hip): 36 multiplications per 4x4 tile of dY where
+ * F(3x3,2x2) needs 64 — the layers of architecture.py:29-31 and normalization.py:89-94 on maps whose H and W are multiples
+ * of 8 (efficient from 64 input and 64 output channels up: a block owns 64 x 64 channels).  Same arguments, layouts and
+ * determinism as csg_wino_bwd_weight; csg_wino4_bwd_weight_workspace < 0: the shape is not served.                   */
+int64_t csg_wino4_bwd_weight_workspace(const csg_wino_desc* d);
+int csg_wino4_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy, float* dw, float* db, float* workspace,
+                         int64_t workspace_bytes, void* stream);
 
 /* ---- K8w4: the same 3x3 / stride 1 / pad 1 layers by Winograd F(4x4,3x3) (csrc/wino4.hip) ------------------------
  * 36 multiplications per 4x4 output tile and (cin,cout) pair — 2.25 per output where F(2x2,3x3) needs 4 — on maps at

@@ -23,11 +23,12 @@ def _free_port():
     return p
 
 
-def _make(world_rank=None):
+def _make(world_rank=None, single_process=False):
     from canonicalsg2im_amd import train as T
     from canonicalsg2im_amd.synth import BatchConfig, make_batch, make_vocab
     vocab = make_vocab("tiny")
-    opt = T.make_opt(vocab, ARGV)
+    # (one process = one device id: DataParallelWithCallback refuses `--gpu_ids 0,1` without a 2-rank process group)
+    opt = T.make_opt(vocab, ARGV[:-1] + ["0"] if single_process else ARGV)
     torch.manual_seed(1234 + (world_rank or 0))          # replicas are built DIFFERENT; rank 0 wins by broadcast
     tr = T.Trainer(opt, torch.device("cuda:0"))
     batch = make_batch(vocab, BatchConfig(4, 64, 2, 5, "packed"), seed=77)
@@ -74,7 +75,7 @@ def test_two_ranks_on_one_gpu_match_and_track_single_process():
     # single-process run of the whole batch from rank 0's initial weights: BatchNorm statistics are
     # global in both runs (SyncBN), so the per-rank mean losses average to the single-process losses
     # up to the N-replica clamp(var,eps) vs var+eps difference (batchnorm.py:65-68 vs :145)
-    T, tr, batch = _make(0)
+    T, tr, batch = _make(0, single_process=True)
     G, Dl = tr.step([None if t is None else t.cuda() for t in batch])
     for k in ("GAN_Img", "GAN_Feat", "bbox_pred"):
         both = 0.5 * (r0["G"][k] + r1["G"][k])

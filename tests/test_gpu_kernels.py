@@ -427,9 +427,9 @@ def test_embed(ops):
         assert torch.equal(t_dev.grad, first), "embedding backward is not bit-reproducible"
     flat_idx, flat_gy = idx.reshape(-1), gy.reshape(-1, 32)
     want = torch.zeros(8, 32)
-    for c0 in range(0, flat_idx.numel(), 1024):
+    for c0 in range(0, flat_idx.numel(), 256):
         part = torch.zeros(8, 32)
-        ii, gg = flat_idx[c0:c0 + 1024], flat_gy[c0:c0 + 1024]
+        ii, gg = flat_idx[c0:c0 + 256], flat_gy[c0:c0 + 256]
         for i in range(8):
             rows = gg[ii == i]
             acc = torch.zeros(32)

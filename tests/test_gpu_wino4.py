@@ -308,3 +308,98 @@ def test_wino34_split_over_input_channels(ops):
     y0 = _raw_wino34(ops, x, w, 1)
     assert _err(outs[0], ref64) < GATE and _err(y0, ref64) < GATE
     assert_close(outs[0], y0, 1e-4, 1e-5 * float(ref64.abs().max()) + 1e-5, "wino34 split vs unsplit")
+
+
+# ------------------------------------------------------------------------------------------------ weight gradient, F(3x3,4x4)
+def _raw_wgrad(ops, x, gy, which):
+    """csg_wino4_bwd_weight / csg_wino_bwd_weight through the C ABI -> (dW in (Cout, Cin, 3, 3) order, db, workspace bytes)."""
+    from canonicalsg2im_amd._lib import check, lib, ptr, stream
+    B, Cin, H, W = x.shape
+    Cout = gy.shape[1]
+    d = _desc(B, H, W, Cin, Cout)
+    wsf, fn = ((lib.csg_wino4_bwd_weight_workspace, lib.csg_wino4_bwd_weight) if which == 4
+               else (lib.csg_wino_bwd_weight_workspace, lib.csg_wino_bwd_weight))
+    nbytes = wsf(d)
+    assert nbytes > 0, (which, x.shape)
+    xd, gyd = ops.nhwc(x.cuda()), ops.nhwc(gy.cuda())
+    ws = torch.empty(nbytes // 4, device="cuda")
+    dwp = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda")
+    check(fn(d, ptr(xd), ptr(gyd), ptr(dwp), ptr(db), ptr(ws), nbytes, stream()), "bwd_weight")
+    dwp2 = torch.empty_like(dwp)
+    check(fn(d, ptr(xd), ptr(gyd), ptr(dwp2), None, ptr(ws), nbytes, stream()), "bwd_weight")
+    assert torch.equal(dwp, dwp2), "weight gradient is not bit-reproducible"
+    return dwp.permute(0, 3, 1, 2).contiguous(), db
+
+
+WG_SHAPES = [(2, 64, 64, 8, 8),          # one region per image: every halo flag at once
+             (1, 64, 64, 16, 24),        # 2 x 3 regions, interior columns
+             (3, 128, 64, 32, 32),       # two cin blocks
+             (2, 64, 192, 40, 16),       # three cout blocks, H != W
+             (2, 72, 100, 16, 16),       # channel tails (72 = 64 + 8, 100 = 64 + 36): zero-filled lanes, masked slab rows
+             (5, 128, 256, 64, 64),      # several slices per (cout, cin) block, odd region counts
+             (1, 256, 128, 128, 128)]    # a generator shape (up_2.conv_0) at batch 1
+
+
+@pytest.mark.parametrize("shape", WG_SHAPES)
+def test_wino4_weight_gradient_vs_fp64(ops, shape):
+    """csg_wino4_bwd_weight (F(3x3,4x4), csrc/wino4w.hip) against the fp64 weight gradient of F.conv2d: dW in the direct
+    kernel's [Cout][3][3][Cin] layout and the bias gradient, < 1e-5 of the gradient's scale (the forward kernel's gate)."""
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + 7)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    gy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, b, padding=1).backward(gy.double())
+    dw, db = _raw_wgrad(ops, x, gy, 4)
+    err = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
+    errb = float((db.double().cpu() - b.grad).abs().max() / b.grad.abs().max())
+    assert err < GATE and errb < GATE, (shape, err, errb)
+
+
+def test_wino4_weight_gradient_error_next_to_f2(ops):
+    """The error of F(3x3,4x4) next to F(3x3,2x2) on the dominant shape's channel counts (128 -> 256, 64 x 64 map, B = 4:
+    16 384 tiles per sum): both far inside the gate; the ratio is recorded by the assertion message of a failure."""
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, H = 4, 128, 256, 64
+    x = torch.randn(B, Cin, H, H, generator=g)
+    gy = torch.randn(B, Cout, H, H, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, padding=1).backward(gy.double())
+    scale = w.grad.abs().max()
+    e4 = float((_raw_wgrad(ops, x, gy, 4)[0].double().cpu() - w.grad).abs().max() / scale)
+    e2 = float((_raw_wgrad(ops, x, gy, 2)[0].double().cpu() - w.grad).abs().max() / scale)
+    assert e4 < GATE and e2 < GATE and e4 < 8.0 * e2 + 1e-6, (e4, e2)
+
+
+def test_wino4_weight_gradient_shapes_it_refuses(ops):
+    from canonicalsg2im_amd._lib import lib
+    for (H, W, ok) in ((8, 8, True), (16, 40, True), (12, 16, False), (16, 20, False), (4, 64, False)):
+        assert (lib.csg_wino4_bwd_weight_workspace(_desc(1, H, W, 64, 64)) >= 0) == ok, (H, W)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 256, 32, 32), (1, 64, 64, 64, 32)])
+def test_wino4_weight_gradient_through_autograd(ops, shape):
+    """ops.conv2d's backward takes the F(3x3,4x4) weight gradient on these shapes (>= 64 channels, H and W multiples of 8,
+    >= 1 024 pixels): dW and db against fp64 autograd, and the same launch with the kernel turned off for comparison."""
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    gy = torch.randn(B, Cout, H, W, generator=g)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    F.conv2d(x.double(), wr, br, padding=1).backward(gy.double())
+    got = {}
+    for on in (True, False):
+        ops.WINO4_WGRAD = on
+        try:
+            wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+            ops.conv2d(x.cuda(), wd, bd, 1, 1).backward(gy.cuda())
+        finally:
+            ops.WINO4_WGRAD = True
+        got[on] = wd.grad.double().cpu()
+        assert float((got[on] - wr.grad).abs().max() / wr.grad.abs().max()) < GATE, (shape, on)
+        assert float((bd.grad.double().cpu() - br.grad).abs().max() / br.grad.abs().max()) < GATE, (shape, on)
+    assert not torch.equal(got[True], got[False])      # (two different kernels did run)
