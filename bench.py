@@ -427,9 +427,9 @@ def main():
             torch.cuda.synchronize()
             pg = _lib.prof_read()
             _lib.prof_enable(0)
-            mk = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "gemm_nt", "gemm_tn", "wino_conv", "wino_wgrad", "wino4_conv")
+            mk = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "gemm_nt", "gemm_tn", "wino_conv", "wino_wgrad", "wino4_conv", "wino4_wgrad")
             alg = sum(pg.get(k, (0.0, 0, 0.0))[2] for k in mk)
-            exe = sum(pg.get(k, (0.0, 0, 0.0))[2] * {"wino_conv": 4.0 / 9.0, "wino_wgrad": 4.0 / 9.0, "wino4_conv": 0.25}.get(k, 1.0)
+            exe = sum(pg.get(k, (0.0, 0, 0.0))[2] * {"wino_conv": 4.0 / 9.0, "wino_wgrad": 4.0 / 9.0, "wino4_conv": 0.25, "wino4_wgrad": 0.25}.get(k, 1.0)
                       for k in mk)
             gen_exec_ratio = exe / alg if alg > 0 else None
 
@@ -505,8 +505,10 @@ def main():
     # 4/9 of it.  Every `frac` below is executed FLOPs / time / peak (a hardware utilisation, <= 1 by construction);
     # the algorithmic rate is reported beside it as `algorithmic` / `algorithmic_over_peak` (it may exceed 1).
     # (F(4x4,3x3): 36 multiplications per 16 outputs where the direct sum needs 144 -> 1/4)
-    EXEC = {"wino_conv": 4.0 / 9.0, "wino_wgrad": 4.0 / 9.0, "wino4_conv": 0.25}
-    mfma_kernels = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "gemm_nt", "gemm_tn", "wino_conv", "wino_wgrad", "wino4_conv")
+    # (F(3x3,4x4) weight gradient, csrc/wino4w.hip: 36 multiplications per 4x4 tile of dY where the direct sum needs 144 -> 1/4)
+    EXEC = {"wino_conv": 4.0 / 9.0, "wino_wgrad": 4.0 / 9.0, "wino4_conv": 0.25, "wino4_wgrad": 0.25}
+    mfma_kernels = ("igemm_fwd", "igemm_fwd64", "igemm_wgrad", "gemm_nt", "gemm_tn", "wino_conv", "wino_wgrad", "wino4_conv",
+                    "wino4_wgrad")
 
     def mfma_rates(table, names, seconds):
         """(algorithmic TFLOP/s, executed TFLOP/s) of the launches `names` in a prof table over `seconds`."""
@@ -571,10 +573,14 @@ def main():
                 executed_tflop_per_step=round(step_exe * elapsed / args.steps, 3),
                 note="sum over every convolution / linear launch of one step (forward, backward-data, weight gradient) "
                      "/ ms_per_step")
-        wms = prof_all.get("igemm_wgrad", (0.0, 0, 0.0))[0] + prof_all.get("wino_wgrad", (0.0, 0, 0.0))[0]
+        wnames = ("igemm_wgrad", "wino_wgrad", "wino4_wgrad")
+        wms = sum(prof_all.get(k, (0.0, 0, 0.0))[0] for k in wnames)
         if wms > 0:
-            walg, wexe = mfma_rates(prof_all, ("igemm_wgrad", "wino_wgrad"), wms * 1e-3)
-            out["roofline_wgrad"] = roof(walg, wexe, kernels="k_wino_wgrad (F(3x3,2x2)) + k_igemm_wgrad")
+            walg, wexe = mfma_rates(prof_all, wnames, wms * 1e-3)
+            out["roofline_wgrad"] = roof(walg, wexe, kernels="k_wino4_wgrad (F(3x3,4x4)) + k_wino_wgrad (F(3x3,2x2)) + k_igemm_wgrad",
+                                         ms_per_step=round(wms / prof_all_steps, 3),
+                                         winograd_ms_per_step=round(sum(prof_all.get(k, (0.0, 0, 0.0))[0] for k in
+                                                                        ("wino_wgrad", "wino4_wgrad")) / prof_all_steps, 3))
         dms = sum(prof_all.get(k, (0.0, 0, 0.0))[0] for k in ("igemm_fwd", "igemm_fwd64", "igemm_wgrad"))
         if dms > 0:
             dalg, dexe = mfma_rates(prof_all, ("igemm_fwd", "igemm_fwd64", "igemm_wgrad"), dms * 1e-3)

@@ -59,6 +59,7 @@ struct Wino4WgParams {
   int RXn, RYn, nregions;        // 8 x 8-pixel stage regions per row / column of an image, in all
   int cblocks, kblocks;          // 64-channel blocks of cout / cin
   int nsplit, rps;               // slices of the regions, regions per slice
+  int dbg;                       // developer ablations (CSG_WW_DBG bit mask): 1 no MFMAs, 2 no transform, 4 no DMA in the loop, 8 no stagger
 };
 
 __device__ __forceinline__ int ww_xcd_remap(int bid, int nblk) {
@@ -118,7 +119,9 @@ __device__ __forceinline__ void ww_g_all(const float (&d)[4], float (&o)[6]) {
 
 typedef __attribute__((address_space(3))) void* ww_lds_ptr;
 
-template <int PH>
+// PH: the block's half of the positions; ISV: the wave's transform role (a template parameter: each role gets its own loop
+// and its own register allocation — under a runtime branch the two roles' live ranges were merged and spilled)
+template <int PH, bool ISV, bool STAG>
 __device__ __forceinline__ void ww_body(const Wino4WgParams& p, const float* __restrict__ x, const float* __restrict__ dy,
                                         float* __restrict__ slabs, float* __restrict__ dbslabs, float* smem, int cb, int kb,
                                         int sp) {
@@ -135,7 +138,7 @@ __device__ __forceinline__ void ww_body(const Wino4WgParams& p, const float* __r
   const __amdgpu_buffer_rsrc_t rsY =
       __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long long)p.B * p.H * p.W * p.y_cs * 4), 0x00020000);
   unsigned xoff[4], yoff[2];
-  int xflag[4];                                  // halo flags: 1 first row, 2 last row, 4 first column, 8 last column
+  int xflags = 0;                                // halo flags, 4 bits per round: 1 first row, 2 last row, 4 first column, 8 last column
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int e = (wave + 8 * i) * 64 + lane;
@@ -143,7 +146,7 @@ __device__ __forceinline__ void ww_body(const Wino4WgParams& p, const float* __r
     const int row = pix / 10, col = pix - row * 10;
     const int ch = kb * 64 + c4 * 4;
     xoff[i] = (pix < 100 && ch < p.Cin) ? (unsigned)((row * p.W + col) * p.x_cs + ch) * 4u : CSG_OOB_OFF;
-    xflag[i] = (row == 0 ? 1 : 0) | (row == 9 ? 2 : 0) | (col == 0 ? 4 : 0) | (col == 9 ? 8 : 0);
+    xflags |= ((row == 0 ? 1 : 0) | (row == 9 ? 2 : 0) | (col == 0 ? 4 : 0) | (col == 9 ? 8 : 0)) << (4 * i);
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -153,31 +156,47 @@ __device__ __forceinline__ void ww_body(const Wino4WgParams& p, const float* __r
     const int ch = cb * 64 + c4 * 4;
     yoff[i] = ch < p.Cout ? (unsigned)((row * p.W + col) * p.y_cs + ch) * 4u : CSG_OOB_OFF;
   }
-  auto dma_stage = [&](int s, int bufsel) {      // stage s of this block -> raw buffer bufsel; past the end: not consumed
-    const int rr = min(r0 + s, p.nregions - 1);
-    const int rx = rr % p.RXn, t = rr / p.RXn;
-    const int ry = t % p.RYn, img = t / p.RYn;
-    const int y0 = ry * 8, x0 = rx * 8;
+  // region of the next stage to fetch, walked incrementally (no divisions in the loop): (rx, ry, img) of region r0 + dma_s
+  int dma_s = 0, dma_rx, dma_ry, dma_img;
+  {
+    const int rr = min(r0, p.nregions - 1);
+    dma_rx = rr % p.RXn;
+    const int t = rr / p.RXn;
+    dma_ry = t % p.RYn;
+    dma_img = t / p.RYn;
+  }
+  auto dma_stage = [&](int bufsel) {             // the next stage of this block -> raw buffer bufsel; past the end: the last
+    const int y0 = dma_ry * 8, x0 = dma_rx * 8;  // region again (never consumed)
     const int edge = (y0 == 0 ? 1 : 0) | (y0 + 8 == p.H ? 2 : 0) | (x0 == 0 ? 4 : 0) | (x0 + 8 == p.W ? 8 : 0);
-    const int pix0 = (img * p.H + y0) * p.W + x0;
+    const int pix0 = (dma_img * p.H + y0) * p.W + x0;
     float* bx = smem + WW_X0 + bufsel * WW_XW + wave * 256;
     float* by = smem + WW_Y0 + bufsel * WW_YW + wave * 256;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ww_lds_ptr)(bx + i * 2048), 16,
-                                               (int)((xflag[i] & edge) ? CSG_OOB_OFF : xoff[i]), pix0 * p.x_cs * 4, 0, 0);
+                                               (int)(((xflags >> (4 * i)) & edge) ? CSG_OOB_OFF : xoff[i]), pix0 * p.x_cs * 4, 0, 0);
     if (wave == 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ww_lds_ptr)(bx + 3 * 2048), 16,
-                                               (int)((xflag[3] & edge) ? CSG_OOB_OFF : xoff[3]), pix0 * p.x_cs * 4, 0, 0);
+                                               (int)(((xflags >> 12) & edge) ? CSG_OOB_OFF : xoff[3]), pix0 * p.x_cs * 4, 0, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (ww_lds_ptr)(by + i * 2048), 16, (int)yoff[i], pix0 * p.y_cs * 4, 0, 0);
+    if (r0 + dma_s + 1 < p.nregions) {           // advance (the last region of the tensor repeats)
+      ++dma_s;
+      if (++dma_rx == p.RXn) {
+        dma_rx = 0;
+        if (++dma_ry == p.RYn) {
+          dma_ry = 0;
+          ++dma_img;
+        }
+      }
+    }
   };
 
   // ---- roles.  Transform: waves 0-3 form V for (cin group, tile pair) = (wave & 1, wave >> 1), waves 4-7 form E' for
   // (cout group, tile pair) likewise; lane = (channel c of the group, tile h of the pair).  MFMA: wave w owns the channel
   // groups (mt, nt) = ((w >> 1) & 1, w & 1) at the local positions pl = 2 k + (w >> 2), k = 0..8.
-  const bool is_v = wave < 4;
+  constexpr bool is_v = ISV;
   const int grp = wave & 1, pr = (wave >> 1) & 1;
   const int mt = (wave >> 1) & 1, nt = wave & 1, plo = wave >> 2;
   // raw words of this lane's tile: X patch rows 4 pr + i, columns 4 h + j; dY rows 4 pr + i, columns 4 h + j
@@ -198,17 +217,36 @@ __device__ __forceinline__ void ww_body(const Wino4WgParams& p, const float* __r
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
 
-  // transform of one stage: raw buffer rb -> operand buffer ob (three rows xi of this block's half)
-  auto transform = [&](int rb, int ob, bool live) {      // live: the stage exists (the bias sum must not count a clamped one)
-    float* dst = opw + ob * (2 * WW_OPH);
+  // ---- one stage in four phases, kept apart by scheduling barriers so that no LDS latency sits in front of an MFMA or a
+  // transform instruction: (1) the raw reads of the transform of stage s + 1 and the operand reads of the MFMAs of stage s are
+  // issued together, (2) the 18 MFMAs run as soon as the operands are in, (3) the transform (its inputs arrived long ago) and
+  // its operand stores, (4) the barrier.
+  float raw[36];                                 // V role: the 6 x 6 patch [i][j]; E' role: the 4 x 4 dY tile [i][j] in raw[0..15]
+  auto load_raw = [&](int rb) {
     if (is_v) {
       const float* src = rawx + rb * WW_XW;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) raw[i * 6 + j] = src[(i * 10 + j) * 64];
+    } else {
+      const float* src = rawy + rb * WW_YW;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[i * 4 + j] = src[(i * 8 + j) * 64];
+    }
+  };
+  // three rows xi of this block's half, into operand buffer ob; live: the stage exists (the bias sum must not count a
+  // clamped one)
+  auto transform = [&](int ob, bool live) {
+    float* dst = opw + ob * (2 * WW_OPH);
+    if (is_v) {
       float t[3][6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        float d[6], o[3];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) d[i] = src[(i * 10 + j) * 64];
+        const float d[6] = {raw[j], raw[6 + j], raw[12 + j], raw[18 + j], raw[24 + j], raw[30 + j]};
+        float o[3];
         ww_bt_rows<PH>(d, o);
 #pragma unroll
         for (int r = 0; r < 3; ++r) t[r][j] = o[r];
@@ -221,13 +259,11 @@ __device__ __forceinline__ void ww_body(const Wino4WgParams& p, const float* __r
         for (int nu = 0; nu < 6; ++nu) dst[(r * 6 + nu) * 256] = v[nu];
       }
     } else {
-      const float* src = rawy + rb * WW_YW;
       float t[3][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float d[4], o[3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] = src[(i * 8 + j) * 64];
+        const float d[4] = {raw[j], raw[4 + j], raw[8 + j], raw[12 + j]};
+        float o[3];
         ww_g_rows<PH>(d, o);
 #pragma unroll
         for (int r = 0; r < 3; ++r) t[r][j] = o[r];
@@ -242,30 +278,67 @@ __device__ __forceinline__ void ww_body(const Wino4WgParams& p, const float* __r
       }
     }
   };
-  // the 18 MFMAs of one stage out of operand buffer ob
+  // the 18 MFMAs of a stage out of operand buffer ob, the operands of position k + 2 fetched while position k multiplies
+  // (a ring of three register pairs per operand: the whole set up front would not fit 256 registers beside the raw patch).
+  // The first two positions are fetched BEFORE the raw reads of the transform (LDS answers in order: the first MFMA then waits
+  // for its own operands only, not for the 16 - 36 raw words behind them).
+  csg_f32x2 er[3], vr[3];
+  auto ops_prefill = [&](int ob) {
+    const float* pe = ope + ob * (2 * WW_OPH);
+    const float* pv = opv + ob * (2 * WW_OPH);
+    er[0] = *(const csg_f32x2*)(pe);
+    vr[0] = *(const csg_f32x2*)(pv);
+    er[1] = *(const csg_f32x2*)(pe + 512);
+    vr[1] = *(const csg_f32x2*)(pv + 512);
+  };
   auto mfmas = [&](int ob) {
+    const float* pe = ope + ob * (2 * WW_OPH);
+    const float* pv = opv + ob * (2 * WW_OPH);
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const csg_f32x2 e = *(const csg_f32x2*)(ope + ob * (2 * WW_OPH) + k * 512);
-      const csg_f32x2 v = *(const csg_f32x2*)(opv + ob * (2 * WW_OPH) + k * 512);
-      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(e.x, v.x, acc[k], 0, 0, 0);
-      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(e.y, v.y, acc[k], 0, 0, 0);
+      if (k + 2 < 9) {
+        er[(k + 2) % 3] = *(const csg_f32x2*)(pe + (k + 2) * 512);
+        vr[(k + 2) % 3] = *(const csg_f32x2*)(pv + (k + 2) * 512);
+      }
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(er[k % 3].x, vr[k % 3].x, acc[k], 0, 0, 0);
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(er[k % 3].y, vr[k % 3].y, acc[k], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two reads of position k + 2 ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // ... then the two MFMAs of position k
     }
   };
 
   if (nst > 0) {
-    dma_stage(0, 0);
-    dma_stage(1, 1);
+    dma_stage(0);
+    dma_stage(1);
     __syncthreads();                             // (its fence waits for this wave's DMAs: vmcnt(0))
-    transform(0, 0, true);
+    load_raw(0);
+    transform(0, true);
     __syncthreads();
     // stage s: DMA of stage s + 2 into the raw buffer stage s left; transform of stage s + 1; MFMAs of stage s
     auto stage = [&](int s, auto par_tag) {
       constexpr int par = decltype(par_tag)::value;
-      dma_stage(s + 2, par);
+      if (!(p.dbg & 4)) dma_stage(par);
+      if (ISV || !STAG) {
+        if (!(p.dbg & 1)) ops_prefill(par);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 2)) load_raw(par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 1)) mfmas(par);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 2)) transform(par ^ 1, s + 1 < nst);
+      } else {
+        // the E' waves run the two halves of a stage in the OTHER order (a stagger: MI355X_MICROARCH.md, two waves per SIMD,
+        // item 9): the partners on a SIMD — wave w and w + 4 — are then never both waiting for their raw reads or both
+        // storing operands; one of them has matrix work while the other transforms
+        if (!(p.dbg & 2)) load_raw(par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 2)) transform(par ^ 1, s + 1 < nst);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 1)) ops_prefill(par);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 1)) mfmas(par);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      transform(par ^ 1, par ^ 1, s + 1 < nst);
-      mfmas(par);
       __syncthreads();
     };
     int s = 0;
@@ -350,6 +423,7 @@ __device__ __forceinline__ void ww_body(const Wino4WgParams& p, const float* __r
   }
 }
 
+template <bool STAG>
 __global__ __launch_bounds__(WW_THREADS, 2) void k_wino4_wgrad(Wino4WgParams p, const float* __restrict__ x,
                                                                const float* __restrict__ dy, float* __restrict__ slabs,
                                                                float* __restrict__ dbslabs) {
@@ -363,10 +437,18 @@ __global__ __launch_bounds__(WW_THREADS, 2) void k_wino4_wgrad(Wino4WgParams p, 
   bid /= p.kblocks;
   const int cb = bid % p.cblocks;
   const int sp = bid / p.cblocks;
-  if (ph == 0)
-    ww_body<0>(p, x, dy, slabs, dbslabs, smem, cb, kb, sp);
-  else
-    ww_body<1>(p, x, dy, slabs, dbslabs, smem, cb, kb, sp);
+  const bool is_v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4;
+  if (ph == 0) {
+    if (is_v)
+      ww_body<0, true, STAG>(p, x, dy, slabs, dbslabs, smem, cb, kb, sp);
+    else
+      ww_body<0, false, STAG>(p, x, dy, slabs, dbslabs, smem, cb, kb, sp);
+  } else {
+    if (is_v)
+      ww_body<1, true, STAG>(p, x, dy, slabs, dbslabs, smem, cb, kb, sp);
+    else
+      ww_body<1, false, STAG>(p, x, dy, slabs, dbslabs, smem, cb, kb, sp);
+  }
 }
 
 static int ww_plan(const csg_wino_desc* d, Wino4WgParams& p, const char* who) {
@@ -397,6 +479,7 @@ static int ww_plan(const csg_wino_desc* d, Wino4WgParams& p, const char* who) {
   if (ns < 1) ns = 1;
   p.rps = (int)((nr + ns - 1) / ns);
   p.nsplit = (int)((nr + p.rps - 1) / p.rps);
+  p.dbg = getenv("CSG_WW_DBG") ? atoi(getenv("CSG_WW_DBG")) : 0;      // (read per call: tools/wgrad_ablate.py flips it)
   return CSG_OK;
 }
 
@@ -424,8 +507,10 @@ int csg_wino4_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy
   const size_t ep_bytes = (size_t)2 * 18 * 32 * WW_EXR * 4;
   const size_t shm = (size_t)WW_LDS_FLOATS * 4 > ep_bytes ? (size_t)WW_LDS_FLOATS * 4 : ep_bytes;
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wino4_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino4_bwd_weight: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    for (const void* fn : {(const void*)k_wino4_wgrad<true>, (const void*)k_wino4_wgrad<false>}) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino4_bwd_weight: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }
     attr_set[dev] = true;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -433,7 +518,10 @@ int csg_wino4_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy
   {
     ProfScope ps(K_WINO4_WGRAD, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
     const dim3 grid((unsigned)(p.cblocks * p.kblocks * 2 * p.nsplit));
-    CSG_LAUNCH(k_wino4_wgrad, grid, dim3(WW_THREADS), shm, s, p, x, dy, workspace, dbslabs);
+    if (p.dbg & 8)
+      CSG_LAUNCH(k_wino4_wgrad<false>, grid, dim3(WW_THREADS), shm, s, p, x, dy, workspace, dbslabs);
+    else
+      CSG_LAUNCH(k_wino4_wgrad<true>, grid, dim3(WW_THREADS), shm, s, p, x, dy, workspace, dbslabs);
     rc = check_launch("csg_wino4_bwd_weight");
     if (rc) return rc;
   }
