@@ -59,7 +59,7 @@ struct Wino4WgParams {
   int RXn, RYn, nregions;        // 8 x 8-pixel stage regions per row / column of an image, in all
   int cblocks, kblocks;          // 64-channel blocks of cout / cin
   int nsplit, rps;               // slices of the regions, regions per slice
-  int dbg;                       // developer ablations (CSG_WW_DBG bit mask): 1 no MFMAs, 2 no transform, 4 no DMA in the loop, 8 no stagger
+  int dbg;                       // developer ablations (CSG_WW_DBG bit mask): 1 no MFMAs, 2 no transform, 4 no DMA in the loop, 8 staggered E' waves
 };
 
 __device__ __forceinline__ int ww_xcd_remap(int bid, int nblk) {
@@ -171,13 +171,21 @@ __device__ __forceinline__ void ww_body(const Wino4WgParams& p, const float* __r
     const int pix0 = (dma_img * p.H + y0) * p.W + x0;
     float* bx = smem + WW_X0 + bufsel * WW_XW + wave * 256;
     float* by = smem + WW_Y0 + bufsel * WW_YW + wave * 256;
+    if (edge == 0) {                             // interior region (most of a large map): no halo lane to mask, no VALU at all
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ww_lds_ptr)(bx + i * 2048), 16,
-                                               (int)(((xflags >> (4 * i)) & edge) ? CSG_OOB_OFF : xoff[i]), pix0 * p.x_cs * 4, 0, 0);
-    if (wave == 0)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ww_lds_ptr)(bx + 3 * 2048), 16,
-                                               (int)(((xflags >> 12) & edge) ? CSG_OOB_OFF : xoff[3]), pix0 * p.x_cs * 4, 0, 0);
+      for (int i = 0; i < 3; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ww_lds_ptr)(bx + i * 2048), 16, (int)xoff[i], pix0 * p.x_cs * 4, 0, 0);
+      if (wave == 0)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ww_lds_ptr)(bx + 3 * 2048), 16, (int)xoff[3], pix0 * p.x_cs * 4, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ww_lds_ptr)(bx + i * 2048), 16,
+                                                 (int)(((xflags >> (4 * i)) & edge) ? CSG_OOB_OFF : xoff[i]), pix0 * p.x_cs * 4, 0, 0);
+      if (wave == 0)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ww_lds_ptr)(bx + 3 * 2048), 16,
+                                                 (int)(((xflags >> 12) & edge) ? CSG_OOB_OFF : xoff[3]), pix0 * p.x_cs * 4, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (ww_lds_ptr)(by + i * 2048), 16, (int)yoff[i], pix0 * p.y_cs * 4, 0, 0);
@@ -327,9 +335,10 @@ __device__ __forceinline__ void ww_body(const Wino4WgParams& p, const float* __r
         __builtin_amdgcn_sched_barrier(0);
         if (!(p.dbg & 2)) transform(par ^ 1, s + 1 < nst);
       } else {
-        // the E' waves run the two halves of a stage in the OTHER order (a stagger: MI355X_MICROARCH.md, two waves per SIMD,
-        // item 9): the partners on a SIMD — wave w and w + 4 — are then never both waiting for their raw reads or both
-        // storing operands; one of them has matrix work while the other transforms
+        // STAG: the E' waves run the two halves of a stage in the OTHER order (a stagger: MI355X_MICROARCH.md, two waves per
+        // SIMD, item 9), so that one partner of a SIMD has matrix work while the other transforms.  Measured equal to the
+        // plain order (0.912 vs 0.901 ms, same box): MFMA-only + transform-only = everything either way — on this chip the
+        // fp32 MFMA and the VALU of a SIMD share their lanes.  Off by default.
         if (!(p.dbg & 2)) load_raw(par ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         if (!(p.dbg & 2)) transform(par ^ 1, s + 1 < nst);
@@ -518,10 +527,10 @@ int csg_wino4_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy
   {
     ProfScope ps(K_WINO4_WGRAD, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, s);
     const dim3 grid((unsigned)(p.cblocks * p.kblocks * 2 * p.nsplit));
-    if (p.dbg & 8)
-      CSG_LAUNCH(k_wino4_wgrad<false>, grid, dim3(WW_THREADS), shm, s, p, x, dy, workspace, dbslabs);
-    else
+    if (p.dbg & 8)                               // the staggered form (measured equal: DESIGN.md 8) stays selectable
       CSG_LAUNCH(k_wino4_wgrad<true>, grid, dim3(WW_THREADS), shm, s, p, x, dy, workspace, dbslabs);
+    else
+      CSG_LAUNCH(k_wino4_wgrad<false>, grid, dim3(WW_THREADS), shm, s, p, x, dy, workspace, dbslabs);
     rc = check_launch("csg_wino4_bwd_weight");
     if (rc) return rc;
   }

@@ -40,7 +40,7 @@ def bench(n=10):
 mfma_ms = flop * 0.25 / 157.3e12 * 1e3
 print("B%d %d->%d %dx%d: MFMA bound at 2.4 GHz %.3f ms" % (B, Cin, Cout, H, H, mfma_ms))
 for dbg, name in ((0, "everything"), (1, "no MFMAs"), (2, "no transform"), (4, "no DMA"), (3, "no MFMAs, no transform (DMA + barriers)"),
-                  (6, "MFMAs + operand reads only"), (5, "transform only"), (7, "barriers only"), (8, "everything, no stagger"), (0, "everything (again)"), (8, "everything, no stagger (again)")):
+                  (6, "MFMAs + operand reads only"), (5, "transform only"), (7, "barriers only"), (8, "everything, staggered"), (0, "everything (again)"), (8, "everything, staggered (again)")):
     os.environ["CSG_WW_DBG"] = str(dbg)
     print("  %-44s %.3f ms" % (name, bench()), flush=True)
 os.environ["CSG_WW_DBG"] = "0"
