@@ -37,6 +37,21 @@ def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
+def active():
+    """True when the data-parallel exchanges run: several ranks — or ONE rank with CSG_DIST_FORCE=1 and an initialised
+    process group (bring-up and tests on a 1-GPU box: every collective is issued, on RCCL when the backend is nccl, and is the
+    identity; the N-replica SyncBN formula is used)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("CSG_DIST_FORCE") == "1"
+
+
+def capturable():
+    """Whether the collectives may be issued inside a HIP-graph capture: RCCL's are (ProcessGroupNCCL records them on its
+    own stream, joined to the capturing stream); gloo's go through the host."""
+    return active() and dist.get_backend() == "nccl"
+
+
 # ---- communication audit (bench.py's "comm" object, tests): what was exchanged since the last comm_reset()
 _COMM = {"grad_allreduce_calls": 0, "grad_allreduce_bytes": 0, "syncbn_allreduce_calls": 0, "syncbn_allreduce_bytes": 0,
          "allgather_calls": 0, "allgather_bytes": 0, "grad_copy_bytes": 0, "wait_events": []}
@@ -60,7 +75,7 @@ def comm_note(kind, nbytes):
 def comm_report(steps=1):
     """Per-step averages of the counters since comm_reset(); `blocked_ms` is the HIP-event time the compute stream spent
     inside GradBuckets.finish() waiting for its collectives (the exposed, non-overlapped part of the gradient exchange)."""
-    out = {"world_size": world_size(), "backend": dist.get_backend() if world_size() > 1 else None}
+    out = {"world_size": world_size(), "backend": dist.get_backend() if active() else None}
     for k, v in _COMM.items():
         if k != "wait_events":
             out[k + "_per_step"] = v / max(steps, 1)
@@ -78,7 +93,7 @@ def all_reduce_stats(sums):
     """SyncBN exchange (reference sync_batchnorm/batchnorm.py:74-83,105-126): every replica
     contributes its per-channel (sum, sum^2) — one fp64 tensor of 2C values per norm — and gets the
     total back.  One all-reduce replaces the reference's ReduceAddCoalesced + Broadcast pair."""
-    if world_size() > 1:
+    if active():
         dist.all_reduce(sums)
         comm_note("syncbn_allreduce", sums.numel() * sums.element_size())
     return sums
@@ -89,7 +104,7 @@ def all_reduce_stats_async(sums):
     total (None on a single rank) — the caller enqueues work that does not need the statistics in between (the gamma half of
     the SPADE convolution in forward, the gamma || beta convolution's backward passes in backward), so the latency of the
     2C-value message hides under a convolution instead of stalling the compute stream."""
-    if world_size() > 1:
+    if active():
         work = dist.all_reduce(sums, async_op=True)
         comm_note("syncbn_allreduce", sums.numel() * sums.element_size())
         return work
@@ -141,6 +156,7 @@ class GradBuckets:
         self.allocations = 0                                    # flat buffers ever allocated (tests: steady state adds none)
         self.rebuilds = 0
         self.late_dropped = 0                                   # late gradients dropped (one step each) before a rebuild
+        self._launch_in_hooks = True
         self._flag = self._flag_host = self._flag_event = None  # the "late gradient seen" float riding in the last bucket
         self._flag_pending = False
         self._late_ids = set()                                  # parameters whose late gradient this rank dropped
@@ -280,7 +296,8 @@ class GradBuckets:
         if id(p) not in self._fired:
             self._fired.add(id(p))
             self._pending[b] -= 1
-        self._launch_ready()
+        if self._launch_in_hooks:
+            self._launch_ready()
 
     def _arm(self):
         self._pending = [len(g) for g in self.members]
@@ -292,16 +309,33 @@ class GradBuckets:
             ops.set_grad_destinations(self._dests)
 
     # ---- per-backward protocol
-    def begin(self):
-        """Call right before `backward()` (after zero_grad): arms the hooks for this backward."""
-        if world_size() == 1 or not self.built:
+    def begin(self, launch=True):
+        """Call right before `backward()` (after zero_grad): arms the hooks for this backward.  `launch=False`: the hooks
+        only move gradients into their slots and launch nothing — the form a HIP-graph capture records (graphs.py): the
+        copies become graph nodes, a replay reports its members with assume_fired(), and flush() issues every collective
+        eagerly after the replay."""
+        if not active() or not self.built:
             return
         self._resolve_flag()
         self._arm()
+        self._launch_in_hooks = launch
+
+    def assume_fired(self, ids):
+        """A HIP-graph REPLAY ran part of this backward: no hook fired, but the captured producers and copies filled the slots
+        of the members `ids` (the set fired_ids() returned after the capturing iteration) — they count as fired."""
+        if not active() or self._state != "armed":
+            return
+        for pid in ids:
+            if pid in self.slot and pid not in self._fired:
+                self._fired.add(pid)
+                self._pending[self.slot[pid][0]] -= 1
+
+    def fired_ids(self):
+        return set(self._fired)
 
     def flush(self):
         """After `backward()`: launch whatever has not been launched yet; the collectives keep running."""
-        if world_size() == 1 or self._state == "flushed":
+        if not active() or self._state == "flushed":
             return
         if not self.built or self._state == "idle":
             # first synchronisation, or the one-shot form (begin() was not called for this backward, so the hooks did
@@ -334,7 +368,7 @@ class GradBuckets:
     def finish(self):
         """Wait for the collectives; gradients are then the mean over ranks — on EVERY member, also those this rank's
         backward left without a gradient.  Returns the bytes exchanged."""
-        if world_size() == 1:
+        if not active():
             return 0
         self.flush()
         timed = _AUDIT[0] and bool(self.flats) and self.flats[0].is_cuda
@@ -363,6 +397,7 @@ class GradBuckets:
                     p.grad = self.slot[id(p)][1]
         self._works = []
         self._state = "idle"
+        self._launch_in_hooks = True
         if self.flats and self.flats[0].is_cuda:
             from . import ops
             ops.clear_grad_destinations()
@@ -371,7 +406,7 @@ class GradBuckets:
     def rebuild(self):
         """COLLECTIVE: re-agree the live set (every rank must call it at the same point, between two steps) — after
         flush() reported a parameter outside the set, or when a branch is switched on.  Gradients currently held are kept."""
-        if world_size() == 1:
+        if not active():
             return
         held = {id(p): p.grad.clone() for p in self.params if p.grad is not None}
         self._build()
@@ -399,7 +434,7 @@ def _avg_op():
 
 def broadcast_module(module, src=0):
     """Make every replica start from rank `src`'s parameters and buffers."""
-    if world_size() == 1:
+    if not active():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)

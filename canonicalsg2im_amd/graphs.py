@@ -32,11 +32,22 @@ second time it is seen: one-off shapes never pay for a capture; the very first i
 optimisers' state, which a capture must find in place); `CSG_GRAPHS=0` turns the whole mechanism off.  Replay is
 limited to one process per node-local GPU without an initialised process group: with N > 1 ranks the SyncBN and gradient
 collectives would have to be captured by RCCL, which cannot be validated on the 1-GPU boxes — there the eager path runs.
+
+Round 5: N > 1 ranks replay too (backend nccl; `CSG_GRAPHS_DIST=0` keeps them eager).  The SyncBN statistics messages are
+captured where they are issued, inside S1-S3 (ProcessGroupNCCL records a collective on its own stream and joins it to the
+capturing one).  The GRADIENT exchange stays outside the graphs: a capture runs under `GradBuckets.begin(launch=False)` — the
+post-accumulate hooks only move gradients into their bucket slots, which the capture records as copies (most weight gradients
+are written into their slots by their producers, `ops.set_grad_destinations`) — every replay reports the members it filled
+(`assume_fired`), `flush()` issues all the buckets' all-reduces eagerly right after S2 (they travel under S3 and the object
+discriminator's update) and after S3, and the Adam steps follow `finish()` outside the graphs.  Exercised on a 1-GPU box by a
+one-rank nccl group under `CSG_DIST_FORCE=1` (every collective is issued on RCCL and is the identity; the N-replica SyncBN
+formula runs): tests/test_gpu_graphs.py::test_one_rank_nccl_group_replays_with_collectives_captured.
 """
 import os
 
 import torch
 
+from . import dist as csg_dist
 from . import ops
 
 ENABLED = os.environ.get("CSG_GRAPHS", "1") != "0"
@@ -81,6 +92,26 @@ class _Marks:
     def report(self):
         n = max(self.steps, 1)
         return {k: {"host_ms": round(v[0] / n, 3), "device_ms": round(v[1] / n, 3)} for k, v in self.acc.items()}
+
+
+def _capture_mode():
+    """"thread_local": another host thread's HIP calls (a pinned-memory loader, an async checkpoint writer, a logger's .cpu())
+    do not break a capture.  With a process group up the capture is "global": the backward's collectives are issued from the
+    autograd engine's thread and ProcessGroupNCCL decides by the stream's capture status whether its watchdog may query a
+    collective's events — under the thread-local mode that status read as 'not capturing' there and the watchdog died on a
+    captured event (hipErrorCapturedEvent; measured on ROCm 7.2 / torch 2.10)."""
+    return os.environ.get("CSG_GRAPH_CAPTURE_MODE") or ("global" if csg_dist.active() else "thread_local")
+
+
+def _quiesce_before_capture():
+    """Drain the device — and, with a process group up, let ProcessGroupNCCL's watchdog finish with the collectives issued so
+    far: it polls the end events of pending works every ~100 ms from its own thread, and a poll that lands inside a capture
+    killed the process half of the time (hipErrorCapturedEvent from WorkNCCL::isCompleted, ROCm 7.2 / torch 2.10,
+    tools/probe/nccl_graph_step_probe.py).  A capture happens once per shape key and encoder bucket."""
+    torch.cuda.synchronize()
+    if csg_dist.active():
+        import time
+        time.sleep(float(os.environ.get("CSG_GRAPH_DRAIN_S", "0.35")))
 
 
 def _pad_objects(n):
@@ -131,6 +162,7 @@ class _SgGraph:
         self.grads = {}
         self.boxes_pred = self.vals = self.bbox_all = None
         self.last_used = 0
+        self.fired = set()
 
     def load(self, triplets, triplet_type):
         T = triplets.shape[1]
@@ -146,11 +178,12 @@ class _SgGraph:
         gs = self.gs
         if self.graph is None:
             g = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
+            _quiesce_before_capture()
             ops.invalidate_weight_caches()
             _drop_stale_autograd(tr.model)
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):    # (another host thread's HIP calls — a pinned-memory
-                for p in tr.sg_params:                                       #  loader, an async checkpoint — do not break the capture)
+            before = tr.g_buckets.fired_ids()
+            with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
+                for p in tr.sg_params:
                     p.grad = None
                 self.boxes_pred = tr.model.sg_to_layout(gs.objs, self.triplets, self.ttype, gs.boxes)[1]
                 out = {}
@@ -161,6 +194,9 @@ class _SgGraph:
                 self.boxes_pred = self.boxes_pred.detach()
             self.graph = g
             self.grads = {p: p.grad for p in tr.sg_params if p.grad is not None}
+            self.fired = tr.g_buckets.fired_ids() - before          # (N > 1) the members this graph's copies fill
+        else:
+            tr.g_buckets.assume_fired(self.fired)
         self.graph.replay()
         for p, gr in self.grads.items():             # (another bucket's buffers, or an eager step's tensors, may be in place)
             p.grad = gr
@@ -184,6 +220,7 @@ class _GraphSet:
         self.g_terms = self.d_terms = None
         self.sg = {}                     # padded triplet count -> _SgGraph
         self.sg_seen = {}
+        self.fired = {}                  # (N > 1) graph name -> ids of the bucket members its captured backward fills
 
     def load(self, imgs, objs, boxes):
         O = objs.shape[1]
@@ -200,10 +237,10 @@ class _GraphSet:
         g = self.graphs.get(name)
         if g is None:
             g = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
+            _quiesce_before_capture()
             ops.invalidate_weight_caches()              # every derived weight is recomputed INSIDE the graph that reads it
             _drop_stale_autograd(self.owner.tr.model, self.owner.tr.discriminator)
-            with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode=_capture_mode()):
                 fn()
             if self.pool is None:
                 self.pool = g.pool()
@@ -236,8 +273,10 @@ class StepGraphs:
     @staticmethod
     def supported(trainer):
         opt = trainer.opt
-        from . import dist as csg_dist
-        return bool(ENABLED and torch.device(trainer.device).type == "cuda" and csg_dist.world_size() == 1
+        # N > 1 ranks: replay needs collectives that can be captured (RCCL's: the SyncBN messages sit in the middle of S1-S3);
+        # CSG_GRAPHS_DIST=0 keeps the eager path there
+        dist_ok = not csg_dist.active() or (csg_dist.capturable() and os.environ.get("CSG_GRAPHS_DIST", "1") != "0")
+        return bool(ENABLED and torch.device(trainer.device).type == "cuda" and dist_ok
                     and not opt.skip_generation and not opt.learned_converse and not (opt.mask_size or 0) > 0
                     and not getattr(opt, "freeze", 0) and hasattr(trainer.model, "layout_to_image_model"))
 
@@ -337,6 +376,12 @@ class StepGraphs:
             self.active, tr._grads_dirty = gs, False
         if use_obj:
             tr.discriminator.obj_discriminator.prefetch_index(objs)
+        # N > 1 ranks (dist.py): the gradient exchange stays OUTSIDE the graphs — the hooks of this backward only move
+        # gradients into their bucket slots (captured as copies; a replay reports the members it filled), the all-reduces are
+        # issued eagerly right after S2 / S3 and travel under what follows; the SyncBN messages are captured inside S1-S3
+        dp = csg_dist.active()
+        if dp:
+            tr.g_buckets.begin(launch=False)
         gs.load(imgs, objs, boxes)
         if mk:
             mk.mark("load+prefetch")
@@ -379,9 +424,16 @@ class StepGraphs:
             torch.autograd.backward(roots, seeds)
             gs.g_roots = None
         first = "s2" not in gs.graphs
+        before = tr.g_buckets.fired_ids() if dp else None
         gs.run("s2", s2)
         if first:
             gs.adopt_grads(tr.g_params)
+            if dp:
+                gs.fired["s2"] = tr.g_buckets.fired_ids() - before
+        elif dp:
+            tr.g_buckets.assume_fired(gs.fired["s2"])
+        if dp:
+            tr.g_buckets.flush()                    # every bucket's all-reduce goes out now and travels under S3
         if mk:
             mk.mark("S2 replay")
         # ---- the generator's Adam step (eager: one fused launch over the encoder's eager and the generator's static grads)
@@ -391,7 +443,8 @@ class StepGraphs:
         if obj_vals is not None:
             G.update(obj_vals)
         G["total_loss"] = torch.stack([v for k, v in G.items() if k != "bbox_pred_all"]).sum()
-        tr.optimizer.step()
+        if not dp:
+            tr.optimizer.step()
         if mk:
             mk.mark("G Adam")
         # ---- S3: the image discriminator's update
@@ -406,11 +459,21 @@ class StepGraphs:
                 for p in tr.d_params:
                     p.grad = None
                 terms["total_img_loss"].backward()
-                tr.discriminator.optimizer_d_img.step()
+                if not dp:                          # (N > 1: Adam follows the exchange, outside the graph)
+                    tr.discriminator.optimizer_d_img.step()
         first = "s3" not in gs.graphs
+        if dp and not tr.d_frozen:
+            tr.d_buckets.begin(launch=False)
+            before = tr.d_buckets.fired_ids()
         gs.run("s3", s3)
         if first:
             gs.adopt_grads(tr.d_params)
+            if dp and not tr.d_frozen:
+                gs.fired["s3"] = tr.d_buckets.fired_ids() - before
+        elif dp and not tr.d_frozen:
+            tr.d_buckets.assume_fired(gs.fired["s3"])
+        if dp and not tr.d_frozen:
+            tr.d_buckets.flush()
         if mk:
             mk.mark("S3 replay")
         vals = gs.d_vals.clone()
@@ -421,10 +484,21 @@ class StepGraphs:
             terms = {k: v.mean() for k, v in terms.items()}
             if not tr.d_frozen:
                 tr.discriminator.optimizer_d_obj.zero_grad(set_to_none=True)
+                tr.dobj_buckets.begin()
                 terms["total_obj_loss"].backward()
-                tr.discriminator.optimizer_d_obj.step()
+                tr.dobj_buckets.flush()
             D.update({k: v.detach() for k, v in terms.items()})
+        if dp and not tr.d_frozen:
+            tr.d_buckets.finish()
+            tr.discriminator.optimizer_d_img.step()
+        if use_obj:
+            if not tr.d_frozen:
+                tr.dobj_buckets.finish()
+                tr.discriminator.optimizer_d_obj.step()
             tr.discriminator.obj_discriminator.release_index()
+        if dp:
+            tr.g_buckets.finish()
+            tr.optimizer.step()
         if mk:
             mk.mark("E3 object D step")
             mk.end()

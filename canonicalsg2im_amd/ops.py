@@ -135,10 +135,11 @@ FEW_ENABLED = os.environ.get("CSG_FEW_OUTPUT_KERNELS", "1") != "0"   # csrc/fewn
 WINO_MIN_PIXELS = int(os.environ.get("CSG_WINO_MIN_PIXELS", "1024"))     # B*H*W below which the direct kernel stays
 WINO_ENABLED = os.environ.get("CSG_WINOGRAD", "1") != "0"
 WINO_WGRAD = os.environ.get("CSG_WINOGRAD_WGRAD", "1") != "0"
-# F(3x3,4x4) weight gradient (csrc/wino4w.hip) where it pays: maps of at least WINO4_WGRAD_MIN_PIXELS pixels per image with H, W
-# multiples of 8 and at least 64 input and output channels (a block owns 64 x 64 channels); 0 turns it off
+# F(3x3,4x4) weight gradient (csrc/wino4w.hip) where it pays: H, W multiples of 8 (8 x 8 maps up: 1.17-1.40x over F(3x3,2x2) on
+# every generator shape at batch 4 and 16, tools/wgrad_bench.py) and at least 64 input and output channels (a block owns
+# 64 x 64 channels: the 32-channel mlp_shared layers stay on F(3x3,2x2)); CSG_WINO4_WGRAD=0 turns it off
 WINO4_WGRAD = os.environ.get("CSG_WINO4_WGRAD", "1") != "0"
-WINO4_WGRAD_MIN_PIXELS = int(os.environ.get("CSG_WINO4_WGRAD_MIN_PIXELS", "1024"))
+WINO4_WGRAD_MIN_PIXELS = int(os.environ.get("CSG_WINO4_WGRAD_MIN_PIXELS", "64"))
 
 # ---- plain GEMM kernels (csrc/gemm.hip) for the 1x1 convolutions / linears they are measured faster on
 GEMM_MODE = os.environ.get("CSG_GEMM", "auto")        # "auto": the measured rule below; "all": every shape the kernels fill the
@@ -802,6 +803,12 @@ def _sync_world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def _multi(world):
+    """Whether the N-replica SyncBN path runs (the statistics message and `clamp(var, eps)^-1/2`): several ranks, or one
+    rank under CSG_DIST_FORCE=1 (csg_dist.active(): RCCL bring-up on a 1-GPU box)."""
+    return world > 1 or csg_dist.active()
+
+
 class _NormAct(torch.autograd.Function):
     """BatchNorm (G=1) or InstanceNorm (G=B) statistics + optional SPADE modulation + LeakyReLU.
 
@@ -826,11 +833,11 @@ class _NormAct(torch.autograd.Function):
             part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float64)
             sums = torch.empty(G * 2 * C, device=dev, dtype=torch.float64)
             check(lib.csg_norm_stats(ptr(x), G, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-            if world > 1:
+            if _multi(world):
                 csg_dist.all_reduce_stats(sums)
             rm = running_mean if (training and not instance and running_mean is not None) else None
             rv = running_var if rm is not None else None
-            check(lib.csg_norm_finalize(ptr(sums), G, C, count, eps, 1 if world > 1 else 0, ptr(mean), ptr(invstd),
+            check(lib.csg_norm_finalize(ptr(sums), G, C, count, eps, 1 if _multi(world) else 0, ptr(mean), ptr(invstd),
                                         ptr(rm), ptr(rv), momentum, stream()), "norm_finalize")
         else:
             mean.copy_(running_mean)
@@ -860,7 +867,7 @@ class _NormAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if not use_batch_stats:
                 dsums.zero_()                       # eval mode: statistics are constants
-            elif world > 1:
+            elif _multi(world):
                 csg_dist.all_reduce_stats(dsums)
             dx = torch.empty_like(x)
             check(lib.csg_norm_apply_bwd_dx(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, ptr(dsums), count,
@@ -888,10 +895,10 @@ class _NormActPair(torch.autograd.Function):
         part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
         sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
         check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-        if world > 1:
+        if _multi(world):
             csg_dist.all_reduce_stats(sums)
         for rm, rv in ((rm0, rv0), (rm1, rv1)):           # same batch statistics, each module's own running buffers
-            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if world > 1 else 0, ptr(mean), ptr(invstd),
+            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if _multi(world) else 0, ptr(mean), ptr(invstd),
                                         ptr(rm), ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
         gb0, gb1 = nhwc(gb0), nhwc(gb1)
         y0, y1 = torch.empty_like(x), torch.empty_like(x)
@@ -918,7 +925,7 @@ class _NormActPair(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             both = dsums[0] + dsums[1]                    # the reductions are linear in dn: 4C doubles
-            if world > 1:
+            if _multi(world):
                 csg_dist.all_reduce_stats(both)
             dx = torch.empty_like(x)
             check(lib.csg_norm_apply_bwd_dx(ptr(dy0), ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, ptr(both), count,
@@ -968,7 +975,7 @@ class _SpadeFused(torch.autograd.Function):
         sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
         check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
         # N > 1: the statistics travel while the gamma halves (which do not need them) are computed
-        pending = csg_dist.all_reduce_stats_async(sums) if world > 1 else None
+        pending = csg_dist.all_reduce_stats_async(sums) if _multi(world) else None
         saved, outs, cfg, launches = [x, mean, invstd], [], [], []
         for k in range(K):
             actv, w, b, rm, rv, slope, in_slope = mods[k * 7:(k + 1) * 7]
@@ -989,7 +996,7 @@ class _SpadeFused(torch.autograd.Function):
             pending.wait()
         for k in range(K):
             rm, rv = mods[k * 7 + 3], mods[k * 7 + 4]
-            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if world > 1 else 0, ptr(mean), ptr(invstd), ptr(rm),
+            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if _multi(world) else 0, ptr(mean), ptr(invstd), ptr(rm),
                                         ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
         for (actv, w, up, bd, gbuf, nh, slope, in_slope) in launches:
             y = torch.empty_like(x)
@@ -1026,7 +1033,7 @@ class _SpadeFused(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             both = dsums[0] + dsums[1] if K == 2 else dsums[0]
             # N > 1: the reductions travel while the convolution's backward passes (which need only d(gamma || beta)) run
-            pending = csg_dist.all_reduce_stats_async(both) if world > 1 else None
+            pending = csg_dist.all_reduce_stats_async(both) if _multi(world) else None
         grads = [None, None, None, None]
         for k in range(K):
             actv, w, gbuf, y = sv[3 + 4 * k:7 + 4 * k]
@@ -1077,7 +1084,7 @@ class _SpadeJoined(torch.autograd.Function):
         part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
         sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
         check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-        pending = csg_dist.all_reduce_stats_async(sums) if world > 1 else None
+        pending = csg_dist.all_reduce_stats_async(sums) if _multi(world) else None
         # the joined convolution through _Conv2d's own forward on a stand-in context (its saved tensors are kept for the
         # backward below)
         fake = types.SimpleNamespace(needs_input_grad=(True, True, True, False))
@@ -1086,7 +1093,7 @@ class _SpadeJoined(torch.autograd.Function):
         gb = _Conv2d.forward(fake, actv, w, b, None, 1, int(pad), ACT_NONE, 0.0, None, None, in_act, False, None, None)
         if pending is not None:
             pending.wait()
-        check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if world > 1 else 0, ptr(mean), ptr(invstd),
+        check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if _multi(world) else 0, ptr(mean), ptr(invstd),
                                     ptr(running_mean), ptr(running_var if running_mean is not None else None), momentum,
                                     stream()), "norm_finalize")
         y = torch.empty_like(x)
@@ -1112,7 +1119,7 @@ class _SpadeJoined(torch.autograd.Function):
         dgb = torch.empty_like(gb)
         check(lib.csg_norm_apply_bwd_reduce(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), None, slope, 1, P, C, ptr(dgb),
                                             ptr(dsums), ptr(part), nch, 2 * C, stream()), "norm_bwd_reduce")
-        pending = csg_dist.all_reduce_stats_async(dsums) if (world > 1 and ctx.needs_input_grad[0]) else None
+        pending = csg_dist.all_reduce_stats_async(dsums) if (_multi(world) and ctx.needs_input_grad[0]) else None
         fake = ctx.conv
         fake.saved_tensors = (cx, cw, None)
         fake.needs_input_grad = (ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3], False)

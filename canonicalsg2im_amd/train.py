@@ -90,7 +90,7 @@ class Trainer:
         sampled for that sample (`conv_counts`).  The data loader reads the updated weights back on the host."""
         eps = float(torch.finfo(torch.float32).eps)                              # np.finfo(np.float32).eps (:345)
         r_all = r
-        if csg_dist.world_size() > 1:
+        if csg_dist.active():
             parts = [torch.empty_like(r) for _ in range(csg_dist.world_size())]
             torch.distributed.all_gather(parts, r.contiguous())
             csg_dist.comm_note("allgather", r.numel() * 4 * csg_dist.world_size())
@@ -138,7 +138,7 @@ class Trainer:
         # soon as the backward has filled it, and the tail keeps travelling while the discriminator losses below are
         # computed — they read neither the generator's parameters nor its gradients (imgs_pred is detached), so
         # applying the generator's Adam step after them changes nothing.
-        g_pending = csg_dist.world_size() > 1
+        g_pending = csg_dist.active()
         if g_pending:
             self.g_buckets.flush()
         else:

@@ -22,7 +22,8 @@ SHAPES = [(16, 128, 256, 256), (16, 128, 128, 256), (16, 128, 64, 256), (16, 64,
           (16, 128, 512, 128), (16, 128, 256, 128), (16, 256, 128, 128), (16, 128, 128, 128),
           (16, 128, 1024, 64), (16, 128, 512, 64), (16, 512, 256, 64), (16, 256, 256, 64),
           (16, 128, 2048, 32), (16, 128, 1024, 32), (16, 1024, 512, 32), (16, 512, 512, 32),
-          (4, 128, 256, 256), (4, 128, 512, 128), (4, 512, 256, 64)]
+          (4, 128, 256, 256), (4, 128, 512, 128), (4, 512, 256, 64),
+          (16, 1024, 1024, 16), (16, 128, 2048, 16), (16, 1024, 1024, 8), (4, 1024, 1024, 16), (4, 128, 2048, 32)]
 ONLY = [int(a) for a in sys.argv[1:] if a.isdigit()]
 if ONLY:
     SHAPES = [SHAPES[i] for i in ONLY]
