@@ -95,12 +95,36 @@ class _Marks:
 
 
 def _capture_mode():
-    """"thread_local": another host thread's HIP calls (a pinned-memory loader, an async checkpoint writer, a logger's .cpu())
-    do not break a capture.  With a process group up the capture is "global": the backward's collectives are issued from the
-    autograd engine's thread and ProcessGroupNCCL decides by the stream's capture status whether its watchdog may query a
-    collective's events — under the thread-local mode that status read as 'not capturing' there and the watchdog died on a
-    captured event (hipErrorCapturedEvent; measured on ROCm 7.2 / torch 2.10)."""
-    return os.environ.get("CSG_GRAPH_CAPTURE_MODE") or ("global" if csg_dist.active() else "thread_local")
+    """torch.cuda.graph's capture_error_mode.  "global" (torch's default) by default: under "thread_local" — which would let
+    another host thread's HIP calls (a pinned-memory loader, an async checkpoint writer) coexist with a capture — a garbage
+    collection that ran INSIDE a capture aborted the process on this stack (ROCm 7.2 / torch 2.10: `Fatal Python error: Aborted
+    ... Garbage-collecting` in the middle of S1, one run in three of tests/test_gpu_modules.py).  CSG_GRAPH_CAPTURE_MODE selects
+    it for integrations that need it; either way the collector is paused for the duration of a capture (`_Capture`)."""
+    return os.environ.get("CSG_GRAPH_CAPTURE_MODE", "global")
+
+
+class _Capture:
+    """`with _Capture(graph, pool): ...` = torch.cuda.graph(...) with Python's garbage collector paused: an object destroyed by
+    a collection in the middle of a capture (another trainer's CUDAGraph, a tensor of a foreign pool) issues HIP calls the
+    capture does not allow."""
+
+    def __init__(self, g, pool=None):
+        self.ctx = torch.cuda.graph(g, pool=pool, capture_error_mode=_capture_mode())
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was_enabled = gc.isenabled()
+        gc.disable()
+        return self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was_enabled:
+                gc.enable()
 
 
 def _quiesce_before_capture():
@@ -182,7 +206,7 @@ class _SgGraph:
             ops.invalidate_weight_caches()
             _drop_stale_autograd(tr.model)
             before = tr.g_buckets.fired_ids()
-            with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
+            with _Capture(g):
                 for p in tr.sg_params:
                     p.grad = None
                 self.boxes_pred = tr.model.sg_to_layout(gs.objs, self.triplets, self.ttype, gs.boxes)[1]
@@ -240,7 +264,7 @@ class _GraphSet:
             _quiesce_before_capture()
             ops.invalidate_weight_caches()              # every derived weight is recomputed INSIDE the graph that reads it
             _drop_stale_autograd(self.owner.tr.model, self.owner.tr.discriminator)
-            with torch.cuda.graph(g, pool=self.pool, capture_error_mode=_capture_mode()):
+            with _Capture(g, self.pool):
                 fn()
             if self.pool is None:
                 self.pool = g.pool()

@@ -803,10 +803,11 @@ def _sync_world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
-def _multi(world):
-    """Whether the N-replica SyncBN path runs (the statistics message and `clamp(var, eps)^-1/2`): several ranks, or one
-    rank under CSG_DIST_FORCE=1 (csg_dist.active(): RCCL bring-up on a 1-GPU box)."""
-    return world > 1 or csg_dist.active()
+def _multi(world, syncs):
+    """Whether the N-replica SyncBN path runs (the statistics message and `clamp(var, eps)^-1/2`) for a layer that `syncs`
+    (a synchronised BatchNorm in training mode — never an InstanceNorm or an eval-mode norm): several ranks, or one rank
+    under CSG_DIST_FORCE=1 (csg_dist.active(): RCCL bring-up on a 1-GPU box)."""
+    return bool(syncs) and (world > 1 or csg_dist.active())
 
 
 class _NormAct(torch.autograd.Function):
@@ -823,7 +824,9 @@ class _NormAct(torch.autograd.Function):
         G = B if instance else 1
         P = (B * H * W) // G
         dev = x.device
-        world = _sync_world() if (sync and not instance and training) else 1
+        syncs = bool(sync and not instance and training)
+        world = _sync_world() if syncs else 1
+        multi = _multi(world, syncs)
         use_batch_stats = training or instance
         mean = torch.empty(G * C, device=dev, dtype=torch.float32)
         invstd = torch.empty(G * C, device=dev, dtype=torch.float32)
@@ -833,11 +836,11 @@ class _NormAct(torch.autograd.Function):
             part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float64)
             sums = torch.empty(G * 2 * C, device=dev, dtype=torch.float64)
             check(lib.csg_norm_stats(ptr(x), G, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-            if _multi(world):
+            if multi:
                 csg_dist.all_reduce_stats(sums)
             rm = running_mean if (training and not instance and running_mean is not None) else None
             rv = running_var if rm is not None else None
-            check(lib.csg_norm_finalize(ptr(sums), G, C, count, eps, 1 if _multi(world) else 0, ptr(mean), ptr(invstd),
+            check(lib.csg_norm_finalize(ptr(sums), G, C, count, eps, 1 if multi else 0, ptr(mean), ptr(invstd),
                                         ptr(rm), ptr(rv), momentum, stream()), "norm_finalize")
         else:
             mean.copy_(running_mean)
@@ -848,13 +851,13 @@ class _NormAct(torch.autograd.Function):
                                      stream()),
               "norm_apply_fwd")
         ctx.save_for_backward(x, gbn, mean, invstd)
-        ctx.cfg = (G, P, C, slope, use_batch_stats, world, count)
+        ctx.cfg = (G, P, C, slope, use_batch_stats, multi, count)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gb, mean, invstd = ctx.saved_tensors
-        G, P, C, slope, use_batch_stats, world, count = ctx.cfg
+        G, P, C, slope, use_batch_stats, multi, count = ctx.cfg
         dy = nhwc(dy)
         dev = dy.device
         dgb = torch.empty_like(gb) if gb is not None else None
@@ -867,7 +870,7 @@ class _NormAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if not use_batch_stats:
                 dsums.zero_()                       # eval mode: statistics are constants
-            elif _multi(world):
+            elif multi:
                 csg_dist.all_reduce_stats(dsums)
             dx = torch.empty_like(x)
             check(lib.csg_norm_apply_bwd_dx(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, ptr(dsums), count,
@@ -888,6 +891,7 @@ class _NormActPair(torch.autograd.Function):
         P = B * H * W
         dev = x.device
         world = _sync_world() if sync else 1
+        multi = _multi(world, sync)
         count = float(P * world)
         mean = torch.empty(C, device=dev, dtype=torch.float32)
         invstd = torch.empty(C, device=dev, dtype=torch.float32)
@@ -895,23 +899,23 @@ class _NormActPair(torch.autograd.Function):
         part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
         sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
         check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-        if _multi(world):
+        if multi:
             csg_dist.all_reduce_stats(sums)
         for rm, rv in ((rm0, rv0), (rm1, rv1)):           # same batch statistics, each module's own running buffers
-            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if _multi(world) else 0, ptr(mean), ptr(invstd),
+            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if multi else 0, ptr(mean), ptr(invstd),
                                         ptr(rm), ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
         gb0, gb1 = nhwc(gb0), nhwc(gb1)
         y0, y1 = torch.empty_like(x), torch.empty_like(x)
         check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, 1, P, C, ptr(y0), ptr(gb1), slope1,
                                      ptr(y1), stream()), "norm_apply_fwd")
         ctx.save_for_backward(x, gb0, gb1, mean, invstd)
-        ctx.cfg = (P, C, slope0, slope1, world, count)
+        ctx.cfg = (P, C, slope0, slope1, multi, count)
         return y0, y1
 
     @staticmethod
     def backward(ctx, dy0, dy1):
         x, gb0, gb1, mean, invstd = ctx.saved_tensors
-        P, C, slope0, slope1, world, count = ctx.cfg
+        P, C, slope0, slope1, multi, count = ctx.cfg
         dy0, dy1 = nhwc(dy0), nhwc(dy1)
         dev = x.device
         nch = _chunks(P, 1)
@@ -925,7 +929,7 @@ class _NormActPair(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             both = dsums[0] + dsums[1]                    # the reductions are linear in dn: 4C doubles
-            if _multi(world):
+            if multi:
                 csg_dist.all_reduce_stats(both)
             dx = torch.empty_like(x)
             check(lib.csg_norm_apply_bwd_dx(ptr(dy0), ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, ptr(both), count,
@@ -967,6 +971,7 @@ class _SpadeFused(torch.autograd.Function):
         P = B * H * W
         dev = x.device
         world = _sync_world() if sync else 1
+        multi = _multi(world, sync)
         count = float(P * world)
         mean = torch.empty(C, device=dev, dtype=torch.float32)
         invstd = torch.empty(C, device=dev, dtype=torch.float32)
@@ -975,7 +980,7 @@ class _SpadeFused(torch.autograd.Function):
         sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
         check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
         # N > 1: the statistics travel while the gamma halves (which do not need them) are computed
-        pending = csg_dist.all_reduce_stats_async(sums) if _multi(world) else None
+        pending = csg_dist.all_reduce_stats_async(sums) if multi else None
         saved, outs, cfg, launches = [x, mean, invstd], [], [], []
         for k in range(K):
             actv, w, b, rm, rv, slope, in_slope = mods[k * 7:(k + 1) * 7]
@@ -996,7 +1001,7 @@ class _SpadeFused(torch.autograd.Function):
             pending.wait()
         for k in range(K):
             rm, rv = mods[k * 7 + 3], mods[k * 7 + 4]
-            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if _multi(world) else 0, ptr(mean), ptr(invstd), ptr(rm),
+            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if multi else 0, ptr(mean), ptr(invstd), ptr(rm),
                                         ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
         for (actv, w, up, bd, gbuf, nh, slope, in_slope) in launches:
             y = torch.empty_like(x)
@@ -1008,13 +1013,13 @@ class _SpadeFused(torch.autograd.Function):
             outs.append(y)
             cfg.append((slope, in_slope, nh))
         ctx.save_for_backward(*saved)
-        ctx.cfg = (K, P, C, B, H, W, world, count, tuple(cfg))
+        ctx.cfg = (K, P, C, B, H, W, multi, count, tuple(cfg))
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *dys):
         import types
-        K, P, C, B, H, W, world, count, cfg = ctx.cfg
+        K, P, C, B, H, W, multi, count, cfg = ctx.cfg
         sv = ctx.saved_tensors
         x, mean, invstd = sv[0], sv[1], sv[2]
         dev = x.device
@@ -1033,7 +1038,7 @@ class _SpadeFused(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             both = dsums[0] + dsums[1] if K == 2 else dsums[0]
             # N > 1: the reductions travel while the convolution's backward passes (which need only d(gamma || beta)) run
-            pending = csg_dist.all_reduce_stats_async(both) if _multi(world) else None
+            pending = csg_dist.all_reduce_stats_async(both) if multi else None
         grads = [None, None, None, None]
         for k in range(K):
             actv, w, gbuf, y = sv[3 + 4 * k:7 + 4 * k]
@@ -1077,6 +1082,7 @@ class _SpadeJoined(torch.autograd.Function):
         P = B * H * W
         dev = x.device
         world = _sync_world() if sync else 1
+        multi = _multi(world, sync)
         count = float(P * world)
         mean = torch.empty(C, device=dev, dtype=torch.float32)
         invstd = torch.empty(C, device=dev, dtype=torch.float32)
@@ -1084,7 +1090,7 @@ class _SpadeJoined(torch.autograd.Function):
         part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
         sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
         check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-        pending = csg_dist.all_reduce_stats_async(sums) if _multi(world) else None
+        pending = csg_dist.all_reduce_stats_async(sums) if multi else None
         # the joined convolution through _Conv2d's own forward on a stand-in context (its saved tensors are kept for the
         # backward below)
         fake = types.SimpleNamespace(needs_input_grad=(True, True, True, False))
@@ -1093,7 +1099,7 @@ class _SpadeJoined(torch.autograd.Function):
         gb = _Conv2d.forward(fake, actv, w, b, None, 1, int(pad), ACT_NONE, 0.0, None, None, in_act, False, None, None)
         if pending is not None:
             pending.wait()
-        check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if _multi(world) else 0, ptr(mean), ptr(invstd),
+        check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if multi else 0, ptr(mean), ptr(invstd),
                                     ptr(running_mean), ptr(running_var if running_mean is not None else None), momentum,
                                     stream()), "norm_finalize")
         y = torch.empty_like(x)
@@ -1104,13 +1110,13 @@ class _SpadeJoined(torch.autograd.Function):
         fake.save_for_backward = None
         fake.saved_tensors = None
         ctx.conv = fake
-        ctx.cfg = (P, C, slope, world, count)
+        ctx.cfg = (P, C, slope, multi, count)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gb, mean, invstd, cx, cw = ctx.saved_tensors
-        P, C, slope, world, count = ctx.cfg
+        P, C, slope, multi, count = ctx.cfg
         dy = nhwc(dy)
         dev = x.device
         nch = _chunks(P, 1)
@@ -1119,7 +1125,7 @@ class _SpadeJoined(torch.autograd.Function):
         dgb = torch.empty_like(gb)
         check(lib.csg_norm_apply_bwd_reduce(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gb), None, slope, 1, P, C, ptr(dgb),
                                             ptr(dsums), ptr(part), nch, 2 * C, stream()), "norm_bwd_reduce")
-        pending = csg_dist.all_reduce_stats_async(dsums) if (_multi(world) and ctx.needs_input_grad[0]) else None
+        pending = csg_dist.all_reduce_stats_async(dsums) if (multi and ctx.needs_input_grad[0]) else None
         fake = ctx.conv
         fake.saved_tensors = (cx, cw, None)
         fake.needs_input_grad = (ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3], False)

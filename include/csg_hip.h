@@ -45,7 +45,12 @@ int csg_version(void);
 const char* csg_last_error(void);
 
 /* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline) -------
- * mode 0 = off, 1 = every launch, 2 = only the dominant convolution kernels (k_wino_conv2<*> and k_igemm_fwd<128>):
+ * DEVELOPER / BENCHMARK ONLY, and the one piece of MUTABLE PROCESS-GLOBAL STATE in the library (a table of pending event
+ * pairs and per-kernel sums behind a mutex, csrc/csg_api.hip): every compute entry point is stateless and re-entrant with
+ * the mode off (the default) — apart from immutable once-per-device attributes (raised dynamic-LDS limits) and the
+ * thread-local text of csg_last_error().  With a mode on, launches are not graph-capturable and calls from several host
+ * threads share one table.
+ * mode 0 = off, 1 = every launch, 2 = only the dominant convolution kernels (k_wino4_conv_v, k_wino_conv2<*>, k_igemm_fwd<128>):
  * 3 = only the streaming (HBM-bound) kernels: normalisation, activation, layout, graph gathers, resampling;
  * an event pair costs ~9 us of queue time, 10 ms per step when all ~1100 launches carry one, 2 ms in mode 2. */
 int csg_prof_enable(int mode);
