@@ -33,7 +33,7 @@ optimisers' state, which a capture must find in place); `CSG_GRAPHS=0` turns the
 limited to one process per node-local GPU without an initialised process group: with N > 1 ranks the SyncBN and gradient
 collectives would have to be captured by RCCL, which cannot be validated on the 1-GPU boxes — there the eager path runs.
 
-Round 5: N > 1 ranks replay too (backend nccl; `CSG_GRAPHS_DIST=0` keeps them eager).  The SyncBN statistics messages are
+Round 5: N > 1 ranks can replay too (backend nccl; opt-in, `CSG_GRAPHS_DIST=1` — validated on one rank only so far).  The SyncBN statistics messages are
 captured where they are issued, inside S1-S3 (ProcessGroupNCCL records a collective on its own stream and joins it to the
 capturing one).  The GRADIENT exchange stays outside the graphs: a capture runs under `GradBuckets.begin(launch=False)` — the
 post-accumulate hooks only move gradients into their bucket slots, which the capture records as copies (most weight gradients
@@ -297,9 +297,10 @@ class StepGraphs:
     @staticmethod
     def supported(trainer):
         opt = trainer.opt
-        # N > 1 ranks: replay needs collectives that can be captured (RCCL's: the SyncBN messages sit in the middle of S1-S3);
-        # CSG_GRAPHS_DIST=0 keeps the eager path there
-        dist_ok = not csg_dist.active() or (csg_dist.capturable() and os.environ.get("CSG_GRAPHS_DIST", "1") != "0")
+        # N > 1 ranks: replay needs collectives that can be captured (RCCL's: the SyncBN messages sit in the middle of S1-S3).
+        # OPT-IN (CSG_GRAPHS_DIST=1): RCCL has executed this path on ONE rank only (tests/test_gpu_graphs.py, CSG_DIST_FORCE);
+        # until it has run on a multi-GPU node the eager path — itself covered by the 2-rank tests — stays the default there
+        dist_ok = not csg_dist.active() or (csg_dist.capturable() and os.environ.get("CSG_GRAPHS_DIST", "0") == "1")
         return bool(ENABLED and torch.device(trainer.device).type == "cuda" and dist_ok
                     and not opt.skip_generation and not opt.learned_converse and not (opt.mask_size or 0) > 0
                     and not getattr(opt, "freeze", 0) and hasattr(trainer.model, "layout_to_image_model"))

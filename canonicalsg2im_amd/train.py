@@ -132,7 +132,12 @@ class Trainer:
         G = self.gans_model(batch, model_out, mode="compute_generator_loss")
         G = {k: (v if k == "bbox_pred_all" else v.mean()) for k, v in G.items()}
         self.optimizer.zero_grad(set_to_none=True)
-        self.g_buckets.begin()
+        # N > 1 with graph replay available: an eager step must issue its collectives in the order a REPLAYED step does
+        # (graphs.py: every bucket's all-reduce after the backward, in bucket order) — two ranks may take different paths in
+        # the same iteration (a shape key one of them has not captured yet), and RCCL matches collectives by issue order.
+        # Without replay the hooks launch each bucket as soon as it is complete, under the rest of the backward.
+        in_hooks = self.graphs is None
+        self.g_buckets.begin(launch=in_hooks)
         G["total_loss"].backward()
         # N > 1: each 64 MB bucket of the generator's gradients (~375 MB in all) is all-reduced on RCCL's stream as
         # soon as the backward has filled it, and the tail keeps travelling while the discriminator losses below are
@@ -154,7 +159,7 @@ class Trainer:
             # the three discriminators' backward passes are independent: every all-reduce is in flight (asynchronous)
             # before the first optimiser step waits for its own
             self.discriminator.optimizer_d_img.zero_grad(set_to_none=True)
-            self.d_buckets.begin()
+            self.d_buckets.begin(launch=in_hooks)
             D["total_img_loss"].backward()
             self.d_buckets.flush()
             if not opt.use_img_disc:                                    # train.py:478-480

@@ -213,7 +213,7 @@ def _one_rank_nccl_worker(rank, port, out):
     bucketed ReduceOp.AVG gradient all-reduces, the fp64 SyncBN statistics messages (N-replica formula), the late-gradient
     flag — and is the identity, so the replayed trainer must track the eager one exactly as it does without a group."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      CSG_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      CSG_DIST_FORCE="1", CSG_GRAPHS_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1)
