@@ -257,13 +257,13 @@ __global__ __launch_bounds__(256) void k_gather_concat_fwd(const float* __restri
 // inside a workgroup 256/LPE edge groups of LPE lanes work on different edges, a lane owns one float4
 // of the D columns, 4 edges are in flight per lane.  Group partials are combined through LDS and
 // segment partials by k_rowsum_finish, both in a fixed order: results are bit-reproducible run to run.
-#define ROWSUM_SEG 64        // edges per segment in edge-balanced mode
+#define ROWSUM_SEG_DEFAULT 64        // edges per segment in edge-balanced mode (CSG_ROWSUM_SEG: developer knob)
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void k_csr_rowsum(const float* __restrict__ src, const float* __restrict__ conf,
                                                      const uint8_t* __restrict__ valid,
                                                      const int32_t* __restrict__ row_ptr,
                                                      const int32_t* __restrict__ col, int O, int T, int D, int stride,
-                                                     int off0, int off1, int LPE, int nseg_max,
+                                                     int off0, int off1, int LPE, int nseg_max, int ROWSUM_SEG,
                                                      float* __restrict__ out, float* __restrict__ cnt_out,
                                                      float* __restrict__ part, float* __restrict__ part_cnt,
                                                      int32_t* __restrict__ seg_info) {
@@ -460,10 +460,14 @@ static inline int rowsum_lpe(int64_t D) {
 }
 // segments per image in edge-balanced mode (0 = sparse graph: one workgroup per row).  Dense mode is chosen
 // from the PADDED triplet count, so a batch whose longest sample is dense uses it for every sample.
+static inline int rowsum_seg() {
+  static const int seg = getenv("CSG_ROWSUM_SEG") ? atoi(getenv("CSG_ROWSUM_SEG")) : ROWSUM_SEG_DEFAULT;
+  return seg >= 16 ? seg : ROWSUM_SEG_DEFAULT;
+}
 static inline int64_t rowsum_nseg(int64_t O, int64_t T) {
   const int64_t deg = O > 0 ? (2 * T + O - 1) / O : 0;
   if (deg <= 48 || O > 1024) return 0;
-  return cdiv(2 * T, ROWSUM_SEG) + O;
+  return cdiv(2 * T, rowsum_seg()) + O;
 }
 // workspace: partial rows (+ counts when weighted) and the (first segment, segments) pair of every row
 static inline int64_t rowsum_ws_bytes(int64_t B, int64_t O, int64_t T, int64_t D, bool weighted) {
@@ -540,19 +544,40 @@ __global__ __launch_bounds__(64) void k_segment_avg_bwd(const float* __restrict_
   float* dhp = dh + bt * Dh;
   const float* dps = dpooled + (b * O + (s_ok ? s : 0)) * H;
   const float* dpo = dpooled + (b * O + (o_ok ? o : 0)) * H;
+  // 16 bytes per lane (H, Dp and the row stride are multiples of 4: host-checked): a quarter of the memory instructions of
+  // the dword form this replaces (round 5: 254 -> see DESIGN 4.5 us per launch on config C5's 94 500 triplets)
   float acc = 0.f;
-  for (int d = threadIdx.x; d < H; d += 64) {
-    float gs = dps[d] * sc_s;
-    float go = dpo[d] * sc_o;
+  const float cg = c;
+  auto gate4 = [&](const float4& hv, float4 g) {
+    if (gate_relu) {
+      if (!(hv.x > 0.f)) g.x = 0.f;
+      if (!(hv.y > 0.f)) g.y = 0.f;
+      if (!(hv.z > 0.f)) g.z = 0.f;
+      if (!(hv.w > 0.f)) g.w = 0.f;
+    }
+    return g;
+  };
+  for (int d = threadIdx.x * 4; d < H; d += 256) {
+    const float4 a = *(const float4*)(dps + d), bq = *(const float4*)(dpo + d);
+    const float4 hs = *(const float4*)(hp + d), ho = *(const float4*)(hp + H + Dp + d);
+    const float4 gs = make_float4(a.x * sc_s, a.y * sc_s, a.z * sc_s, a.w * sc_s);
+    const float4 go = make_float4(bq.x * sc_o, bq.y * sc_o, bq.z * sc_o, bq.w * sc_o);
     // gate_relu: h is the output of a ReLU and dh goes to that ReLU's producer as the gradient of its PRE-activation
-    dhp[d] = (gate_relu && !(hp[d] > 0.f)) ? 0.f : gs * c;
-    dhp[H + Dp + d] = (gate_relu && !(hp[H + Dp + d] > 0.f)) ? 0.f : go * c;
-    acc += gs * hp[d] + go * hp[H + Dp + d];
+    *(float4*)(dhp + d) = gate4(hs, make_float4(gs.x * cg, gs.y * cg, gs.z * cg, gs.w * cg));
+    *(float4*)(dhp + H + Dp + d) = gate4(ho, make_float4(go.x * cg, go.y * cg, go.z * cg, go.w * cg));
+    acc += gs.x * hs.x + go.x * ho.x;
+    acc += gs.y * hs.y + go.y * ho.y;
+    acc += gs.z * hs.z + go.z * ho.z;
+    acc += gs.w * hs.w + go.w * ho.w;
   }
-  for (int d = threadIdx.x; d < Dp; d += 64) {
-    float gp = dnew_p ? dnew_p[bt * Dp + d] : 0.f;
-    dhp[H + d] = (gate_relu && !(hp[H + d] > 0.f)) ? 0.f : gp * c;
-    acc += gp * hp[H + d];
+  for (int d = threadIdx.x * 4; d < Dp; d += 256) {
+    const float4 gp = dnew_p ? *(const float4*)(dnew_p + bt * Dp + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 hv = *(const float4*)(hp + H + d);
+    *(float4*)(dhp + H + d) = gate4(hv, make_float4(gp.x * cg, gp.y * cg, gp.z * cg, gp.w * cg));
+    acc += gp.x * hv.x;
+    acc += gp.y * hv.y;
+    acc += gp.z * hv.z;
+    acc += gp.w * hv.w;
   }
   acc = wave_sum(acc);
   if (threadIdx.x == 0) {
@@ -685,7 +710,7 @@ int csg_gather_concat_bwd(const float* dcat, const int32_t* row_ptr, const int32
     int32_t* seg_info = ns ? (int32_t*)(part + B * ns * Din) : nullptr;
     CSG_LAUNCH(k_csr_rowsum<false>, dim3((unsigned)(ns ? ns : O), (unsigned)B), dim3(256), 0, s, dcat,
                        (const float*)nullptr, (const uint8_t*)nullptr, row_ptr, col, (int)O, (int)T, (int)Din,
-                       (int)(2 * Din + Dp), 0, (int)(Din + Dp), rowsum_lpe(Din), (int)ns, dobj, (float*)nullptr, part,
+                       (int)(2 * Din + Dp), 0, (int)(Din + Dp), rowsum_lpe(Din), (int)ns, rowsum_seg(), dobj, (float*)nullptr, part,
                        (float*)nullptr, seg_info);
     if (ns)
       CSG_LAUNCH(k_rowsum_finish<false>, dim3((unsigned)(B * O)), dim3(1024), 0, s, (const float*)part,
@@ -723,7 +748,7 @@ int csg_segment_avg_fwd(const float* h, const float* conf, const uint8_t* valid,
   int32_t* seg_info = ns ? (int32_t*)(part_cnt + B * ns) : nullptr;
   CSG_LAUNCH(k_csr_rowsum<true>, dim3((unsigned)(ns ? ns : O), (unsigned)B), dim3(256), 0, s, h, conf, valid,
                      row_ptr, col, (int)O, (int)T, (int)H, (int)(2 * H + Dp), 0, (int)(H + Dp), rowsum_lpe(H), (int)ns,
-                     pooled, cnt, part, part_cnt, seg_info);
+                     rowsum_seg(), pooled, cnt, part, part_cnt, seg_info);
   if (ns)
     CSG_LAUNCH(k_rowsum_finish<true>, dim3((unsigned)(B * O)), dim3(1024), 0, s, (const float*)part,
                        (const float*)part_cnt, (const int32_t*)seg_info, (int)O, (int)H, rowsum_lpe(H), (int)ns, pooled,
@@ -741,6 +766,10 @@ int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* 
                         int64_t B, int64_t O, int64_t T, int64_t H, int64_t Dp, int32_t gate_relu, float* dh,
                         float* dconf, float* dcnt_scratch, void* stream) {
   CSG_REQUIRE(B > 0 && O > 0 && T >= 0 && H > 0 && Dp >= 0, CSG_E_BADSHAPE, "csg_segment_avg_bwd: bad shape");
+  CSG_REQUIRE(H % 4 == 0 && Dp % 4 == 0, CSG_E_BADSHAPE, "csg_segment_avg_bwd: H=%ld and Dp=%ld must be multiples of 4", (long)H,
+              (long)Dp);
+  CSG_REQUIRE((((uintptr_t)dpooled | (uintptr_t)h | (uintptr_t)dh | (uintptr_t)dnew_p) & 15) == 0, CSG_E_UNSUPPORTED,
+              "csg_segment_avg_bwd: pointers must be 16-byte aligned");
   if (T == 0) return CSG_OK;
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_SEGAVG_BWD, (double)B * T * (2.0 * H + Dp) * 8, s);   // h read + dh written (dpooled rows are L2 hits)
