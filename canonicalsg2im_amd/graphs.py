@@ -113,9 +113,8 @@ class _Capture:
 
     def __enter__(self):
         import gc
-        gc.collect()
-        self.was_enabled = gc.isenabled()
-        gc.disable()
+        self.was_enabled = gc.isenabled()     # (paused, not run: a full collection costs ~100 ms of host time per capture —
+        gc.disable()                          #  25 ms per step of bench.py's 4-step VGG leg, whose encoder graph is captured there)
         return self.ctx.__enter__()
 
     def __exit__(self, *exc):
