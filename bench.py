@@ -164,11 +164,12 @@ def c5_leg(dev, steps=6, warmup=3, batch=6):
     ms = 1000.0 * (time.perf_counter() - t0) / steps
     finite = bool(torch.isfinite(G["total_loss"]).item() and torch.isfinite(Dl["total_img_loss"]).item())
     tr.use_graphs = False
-    tr.step(batches[0])
+    for i in range(3):                                   # (eager warm-up: allocator and clocks in steady state before the table)
+        tr.step(batches[i % 3])
     torch.cuda.synchronize()
     _lib.prof_reset()
     _lib.prof_enable(1)
-    nprof = 2
+    nprof = 3
     for i in range(nprof):
         tr.step(batches[i % 3])
     torch.cuda.synchronize()
@@ -556,8 +557,8 @@ def main():
                 peak_clock_note="peak = 256 CUs x 256 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md); under this load the shader "
                                 "clock reads ~2.0 GHz (s_memtime vs wall clock, DESIGN.md 4.1b), where the same product is 131 TFLOP/s",
                 traffic=traffic,
-                traffic_source="profiles/pmc_traffic.json (builder-run capture of an earlier build of this kernel, not "
-                               "observed by this run)" if traffic is not None else None,
+                traffic_source="profiles/pmc_traffic.json = profiles/r05k_pmc_traffic.json (builder-run capture, not observed "
+                               "by this run)" if traffic is not None else None,
                 traffic_note="HBM bytes per launch (read x2-corrected FETCH_SIZE + WRITE_SIZE, two rocprofv3 --pmc passes "
                              "of this workload taken by the builder and committed as profiles/pmc_traffic.json: a constant "
                              "of that capture — a --pmc pass cannot run inside this process)",
