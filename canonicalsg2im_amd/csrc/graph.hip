@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void k_gather_concat_fwd(const float* __restri
 // inside a workgroup 256/LPE edge groups of LPE lanes work on different edges, a lane owns one float4
 // of the D columns, 4 edges are in flight per lane.  Group partials are combined through LDS and
 // segment partials by k_rowsum_finish, both in a fixed order: results are bit-reproducible run to run.
-#define ROWSUM_SEG_DEFAULT 64        // edges per segment in edge-balanced mode (CSG_ROWSUM_SEG: developer knob)
+#define ROWSUM_SEG_DEFAULT 128       // edges per segment in edge-balanced mode (CSG_ROWSUM_SEG: developer knob; 64 / 128 / 256
+                                     // measured 112 / 102 / 135 us per forward launch on config C5)
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void k_csr_rowsum(const float* __restrict__ src, const float* __restrict__ conf,
                                                      const uint8_t* __restrict__ valid,
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(64) void k_segment_avg_bwd(const float* __restrict_
   const float* dps = dpooled + (b * O + (s_ok ? s : 0)) * H;
   const float* dpo = dpooled + (b * O + (o_ok ? o : 0)) * H;
   // 16 bytes per lane (H, Dp and the row stride are multiples of 4: host-checked): a quarter of the memory instructions of
-  // the dword form this replaces (round 5: 254 -> see DESIGN 4.5 us per launch on config C5's 94 500 triplets)
+  // the dword form this replaces (round 5: 234 -> 148 us per launch on config C5's 94 500 triplets, 44 % -> 69 % of the HBM peak)
   float acc = 0.f;
   const float cg = c;
   auto gate4 = [&](const float4& hv, float4 g) {
