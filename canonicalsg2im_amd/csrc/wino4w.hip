@@ -478,8 +478,10 @@ static int ww_plan(const csg_wino_desc* d, Wino4WgParams& p, const char* who) {
   p.nregions = (int)nr;
   p.cblocks = (d->Cout + 63) / 64;
   p.kblocks = (d->Cin + 63) / 64;
-  // one block per CU is resident: aim at ~2 waves of blocks (512), at least 16 stages per block, at most 256 slices
-  static const int target = getenv("CSG_WINO4_WGRAD_BLOCKS") ? atoi(getenv("CSG_WINO4_WGRAD_BLOCKS")) : 512;
+  // one block per CU is resident: aim at ONE wave of blocks (256: every CU gets one block of equal length — measured 256 / 512 /
+  // 768 / 1024: 4.92 / 5.00 / 5.13 / 5.24 ms over eight generator shapes, fewer slabs to sum and fewer epilogues), at least 16
+  // stages per block, at most 256 slices
+  static const int target = getenv("CSG_WINO4_WGRAD_BLOCKS") ? atoi(getenv("CSG_WINO4_WGRAD_BLOCKS")) : 256;
   const int tiles2d = p.cblocks * p.kblocks * 2;
   int ns = (target + tiles2d - 1) / tiles2d;
   const int max_ns = (int)((nr + 15) / 16);
