@@ -496,7 +496,7 @@ def main():
     }
     if graph_stats is not None:
         out["hip_graphs"] = dict(graph_stats, eager_ms_per_step=round(eager_ms, 2),
-                                 note="timed region: generator + PatchGAN forward/backward/Adam replayed from 3 captured HIP "
+                                 note="timed region: generator + PatchGAN forward/backward/Adam replayed from 4 captured HIP "
                                       "graphs per step and the scene-graph encoder from its own (encoder_*: one per bucket of "
                                       "the batch's triplet count), object-crop discriminator enqueued eagerly "
                                       "(canonicalsg2im_amd/graphs.py); eager_ms_per_step = the same steps without replay "

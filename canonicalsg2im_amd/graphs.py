@@ -16,6 +16,12 @@ captured once per shape key into three HIP graphs and replayed:
         ground-truth boxes (sg2im/meta_models.py:47 of the reference).  It takes 3.8 ms of enqueue off the host (13.4 ->
         9.6 ms per step) and nothing off the step: the host was already ahead of the device (tools/graph_timing.py)
 
+    (round 5) S1 is captured as two graphs — the generator's forward, then the PatchGAN passes and the image terms — and the small,
+    latency-bound pieces run on side streams BESIDE the replays (`CSG_GRAPH_OVERLAP=0`: one stream): the encoder (S0 or eager)
+    beside S1 / S2, the object discriminator's terms for the generator beside the PatchGAN passes of S1, the generator's Adam
+    step and the object discriminator's update beside S3; each is joined where its result is first needed.  C3 80.2 -> 75.9 ms,
+    C4 32.8 -> 28.8 ms, C2 33.1 -> 29.3 ms per step (tools/graph_timing.py, same box); same kernels, same bits.
+
 What stays eager, between the replays, is what follows the data: the object-crop discriminator (one crop per real object),
 and the encoder on graphs of more than 2 048 triplets per sample (config C5) or in a bucket seen for the first time.  The number of
 objects enters the static part only through the layout kernels' (vecs, boxes, valid) operands: they are padded to a
@@ -59,6 +65,10 @@ MAX_SG_GRAPHS = int(os.environ.get("CSG_GRAPH_MAX_SG", "8"))             # tripl
 SG_MAX_TRIPLETS = int(os.environ.get("CSG_GRAPH_SG_MAX_T", "2048"))      # larger graphs (config C5: thousands of triplets per scene) are
 #                                                                          GPU-bound in the encoder and rarely repeat a bucket: eager
 TIMING = os.environ.get("CSG_GRAPH_TIMING") == "1"      # developer aid: per-segment host / device time of the replayed step
+# the small, latency-bound pieces of the step on a second stream beside the replays (round 5): the scene-graph encoder beside
+# S1 / S2, the generator's Adam step and the object discriminator's update beside S3.  0: everything on one stream
+OVERLAP = os.environ.get("CSG_GRAPH_OVERLAP", "1") != "0"
+SPLIT_S1 = os.environ.get("CSG_GRAPH_SPLIT_S1", "1") != "0"      # S1 as two graphs with the object terms beside the second
 
 
 class _Marks:
@@ -290,6 +300,7 @@ class StepGraphs:
         self.active = None
         self.replays = self.eager_steps = self.captures = 0
         self.sg_replays = self.sg_captures = 0
+        self.side = self.side2 = None    # streams of the overlapped pieces (OVERLAP)
         self.marks = _Marks() if TIMING else None
 
     # ---- eligibility
@@ -392,7 +403,7 @@ class StepGraphs:
         gm, gen = tr.gans_model, tr.model.layout_to_image_model
         imgs, objs, boxes = batch[0], batch[1], batch[2]
         use_obj = not opt.use_img_disc
-        mk = self.marks if (self.marks is not None and len(gs.graphs) == 3) else None
+        mk = self.marks if (self.marks is not None and len(gs.graphs) == (4 if SPLIT_S1 else 3)) else None
         if mk:
             mk.begin()
         if self.active is not gs or tr._grads_dirty:
@@ -411,31 +422,61 @@ class StepGraphs:
             mk.mark("load+prefetch")
         G = {}
         self.boxes_pred = None
-        self._graph_encoder(gs, batch, G)
+        # The encoder (E0: ~150 small dependent launches, 3 ms of device time whatever the batch) shares nothing with the
+        # generator's pass — the generator consumes the ground-truth boxes (sg2im/meta_models.py:47 of the reference) — so it runs
+        # on a second stream beside S1 / S2 and is joined where its loss value and its gradients are first needed (the total,
+        # the generator's Adam step).  One rank only: with N > 1 its hooks and the bucket exchange stay in stream order.
+        conc = OVERLAP and not dp
+        main = torch.cuda.current_stream()
+        if conc:
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            self.side.wait_stream(main)                  # (the static inputs gs.load just filled)
+            with torch.cuda.stream(self.side):
+                self._graph_encoder(gs, batch, G)
+        else:
+            self._graph_encoder(gs, batch, G)
         if mk:
             mk.mark("E0 graph encoder")
         # ---- S1: generator forward + the generator's image terms (the discriminators are frozen)
         tr._d_requires_grad(False)
 
-        def s1():
-            gs.img = gen(gs.objs, gs.boxes, None, test_mode=False)
+        # S1 is two graphs (round 5): the generator's forward, then the PatchGAN passes and the image terms.  In between the
+        # object discriminator's terms for the generator (E1: crops of the fresh image through the object discriminator and
+        # back to the image, 0.8 ms of small launches) start on a stream of their own and run beside the PatchGAN passes;
+        # S2 — which injects their gradient at the image — waits for them.
+        def s1b():
             terms = gm.generator_image_terms(gs.imgs, gs.objs, gs.boxes, None, gs.img)
             gs.g_roots = [v.mean() for v in terms.values()]
             gs.g_terms = list(terms.keys())
             gs.g_vals = torch.stack([v.detach() for v in gs.g_roots])
+
+        def s1():
+            gs.img = gen(gs.objs, gs.boxes, None, test_mode=False)
             gs.fake = gs.img.detach()
+            if not SPLIT_S1:
+                s1b()
         gs.run("s1", s1)
-        if mk:
-            mk.mark("S1 replay")
         # ---- eager: the object discriminator's terms and their gradient at the image
         obj_vals = None
         if use_obj:
-            obj_vals, d_img = self._object_terms_for_generator(gs.img, objs, boxes)
-            if gs.d_img is None:
-                gs.d_img = torch.empty_like(d_img)
-            gs.d_img.copy_(d_img)
+            import contextlib
+            if conc:
+                if self.side2 is None:
+                    self.side2 = torch.cuda.Stream()
+                self.side2.wait_stream(main)
+            with (torch.cuda.stream(self.side2) if conc else contextlib.nullcontext()):
+                obj_vals, d_img = self._object_terms_for_generator(gs.img, objs, boxes)
+                if gs.d_img is None:
+                    gs.d_img = torch.empty_like(d_img)
+                gs.d_img.copy_(d_img)
+
+        if SPLIT_S1:
+            gs.run("s1b", s1b)
+        if conc and use_obj:
+            main.wait_stream(self.side2)
         if mk:
-            mk.mark("E1 object terms (G)")
+            mk.mark("S1 replay + E1 object terms (G)")
 
         # ---- S2: backward of S1's terms (+ the injected image gradient)
         def s2():
@@ -461,13 +502,21 @@ class StepGraphs:
         if mk:
             mk.mark("S2 replay")
         # ---- the generator's Adam step (eager: one fused launch over the encoder's eager and the generator's static grads)
+        if conc:
+            main.wait_stream(self.side)                  # the encoder's loss value and gradients
         vals = gs.g_vals.clone()
         for i, k in enumerate(gs.g_terms):
             G[k] = vals[i]
         if obj_vals is not None:
             G.update(obj_vals)
         G["total_loss"] = torch.stack([v for k, v in G.items() if k != "bbox_pred_all"]).sum()
-        if not dp:
+        if conc:
+            # Adam only touches the encoder's / generator's parameters, gradients and moments; S3 reads gs.fake (detached) and
+            # the discriminator: the two run side by side, and the object discriminator's update follows Adam on the side stream
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                tr.optimizer.step()
+        elif not dp:
             tr.optimizer.step()
         if mk:
             mk.mark("G Adam")
@@ -502,27 +551,33 @@ class StepGraphs:
             mk.mark("S3 replay")
         vals = gs.d_vals.clone()
         D = {k: vals[i] for i, k in enumerate(gs.d_terms)}
-        # ---- eager: the object discriminator's update
+        # ---- eager: the object discriminator's update (beside S3 on the side stream: its own networks, gs.fake and the batch)
         if use_obj:
-            terms = gm.discriminator_object_terms(imgs, objs, boxes, None, gs.fake, None)
-            terms = {k: v.mean() for k, v in terms.items()}
-            if not tr.d_frozen:
-                tr.discriminator.optimizer_d_obj.zero_grad(set_to_none=True)
-                tr.dobj_buckets.begin()
-                terms["total_obj_loss"].backward()
-                tr.dobj_buckets.flush()
-            D.update({k: v.detach() for k, v in terms.items()})
+            import contextlib
+            with (torch.cuda.stream(self.side) if conc else contextlib.nullcontext()):
+                terms = gm.discriminator_object_terms(imgs, objs, boxes, None, gs.fake, None)
+                terms = {k: v.mean() for k, v in terms.items()}
+                if not tr.d_frozen:
+                    tr.discriminator.optimizer_d_obj.zero_grad(set_to_none=True)
+                    tr.dobj_buckets.begin()
+                    terms["total_obj_loss"].backward()
+                    tr.dobj_buckets.flush()
+                    if conc:
+                        tr.discriminator.optimizer_d_obj.step()
+                D.update({k: v.detach() for k, v in terms.items()})
         if dp and not tr.d_frozen:
             tr.d_buckets.finish()
             tr.discriminator.optimizer_d_img.step()
         if use_obj:
-            if not tr.d_frozen:
+            if not tr.d_frozen and not conc:
                 tr.dobj_buckets.finish()
                 tr.discriminator.optimizer_d_obj.step()
             tr.discriminator.obj_discriminator.release_index()
         if dp:
             tr.g_buckets.finish()
             tr.optimizer.step()
+        if conc:
+            main.wait_stream(self.side)                  # the next step (and the caller) see the updated parameters
         if mk:
             mk.mark("E3 object D step")
             mk.end()
