@@ -7,6 +7,7 @@ contributes the `.module` level of the checkpoint keys."""
 import torch
 import torch.nn as nn
 
+from .. import streams
 from ..spade.models import networks as spade_nets
 from ..spade.models.networks.sync_batchnorm import DataParallelWithCallback
 from .model import Sg2LayoutModel
@@ -33,12 +34,22 @@ class MetaGeneratorModel(nn.Module):
 
     def forward(self, objs, triplets, triplet_type, boxes_gt=None, masks_gt=None, test_mode=False):
         img = boxes_pred = masks_pred = None
+        side = None
         if self.has_graph:
-            boxes_pred, masks_pred = self.sg_to_layout(objs, triplets, triplet_type, boxes_gt)[1:]
+            # the generator below consumes the ground-truth boxes / masks (reference :47-49): when it does not need the
+            # encoder's outputs the encoder runs beside it on a stream of its own (canonicalsg2im_amd/streams.py)
+            independent = self.has_image and boxes_gt is not None and (masks_gt is not None or not self.args.get("mask_size"))
+            if independent and torch.is_grad_enabled() and streams.usable(objs):
+                with streams.beside("encoder", objs.device) as side:
+                    boxes_pred, masks_pred = self.sg_to_layout(objs, triplets, triplet_type, boxes_gt)[1:]
+            else:
+                boxes_pred, masks_pred = self.sg_to_layout(objs, triplets, triplet_type, boxes_gt)[1:]
         if self.has_image:
             # ground truth wins over the prediction wherever it is given (reference :47-49)
             img = self.layout_to_image_model(objs, boxes_gt if boxes_gt is not None else boxes_pred,
                                              masks_gt if masks_gt is not None else masks_pred, test_mode=test_mode)
+        if side is not None:
+            streams.join(side, boxes_pred, masks_pred)
         return img, boxes_pred, masks_pred
 
 

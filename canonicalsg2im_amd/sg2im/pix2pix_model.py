@@ -8,7 +8,7 @@ the (B,O,M,M) masks, cross-entropy on the crop logits — SURVEY.md §2.2 K12)."
 import torch
 import torch.nn.functional as F
 
-from .. import ops
+from .. import ops, streams
 from ..spade.models import networks
 from .losses import get_gan_losses
 
@@ -120,9 +120,18 @@ class Pix2PixModel(torch.nn.Module):
         if not opt.skip_graph_model:
             self._layout_terms(out, objs, boxes, boxes_pred, masks, masks_pred)
         if not opt.skip_generation:
-            out.update(self.generator_image_terms(imgs, objs, boxes, masks, imgs_pred))
-            if not opt.use_img_disc:
-                out.update(self.generator_object_terms(imgs_pred, objs, boxes, masks, masks_pred))
+            if not opt.use_img_disc and streams.usable(imgs_pred) and torch.is_grad_enabled():
+                # the object discriminator's passes (crops of the fresh image: a handful of small launches) beside the
+                # PatchGAN's (canonicalsg2im_amd/streams.py); dictionary order as in the sequential form
+                with streams.beside("object_d", imgs_pred.device) as side:
+                    obj_terms = self.generator_object_terms(imgs_pred, objs, boxes, masks, masks_pred)
+                out.update(self.generator_image_terms(imgs, objs, boxes, masks, imgs_pred))
+                streams.join(side, obj_terms)
+                out.update(obj_terms)
+            else:
+                out.update(self.generator_image_terms(imgs, objs, boxes, masks, imgs_pred))
+                if not opt.use_img_disc:
+                    out.update(self.generator_object_terms(imgs_pred, objs, boxes, masks, masks_pred))
         out['total_loss'] = _total(out, skip=("bbox_pred_all",))
         return out
 
@@ -158,8 +167,15 @@ class Pix2PixModel(torch.nn.Module):
     def compute_discriminator_loss(self, batch, model_out):
         imgs, objs, boxes, masks = batch[0], batch[1], batch[2], batch[6]
         fake_img = model_out[0].detach()
-        out = self.discriminator_image_terms(imgs, objs, boxes, masks, fake_img)
         if self.opt.use_img_disc:
+            return self.discriminator_image_terms(imgs, objs, boxes, masks, fake_img)
+        if streams.usable(fake_img) and torch.is_grad_enabled():
+            with streams.beside("object_d", fake_img.device) as side:
+                obj_terms = self.discriminator_object_terms(imgs, objs, boxes, masks, fake_img, model_out[2])
+            out = self.discriminator_image_terms(imgs, objs, boxes, masks, fake_img)
+            streams.join(side, obj_terms)
+            out.update(obj_terms)
             return out
+        out = self.discriminator_image_terms(imgs, objs, boxes, masks, fake_img)
         out.update(self.discriminator_object_terms(imgs, objs, boxes, masks, fake_img, model_out[2]))
         return out

@@ -286,3 +286,11 @@ def test_data_parallel_wrapper_refuses_several_devices_without_a_process_group()
     assert dp.module is lin and dp.device_ids == [0, 1, 2, 3]          # constructing is fine (checkpoint tools do it)
     with pytest.raises(RuntimeError, match="one process per GPU"):
         dp(x)
+
+
+def test_side_streams_are_a_no_op_off_the_gpu():
+    """canonicalsg2im_amd/streams.py only engages for HIP tensors outside a capture; on the CPU the modules take their plain
+    sequential path (there is no CPU product path, but module construction / host logic tests run here)."""
+    from canonicalsg2im_amd import streams
+    assert streams.usable(torch.zeros(2)) is False
+    assert streams.usable(None) is False
