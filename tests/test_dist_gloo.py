@@ -144,6 +144,31 @@ def _worker(rank, world, port, out):
     (net(x).pow(2).mean() + unused(x4).pow(2).mean()).backward()
     buckets.finish()
     assert buckets.rebuilds == 1
+    # the replayed-backward protocol (graphs.py with N > 1): begin(launch=False) arms the hooks in copy-only mode, a HIP-graph
+    # replay fills the slots without running a hook and reports its members with assume_fired(); flush() then issues every
+    # bucket's collective and finish() averages — here the "replay" is a plain write into the slots
+    for p in list(net.parameters()) + list(unused.parameters()):
+        p.grad = None
+    buckets.begin(launch=False)
+    net(x).pow(2).mean().backward()                           # (a capturing iteration: hooks copy, nothing is launched)
+    assert len(buckets._works) == 0
+    fired = buckets.fired_ids()
+    buckets.finish()
+    for p, g in zip(net.parameters(), averaged):
+        assert torch.equal(p.grad, g)
+    buckets.begin(launch=False)
+    for p in net.parameters():                                # the replay: slots rewritten in place, no hook runs
+        buckets.slot[id(p)][1].fill_(float(rank + 1))
+    buckets.assume_fired(fired)
+    buckets.finish()
+    for p in net.parameters():
+        assert torch.allclose(p.grad, torch.full_like(p.grad, 1.5)), "replayed slots must be exchanged, not zeroed"
+    assert unused.weight.grad is not None and float(unused.weight.grad.abs().max()) == 0.0    # member without a gradient: zeros
+    for p in list(net.parameters()) + list(unused.parameters()):      # (back to the real gradients for the checks below)
+        p.grad = None
+    buckets.begin()
+    net(x).pow(2).mean().backward()
+    buckets.finish()
     # a rank-local first step: rank 1's shard leaves the second Linear without a gradient BEFORE any bucket exists —
     # the union still puts it into the buckets of both ranks
     net2 = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
