@@ -26,7 +26,10 @@
 //     waves 4-7 each form E' = rows xi of G' dY G'^T for one (cout group, tile pair) — 16 raw reads, ~50 VALU, 18 stores.
 //     (Waves w and w + 4 share a SIMD: every SIMD carries one wave of either role.)
 //   * one stage later every wave runs its 18 MFMAs out of the operand buffer (one ds_read_b64 per operand: both tile
-//     pairs), one barrier per stage.
+//     pairs; a three-deep register ring fetched two positions ahead), one barrier per stage.  The two roles are template
+//     parameters of the loop (their own register allocations: 208 VGPRs, no scratch); a launch is ONE wave of blocks (256).
+//   * measured (tools/wgrad_bench.py, tools/wgrad_ablate.py): 1.2-1.4x over F(3x3,2x2) from 8 x 8 maps up; MFMA-only +
+//     transform-only = everything (the fp32 MFMA and the VALU of a SIMD share their lanes), matrix pipe 52 % busy.
 //   * the bias gradient is free: G' row 1 is (1,1,1,1), so E'[1][1] IS the sum of the dY tile.
 //   * epilogue: accumulators through LDS (two rounds of 36), every thread applies A^T (.) A with the scales of G folded in
 //     to its (cout, cin) pairs and writes the 3 x 3 taps of its slab; slabs are summed in order by k_slab_reduce
