@@ -120,6 +120,7 @@ SIGNATURES = {
     "csg_wino4_bwd_weight_workspace": (c_i64, [ctypes.POINTER(WinoDesc)]),
     "csg_wino4_bwd_weight": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_wino4_supported": (c_i32, [ctypes.POINTER(WinoDesc)]),
+    "csg_wino4_persistent": (c_i32, [c_i32]),
     "csg_wino4_pack_bytes": (c_i64, [c_i64, c_i64]),
     "csg_wino4_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
     "csg_wino4_conv_workspace": (c_i64, [ctypes.POINTER(WinoDesc)]),

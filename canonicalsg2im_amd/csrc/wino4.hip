@@ -78,10 +78,16 @@ typedef const volatile __attribute__((address_space(3))) csg_f32x2* w4_lds_cv2;
 // at the phase boundaries of the kernel; csg_wino4_trace_read copies them out.
 #ifdef W4_TRACE
 __device__ unsigned long long w4_trace[8192 * 8];
+__device__ unsigned long long w4_trace2[8192 * 8];   // per item (persistent) / per block: stage-level markers
 #define W4_T(i)                                                                                   \
   if (threadIdx.x == 0 && blockIdx.x < 8192) w4_trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();
+// persistent form: the same table indexed by ITEM (markers 0 item start | 3 main loop done | 6 epilogue done | 7 V[0] of the next item)
+#define W4_TI(i)                                                                                   \
+  if (threadIdx.x == 0 && (P ? v : (int)blockIdx.x) < 8192)                                        \
+    w4_trace2[(P ? v : (int)blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter();
 #else
 #define W4_T(i)
+#define W4_TI(i)
 #endif
 
 struct Wino4Params {
@@ -101,6 +107,7 @@ struct Wino4Params {
   int nstage;          // Cin / 8
   int ksplit, sps;     // input-channel stages cut into ksplit ranges of sps stages, one output slab each
   long long slab;      // floats per slab (B*H*W*y_cs)
+  int nitems;          // persistent kernel: (image, region, channel block) items of the launch
 };
 
 __device__ __forceinline__ int w4_xcd_remap(int bid, int nblk) {
@@ -213,21 +220,23 @@ __device__ __forceinline__ csg_f32x2 w4_pfma(float c, csg_f32x2 a, csg_f32x2 b) 
 // map being normalised, laid out like y), `gate` the gamma map an earlier launch of the same operand wrote (pixel stride
 // g_cs), mod_mean / mod_invstd the batch statistics per channel.  beta never reaches memory, and the separate apply pass
 // (x, gamma, beta read; y written) is gone.
-template <int MODE>
+// NB = output columns per round: 2 in the one-item kernel (exchange buffer over the whole staging area), 1 in the
+// persistent kernel (the exchange buffer must fit in the V buffers, the raw buffers hold the next item's first stages).
+template <int MODE, int NB>
 __device__ __forceinline__ void w4_store_columns(const Wino4Params& p, const float* rbuf, int tig, int round, int nt32,
                                                  int img, int X0, int Y0, const float* __restrict__ bias,
                                                  const float* __restrict__ res, const float* __restrict__ gate,
                                                  float* __restrict__ y) {
-  for (int item = tig; item < 512; item += W4_THREADS / 2) {  // 32 tiles x 8 channel quads x 2 columns
+  for (int item = tig; item < 256 * NB; item += W4_THREADS / 2) {  // 32 tiles x 8 channel quads x NB columns
     const int cq = item & 7, tile = (item >> 3) & 31, bb = item >> 8;
     const int n = nt32 * 32 + cq * 4;
     const int ttx = tile & (W4_TW - 1), tty = tile >> 3;
-    const int oy = Y0 + 4 * tty, ox = X0 + 4 * ttx + 2 * round + bb;
+    const int oy = Y0 + 4 * tty, ox = X0 + 4 * ttx + NB * round + bb;
     if (n < p.Cout && oy < p.Ho && ox < p.Wo) {    // Ho and Wo are multiples of 4: a tile is wholly inside or outside
       csg_f32x2 lo[6], hi[6];
 #pragma unroll
       for (int xi = 0; xi < 6; ++xi) {
-        const csg_f32x4 r = *(const csg_f32x4*)(rbuf + ((xi * 2 + bb) * 32 + tile) * W4_RSE + cq * 4);
+        const csg_f32x4 r = *(const csg_f32x4*)(rbuf + ((xi * NB + bb) * 32 + tile) * W4_RSE + cq * 4);
         lo[xi] = __builtin_shufflevector(r, r, 0, 1);
         hi[xi] = __builtin_shufflevector(r, r, 2, 3);
       }
@@ -305,53 +314,79 @@ __device__ __forceinline__ void w4_store_columns(const Wino4Params& p, const flo
   }
 }
 
-__device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[6], const Wino4Params& p, float* smem, int tid, int wave, int grp,
+template <int NB>
+__device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[6], const Wino4Params& p, float* rbase, int tid, int wave, int grp,
                                             int j, int h, int nt32, int img, int X0, int Y0, const float* __restrict__ bias,
                                             const float* __restrict__ res, const float* __restrict__ gate,
                                             float* __restrict__ y) {
-  // Per wave (row xi): R[b] = sum_nu M[xi][nu] A^T[b][nu]; then Y[a][b] = sum_xi A^T[a][xi] R_xi[b] through LDS, two
-  // output columns b per round: rbuf[xi][b & 1][32 tiles][W4_RSE]
-  float* rbuf = smem + grp * W4_RBUF;            // this channel group's exchange buffer
+  // Per wave (row xi): R[b] = sum_nu M[xi][nu] A^T[b][nu]; then Y[a][b] = sum_xi A^T[a][xi] R_xi[b] through LDS, NB
+  // output columns b per round: rbuf[xi][b % NB][32 tiles][W4_RSE]
+  float* rbuf = rbase + grp * (W4_RBUF / 2 * NB);   // this channel group's exchange buffer
   const int tig = tid - grp * (W4_THREADS / 2);  // thread index inside the channel group
   const bool plain = p.act == CSG_ACT_NONE && res == nullptr && gate == nullptr;
-  __syncthreads();                               // every wave is done reading the staging buffers
-  W4_T(3)
+  if (NB == 2) {
+    __syncthreads();                             // every wave is done reading the staging buffers
+    W4_T(3)
+  }
+  // NB = 1: all four columns are reduced over nu FIRST (64 registers in place of the 96 accumulators), so that the three
+  // store phases that follow a not-yet-written column do not have to carry the accumulators next to their own operands
+  csg_f32x2 rr[NB == 1 ? 4 : 1][8];
+  if (NB == 1) {
 #pragma unroll
-  for (int round = 0; round < 2; ++round) {
+    for (int ge = 0; ge < 8; ++ge) {
+#define W4_M(K) csg_f32x2{acc[K][2 * ge], acc[K][2 * ge + 1]}
+      const csg_f32x2 m0 = W4_M(0), m1 = W4_M(1), m2 = W4_M(2), m3 = W4_M(3), m4 = W4_M(4), m5 = W4_M(5);
+#undef W4_M
+      rr[0][ge] = ((m0 + m1) + (m2 + m3)) + m4;
+      rr[NB == 1 ? 1 : 0][ge] = w4_pfma(-2.0f, m4, w4_pfma(0.5f, m3, m1 - m2));
+      rr[NB == 1 ? 2 : 0][ge] = w4_pfma(4.0f, m4, w4_pfma(0.25f, m3, m1 + m2));
+      rr[NB == 1 ? 3 : 0][ge] = w4_pfma(-8.0f, m4, w4_pfma(0.125f, m3, m1 - m2)) + m5;
+    }
+    // pinned here: the compiler would otherwise sink the later columns into their rounds and keep the accumulators alive
+#pragma unroll
+    for (int b = 0; b < (NB == 1 ? 4 : 1); ++b)
+#pragma unroll
+      for (int ge = 0; ge < 8; ++ge) asm volatile("" : "+v"(rr[b][ge]));
+  }
+#pragma unroll
+  for (int round = 0; round < 4 / NB; ++round) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       csg_f32x2 r0[2], r1[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
+        if (NB == 1) {
+          r0[e] = rr[NB == 1 ? round : 0][2 * g + e];
+          continue;
+        }
 #define W4_M(K) csg_f32x2{acc[K][4 * g + 2 * e], acc[K][4 * g + 2 * e + 1]}
         const csg_f32x2 m0 = W4_M(0), m1 = W4_M(1), m2 = W4_M(2), m3 = W4_M(3), m4 = W4_M(4), m5 = W4_M(5);
 #undef W4_M
-        if (round == 0) {
-          r0[e] = ((m0 + m1) + (m2 + m3)) + m4;
-          r1[e] = w4_pfma(-2.0f, m4, w4_pfma(0.5f, m3, m1 - m2));
-        } else {
-          r0[e] = w4_pfma(4.0f, m4, w4_pfma(0.25f, m3, m1 + m2));
-          r1[e] = w4_pfma(-8.0f, m4, w4_pfma(0.125f, m3, m1 - m2)) + m5;
-        }
+        const int b0 = NB * round;               // first output column of this round
+        if (b0 == 0) r0[e] = ((m0 + m1) + (m2 + m3)) + m4;
+        if (b0 == 2) r0[e] = w4_pfma(4.0f, m4, w4_pfma(0.25f, m3, m1 + m2));
+        if (b0 == 0) r1[e] = w4_pfma(-2.0f, m4, w4_pfma(0.5f, m3, m1 - m2));
+        if (b0 == 2) r1[e] = w4_pfma(-8.0f, m4, w4_pfma(0.125f, m3, m1 - m2)) + m5;
       }
       const int ch = 8 * g + 4 * h;
-      *(float4*)(rbuf + ((wave * 2 + 0) * 32 + j) * W4_RSE + ch) = make_float4(r0[0].x, r0[0].y, r0[1].x, r0[1].y);
-      *(float4*)(rbuf + ((wave * 2 + 1) * 32 + j) * W4_RSE + ch) = make_float4(r1[0].x, r1[0].y, r1[1].x, r1[1].y);
+      *(float4*)(rbuf + ((wave * NB + 0) * 32 + j) * W4_RSE + ch) = make_float4(r0[0].x, r0[0].y, r0[1].x, r0[1].y);
+      if (NB == 2)
+        *(float4*)(rbuf + ((wave * NB + 1) * 32 + j) * W4_RSE + ch) = make_float4(r1[0].x, r1[0].y, r1[1].x, r1[1].y);
     }
     __syncthreads();
-    if (round == 0) { W4_T(4) }
+    if (NB == 2 && round == 0) { W4_T(4) }
     if (p.mod)
-      w4_store_columns<2>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
+      w4_store_columns<2, NB>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
     else if (plain)
-      w4_store_columns<0>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
+      w4_store_columns<0, NB>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
     else
-      w4_store_columns<1>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
-    if (round == 0) {
-      __syncthreads();                           // the exchange buffer is rewritten by round 1
-      W4_T(5)
+      w4_store_columns<1, NB>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
+    if (round + 1 < 4 / NB) {
+      __syncthreads();                           // the exchange buffer is rewritten by the next round
+      if (NB == 2) { W4_T(5) }
     }
   }
-  W4_T(6)
+  if (NB == 2) { W4_T(6) }
 }
 
 // ---- epilogue of F(3x3,4x4): A^T = [[1,1,1,1,1,0],[0,1,-1,1/2,-2,0],[0,1,1,1/4,4,1]] (the first three rows of the
@@ -483,7 +518,24 @@ struct W4Geo {
   static_assert((T * RS) % 64 == 0 && R * C * 2 <= W4_NLD * W4_THREADS && (C + T - 1) / T <= W4_CQ, "staging geometry");
 };
 #define W4V_RAW0 0
-template <int T>
+// the kernel-argument segment of k_wino4_conv_v as the persistent form reads it back in its epilogue
+struct W4KernArgs {
+  Wino4Params p;
+  const float* x;
+  const float4* up;
+  const float* bias;
+  const float* res;
+  const float* gate;
+  float* y;
+};
+typedef const __attribute__((address_space(4))) W4KernArgs* w4_kernargs_ptr;
+// P = persistent: 256 blocks (one per CU) walk the (region, channel block) items of their XCD's share, and the stream of
+// stages runs ACROSS items — the last two stages of an item store the first two stages of the next one (raw[0], raw[1]),
+// the third is in flight and the U ring already holds the next item's operands when the epilogue starts; the epilogue
+// exchanges one output column per round inside the V buffers.  What a one-item block pays outside its loop on a
+// Cin = 128 layer (profiles/r05p_conv_phase_trace.txt: 7.7k cycles until the first stage lands + 2.6k to prime, of
+// 121k) shrinks to the transform of the first stage.  Same arithmetic in the same order: bit-identical outputs.
+template <int T, bool P>
 __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, const float* __restrict__ x,
                                                                  const float4* __restrict__ up,
                                                                  const float* __restrict__ bias,
@@ -491,6 +543,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
                                                                  const float* __restrict__ gate, float* __restrict__ y) {
   typedef W4Geo<T> Geo;
   constexpr int W4_RS = Geo::RS, W4_BUFW = Geo::BUFW, W4V_V0 = Geo::V0, W4V_OFFTAB = Geo::OFFTAB;
+  static_assert(!P || T == 4, "the persistent form serves F(4x4,3x3)");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   W4_T(0)
@@ -498,49 +551,86 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   const int grp = wave12 >= 6 ? 1 : 0;           // consumer: channel group; producer: channel pairs 2 grp + {0, 1}
   const int wave = wave12 - 6 * grp;             // row xi of the transformed domain (both roles)
 
-  int bid = w4_xcd_remap(blockIdx.x, gridDim.x);
-  const int split = bid % p.ksplit;
-  bid /= p.ksplit;
-  const int nb = bid % p.nblocks;
-  bid /= p.nblocks;
-  const int bx = bid % p.tbx;
-  bid /= p.tbx;
-  const int by = bid % p.tby;
-  const int img = bid / p.tby;
-  const int X0 = bx * T * W4_TW, Y0 = by * T * W4_TH;
+  // items: (image, region row, region column, channel block[, input-channel range]); the channel block runs fastest, so
+  // the blocks of an XCD that run together read the same input region out of its L2
+  int nb, img, X0, Y0, split = 0;
+  auto decode = [&](int item) {
+    if (!P) {
+      split = item % p.ksplit;
+      item /= p.ksplit;
+    }
+    nb = item % p.nblocks;
+    item /= p.nblocks;
+    const int bx = item % p.tbx;
+    item /= p.tbx;
+    const int by = item % p.tby;
+    img = item / p.tby;
+    X0 = bx * T * W4_TW;
+    Y0 = by * T * W4_TH;
+  };
+  // persistent walk: XCD x (blockIdx & 7) owns the contiguous share [v_lo, v_hi) of the items, block idx of that XCD
+  // takes every (gridDim / 8)-th of them — at any time the 32 CUs of an XCD work on 32 consecutive items
+  int v = 0, v_hi = 0, v_step = 1;
+  if (P) {
+    const int q = p.nitems >> 3, r = p.nitems & 7, xcd = blockIdx.x & 7;
+    const int v_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    v_hi = v_lo + q + (xcd < r ? 1 : 0);
+    v_step = gridDim.x >> 3;
+    v = v_lo + (blockIdx.x >> 3);
+    if (v >= v_hi) return;
+    decode(v);
+  } else {
+    decode(w4_xcd_remap(blockIdx.x, gridDim.x));
+  }
 
   const csg_i32x4 rsX = csg_make_srd(x, (long long)p.B * p.H * p.W * p.x_cs * 4);
   const csg_i32x4 rsU = csg_make_srd(up, (long long)36 * p.NT32 * p.Q8 * 64 * 16);
 
-  // ---- staging plan (as k_wino4_conv: two 16-byte pieces per thread and stage, offsets parked in LDS)
-  unsigned* s_off = (unsigned*)(smem + W4V_OFFTAB) + tid * 4;
-  {
+  // ---- staging plan (as k_wino4_conv: two 16-byte pieces per thread and stage, offsets parked in LDS); the persistent
+  // kernel keeps two tables, this item's and the next one's (every thread reads its own entry only: no barrier)
+  unsigned* const s_tab = (unsigned*)(smem + W4V_OFFTAB) + tid * 4;
+  int tsel = 0;                                  // which of the two tables is this item's
+#define W4_TAB(k) (s_tab + (P ? (k) * (W4_THREADS * 4) : 0))
+  auto fill_plan = [&](unsigned* tab, bool valid) {
     unsigned goff[W4_NLD], loffp = 0;
+    // persistent: the thread index is recovered from the table address (one register less across the main loop) and made
+    // opaque, so that nothing of the plan is hoisted out of the item loop and kept
+    int tid_o = P ? (int)(s_tab - (unsigned*)(smem + W4V_OFFTAB)) >> 2 : tid;
+    if (P) asm volatile("" : "+v"(tid_o));
 #pragma unroll
     for (int i = 0; i < W4_NLD; ++i) {
-      const int e = tid + W4_THREADS * i;
+      const int e = tid_o + W4_THREADS * i;
       goff[i] = CSG_OOB_OFF;
-      int lo = (W4_BUFW - 16) / 4 + (tid & 3);
+      int lo = (W4_BUFW - 16) / 4 + (tid_o & 3);
       if (e < Geo::R * Geo::C * 2) {
         const int pix = e >> 1, c4 = e & 1;
         const int row = pix / Geo::C, col = pix - row * Geo::C;
         const int iy = Y0 + row - p.pad, ix = X0 + col - p.pad;
         lo = (row * W4_RS + ((col % T) * W4_CQ + (col / T)) * W4_PS + c4 * 4) / 4 + ((row / T) << 13);
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+        if (valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
           goff[i] = (unsigned)(((img * p.H + iy) * p.W + ix) * p.x_cs + c4 * 4) * 4u;
       }
       loffp |= (unsigned)lo << (16 * i);
     }
-    *(uint4*)s_off = make_uint4(goff[0], goff[1], loffp, 0u);
-  }
+    *(uint4*)tab = make_uint4(goff[0], goff[1], loffp, 0u);
+  };
+  fill_plan(W4_TAB(0), true);
+  const int s_begin = split * p.sps, s_end = min(p.nstage, s_begin + p.sps);
   csg_f32x4 st[W4_NLD];
-  auto load_stage = [&](int s) {                 // s past the end: finite garbage or zeros, never consumed
-    const uint2 go = *(const uint2*)s_off;
+  // one-item kernel: s past the end loads finite garbage or zeros, never consumed; persistent: the next item's stages
+  // (only stages 0 and 1: they are stored by this item's last two stages; stage 2 is fetched behind the epilogue)
+  // Every call issues its two loads, also the one whose data nobody stores (the last stage of an item: stage 2 of the
+  // next item again) — the wait counts in front of the MFMAs are only exact when the number of loads in flight is
+  // the same on every path.
+  auto load_stage = [&](int s) {
+    const bool over = P && s >= s_end;
+    const uint2 go = *(const uint2*)W4_TAB(over ? tsel ^ 1 : tsel);
+    if (over) s -= s_end;
     st[0] = csg_buf_load_x4(rsX, (int)go.x, s * (W4_PS * 4), 0);
     st[1] = csg_buf_load_x4(rsX, (int)go.y, s * (W4_PS * 4), 0);
   };
   auto store_stage = [&](float* base) {
-    const unsigned lp = s_off[2];
+    const unsigned lp = s_tab[2];
 #pragma unroll
     for (int i = 0; i < W4_NLD; ++i) {
       const unsigned lo = (i & 1) ? (lp >> 16) : (lp & 0xffffu);
@@ -555,27 +645,25 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   const int rb = wave == 0 ? 0 : 1;
   // producer: raw words of (row T ty + rb, column T tx, channel pair q = 2 grp + h); rows rb + i of the window sit in the
   // next row group (two more words of skew) from i = T - rb on
+  // (the offsets of the later rows are compile-time constants inside the per-xi copies of the transform: one base register)
   const float* p0 = smem + W4V_RAW0 + (T * ty + rb) * W4_RS + 2 * ty + tx * W4_PS + 4 * grp + 2 * h;
-  const float* p2 = p0 + 2 * W4_RS + (T == 3 ? 2 * rb : 0);
-  const float* p3 = p0 + 3 * W4_RS + (T == 3 ? 2 : 2 * rb);
   // producer: V words of (xi = wave, nu = 0, half h, tile j), channel pair slot grp;  consumer: the same row, float4
   float* pv = smem + W4V_V0 + (((wave * 6) * 2 + h) * 32 + j) * 4;
 
-  const int nt32 = nb * 2 + grp;
-  const int nt32u = nt32 + p.nt_off;             // tile of the packed operand (a launch may compute a slice of the outputs)
-  const unsigned uoff = nt32u < p.NT32 ? (unsigned)((((wave * 6) * p.NT32 + nt32u) * p.Q8) * 64 + lane) * 16u : CSG_OOB_OFF;
+  int nt32 = nb * 2 + grp;
+  // U operand of (position (xi = wave, nu), k-oct q, this wave's 32-channel tile): wave-uniform base in a scalar
+  // register, the lane's 16 bytes in a vector register (out of range when the tile lies beyond Cout)
+  auto u_tile = [&]() { return ((wave * 6) * p.NT32 + nt32 + p.nt_off) * p.Q8 * 1024; };
+  const unsigned ulane = nt32 + p.nt_off < p.NT32 || P ? (unsigned)lane * 16u : CSG_OOB_OFF;   // P: Cout % 64 == 0
+  int ubase = u_tile();
   const int ustride = p.NT32 * p.Q8 * 1024;
   csg_f32x4 ur[3];                               // ring: the operands of position nu are fetched three positions ahead
   auto load_ur = [&](int slot, int nu, int s) {
     const int qq = min(s, p.Q8 - 1);
-    ur[slot] = csg_buf_load_x4(rsU, (int)uoff, nu * ustride + qq * 1024, 0);
+    ur[slot] = csg_buf_load_x4(rsU, (int)ulane, ubase + nu * ustride + qq * 1024, 0);
   };
 
   f32x16 acc[6];
-#pragma unroll
-  for (int nu = 0; nu < 6; ++nu)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
 
   // V[xi = wave][0..5] of (tile j, channel pair 2 grp + h) out of raw buffer rbufsel, into V buffer vbufsel.  The row
   // combination is specialised per xi (a scalar switch around six copies of this code): rows 1..4 of B^T touch four
@@ -585,14 +673,16 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   //   xi = 3: (e3 - e1) + 2 (e2 - e0)        xi = 4: (e3 - e1) - 0.5 (e2 - e0)
   auto produce_xi = [&](auto xi_tag, int rbufsel, int vbufsel) {
     constexpr int XI = decltype(xi_tag)::value;
+    constexpr int RBC = XI == 0 ? 0 : 1;         // = rb of this wave
+    constexpr int O2 = 2 * W4_RS + (T == 3 ? 2 * RBC : 0), O3 = 3 * W4_RS + (T == 3 ? 2 : 2 * RBC);
     csg_f32x2 t[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const int co = rbufsel * W4_BUFW + ((c % T) * W4_CQ + (c / T)) * W4_PS;
       const csg_f32x2 e0 = *(w4_lds_cv2)(p0 + co);
       const csg_f32x2 e1 = *(w4_lds_cv2)(p0 + co + W4_RS);
-      const csg_f32x2 e2 = *(w4_lds_cv2)(p2 + co);
-      const csg_f32x2 e3 = *(w4_lds_cv2)(p3 + co);
+      const csg_f32x2 e2 = *(w4_lds_cv2)(p0 + co + O2);
+      const csg_f32x2 e3 = *(w4_lds_cv2)(p0 + co + O3);
       if (XI == 0 || XI == 5) {
         const csg_f32x2 e4 = *(w4_lds_cv2)(p0 + co + 4 * W4_RS + 2);
         t[c] = w4_pfma(1.5f, e3 - e1, w4_pfma(-2.0f, e2, e0 + e4));
@@ -616,9 +706,17 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       v[4] = w4_pfma(-0.5f, s31, s42);
       v[5] = w4_pfma(1.5f, s42, w4_pfma(-2.0f, t[3], t[1] + t[5]));
     }
+    // persistent: the write address is formed here from the read base (an opaque zero keeps it from being hoisted into a
+    // register of its own that lives across the whole item loop — the kernel sits at its register limit)
+    int goff2 = 2 * grp;
+    if (P) {
+      int z;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      goff2 += z;
+    }
 #pragma unroll
     for (int nu = 0; nu < 6; ++nu)
-      *(csg_f32x2*)(pv + vbufsel * W4_VBUF + nu * 256 + 2 * grp) = v[nu];
+      *(csg_f32x2*)(pv + vbufsel * W4_VBUF + nu * 256 + goff2) = v[nu];
   };
   auto produce = [&](int rbufsel, int vbufsel) {
     switch (wave) {
@@ -660,7 +758,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef W4_NO_PRODUCE
-    produce(par ^ 1, par ^ 1);                   // V[k+1] from raw[k+1]
+    if (s + 1 < s_end) produce(par ^ 1, par ^ 1);   // V[k+1] from raw[k+1]
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef W4_NO_MFMA
@@ -671,11 +769,10 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     load_stage(s + 3);
   };
 
-  const int s_begin = split * p.sps, s_end = min(p.nstage, s_begin + p.sps);
   y += (long long)split * p.slab;
   {
     // prologue: the first two stages travel together (one exposed memory latency instead of two)
-    const uint2 go = *(const uint2*)s_off;
+    const uint2 go = *(const uint2*)W4_TAB(0);
     const csg_f32x4 a0 = csg_buf_load_x4(rsX, (int)go.x, s_begin * (W4_PS * 4), 0);
     const csg_f32x4 a1 = csg_buf_load_x4(rsX, (int)go.y, s_begin * (W4_PS * 4), 0);
     load_stage(s_begin + 1);
@@ -695,21 +792,81 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     load_stage(s_begin + 2);
   }
   W4_T(2)
-  int s = s_begin;
-  for (; s + 1 < s_end; s += 2) {
-    stage(s, std::integral_constant<int, 0>());
-    stage(s + 1, std::integral_constant<int, 1>());
+  for (;;) {
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
+    bool more = false;
+    int item_n = 0;
+    W4_TI(0)
+    if (P) {
+      // the next item's plan: its first two stages enter the pipeline three stages before this item ends
+      const int item_c = v;
+      more = v + v_step < v_hi;
+      item_n = more ? v + v_step : v;
+      decode(item_n);
+      fill_plan(W4_TAB(tsel ^ 1), more);
+      decode(item_c);
+    }
+    int s = s_begin;
+    W4_TI(1)
+    for (; s + 1 < s_end; s += 2) {
+      stage(s, std::integral_constant<int, 0>());
+      stage(s + 1, std::integral_constant<int, 1>());
+#ifdef W4_TRACE
+      if (s == s_begin) { W4_TI(2) }
+      if (s + 4 == s_end) { W4_TI(4) }
+#endif
+    }
+    if (s < s_end) stage(s, std::integral_constant<int, 0>());
+    W4_TI(3)
+    if (T == 4 && P) {
+      // the epilogue's addresses and parameters are formed HERE, not kept across the main loop: the thread index goes
+      // through an opaque copy and the parameters are read back from the kernel-argument segment (scalar loads)
+      int tid_o = (int)(s_tab - (unsigned*)(smem + W4V_OFFTAB)) >> 2;
+      asm volatile("" : "+v"(tid_o));
+      w4_kernargs_ptr ka = (w4_kernargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ka));
+      Wino4Params pe = p;
+#define W4_F(f) pe.f = ka->p.f;
+      W4_F(Cout) W4_F(y_cs) W4_F(Ho) W4_F(Wo) W4_F(act) W4_F(slope) W4_F(gate_slope) W4_F(mod) W4_F(g_cs) W4_F(mod_slope)
+      W4_F(mod_mean) W4_F(mod_invstd)
+#undef W4_F
+      w4_epilogue<1>(acc, pe, smem + W4V_V0, tid_o, wave, grp, tid_o & 31, (tid_o >> 5) & 1, nt32, img, X0, Y0, ka->bias,
+                     ka->res, ka->gate, ka->y);
+    } else if (T == 4) {
+      w4_epilogue<2>(acc, p, smem, tid, wave, grp, j, h, nt32, img, X0, Y0, bias, res, gate, y);
+    } else {
+      w3_epilogue(acc, p, smem, tid, wave, grp, j, h, nt32, img, X0, Y0, bias, res, gate, y);
+    }
+    W4_TI(6)
+    if (!P || !more) break;
+    // the next item: raw[0] and raw[1] are in place; its U ring and its stage 2 travel while V[0] is formed
+    v = item_n;
+    decode(v);
+    nt32 = nb * 2 + grp;
+    ubase = u_tile();
+    tsel ^= 1;
+#pragma unroll
+    for (int nu = 0; nu < 3; ++nu) load_ur(nu, nu, 0);
+    load_stage(2);
+    __syncthreads();                             // the exchange buffer sat in the V buffers
+    produce(0, 0);
+    __syncthreads();
+#ifdef W4_TRACE
+    if (P && threadIdx.x == 0 && v - v_step < 8192 && v - v_step >= 0) w4_trace2[(v - v_step) * 8 + 7] = __builtin_readcyclecounter();
+#endif
   }
-  if (s < s_end) stage(s, std::integral_constant<int, 0>());
-  if (T == 4)
-    w4_epilogue(acc, p, smem, tid, wave, grp, j, h, nt32, img, X0, Y0, bias, res, gate, y);
-  else
-    w3_epilogue(acc, p, smem, tid, wave, grp, j, h, nt32, img, X0, Y0, bias, res, gate, y);
+#undef W4_TAB
 }
 
 #ifdef W4_TRACE
 extern "C" int csg_wino4_trace_read(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w4_trace), (size_t)n * 8);
+}
+extern "C" int csg_wino4_trace2_read(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w4_trace2), (size_t)n * 8);
 }
 #endif
 
@@ -745,30 +902,67 @@ static int w4_plan(const csg_wino_desc* d, int T, int pad, Wino4Params& p, size_
   p.ksplit = 1;
   p.sps = p.nstage;
   p.slab = (long long)d->B * Ho * Wo * d->y_cs;
+  p.nitems = 0;
   shm = (size_t)((T == 4 ? W4Geo<4>::OFFTAB : W4Geo<3>::OFFTAB) + W4_THREADS * 4) * 4;
   return CSG_OK;
 }
 
 // the launch shared by both tile sizes
-template <int T>
-static int w4_launch(Wino4Params& p, size_t shm, int kid, double flops, const float* x, const float* packed,
-                     const float* bias, const float* residual, const float* gate, float* y, float* workspace,
-                     float* y_final, hipStream_t s, const char* who) {
+template <int T, bool P>
+static int w4_set_lds_limit(const char* who) {
   static bool attr_set[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wino4_conv_v<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_wino4_conv_v<T, P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (P ? 160 : 128) * 1024);
     CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(e));
     attr_set[dev] = true;
   }
+  return CSG_OK;
+}
+
+// blocks of the persistent form: one per CU, a multiple of 8 (one share per XCD); 0 = the launch does not qualify.
+// CSG_WINO4_PERSIST=0 switches it off (A/B runs).
+static int w4_persist_on = -1;                     // -1: CSG_WINO4_PERSIST (default 1) decides at the first launch
+static int w4_persistent_blocks(const Wino4Params& p, int64_t items) {
+  static int cus[16] = {};
+  if (w4_persist_on < 0) w4_persist_on = getenv("CSG_WINO4_PERSIST") ? atoi(getenv("CSG_WINO4_PERSIST")) : 1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!w4_persist_on || dev < 0 || dev >= 16) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = -1;
+    cus[dev] = n;
+  }
+  const int g = cus[dev] > 0 ? (cus[dev] & ~7) : 0;
+  if (g == 0 || p.ksplit != 1 || (p.nstage & 1) || p.nstage < 4 || (p.Cout & 63) || items < 2 * (int64_t)g) return 0;
+#ifdef W4_TRACE
+  if (w4_persist_on == 2 && (items & 7) == 0) return (int)items;   // experiment: the persistent code, one item per block
+#endif
+  return g;
+}
+
+template <int T>
+static int w4_launch(Wino4Params& p, size_t shm, int kid, double flops, const float* x, const float* packed,
+                     const float* bias, const float* residual, const float* gate, float* y, float* workspace,
+                     float* y_final, hipStream_t s, const char* who) {
   CSG_REQUIRE(shm <= 128 * 1024, CSG_E_UNSUPPORTED, "%s: %zu bytes of LDS", who, shm);
   const int64_t grid = (int64_t)p.B * p.tby * p.tbx * p.nblocks * p.ksplit;
   CSG_REQUIRE(grid < (1ll << 31), CSG_E_UNSUPPORTED, "%s: grid too large", who);
+  p.nitems = (int)grid;
+  const int pblocks = T == 4 ? w4_persistent_blocks(p, grid) : 0;
+  int rc = pblocks ? w4_set_lds_limit<4, true>(who) : w4_set_lds_limit<T, false>(who);
+  if (rc) return rc;
   ProfScope ps(kid, flops, s);
-  CSG_LAUNCH(k_wino4_conv_v<T>, dim3((unsigned)grid), dim3(W4_THREADS), shm, s, p, x, (const float4*)packed, bias, residual,
-             gate, y);
-  int rc = check_launch(who);
+  if (pblocks)
+    CSG_LAUNCH((k_wino4_conv_v<4, true>), dim3((unsigned)pblocks), dim3(W4_THREADS), shm + W4_THREADS * 16, s, p, x,
+               (const float4*)packed, bias, residual, gate, y);
+  else
+    CSG_LAUNCH((k_wino4_conv_v<T, false>), dim3((unsigned)grid), dim3(W4_THREADS), shm, s, p, x, (const float4*)packed, bias,
+               residual, gate, y);
+  rc = check_launch(who);
   if (rc == CSG_OK && p.ksplit > 1) {
     launch_slab_reduce(workspace, p.slab, y_final, nullptr, 0, nullptr, p.ksplit, s);
     rc = check_launch("csg_wino4_conv(slab sum)");
@@ -794,6 +988,12 @@ int32_t csg_wino4_supported(const csg_wino_desc* d) {
   static const int on = getenv("CSG_WINO4") ? atoi(getenv("CSG_WINO4")) : 1;
   if (!on || d == nullptr) return 0;
   return (d->H % 4 == 0 && d->W % 4 == 0 && d->W >= 32 && d->H >= 16 && d->Cin % 8 == 0 && d->Cout % 4 == 0) ? 1 : 0;
+}
+
+int32_t csg_wino4_persistent(int32_t on) {
+  const int prev = w4_persist_on;
+  if (on >= 0) w4_persist_on = on != 0;
+  return prev;
 }
 
 int64_t csg_wino4_pack_bytes(int64_t N, int64_t K) {

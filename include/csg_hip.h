@@ -258,6 +258,12 @@ int csg_wino4_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy
  * epilogue as csg_wino_conv; the packed operand has 36 positions (csg_wino4_pack_bytes / csg_wino4_pack_weights, same
  * arguments as the F(2x2,3x3) pack).  csg_wino4_supported(d) = 1 when a layer is served (0 also when CSG_WINO4=0).   */
 int32_t csg_wino4_supported(const csg_wino_desc* d);
+/* Launches with at least two (region, 64-channel block) items per CU, an even number of 8-channel stages (>= 4) and
+ * Cout a multiple of 64 run as ONE block per CU that walks its items with the stage pipeline carried across them
+ * (bit-identical outputs).  csg_wino4_persistent(0 | 1) switches that form off / on for the process
+ * and returns the previous setting (-1 = not yet decided: CSG_WINO4_PERSIST, default 1); a negative argument only
+ * queries.  For A/B measurements and the parity tests — not needed in normal use.                                    */
+int32_t csg_wino4_persistent(int32_t on);
 int64_t csg_wino4_pack_bytes(int64_t N, int64_t K);
 int csg_wino4_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int64_t Cout, int64_t Cin,
                            int32_t backward_data, const float* sigma, float* packed, void* stream);

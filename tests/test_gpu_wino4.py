@@ -155,6 +155,88 @@ def test_wino4_split_over_input_channels(ops, shape):
     assert lib.csg_wino4_conv_workspace(d) == 0                  # with an epilogue the plan never splits
 
 
+def _both_forms(fn):
+    """fn() with the persistent form of k_wino4_conv_v switched on, then off (csg_wino4_persistent)."""
+    from canonicalsg2im_amd._lib import lib
+    prev = lib.csg_wino4_persistent(1)
+    try:
+        a = fn()
+        lib.csg_wino4_persistent(0)
+        b = fn()
+    finally:
+        lib.csg_wino4_persistent(prev if prev >= 0 else 1)
+    return a, b
+
+
+# at least two (region, 64-channel block) items per CU (>= 512 on 256 CUs), an even stage count, Cout % 64 == 0
+PERSISTENT_SHAPES = [
+    (2, 32, 512, 128, 128),     # 4 stages: the shortest pipeline the persistent form takes (mlp_shared-like)
+    (3, 128, 256, 112, 96),     # the SPADE gamma/beta shape; 7 x 3 regions per image: 252 items per XCD share, ragged walk
+    (1, 64, 64, 272, 512),      # one channel block per region
+]
+
+
+@pytest.mark.parametrize("shape", PERSISTENT_SHAPES)
+def test_wino4_persistent_form_is_bit_identical(ops, shape):
+    """One block per CU walking its items with the stage pipeline carried across them (wino4.hip, k_wino4_conv_v<4, true>)
+    against one block per item: same arithmetic in the same order — equal bits — and both inside the fp64 gate."""
+    B, Cin, Cout, H, W = shape
+    x, w, b = _data(shape, relu_in=Cin == 128)
+    ref64 = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    yp, y1 = _both_forms(lambda: _raw_wino4(ops, x, w, b))
+    assert torch.equal(yp, y1), "persistent vs one-item %s: max diff %.3e" % (shape, float((yp - y1).abs().max()))
+    assert _err(yp, ref64) < GATE
+    yp2, _ = _both_forms(lambda: _raw_wino4(ops, x, w, b))
+    assert torch.equal(yp, yp2)                                  # and from run to run
+
+
+def test_wino4_persistent_form_epilogues(ops):
+    """Activation / residual / gate epilogues and the SPADE modulation (csg_wino4_conv_part: gamma half, then the beta
+    half writing leaky(xhat (1 + gamma) + beta)) through the persistent form, bit-identical to the one-item form."""
+    from canonicalsg2im_amd._lib import check, lib, ptr, stream
+    shape = (2, 32, 256, 128, 128)
+    B, Cin, Cout, H, W = shape
+    x, w, b = _data(shape)
+    g = torch.Generator().manual_seed(5)
+    r = torch.randn(B, Cout, H, W, generator=g)
+    gt = torch.randn(B, Cout, H, W, generator=g)
+    pre = F.conv2d(x, w, b, padding=1)
+    for name, kw, want in (
+            ("leaky", dict(bias=b, act=ops.ACT_LEAKY, slope=0.2), F.leaky_relu(pre, 0.2)),
+            ("tanh", dict(bias=b, act=ops.ACT_TANH), torch.tanh(pre)),
+            ("residual", dict(bias=b, res=r), pre + r),
+            ("gate", dict(gate=gt, gate_slope=0.2),
+             F.conv2d(x, w, None, padding=1) * torch.where(gt > 0, torch.ones_like(gt), torch.full_like(gt, 0.2)))):
+        yp, y1 = _both_forms(lambda: _raw_wino4(ops, x, w, **kw))
+        assert torch.equal(yp, y1), name
+        assert_close(yp, want, 1e-4, 2e-5, "persistent %s epilogue" % name)
+
+    # the modulation: w holds gamma || beta (2 C output channels), C = 128
+    C = Cout // 2
+    xm = torch.randn(B, C, H, W, generator=g) * 2.0 + 0.5
+    mean = xm.mean(dim=(0, 2, 3))
+    invstd = 1.0 / torch.sqrt(xm.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    xd, xmd = ops.nhwc(x.cuda()), ops.nhwc(xm.cuda())
+    up = ops.wino_pack(w.cuda(), False, None, 4)
+    bd, md, rd = b.cuda(), mean.cuda(), invstd.cuda()
+
+    def modulated():
+        gbuf = ops.empty_nhwc(B, C, H, W, xd.device)
+        y = ops.empty_nhwc(B, C, H, W, xd.device)
+        d = _desc(B, H, W, Cin, C)
+        check(lib.csg_wino4_conv_part(d, ptr(xd), ptr(up), 0, 2 * C // 32, ptr(bd), None, None, 0, None, None, 1.0, ptr(gbuf),
+                                      stream()), "gamma half")
+        check(lib.csg_wino4_conv_part(d, ptr(xd), ptr(up), C // 32, 2 * C // 32, ptr(bd[C:]), ptr(xmd), ptr(gbuf), C, ptr(md),
+                                      ptr(rd), 0.2, ptr(y), stream()), "beta half")
+        return y
+
+    yp, y1 = _both_forms(modulated)
+    assert torch.equal(yp, y1)
+    xhat = (xm - mean[None, :, None, None]) * invstd[None, :, None, None]
+    want = F.leaky_relu(xhat * (1 + pre[:, :C]) + pre[:, C:], 0.2)
+    assert_close(yp, want, 1e-4, 5e-5, "persistent modulation epilogue")
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 256, 32, 64), (1, 64, 64, 64, 32)])
 def test_wino4_backward_data_through_autograd(ops, shape):
     """conv2d on a >= 32-wide map: forward and backward-data both run F(4x4,3x3) (the weight gradient stays on

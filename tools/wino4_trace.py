@@ -66,6 +66,24 @@ for lo, hi, tag in ((0, min(256, n), "first wave of blocks"), (min(256, n), n, "
         dlt = (tt[:, 6] - tt[:, 0]) if i == 6 else (tt[:, i + 1] - tt[:, i])
         print("  %-28s median %8.0f cycles   p10 %8.0f   p90 %8.0f" % (nm, np.median(dlt), np.percentile(dlt, 10),
                                                                       np.percentile(dlt, 90)))
+buf2 = (ctypes.c_ulonglong * (n * 8))()
+assert raw.csg_wino4_trace2_read(buf2, n * 8) == 0
+t2 = np.frombuffer(buf2, dtype=np.uint64).reshape(n, 8).astype(np.int64)
+persistent = bool((t2[:, 7] > 0).any())
+# stage-level markers per ITEM (persistent form) or per block: 0 top | 1 main loop starts | 2 stages 0, 1 done | 4 all but the
+# last two stages done | 3 main loop done | 6 epilogue done | 7 (persistent) V[0] of the next item formed
+tt = t2[(t2[:, 7] > 0) if persistent else (t2[:, 3] > 0)]
+if len(tt) == 0:
+    tt = t2[t2[:, 3] > 0]
+    persistent = False
+print("%s, %d rows:" % ("persistent form, items with a successor" if persistent else "one block per item", len(tt)))
+rows = [("0-1 zero (+ next plan)", tt[:, 1] - tt[:, 0]), ("1-2 stages 0, 1", tt[:, 2] - tt[:, 1]),
+        ("2-4 middle stages", tt[:, 4] - tt[:, 2]), ("4-3 last two stages", tt[:, 3] - tt[:, 4]),
+        ("0-3 plan + main loop", tt[:, 3] - tt[:, 0])]
+if persistent:
+    rows += [("3-6 epilogue", tt[:, 6] - tt[:, 3]), ("6-7 next ring + V[0]", tt[:, 7] - tt[:, 6]), ("0-7 whole item", tt[:, 7] - tt[:, 0])]
+for nm, dlt in rows:
+    print("  %-28s median %8.0f cycles   p10 %8.0f   p90 %8.0f" % (nm, np.median(dlt), np.percentile(dlt, 10), np.percentile(dlt, 90)))
 span = (t[:, 6].max() - t[:, 0].min())
 print("span first entry -> last exit (traced blocks): %d cycles; kernel %.3f ms => %.0f MHz if they cover the launch" %
       (span, e0.elapsed_time(e1), span / e0.elapsed_time(e1) / 1e3))
