@@ -619,9 +619,8 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   csg_f32x4 st[W4_NLD];
   // one-item kernel: s past the end loads finite garbage or zeros, never consumed; persistent: the next item's stages
   // (only stages 0 and 1: they are stored by this item's last two stages; stage 2 is fetched behind the epilogue)
-  // Every call issues its two loads, also the one whose data nobody stores (the last stage of an item: stage 2 of the
-  // next item again) — the wait counts in front of the MFMAs are only exact when the number of loads in flight is
-  // the same on every path.
+  // Every call issues its two loads (the last stage of an item: stage 2 of the next one, carried across the epilogue):
+  // the wait counts in front of the MFMAs are only exact when the number of loads in flight is the same on every path.
   auto load_stage = [&](int s) {
     const bool over = P && s >= s_end;
     const uint2 go = *(const uint2*)W4_TAB(over ? tsel ^ 1 : tsel);
@@ -655,12 +654,13 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   // register, the lane's 16 bytes in a vector register (out of range when the tile lies beyond Cout)
   auto u_tile = [&]() { return ((wave * 6) * p.NT32 + nt32 + p.nt_off) * p.Q8 * 1024; };
   const unsigned ulane = nt32 + p.nt_off < p.NT32 || P ? (unsigned)lane * 16u : CSG_OOB_OFF;   // P: Cout % 64 == 0
-  int ubase = u_tile();
+  int ubase = u_tile(), ubase_nxt = ubase;
   const int ustride = p.NT32 * p.Q8 * 1024;
   csg_f32x4 ur[3];                               // ring: the operands of position nu are fetched three positions ahead
-  auto load_ur = [&](int slot, int nu, int s) {
-    const int qq = min(s, p.Q8 - 1);
-    ur[slot] = csg_buf_load_x4(rsU, (int)ulane, ubase + nu * ustride + qq * 1024, 0);
+  auto load_ur = [&](int slot, int nu, int s) {  // persistent, s past the end: the first k-oct of the next item
+    const bool over = P && s >= s_end;
+    const int qq = over ? 0 : min(s, p.Q8 - 1);
+    ur[slot] = csg_buf_load_x4(rsU, (int)ulane, (over ? ubase_nxt : ubase) + nu * ustride + qq * 1024, 0);
   };
 
   f32x16 acc[6];
@@ -807,7 +807,10 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       item_n = more ? v + v_step : v;
       decode(item_n);
       fill_plan(W4_TAB(tsel ^ 1), more);
+      nt32 = nb * 2 + grp;
+      ubase_nxt = u_tile();
       decode(item_c);
+      nt32 = nb * 2 + grp;
     }
     int s = s_begin;
     W4_TI(1)
@@ -842,15 +845,12 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     }
     W4_TI(6)
     if (!P || !more) break;
-    // the next item: raw[0] and raw[1] are in place; its U ring and its stage 2 travel while V[0] is formed
+    // the next item: raw[0] and raw[1] are in place, its U ring is loaded and its stage 2 in flight (the last stage's loads)
     v = item_n;
     decode(v);
     nt32 = nb * 2 + grp;
-    ubase = u_tile();
+    ubase = ubase_nxt;
     tsel ^= 1;
-#pragma unroll
-    for (int nu = 0; nu < 3; ++nu) load_ur(nu, nu, 0);
-    load_stage(2);
     __syncthreads();                             // the exchange buffer sat in the V buffers
     produce(0, 0);
     __syncthreads();
