@@ -549,8 +549,12 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if args.config == "C3" and H == 256 and args.batch == 16 and not args.use_img_disc and not args.vgg_loss:
-                key = {"wino4_conv": "k_wino4_conv_v<4>", "wino_conv": "k_wino_conv2<16, 2>"}.get(dom, "k_igemm_fwd<128>")
-                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+                # every instantiation of the dominant kernel (k_wino4_conv_v<4, true | false>: the persistent form and the
+                # one-block-per-item form), weighted by the launches profiled
+                key = {"wino4_conv": "k_wino4_conv_v<4", "wino_conv": "k_wino_conv2<16, 2>"}.get(dom, "k_igemm_fwd<128")
+                hits = [v for k, v in pmc["kernels"].items() if k.startswith(key)]
+                traffic = int(round(sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in hits) /
+                                    sum(v["launches_profiled"] for v in hits)))
         except (OSError, KeyError, ValueError):
             pass
         if n:
@@ -569,7 +573,7 @@ def main():
                 peak_clock_note="peak = 256 CUs x 256 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md); under this load the shader "
                                 "clock reads ~2.0 GHz (s_memtime vs wall clock, DESIGN.md 4.1b), where the same product is 131 TFLOP/s",
                 traffic=traffic,
-                traffic_source="profiles/pmc_traffic.json = profiles/r05k_pmc_traffic.json (builder-run capture, not observed "
+                traffic_source="profiles/pmc_traffic.json = " + str(pmc.get("capture", "the builder's last PMC capture")) + " (builder-run capture, not observed "
                                "by this run)" if traffic is not None else None,
                 traffic_note="HBM bytes per launch (read x2-corrected FETCH_SIZE + WRITE_SIZE, two rocprofv3 --pmc passes "
                              "of this workload taken by the builder and committed as profiles/pmc_traffic.json: a constant "

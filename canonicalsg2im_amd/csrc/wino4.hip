@@ -800,16 +800,18 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     bool more = false;
     int item_n = 0;
     W4_TI(0)
+    int nb_n = nb, img_n = img, X0_n = X0, Y0_n = Y0;
     if (P) {
       // the next item's plan: its first two stages enter the pipeline three stages before this item ends
-      const int item_c = v;
+      const int nb_c = nb, img_c = img, X0_c = X0, Y0_c = Y0;
       more = v + v_step < v_hi;
       item_n = more ? v + v_step : v;
-      decode(item_n);
+      if (more) decode(item_n);
       fill_plan(W4_TAB(tsel ^ 1), more);
       nt32 = nb * 2 + grp;
       ubase_nxt = u_tile();
-      decode(item_c);
+      nb_n = nb; img_n = img; X0_n = X0; Y0_n = Y0;
+      nb = nb_c; img = img_c; X0 = X0_c; Y0 = Y0_c;
       nt32 = nb * 2 + grp;
     }
     int s = s_begin;
@@ -847,7 +849,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     if (!P || !more) break;
     // the next item: raw[0] and raw[1] are in place, its U ring is loaded and its stage 2 in flight (the last stage's loads)
     v = item_n;
-    decode(v);
+    nb = nb_n; img = img_n; X0 = X0_n; Y0 = Y0_n;
     nt32 = nb * 2 + grp;
     ubase = ubase_nxt;
     tsel ^= 1;

@@ -32,7 +32,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" 
   > /dev/null 2> "$O/p_err3.txt"
 first_csv "$O/pmc_fetch" '*counter_collection.csv' > /dev/null
 first_csv "$O/pmc_write" '*counter_collection.csv' > /dev/null
-python3 tools/pmc_traffic.py "$O/pmc_fetch" "$O/pmc_write" > "$O/${TAG}_pmc_traffic.json.tmp"
+python3 tools/pmc_traffic.py "$O/pmc_fetch" "$O/pmc_write" "$TAG" > "$O/${TAG}_pmc_traffic.json.tmp"
 mv "$O/${TAG}_pmc_traffic.json.tmp" "$O/${TAG}_pmc_traffic.json"
 rm -rf "$O/pmc_fetch" "$O/pmc_write"
 
@@ -49,6 +49,7 @@ python3 bench.py --config C5 --batch 6 --no_cpu_baseline --no_vgg_variant \
   > "$O/${TAG}_bench_C5_dense_graphs.json" 2> /dev/null
 python3 tools/conv_shapes.py > "$O/${TAG}_conv_shapes.txt" 2> /dev/null
 python3 tools/wgrad_bench.py > "$O/${TAG}_wgrad_bench.txt" 2> /dev/null
+python3 tools/wino4_ab.py 2> /dev/null | grep -v amdgpu > "$O/${TAG}_wino4_ab.txt" || true
 python3 tools/wgrad_ablate.py 2> /dev/null | grep -v amdgpu > "$O/${TAG}_wgrad_ablate.txt" || true
 python3 tools/graph_timing.py C4 2> /dev/null | grep '^C4' > "$O/${TAG}_graph_timing_C4.txt" || true
 

@@ -38,7 +38,8 @@ def main():
         wr = write[k] * 1024.0 / max(nw[k], 1)
         out[k] = {"launches_profiled": nf[k], "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "hbm_bytes_per_launch": round(rd + wr)}
-    print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per the gfx950 "
+    tag = sys.argv[3] if len(sys.argv) > 3 else None
+    print(json.dumps({"capture": ("profiles/%s_pmc_traffic.json" % tag) if tag else "untagged capture", "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per the gfx950 "
                                 "note of MI355X_MICROARCH.md; command: bench.py --steps 2 --warmup 1 --no_cpu_baseline "
                                 "--no_gen_metric --no_prof", "kernels": out}, indent=1))
 
