@@ -87,6 +87,8 @@ SIGNATURES = {
                                     c_p, c_p, c_p, c_p]),
     "csg_layout_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64,
                                c_i64, c_p]),
+    "csg_disc_input_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_i64,
+                                   c_i64, c_p, c_i64, c_p]),
     "csg_layout_bwd_workspace": (c_i64, [c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32]),
     "csg_layout_bwd": (c_i32, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                c_i64, c_p, c_i32, c_p, c_p, c_p, c_i64, c_p]),

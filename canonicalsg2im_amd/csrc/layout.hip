@@ -120,11 +120,24 @@ __device__ __forceinline__ void mask_weight_grad(const float* __restrict__ mk, i
 #define LAY_PXC 256  // max pixels per block chunk
 #define LAY_EPT 8    // float4 elements per thread
 
+// The image discriminator's input cat([img, layout]) (discriminator.py:120) in one pass: with `img` set, the thread that
+// owns channel quad 0 of a pixel also writes the channels behind the layout — [img(3) | zeros] up to the pixel stride.
+struct LayTail {
+  const float* img;        // (B,3,H,W) with element strides sb, sc, sh, sw; nullptr: no tail
+  long long sb, sc, sh, sw;
+  int nquads;              // float4 quads per pixel behind the S layout channels (out_cs - S) / 4
+};
+__device__ __forceinline__ void lay_write_tail(const LayTail& t, float* px, int S, int b, int y, int x) {
+  const float* ip = t.img + b * t.sb + y * t.sh + x * t.sw;
+  *(float4*)(px + S) = make_float4(ip[0], ip[t.sc], ip[2 * t.sc], 0.f);
+  for (int q = 1; q < t.nquads; ++q) *(float4*)(px + S + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ vecs, const float* __restrict__ boxes,
                                                      const uint8_t* __restrict__ valid,
                                                      const float* __restrict__ masks, int M, int O, int S, int H,
                                                      int W, int OH, int OW, int pxc, float* __restrict__ out,
-                                                     int out_cs, int out_off) {
+                                                     int out_cs, int out_off, LayTail tail) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_wx = sm;                       // [LAY_OB][pxc]
   float* s_vec = sm + LAY_OB * pxc;       // [LAY_OB][S]
@@ -270,7 +283,10 @@ __global__ __launch_bounds__(256) void k_layout_fwd(const float* __restrict__ ve
   float* orow = out + ((int64_t)(b * OH + y) * OW + x0) * out_cs + out_off;
 #pragma unroll
   for (int i = 0; i < LAY_EPT; ++i) {
-    if (blocked ? ex[i] < npx : tid + 256 * i < nel) *(float4*)&orow[(int64_t)ex[i] * out_cs + eq[i] * 4] = acc[i];
+    if (blocked ? ex[i] < npx : tid + 256 * i < nel) {
+      *(float4*)&orow[(int64_t)ex[i] * out_cs + eq[i] * 4] = acc[i];
+      if (tail.img != nullptr && eq[i] == 0) lay_write_tail(tail, orow + (int64_t)ex[i] * out_cs, S, b, y, x0 + ex[i]);
+    }
   }
 }
 
@@ -283,7 +299,7 @@ template <int ROWS>
 __global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict__ vecs, const float* __restrict__ boxes,
                                                           const uint8_t* __restrict__ valid, int O, int S, int H, int W,
                                                           int OH, int OW, int pxc, float* __restrict__ out, int out_cs,
-                                                          int out_off) {
+                                                          int out_off, LayTail tail) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_wx = sm;                         // [LAY_OB][pxc]
   float* s_vec = sm + LAY_OB * pxc;         // [LAY_OB][S]
@@ -388,7 +404,10 @@ __global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict
     float* orow = out + ((int64_t)(b * OH + y0 + r) * OW + x0) * out_cs + out_off;
 #pragma unroll
     for (int i = 0; i < LAY_EPT; ++i)
-      if (px0 + i < npx) *(float4*)&orow[(int64_t)(px0 + i) * out_cs + q4] = acc[r][i];
+      if (px0 + i < npx) {
+        *(float4*)&orow[(int64_t)(px0 + i) * out_cs + q4] = acc[r][i];
+        if (tail.img != nullptr && q4 == 0) lay_write_tail(tail, orow + (int64_t)(px0 + i) * out_cs, S, b, y0 + r, x0 + px0 + i);
+      }
   }
 }
 
@@ -897,9 +916,30 @@ int csg_layout_paint(const float* vecs, const float* boxes, const float* masks, 
   return check_launch("csg_layout_paint");
 }
 
+static int layout_fwd_launch(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M,
+                             int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* out,
+                             int64_t out_cs, int64_t out_off, const LayTail& tail, void* stream);
+
 int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M,
                    int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* out,
                    int64_t out_cs, int64_t out_off, void* stream) {
+  const LayTail none = {nullptr, 0, 0, 0, 0, 0};
+  return layout_fwd_launch(vecs, boxes, valid, masks, M, B, O, S, H, W, OH, OW, out, out_cs, out_off, none, stream);
+}
+
+int csg_disc_input_fwd(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M, int64_t B,
+                       int64_t O, int64_t S, int64_t H, int64_t W, const float* img, int64_t img_sb, int64_t img_sc,
+                       int64_t img_sh, int64_t img_sw, float* out, int64_t out_cs, void* stream) {
+  CSG_REQUIRE(img != nullptr && out_cs >= S + 4 && out_cs % 4 == 0, CSG_E_BADSHAPE,
+              "csg_disc_input_fwd: needs an image and a pixel stride of at least S + 4 = %ld floats (got %ld)", (long)(S + 4),
+              (long)out_cs);
+  const LayTail tail = {img, (long long)img_sb, (long long)img_sc, (long long)img_sh, (long long)img_sw, (int)((out_cs - S) / 4)};
+  return layout_fwd_launch(vecs, boxes, valid, masks, M, B, O, S, H, W, H, W, out, out_cs, 0, tail, stream);
+}
+
+static int layout_fwd_launch(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M,
+                             int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* out,
+                             int64_t out_cs, int64_t out_off, const LayTail& tail, void* stream) {
   CSG_REQUIRE(masks == nullptr || (M >= 1 && M <= 1024), CSG_E_BADSHAPE, "csg_layout_fwd: bad mask size %ld", (long)M);
   CSG_REQUIRE(B > 0 && O >= 0 && S > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, CSG_E_BADSHAPE,
               "csg_layout_fwd: bad shape");
@@ -921,12 +961,12 @@ int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, 
     const size_t shm4 = (size_t)(LAY_OB * pxc + LAY_OB * S) * 4 + (size_t)LAY_CULL * ROWS * 4 + (size_t)LAY_CULL * 4 + 16;
     dim3 grid4((unsigned)cdiv(OW, pxc), (unsigned)cdiv(OH, ROWS), (unsigned)B);
     CSG_LAUNCH(k_layout_fwd_rows<ROWS>, grid4, dim3(256), shm4, s, vecs, boxes, valid, (int)O, (int)S, (int)H, (int)W,
-                       (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off);
+                       (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off, tail);
     return check_launch("csg_layout_fwd");
   }
   dim3 grid((unsigned)cdiv(OW, pxc), (unsigned)OH, (unsigned)B);
   CSG_LAUNCH(k_layout_fwd, grid, dim3(256), shm, s, vecs, boxes, valid, masks, (int)M, (int)O, (int)S, (int)H,
-                     (int)W, (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off);
+                     (int)W, (int)OH, (int)OW, pxc, out, (int)out_cs, (int)out_off, tail);
   return check_launch("csg_layout_fwd");
 }
 

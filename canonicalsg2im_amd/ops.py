@@ -1576,13 +1576,13 @@ class _DiscInput(torch.autograd.Function):
         masks, M = _prep_masks(masks)
         B, O, S = vecs.shape
         Ct = (S + 3 + 3) // 4 * 4
-        # the layout kernel writes channels [0, S) of every pixel; only the image and the pad channels are filled here
+        # one pass writes every channel of every pixel: the layout, the image behind it, the zero pad
         buf = torch.empty((B, H, H, Ct), device=vecs.device, dtype=torch.float32)
-        buf[..., S:S + 3] = img.permute(0, 2, 3, 1)
-        if Ct > S + 3:
-            buf[..., S + 3:] = 0.0
-        check(lib.csg_layout_fwd(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, H, H, ptr(buf), Ct, 0,
-                                 stream()), "layout_fwd")
+        if tuple(img.shape) != (B, 3, H, H):
+            raise RuntimeError("disc_input: image %s does not fit (B=%d, 3, %d, %d)" % (tuple(img.shape), B, H, H))
+        sb, sc, sh, sw = img.stride()
+        check(lib.csg_disc_input_fwd(ptr(vecs), ptr(boxes), ptr(valid), ptr(masks), M, B, O, S, H, H, ptr(img), sb, sc, sh, sw,
+                                     ptr(buf), Ct, stream()), "disc_input_fwd")
         ctx.save_for_backward(boxes, valid, masks, vecs if ctx.needs_input_grad[2] or ctx.needs_input_grad[4] else None)
         ctx.meta = (B, O, S, H, Ct, M)
         return buf.permute(0, 3, 1, 2)

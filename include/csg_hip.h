@@ -124,6 +124,14 @@ int csg_segment_avg_bwd(const float* dpooled, const float* dnew_p, const float* 
 int csg_layout_fwd(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M,
                    int64_t B, int64_t O, int64_t S, int64_t H, int64_t W, int64_t OH, int64_t OW, float* out,
                    int64_t out_cs, int64_t out_off, void* stream);
+/* The image discriminator's input `torch.cat([img, layout], dim=1)` (spade/models/networks/discriminator.py:120) built
+ * in one pass at full resolution: out (B,H,W,out_cs) NHWC with channels [layout(S) | img(3) | zeros], out_cs >= S + 4 a
+ * multiple of 4 (the first convolution's weight is permuted to that order by the caller).  `img` (B,3,H,W) fp32 with
+ * element strides (img_sb, img_sc, img_sh, img_sw) — contiguous or channels-last alike.  The layout channels are exactly
+ * csg_layout_fwd's.                                                                                                    */
+int csg_disc_input_fwd(const float* vecs, const float* boxes, const uint8_t* valid, const float* masks, int64_t M, int64_t B,
+                       int64_t O, int64_t S, int64_t H, int64_t W, const float* img, int64_t img_sb, int64_t img_sc,
+                       int64_t img_sh, int64_t img_sw, float* out, int64_t out_cs, void* stream);
 /* dvecs (B,O,S) = (accumulate ? dvecs : 0) + sum_{y,x} dout * cov * cov.  With `dboxes` (B,O,4) non-NULL (needs
  * `vecs`) the gradient w.r.t. [x0,y0,w,h] is produced too: the grid of layout.py:98-110 is differentiable in the
  * box, and grid_sample's backward w.r.t. its grid is the bilinear weights' derivative.

@@ -328,10 +328,13 @@ def test_layout_pyramid_vs_oracle(ops):
     assert_close(vd.grad, vr.grad, RTOL, 2e-5, "pyramid dvecs")
 
 
-def test_disc_input(ops):
+@pytest.mark.parametrize("S,H,channels_last", [(8, 32, False), (32, 64, True), (12, 16, False)])
+def test_disc_input(ops, S, H, channels_last):
+    """[layout | img | zero pad] written by ONE kernel (csg_disc_input_fwd): layout channels as csg_layout_fwd, the image
+    copied bit for bit from a contiguous or a channels-last tensor, pad channels zero (S = 12: no pad quad beyond the image's)."""
     import oracle
     g = torch.Generator().manual_seed(22)
-    B, O, S, H = 2, 9, 8, 32
+    B, O = 2, 9
     vecs, img = torch.randn(B, O, S, generator=g), torch.randn(B, 3, H, H, generator=g)
     wh = torch.rand(B, O, 2, generator=g) * 0.4 + 0.05
     boxes = torch.cat([torch.rand(B, O, 2, generator=g) * (1 - wh), wh], -1)
@@ -339,12 +342,19 @@ def test_disc_input(ops):
     valid[0, -3:] = False
     vr, ir = vecs.clone().requires_grad_(True), img.clone().requires_grad_(True)
     seg = torch.cat([oracle.boxes_to_layout(vr[b][valid[b]], boxes[b][valid[b]], H, H) for b in range(B)], 0)
-    ref = torch.cat([seg, ir, torch.zeros(B, 1, H, H)], 1)
+    Ct = (S + 3 + 3) // 4 * 4
+    ref = torch.cat([seg, ir, torch.zeros(B, Ct - S - 3, H, H)], 1)
     gy = torch.randn(ref.shape, generator=g)
     ref.backward(gy)
-    vd, idv = dev(vecs, True), dev(img, True)
+    vd = dev(vecs, True)
+    idv = img.cuda()
+    if channels_last:
+        idv = idv.contiguous(memory_format=torch.channels_last)
+    idv.requires_grad_(True)
     buf = ops.disc_input(idv, vd, boxes.cuda(), valid.to(torch.uint8).cuda(), H)
+    assert buf.shape[1] == Ct
     assert_close(buf, ref, RTOL, 5e-6, "disc input buffer")
+    assert torch.equal(buf[:, S:S + 3].cpu(), img) and float(buf[:, S + 3:].abs().sum()) == 0.0
     buf.backward(gy.cuda())
     assert_close(vd.grad, vr.grad, RTOL, 2e-5, "disc input dvecs")
     assert_close(idv.grad, ir.grad, 0, 0, "disc input dimg")
