@@ -37,6 +37,12 @@ class WinoDesc(ctypes.Structure):
                 ("y_cs", c_i32), ("act", c_i32), ("slope", c_f32)]
 
 
+class WinoPackItem(ctypes.Structure):
+    """Mirror of `csg_wino_pack_item` (include/csg_hip.h)."""
+    _fields_ = [("w", c_p), ("s_o", c_i64), ("s_i", c_i64), ("s_h", c_i64), ("s_w", c_i64), ("Cout", c_i64), ("Cin", c_i64),
+                ("backward_data", c_i32), ("variant", c_i32), ("packed", c_p)]
+
+
 class FewDesc(ctypes.Structure):
     """Mirror of `csg_few_desc` (include/csg_hip.h)."""
     _fields_ = [("B", c_i32), ("IH", c_i32), ("IW", c_i32), ("Cin", c_i32), ("x_cs", c_i32), ("KH", c_i32), ("KW", c_i32),
@@ -123,6 +129,7 @@ SIGNATURES = {
     "csg_wino4_bwd_weight": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "csg_wino4_supported": (c_i32, [ctypes.POINTER(WinoDesc)]),
     "csg_wino4_persistent": (c_i32, [c_i32]),
+    "csg_wino_pack_weights_multi": (c_i32, [ctypes.POINTER(WinoPackItem), c_i32, c_p]),
     "csg_wino4_pack_bytes": (c_i64, [c_i64, c_i64]),
     "csg_wino4_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
     "csg_wino4_conv_workspace": (c_i64, [ctypes.POINTER(WinoDesc)]),

@@ -33,6 +33,7 @@
 
 #include "csg_buffer.h"
 #include "csg_common.h"
+#include "csg_pack.h"
 #include "csg_reduce.h"
 
 using namespace csg;
@@ -77,12 +78,11 @@ __device__ __forceinline__ int wn_xcd_remap(int bid, int nblk) {
 // along whichever of n / k is the contiguous axis of the parameter (each weight is read from memory once), a thread
 // then forms G g G^T for its (n, 4 k) and writes its 16 float4 — 1 KB contiguous per wave and position.
 #define WP_LD 33
-__global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, int64_t s_n, int64_t s_k, int64_t s_h,
-                                                    int64_t s_w, int flip, int N, int K, const float* __restrict__ sigma,
-                                                    int NT32, int Q8, float4* __restrict__ up) {
+__device__ __forceinline__ void wn_pack_tile(const float* __restrict__ w, int64_t s_n, int64_t s_k, int64_t s_h,
+                                             int64_t s_w, int flip, int N, int K, const float* __restrict__ sigma,
+                                             int NT32, int Q8, float4* __restrict__ up, int qb, int nt) {
   __shared__ float g[9][32][WP_LD];
-  const int tid = threadIdx.x;
-  const int qb = blockIdx.x, nt = blockIdx.y;         // k range [32 qb, 32 qb + 32), n range [32 nt, 32 nt + 32)
+  const int tid = threadIdx.x;                         // k range [32 qb, 32 qb + 32), n range [32 nt, 32 nt + 32)
   const bool k_fast = s_k <= s_n;
   const float sg = sigma != nullptr ? sigma[0] : 1.0f;
   // all 36 loads of a thread are issued before the first LDS store (one load per loop trip costs a full memory
@@ -132,6 +132,21 @@ __global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, 
 #pragma unroll
   for (int p = 0; p < 16; ++p)
     up[(((int64_t)p * NT32 + nt) * Q8 + q) * 64 + lane] = make_float4(u[p][0], u[p][1], u[p][2], u[p][3]);
+}
+
+__global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, int64_t s_n, int64_t s_k, int64_t s_h,
+                                                    int64_t s_w, int flip, int N, int K, const float* __restrict__ sigma,
+                                                    int NT32, int Q8, float4* __restrict__ up) {
+  wn_pack_tile(w, s_n, s_k, s_h, s_w, flip, N, K, sigma, NT32, Q8, up, blockIdx.x, blockIdx.y);
+}
+
+// several weights per launch: block -> item by the table's block offsets (csg_pack.h)
+__global__ __launch_bounds__(256) void k_wino_pack_multi(PackMulti pm) {
+  int i = 0;
+  while (i + 1 < pm.n && (int)blockIdx.x >= pm.it[i + 1].start) ++i;
+  const PackMultiItem& d = pm.it[i];
+  const int local = blockIdx.x - d.start, nqb = (d.Q8 + 3) >> 2;
+  wn_pack_tile(d.w, d.s_n, d.s_k, d.s_h, d.s_w, d.flip, d.N, d.K, nullptr, d.NT32, d.Q8, d.up, local % nqb, local / nqb);
 }
 
 // ------------------------------------------------------------------------------------ convolution
@@ -743,6 +758,12 @@ int csg_wino_pack_weights(const float* w, int64_t s_o, int64_t s_i, int64_t s_h,
   CSG_LAUNCH(k_wino_pack, dim3((unsigned)cdiv(Q8, 4), (unsigned)NT32), dim3(256), 0, s, w, s_n, s_k, s_h, s_w,
                      backward_data ? 1 : 0, (int)N, (int)K, sigma, NT32, Q8, (float4*)packed);
   return check_launch("csg_wino_pack_weights");
+}
+
+int csg_wino2_pack_multi_launch(const PackMulti* pm, int blocks, double bytes, hipStream_t s) {
+  ProfScope ps(K_WINO_PACK, bytes, s);
+  CSG_LAUNCH(k_wino_pack_multi, dim3((unsigned)blocks), dim3(256), 0, s, *pm);
+  return check_launch("csg_wino_pack_weights_multi(F(2x2,3x3))");
 }
 
 // Split over the input channels when the tile grid alone cannot fill the chip (backward-data of the gamma/beta

@@ -55,6 +55,7 @@
 
 #include "csg_buffer.h"
 #include "csg_common.h"
+#include "csg_pack.h"
 #include "csg_reduce.h"
 
 using namespace csg;
@@ -128,12 +129,11 @@ __device__ __forceinline__ int w4_xcd_remap(int bid, int nblk) {
 #define WP4_LD 33
 // RT = 3: F(4x4,3x3); RT = 4: F(3x3,4x4) — the same six points, G = rows c_k (1, p_k, .., p_k^(RT-1)), last row e_(RT-1)
 template <int RT>
-__global__ __launch_bounds__(256) void k_wino4_pack(const float* __restrict__ w, int64_t s_n, int64_t s_k, int64_t s_h,
-                                                     int64_t s_w, int flip, int N, int K, const float* __restrict__ sigma,
-                                                     int NT32, int Q8, float4* __restrict__ up) {
+__device__ __forceinline__ void w4_pack_tile(const float* __restrict__ w, int64_t s_n, int64_t s_k, int64_t s_h,
+                                             int64_t s_w, int flip, int N, int K, const float* __restrict__ sigma,
+                                             int NT32, int Q8, float4* __restrict__ up, int qb, int nt) {
   __shared__ float g[RT][32][WP4_LD];                  // the RT row taps of one column tap b
-  const int tid = threadIdx.x;
-  const int qb = blockIdx.x, nt = blockIdx.y;         // k range [32 qb, 32 qb + 32), n range [32 nt, 32 nt + 32)
+  const int tid = threadIdx.x;                         // k range [32 qb, 32 qb + 32), n range [32 nt, 32 nt + 32)
   const bool k_fast = s_k <= s_n;
   const float sg = sigma != nullptr ? sigma[0] : 1.0f;
   const int lane = tid & 63, ql = tid >> 6;            // 4 q per block, one per wave
@@ -202,6 +202,22 @@ __global__ __launch_bounds__(256) void k_wino4_pack(const float* __restrict__ w,
       }
       up[(((int64_t)(xi * 6 + nu) * NT32 + nt) * Q8 + q) * 64 + lane] = make_float4(u[0], u[1], u[2], u[3]);
     }
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) void k_wino4_pack(const float* __restrict__ w, int64_t s_n, int64_t s_k, int64_t s_h,
+                                                     int64_t s_w, int flip, int N, int K, const float* __restrict__ sigma,
+                                                     int NT32, int Q8, float4* __restrict__ up) {
+  w4_pack_tile<RT>(w, s_n, s_k, s_h, s_w, flip, N, K, sigma, NT32, Q8, up, blockIdx.x, blockIdx.y);
+}
+
+// several (Cout,Cin,3,3) weights per launch: block -> item by the table's block offsets (csg_pack.h)
+__global__ __launch_bounds__(256) void k_wino4_pack_multi(PackMulti pm) {
+  int i = 0;
+  while (i + 1 < pm.n && (int)blockIdx.x >= pm.it[i + 1].start) ++i;
+  const PackMultiItem& d = pm.it[i];
+  const int local = blockIdx.x - d.start, nqb = (d.Q8 + 3) >> 2;
+  w4_pack_tile<3>(d.w, d.s_n, d.s_k, d.s_h, d.s_w, d.flip, d.N, d.K, nullptr, d.NT32, d.Q8, d.up, local % nqb, local / nqb);
 }
 
 // Two fp32 lanes per VALU instruction (v_pk_fma_f32 / v_pk_add_f32): on this chip every VALU cycle of a SIMD is a cycle
@@ -990,6 +1006,61 @@ int32_t csg_wino4_supported(const csg_wino_desc* d) {
   static const int on = getenv("CSG_WINO4") ? atoi(getenv("CSG_WINO4")) : 1;
   if (!on || d == nullptr) return 0;
   return (d->H % 4 == 0 && d->W % 4 == 0 && d->W >= 32 && d->H >= 16 && d->Cin % 8 == 0 && d->Cout % 4 == 0) ? 1 : 0;
+}
+
+int csg_wino4_pack_multi_launch(const PackMulti* pm, int blocks, double bytes, hipStream_t s) {
+  ProfScope ps(K_WINO_PACK, bytes, s);
+  CSG_LAUNCH(k_wino4_pack_multi, dim3((unsigned)blocks), dim3(256), 0, s, *pm);
+  return check_launch("csg_wino_pack_weights_multi(F(4x4,3x3))");
+}
+
+int csg_wino_pack_weights_multi(const csg_wino_pack_item* items, int32_t n, void* stream) {
+  CSG_REQUIRE(n >= 0 && (items != nullptr || n == 0), CSG_E_BADSHAPE, "csg_wino_pack_weights_multi: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  for (int variant = 2; variant <= 4; variant += 2) {
+    PackMulti pm;
+    int cnt = 0, blocks = 0;
+    double bytes = 0.0;
+    auto flush = [&]() -> int {
+      if (cnt == 0) return CSG_OK;
+      pm.n = cnt;
+      const int rc = variant == 4 ? csg_wino4_pack_multi_launch(&pm, blocks, bytes, s)
+                                  : csg_wino2_pack_multi_launch(&pm, blocks, bytes, s);
+      cnt = 0;
+      blocks = 0;
+      bytes = 0.0;
+      return rc;
+    };
+    for (int i = 0; i < n; ++i) {
+      const csg_wino_pack_item& it = items[i];
+      CSG_REQUIRE(it.variant == 2 || it.variant == 4, CSG_E_UNSUPPORTED,
+                  "csg_wino_pack_weights_multi: item %d: variant %d (2 = F(2x2,3x3), 4 = F(4x4,3x3))", i, it.variant);
+      if (it.variant != variant) continue;
+      CSG_REQUIRE(it.w != nullptr && it.packed != nullptr && it.Cout > 0 && it.Cin > 0 && ((uintptr_t)it.packed % 16) == 0,
+                  CSG_E_BADSHAPE, "csg_wino_pack_weights_multi: item %d: bad arguments", i);
+      const int64_t N = it.backward_data ? it.Cin : it.Cout, K = it.backward_data ? it.Cout : it.Cin;
+      const int64_t s_n = it.backward_data ? it.s_i : it.s_o, s_k = it.backward_data ? it.s_o : it.s_i;
+      const int64_t span = (it.Cout - 1) * it.s_o + (it.Cin - 1) * it.s_i + 2 * it.s_h + 2 * it.s_w;
+      CSG_REQUIRE(span < (1ll << 31) && s_n >= 0 && s_k >= 0 && it.s_h >= 0 && it.s_w >= 0, CSG_E_UNSUPPORTED,
+                  "csg_wino_pack_weights_multi: item %d: weight too large for 32-bit element offsets", i);
+      const int NT32 = (int)cdiv(N, 32), Q8 = (int)cdiv(K, 8);
+      const int nb = (int)cdiv(Q8, 4) * NT32;
+      if (cnt == CSG_PACK_MULTI || blocks + nb > (1 << 20)) {
+        const int rc = flush();
+        if (rc) return rc;
+      }
+      PackMultiItem& d = pm.it[cnt++];
+      d.w = it.w; d.up = (float4*)it.packed;
+      d.s_n = (int)s_n; d.s_k = (int)s_k; d.s_h = (int)it.s_h; d.s_w = (int)it.s_w;
+      d.flip = it.backward_data ? 1 : 0; d.N = (int)N; d.K = (int)K; d.NT32 = NT32; d.Q8 = Q8;
+      d.start = blocks;
+      blocks += nb;
+      bytes += (double)it.Cout * it.Cin * 9 * 4 + (double)(variant == 4 ? 36 : 16) * NT32 * Q8 * 64 * 16;
+    }
+    const int rc = flush();
+    if (rc) return rc;
+  }
+  return CSG_OK;
 }
 
 int32_t csg_wino4_persistent(int32_t on) {

@@ -15,12 +15,12 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _register
 
 from . import _lib
 from . import dist as csg_dist
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, GemmDesc, WinoDesc, check, lib, ptr, stream
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, GemmDesc, WinoDesc, WinoPackItem, check, lib, ptr, stream
 
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "nearest_resize", "avgpool3s2", "embed", "real_object_mask",
     "norm_act_pair", "graph_csr", "gather_concat", "segment_avg", "layout_pyramid", "layout_paint", "disc_input", "crop_objects", "maxpool2", "avgpool2", "l1_mean",
-    "invalidate_weight_caches", "pack_conv_weight", "wino_pack", "wino_eligible", "wino_variant", "spectral_weight", "spectral_weights", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
+    "invalidate_weight_caches", "pack_conv_weight", "wino_pack", "prepack_weights", "wino_eligible", "wino_variant", "spectral_weight", "spectral_weights", "ACT_NONE", "ACT_LEAKY", "ACT_TANH",
 ]
 
 
@@ -214,8 +214,14 @@ def wino34_eligible(B, H, W, Cin, Cout, KH, KW, stride, pad, backward=False):
 def wino_pack(weight, backward_data, sigma=None, variant=2):
     """Transformed weights U = G g G^T of a (Cout,Cin,3,3) weight in the MFMA operand order of k_wino_conv
     (variant 2: 16 positions) or k_wino4_conv (variant 4: 36 positions); variant 34: a (Cout,Cin,4,4) weight for
-    F(3x3,4x4), 36 positions."""
+    F(3x3,4x4), 36 positions.  A network that called `prepack_weights` at the top of its forward finds its operands
+    ready (one multi-tensor launch) — this call then hands that buffer out."""
     w = _f32(weight.detach())                    # any strides: contiguous and channels-last parameters alike
+    if sigma is None and variant in (2, 4):
+        ready = take_prepacked(w, backward_data, variant)
+        if ready is not None:
+            return ready
+        _note_pack_request(w, backward_data, variant)
     Cout, Cin = w.shape[0], w.shape[1]
     N, K = (Cin, Cout) if backward_data else (Cout, Cin)
     nbytes = lib.csg_wino4_pack_bytes(N, K) if variant in (4, 34) else lib.csg_wino_pack_bytes(N, K)
@@ -225,6 +231,133 @@ def wino_pack(weight, backward_data, sigma=None, variant=2):
     check(fn(ptr(w), st[0], st[1], st[2], st[3], Cout, Cin, 1 if backward_data else 0, ptr(sigma), ptr(packed), stream()),
           "wino_pack_weights")
     return packed
+
+
+# ---- multi-tensor packs.  One pack costs ~7 us of fixed latency whatever the weight's size (tools/pack_bench.py) and a
+# generator step needs about a hundred (forward and backward-data operand of every 3x3 convolution).  A network calls
+# `prepack_weights(root)` at the top of its forward (after spectral_norm.prepare): every operand its previous passes asked
+# for is produced by ONE launch per 24 weights and parked in _PREPACKED under (address, direction, variant), tagged with the
+# weight's shape, strides and the weight epoch; `wino_pack` hands a parked buffer out when the tag fits the weight it is
+# given.  The convolution Functions take the backward-data operand at FORWARD time and keep it in their ctx — whatever
+# happens to the registry between a forward and its backward (another network's optimiser step bumps the epoch), the
+# backward uses the operand of the weights its forward saw.  What a pass asks for that was not parked is packed on the spot
+# (as before) and noted on the owning module for the next pass.
+PREPACK = os.environ.get("CSG_PREPACK", "1") != "0"
+_PREPACKED = {}          # (data_ptr, backward_data, variant) -> (packed, shape, strides, epoch)
+_PACK_OWNER = {}         # data_ptr -> (weakref to module, attribute): who to note a request on
+
+
+def _pack_tag(w):
+    return (tuple(w.shape), tuple(w.stride()), weight_epoch())
+
+
+def take_prepacked(w, backward_data, variant):
+    """The parked operand of `w` (a detached fp32 weight), or None.  Taken once: the registry forgets it."""
+    if not _PREPACKED:
+        return None
+    hit = _PREPACKED.pop((w.data_ptr(), bool(backward_data), int(variant)), None)
+    if hit is None:
+        return None
+    packed, shape, strides, epoch = hit
+    if (shape, strides, epoch) != _pack_tag(w) or packed.device != w.device:
+        return None
+    return packed
+
+
+def _note_pack_request(w, backward_data, variant):
+    owner = _PACK_OWNER.get(w.data_ptr())
+    if owner is None:
+        return
+    mod = owner[0]()
+    if mod is not None:
+        mod.__dict__.setdefault("_pp_plan", {}).setdefault(owner[1], set()).add((bool(backward_data), int(variant)))
+
+
+def _prepack_sources(root):
+    """(module, attribute) of every 3x3 weight under `root` a convolution may be handed: `weight` of a Conv2d (the
+    spectrally normalised ones through the weight spectral_norm.prepare parked), `_joined_w` of a SPADE layer."""
+    cached = root.__dict__.get("_pp_srcs")
+    if cached is not None and cached[1]:
+        return cached[0]
+    out, complete, halves = [], True, set()
+    for m in root.modules():
+        if hasattr(m, "mlp_gamma") and hasattr(m, "mlp_beta"):
+            halves.update((id(m.mlp_gamma), id(m.mlp_beta)))      # convolved as ONE weight, never on their own
+            if m.__dict__.get("_joined_w") is None and hasattr(m, "joined_weight") and m.mlp_gamma.weight.is_cuda:
+                m.joined_weight()
+            if m.__dict__.get("_joined_w") is not None:
+                out.append((m, "_joined_w"))
+            else:
+                complete = False                      # the halves are joined at the layer's first call
+        if isinstance(m, torch.nn.Conv2d) and tuple(m.kernel_size) == (3, 3) and id(m) not in halves:
+            out.append((m, "weight"))
+    root.__dict__["_pp_srcs"] = (out, complete)
+    return out
+
+
+def _prepack_weight_of(m, attr):
+    if attr == "_joined_w":
+        j = m.__dict__.get("_joined_w")
+        if j is None or j.data_ptr() != m.mlp_gamma.weight.data_ptr():
+            return None
+        return j
+    if hasattr(m, "weight_orig"):                     # spectrally normalised: W / sigma of this call, if prepared
+        ready = m.__dict__.get("_sn_prepared")
+        return ready[1] if (ready is not None and ready[0] == "weight") else None
+    return m.weight
+
+
+def prepack_weights(root):
+    """Pack, in one launch per 24 weights, every Winograd operand the previous passes through `root` asked for."""
+    if not PREPACK:
+        return
+    import weakref
+    mine = root.__dict__.setdefault("_pp_keys", [])
+    for k in mine:                                    # operands of the previous pass nobody took
+        _PREPACKED.pop(k, None)
+    del mine[:]
+    grad = torch.is_grad_enabled()
+    items, keep = [], []
+    for m, attr in _prepack_sources(root):
+        wt = _prepack_weight_of(m, attr)
+        if wt is None or not wt.is_cuda or wt.dim() != 4 or wt.dtype != torch.float32:
+            continue
+        w = wt.detach()
+        _PACK_OWNER[w.data_ptr()] = (weakref.ref(m), attr)
+        plan = m.__dict__.get("_pp_plan", {}).get(attr)
+        if not plan:
+            continue
+        Cout, Cin = w.shape[0], w.shape[1]
+        st = w.stride()
+        tag = _pack_tag(w)
+        for backward_data, variant in sorted(plan):
+            if backward_data and not grad:
+                continue
+            N, K = (Cin, Cout) if backward_data else (Cout, Cin)
+            nbytes = lib.csg_wino4_pack_bytes(N, K) if variant == 4 else lib.csg_wino_pack_bytes(N, K)
+            packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+            it = WinoPackItem()
+            it.w, it.s_o, it.s_i, it.s_h, it.s_w = w.data_ptr(), st[0], st[1], st[2], st[3]
+            it.Cout, it.Cin, it.backward_data, it.variant, it.packed = Cout, Cin, 1 if backward_data else 0, variant, packed.data_ptr()
+            items.append(it)
+            key = (w.data_ptr(), backward_data, variant)
+            keep.append((key, (packed,) + tag))
+    if not items:
+        return
+    arr = (WinoPackItem * len(items))(*items)
+    check(lib.csg_wino_pack_weights_multi(arr, len(items), stream()), "wino_pack_weights_multi")
+    for key, val in keep:
+        _PREPACKED[key] = val
+        mine.append(key)
+
+
+def _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad):
+    """At FORWARD time: (variant, parked backward-data operand or None) of a convolution whose backward-data pass will run
+    Winograd — kept in the Function's ctx, so that the backward uses the operand of the weights its forward saw."""
+    if not _PREPACKED or not wino_eligible(B, IH, IW, Cout, Cin, KH, KW, stride, pad):
+        return None
+    var = wino_variant(B, IH, IW, Cout, Cin)
+    return (var, take_prepacked(_f32(weight.detach()), True, var))
 
 
 def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what, gate=None, gate_slope=0.0, variant=2):
@@ -368,6 +501,8 @@ class _Conv2d(torch.autograd.Function):
             y = empty_nhwc(B, Cout, OH, OW, x.device)
             var = wino_variant(B, IH, IW, Cin, Cout)
             up = _frozen_pack(packs, False, var) if (packs is not None and len(packs) > 2) else wino_pack(weight, False, None, var)
+            if packs is None and ctx.needs_input_grad[0]:
+                ctx.ut_pre = _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad)
             _wino_launch(x, up, bias.detach() if bias is not None else None, res, y, B, IH, IW, Cin, Cout, act, slope,
                          "wino_conv_fwd", variant=var)
         elif dx_range is None and packs is None and wino34_eligible(
@@ -453,8 +588,13 @@ class _Conv2d(torch.autograd.Function):
         elif ctx.needs_input_grad[0] and wino_eligible(B, IH, IW, Cout, Cin, KH, KW, stride, pad):
             # dX = conv3x3(dY, flipped W^T): the same Winograd kernel with the roles of the channel counts swapped
             var = wino_variant(B, IH, IW, Cout, Cin)
-            ut = _frozen_pack(ctx.packs, True, var) if (ctx.packs is not None and len(ctx.packs) > 3) else \
-                wino_pack(weight, True, None, var)
+            pre = getattr(ctx, "ut_pre", None)           # parked at forward time (prepack_weights)
+            if ctx.packs is not None and len(ctx.packs) > 3:
+                ut = _frozen_pack(ctx.packs, True, var)
+            elif pre is not None and pre[1] is not None and pre[0] == var:
+                ut = pre[1]
+            else:
+                ut = wino_pack(weight, True, None, var)
             dx = empty_nhwc(B, Cin, IH, IW, dy.device)
             gated = _wino_launch(dpre, ut, None, None, dx, B, IH, IW, Cout, Cin, ACT_NONE, 0.0, "wino_conv_bwd_data",
                                  gate=x if ctx.in_act is not None else None,
@@ -981,7 +1121,7 @@ class _SpadeFused(torch.autograd.Function):
         check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
         # N > 1: the statistics travel while the gamma halves (which do not need them) are computed
         pending = csg_dist.all_reduce_stats_async(sums) if multi else None
-        saved, outs, cfg, launches = [x, mean, invstd], [], [], []
+        saved, outs, cfg, launches, pres = [x, mean, invstd], [], [], [], []
         for k in range(K):
             actv, w, b, rm, rv, slope, in_slope = mods[k * 7:(k + 1) * 7]
             actv = nhwc(_f32(actv))
@@ -990,6 +1130,7 @@ class _SpadeFused(torch.autograd.Function):
                 raise RuntimeError("spade_fused: weight %s / actv %s do not fit x %s" % (tuple(w.shape), tuple(actv.shape),
                                                                                          tuple(x.shape)))
             up = wino_pack(w, False, None, 4)
+            pres.append(_take_bwd_operand(w, B, H, W, nh, 2 * C, 3, 3, 1, 1) if ctx.needs_input_grad[4 + k * 7] else None)
             bd = b.detach().contiguous()
             gbuf = empty_nhwc(B, C, H, W, dev)                # gamma only: beta is consumed in the epilogue that forms it
             d = _wino_desc(B, H, W, nh, C)
@@ -1014,6 +1155,7 @@ class _SpadeFused(torch.autograd.Function):
             cfg.append((slope, in_slope, nh))
         ctx.save_for_backward(*saved)
         ctx.cfg = (K, P, C, B, H, W, multi, count, tuple(cfg))
+        ctx.ut_pres = pres
         return tuple(outs)
 
     @staticmethod
@@ -1050,7 +1192,7 @@ class _SpadeFused(torch.autograd.Function):
                 saved_tensors=(actv, w, None), geom=(B, H, W, nh, 2 * C, 3, 3, 1, 1, H, W, ACT_NONE, 0.0),
                 in_act=(ACT_LEAKY, in_slope) if in_slope is not None else None, grad_is_pre=False, few=None, dx_range=None,
                 packs=None, needs_input_grad=(need[0], need[1], need[2], False), has_bias=True, has_res=False, cout_w=2 * C,
-                pre_slope=None)
+                pre_slope=None, ut_pre=ctx.ut_pres[k])
             r = _Conv2d.backward(fake, dgbs[k])
             grads += [r[0], r[1], r[2], None, None, None, None]
         if ctx.needs_input_grad[0]:

@@ -73,6 +73,7 @@ class SPADEGenerator(BaseNetwork):
         if self.sw != self.sh:
             raise NotImplementedError("aspect_ratio != 1 is not on the hot path")
         csg_spectral_norm.prepare(self)              # all 18 spectrally normalised weights in one launch per stage
+        ops.prepack_weights(self)                    # and the Winograd operands of every 3x3 weight in one launch per 24
         H = self.opt.image_size[0]
         levels = [self.sw << k for k in range(H.bit_length()) if (self.sw << k) <= H]
         valid = real_object_mask(objs, self.opt.vocab)

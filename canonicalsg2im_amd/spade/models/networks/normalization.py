@@ -167,6 +167,12 @@ class SPADE(nn.Module):
                 and ops.spade_fused_eligible(x, self.mlp_gamma.weight.shape[1], self.mlp_gamma.weight.shape[0],
                                              self.mlp_gamma.weight.shape[2], pn.training))
 
+    def joined_weight(self):
+        """The gamma || beta weight as ONE (2C, nhidden, ks, ks) tensor (the two parameters' own memory), joined now if it
+        is not yet — ops.prepack_weights asks before the layer's first call."""
+        _joined(self, "_joined_w", self.mlp_gamma.weight, self.mlp_beta.weight)
+        return self.__dict__.get("_joined_w")
+
     def fused_operands(self, x, segmap, slope):
         if isinstance(segmap, SegPyramid):
             seg = segmap.at(x.size(2))

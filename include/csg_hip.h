@@ -266,6 +266,20 @@ int csg_wino4_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy
  * epilogue as csg_wino_conv; the packed operand has 36 positions (csg_wino4_pack_bytes / csg_wino4_pack_weights, same
  * arguments as the F(2x2,3x3) pack).  csg_wino4_supported(d) = 1 when a layer is served (0 also when CSG_WINO4=0).   */
 int32_t csg_wino4_supported(const csg_wino_desc* d);
+/* Several (Cout,Cin,3,3) weights packed by ONE launch per kernel family and 24 items: a pack costs ~7 us of fixed latency
+ * whatever its size (tools/pack_bench.py) and a generator step needs about a hundred.  Each item is what
+ * csg_wino_pack_weights (variant 2, F(2x2,3x3)) / csg_wino4_pack_weights (variant 4, F(4x4,3x3)) take, without the
+ * spectral-norm divisor; outputs are bit-identical to the one-weight calls.  `items` is host memory, read during the
+ * call (the table travels in the kernel arguments: the launch can be captured in a HIP graph).                        */
+typedef struct csg_wino_pack_item {
+  const float* w;            /* (Cout,Cin,3,3) with element strides s_o, s_i, s_h, s_w */
+  int64_t s_o, s_i, s_h, s_w;
+  int64_t Cout, Cin;
+  int32_t backward_data;     /* 1: the operand of the backward-data pass (channel roles swapped, taps flipped) */
+  int32_t variant;           /* 2 | 4 */
+  float* packed;             /* csg_wino_pack_bytes / csg_wino4_pack_bytes (N, K) bytes, 16-byte aligned */
+} csg_wino_pack_item;
+int csg_wino_pack_weights_multi(const csg_wino_pack_item* items, int32_t n, void* stream);
 /* Launches with at least two (region, 64-channel block) items per CU, an even number of 8-channel stages (>= 4) and
  * Cout a multiple of 64 run as ONE block per CU that walks its items with the stage pipeline carried across them
  * (bit-identical outputs).  csg_wino4_persistent(0 | 1) switches that form off / on for the process

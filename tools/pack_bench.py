@@ -1,4 +1,5 @@
-"""k_wino_pack per weight shape (channels-last parameters, forward and backward-data operands): us and GB/s."""
+"""Winograd weight packs (k_wino4_pack<3>, k_wino_pack) at the generator's weight shapes: us per launch in a tight loop and
+inside a replayed HIP graph of 64 back-to-back packs (what a training step pays)."""
 import os
 import sys
 
@@ -10,21 +11,33 @@ import __graft_entry__ as ge  # noqa: E402
 ge.build()
 from canonicalsg2im_amd import ops  # noqa: E402
 
-SHAPES = [(32, 128), (128, 128), (128, 256), (128, 512), (128, 1024), (128, 2048), (64, 64), (128, 64), (256, 128),
-          (256, 256), (512, 256), (512, 512), (1024, 512), (1024, 1024)]
-for Cin, Cout in SHAPES:
+SHAPES = [(128, 32), (256, 128), (512, 128), (1024, 128), (2048, 128), (64, 128), (128, 256), (256, 512), (512, 1024), (1024, 1024)]
+
+
+def timed(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+print("%-14s %8s %8s %8s %8s | graph of 64: us per pack" % ("Cout x Cin", "F4 fwd", "F4 bwd", "F2 fwd", "F2 bwd"))
+for Cout, Cin in SHAPES:
     w = torch.randn(Cout, Cin, 3, 3, device="cuda").contiguous(memory_format=torch.channels_last)
-    row = []
-    for bwd in (False, True):
+    row = [timed(lambda: ops.wino_pack(w, bd, None, var)) for var in (4, 2) for bd in (False, True)]
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
         for _ in range(3):
-            ops.wino_pack(w, bwd)
+            ops.wino_pack(w, False, None, 4)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            ops.wino_pack(w, bwd)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
-        row.append("%s %7.1f us %6.0f GB/s" % ("dgrad" if bwd else "fwd  ", us, Cin * Cout * 4 * 25 / us / 1e3))
-    print("Cin %4d Cout %4d  %s | %s" % (Cin, Cout, row[0], row[1]), flush=True)
+        with torch.cuda.graph(g, stream=s):
+            keep = [ops.wino_pack(w, i & 1 == 1, None, 4) for i in range(64)]
+    us = timed(g.replay, 20) / 64
+    print("%5d x %-6d %8.1f %8.1f %8.1f %8.1f | %8.1f" % (Cout, Cin, row[0], row[1], row[2], row[3], us), flush=True)
