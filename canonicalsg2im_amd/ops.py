@@ -316,6 +316,10 @@ def prepack_weights(root):
     for k in mine:                                    # operands of the previous pass nobody took
         _PREPACKED.pop(k, None)
     del mine[:]
+    owned = root.__dict__.setdefault("_pp_owned", [])
+    for k in owned:                                   # addresses of the previous pass's weights (W / sigma tensors are
+        _PACK_OWNER.pop(k, None)                      # new allocations every pass: the map must not grow with the steps)
+    del owned[:]
     grad = torch.is_grad_enabled()
     items, keep = [], []
     for m, attr in _prepack_sources(root):
@@ -324,6 +328,7 @@ def prepack_weights(root):
             continue
         w = wt.detach()
         _PACK_OWNER[w.data_ptr()] = (weakref.ref(m), attr)
+        owned.append(w.data_ptr())
         plan = m.__dict__.get("_pp_plan", {}).get(attr)
         if not plan:
             continue

@@ -122,6 +122,7 @@ def test_training_steps_with_and_without_the_registry_are_bit_identical(ops, mon
         assert torch.equal(ia, ib), "step %d image" % it
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
+    assert len(ops._PACK_OWNER) < 200 and len(ops._PREPACKED) < 200      # neither map grows with the steps
     # one-weight packs: every step the same number without the registry; with it, the first step asks and is noted, and
     # from the second step on every operand of the generator is found ready
     assert sb[0] == sb[1] == sb[2] == sb[3] and sa[0] == sb[0], (sa, sb)
