@@ -45,6 +45,12 @@
 // MFMA runs at the fp32 VALU rate and VALU work of the same SIMD does not hide under it.  (3) Hence this form: the
 // transform is computed once per block instead of once per channel group (~4 instead of ~8 VALU per MFMA): 1.19-1.40x
 // FASTER than F(2x2,3x3) on the generator's shapes (128 -> 256 channels at 256 x 256: 2.07 vs 2.46 ms).
+// (4) Round 5: on large grids the kernel runs as ONE block per CU that walks its items with the stage pipeline carried
+// across them (k_wino4_conv_v<4, true>, below): what a block paid outside its loop on a Cin = 128 layer — 8-9 k cycles
+// until the first stage lands, 2.5 k to prime, of 122 k — shrinks to the transform of the first stage; 1.03-1.06x on the
+// 256 x 256 and 128 x 128 layers, 1.13x at Cin = 32, bit-identical outputs.  Two things had made the same idea lose in
+// round 3: loads issued on some paths only (the compiler's vmcnt waits then also cover the staging loads issued a moment
+// earlier: +6 % per stage), and values hoisted out of / sunk into the item loop that spilled around the main loop.
 // Two details that cost 10 %: a volatile LDS read through a GENERIC pointer becomes a FLAT load with a 64-bit address
 // of its own (w4_lds_cv2 below), and hipcc merges neighbouring ds_read_b64 into ds_read2_b64, which is served on a
 // 32-bank map in 16-lane groups where the skewed layout is 2-way conflicted.
