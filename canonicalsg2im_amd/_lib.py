@@ -144,6 +144,8 @@ SIGNATURES = {
     "csg_colsum": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_norm_stats": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_norm_finalize": (c_i32, [c_p, c_i64, c_i64, c_f64, c_f32, c_i32, c_p, c_p, c_p, c_p, c_f32, c_p]),
+    "csg_norm_stats_finalize": (c_i32, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_f64, c_f32, c_p, c_p, c_p, c_p, c_p, c_p, c_f32,
+                                        c_p]),
     "csg_norm_apply_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_f32, c_p, c_p]),
     "csg_norm_apply_bwd_reduce": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64,
                                           c_i64, c_p]),

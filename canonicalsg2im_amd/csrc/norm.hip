@@ -116,6 +116,67 @@ __global__ __launch_bounds__(256) void k_partial_reduce(const double* __restrict
   }
 }
 
+// One-rank statistics: the second stage of the reduction and the finalisation in ONE launch.  A block owns 16 channels:
+// columns c0..c0+15 (sums) and C+c0..C+c0+15 (sums of squares) of the partial table, each reduced exactly as
+// k_partial_reduce reduces a column (same chunk lanes, same order: bit-identical sums), then mean / invstd / running
+// statistics as k_norm_finalize forms them (mode 0).  Up to two modules' running buffers (norm_0 and norm_s of a residual
+// block see the same batch).
+__global__ __launch_bounds__(256) void k_partial_reduce_finalize(const double* __restrict__ partial, int C, int nchunk,
+                                                                  double count, float eps, float* __restrict__ mean,
+                                                                  float* __restrict__ invstd, float* __restrict__ rmean,
+                                                                  float* __restrict__ rvar, float* __restrict__ rmean2,
+                                                                  float* __restrict__ rvar2, float momentum) {
+  __shared__ double sm[8][32];
+  __shared__ double tot[32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int g = blockIdx.y, c = blockIdx.x * 16 + (cl & 15);
+  const int ncols = 2 * C;
+  const int j = (cl < 16 ? 0 : C) + c;
+  double a = 0.0;
+  if (c < C) {
+    const double* p = partial + (int64_t)g * nchunk * ncols + j;
+    int k = rl;
+    for (; k + 24 < nchunk; k += 32) {
+      const double v0 = p[(int64_t)k * ncols], v1 = p[(int64_t)(k + 8) * ncols];
+      const double v2 = p[(int64_t)(k + 16) * ncols], v3 = p[(int64_t)(k + 24) * ncols];
+      a += v0;
+      a += v1;
+      a += v2;
+      a += v3;
+    }
+    for (; k < nchunk; k += 8) a += p[(int64_t)k * ncols];
+  }
+  sm[rl][cl] = a;
+  __syncthreads();
+  if (rl == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += sm[r][cl];
+    tot[cl] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && c < C) {
+    const double S = tot[threadIdx.x], SS = tot[threadIdx.x + 16];
+    const double m = S / count;
+    double var = (SS - S * m) / count;
+    if (var < 0.0) var = 0.0;
+    const float fv = (float)var;
+    mean[(int64_t)g * C + c] = (float)m;
+    invstd[(int64_t)g * C + c] = 1.0f / sqrtf(fv + eps);
+    if (g == 0) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      if (rmean != nullptr) {
+        rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)m;
+        rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
+      }
+      if (rmean2 != nullptr) {
+        rmean2[c] = (1.0f - momentum) * rmean2[c] + momentum * (float)m;
+        rvar2[c] = (1.0f - momentum) * rvar2[c] + momentum * (float)unb;
+      }
+    }
+  }
+}
+
 __global__ void k_norm_finalize(const double* __restrict__ sums, int G, int C, double count, float eps, int mode,
                                 float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
                                 float* __restrict__ rvar, float momentum) {
@@ -476,6 +537,28 @@ int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums
   CSG_LAUNCH(k_partial_reduce<double>, dim3((unsigned)cdiv(2 * C, 32), (unsigned)G), dim3(256), 0, s, partial,
                      (int)(2 * C), (int)nchunk, (int)(2 * C), sums);
   return check_launch("csg_norm_stats");
+}
+
+int csg_norm_stats_finalize(const float* x, int64_t G, int64_t P, int64_t C, double* partial, int64_t nchunk, double count,
+                            float eps, float* mean, float* invstd, float* running_mean, float* running_var,
+                            float* running_mean2, float* running_var2, float momentum, void* stream) {
+  CSG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0 && count > 0, CSG_E_BADSHAPE,
+              "csg_norm_stats_finalize: bad shape G=%ld P=%ld C=%ld", (long)G, (long)P, (long)C);
+  CSG_REQUIRE(nchunk >= 1 && nchunk <= 65535 && G <= 65535, CSG_E_BADSHAPE, "csg_norm_stats_finalize: bad nchunk");
+  CSG_REQUIRE((running_mean == nullptr && running_mean2 == nullptr) || G == 1, CSG_E_UNSUPPORTED,
+              "csg_norm_stats_finalize: running stats need G == 1");
+  CSG_REQUIRE((running_mean == nullptr) == (running_var == nullptr) && (running_mean2 == nullptr) == (running_var2 == nullptr),
+              CSG_E_BADSHAPE, "csg_norm_stats_finalize: running mean and variance come together");
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope p(K_NORM_STATS, (double)G * P * C * 4, s);
+    CSG_LAUNCH(k_norm_stats_partial, dim3((unsigned)nchunk, (unsigned)G), dim3(256), 256 * 8 * 8, s, x, P, (int)C, C,
+               (int)nchunk, partial);
+  }
+  ProfScope p(K_NORM_FINALIZE, (double)G * C * 24, s);
+  CSG_LAUNCH(k_partial_reduce_finalize, dim3((unsigned)cdiv(C, 16), (unsigned)G), dim3(256), 0, s, partial, (int)C, (int)nchunk,
+             count, eps, mean, invstd, running_mean, running_var, running_mean2, running_var2, momentum);
+  return check_launch("csg_norm_stats_finalize");
 }
 
 int csg_norm_finalize(const double* sums, int64_t G, int64_t C, double count, float eps, int32_t mode, float* mean,

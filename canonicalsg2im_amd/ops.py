@@ -979,14 +979,17 @@ class _NormAct(torch.autograd.Function):
         if use_batch_stats:
             nch = _chunks(P, G)
             part = torch.empty(G * nch * 2 * C, device=dev, dtype=torch.float64)
-            sums = torch.empty(G * 2 * C, device=dev, dtype=torch.float64)
-            check(lib.csg_norm_stats(ptr(x), G, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-            if multi:
-                csg_dist.all_reduce_stats(sums)
             rm = running_mean if (training and not instance and running_mean is not None) else None
             rv = running_var if rm is not None else None
-            check(lib.csg_norm_finalize(ptr(sums), G, C, count, eps, 1 if multi else 0, ptr(mean), ptr(invstd),
-                                        ptr(rm), ptr(rv), momentum, stream()), "norm_finalize")
+            if not multi:                            # one rank: second reduction stage and finalisation in one launch
+                check(lib.csg_norm_stats_finalize(ptr(x), G, P, C, ptr(part), nch, count, eps, ptr(mean), ptr(invstd), ptr(rm),
+                                                  ptr(rv), None, None, momentum, stream()), "norm_stats_finalize")
+            else:
+                sums = torch.empty(G * 2 * C, device=dev, dtype=torch.float64)
+                check(lib.csg_norm_stats(ptr(x), G, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
+                csg_dist.all_reduce_stats(sums)
+                check(lib.csg_norm_finalize(ptr(sums), G, C, count, eps, 1, ptr(mean), ptr(invstd), ptr(rm), ptr(rv), momentum,
+                                            stream()), "norm_finalize")
         else:
             mean.copy_(running_mean)
             invstd.copy_(torch.rsqrt(running_var + eps))
@@ -1042,13 +1045,17 @@ class _NormActPair(torch.autograd.Function):
         invstd = torch.empty(C, device=dev, dtype=torch.float32)
         nch = _chunks(P, 1)
         part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
-        sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
-        check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-        if multi:
+        if not multi:                                # same batch statistics, each module's own running buffers: one launch
+            check(lib.csg_norm_stats_finalize(ptr(x), 1, P, C, ptr(part), nch, count, eps, ptr(mean), ptr(invstd), ptr(rm0),
+                                              ptr(rv0 if rm0 is not None else None), ptr(rm1),
+                                              ptr(rv1 if rm1 is not None else None), momentum, stream()), "norm_stats_finalize")
+        else:
+            sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+            check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
             csg_dist.all_reduce_stats(sums)
-        for rm, rv in ((rm0, rv0), (rm1, rv1)):           # same batch statistics, each module's own running buffers
-            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if multi else 0, ptr(mean), ptr(invstd),
-                                        ptr(rm), ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
+            for rm, rv in ((rm0, rv0), (rm1, rv1)):
+                check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1, ptr(mean), ptr(invstd), ptr(rm),
+                                            ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
         gb0, gb1 = nhwc(gb0), nhwc(gb1)
         y0, y1 = torch.empty_like(x), torch.empty_like(x)
         check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gb0), slope0, 1, P, C, ptr(y0), ptr(gb1), slope1,
@@ -1122,10 +1129,18 @@ class _SpadeFused(torch.autograd.Function):
         invstd = torch.empty(C, device=dev, dtype=torch.float32)
         nch = _chunks(P, 1)
         part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
-        sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
-        check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-        # N > 1: the statistics travel while the gamma halves (which do not need them) are computed
-        pending = csg_dist.all_reduce_stats_async(sums) if multi else None
+        pending = sums = None
+        if not multi:                                # one rank: statistics finalised right away (two launches in all)
+            r0, r1 = (mods[3], mods[4]), ((mods[10], mods[11]) if K == 2 else (None, None))
+            check(lib.csg_norm_stats_finalize(ptr(x), 1, P, C, ptr(part), nch, count, eps, ptr(mean), ptr(invstd), ptr(r0[0]),
+                                              ptr(r0[1] if r0[0] is not None else None), ptr(r1[0]),
+                                              ptr(r1[1] if r1[0] is not None else None), momentum, stream()),
+                  "norm_stats_finalize")
+        else:
+            sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+            check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
+            # N > 1: the statistics travel while the gamma halves (which do not need them) are computed
+            pending = csg_dist.all_reduce_stats_async(sums)
         saved, outs, cfg, launches, pres = [x, mean, invstd], [], [], [], []
         for k in range(K):
             actv, w, b, rm, rv, slope, in_slope = mods[k * 7:(k + 1) * 7]
@@ -1145,9 +1160,9 @@ class _SpadeFused(torch.autograd.Function):
             launches.append((actv, w, up, bd, gbuf, nh, slope, in_slope))
         if pending is not None:
             pending.wait()
-        for k in range(K):
+        for k in range(K if multi else 0):
             rm, rv = mods[k * 7 + 3], mods[k * 7 + 4]
-            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if multi else 0, ptr(mean), ptr(invstd), ptr(rm),
+            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1, ptr(mean), ptr(invstd), ptr(rm),
                                         ptr(rv if rm is not None else None), momentum, stream()), "norm_finalize")
         for (actv, w, up, bd, gbuf, nh, slope, in_slope) in launches:
             y = torch.empty_like(x)
@@ -1235,9 +1250,15 @@ class _SpadeJoined(torch.autograd.Function):
         invstd = torch.empty(C, device=dev, dtype=torch.float32)
         nch = _chunks(P, 1)
         part = torch.empty(nch * 2 * C, device=dev, dtype=torch.float64)
-        sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
-        check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
-        pending = csg_dist.all_reduce_stats_async(sums) if multi else None
+        pending = sums = None
+        if not multi:
+            check(lib.csg_norm_stats_finalize(ptr(x), 1, P, C, ptr(part), nch, count, eps, ptr(mean), ptr(invstd),
+                                              ptr(running_mean), ptr(running_var if running_mean is not None else None), None,
+                                              None, momentum, stream()), "norm_stats_finalize")
+        else:
+            sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+            check(lib.csg_norm_stats(ptr(x), 1, P, C, ptr(sums), ptr(part), nch, stream()), "norm_stats")
+            pending = csg_dist.all_reduce_stats_async(sums)
         # the joined convolution through _Conv2d's own forward on a stand-in context (its saved tensors are kept for the
         # backward below)
         fake = types.SimpleNamespace(needs_input_grad=(True, True, True, False))
@@ -1246,9 +1267,10 @@ class _SpadeJoined(torch.autograd.Function):
         gb = _Conv2d.forward(fake, actv, w, b, None, 1, int(pad), ACT_NONE, 0.0, None, None, in_act, False, None, None)
         if pending is not None:
             pending.wait()
-        check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1 if multi else 0, ptr(mean), ptr(invstd),
-                                    ptr(running_mean), ptr(running_var if running_mean is not None else None), momentum,
-                                    stream()), "norm_finalize")
+        if multi:
+            check(lib.csg_norm_finalize(ptr(sums), 1, C, count, eps, 1, ptr(mean), ptr(invstd),
+                                        ptr(running_mean), ptr(running_var if running_mean is not None else None), momentum,
+                                        stream()), "norm_finalize")
         y = torch.empty_like(x)
         check(lib.csg_norm_apply_fwd(ptr(x), ptr(mean), ptr(invstd), ptr(gb), slope, 1, P, C, ptr(y), None, 1.0, None, stream()),
               "norm_apply_fwd")

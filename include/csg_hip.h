@@ -398,6 +398,13 @@ int csg_norm_stats(const float* x, int64_t G, int64_t P, int64_t C, double* sums
  * (batchnorm.py:145, N-replica path).  running_* may be NULL; running_var gets the unbiased var. */
 int csg_norm_finalize(const double* sums, int64_t G, int64_t C, double count, float eps, int32_t mode, float* mean,
                       float* invstd, float* running_mean, float* running_var, float momentum, void* stream);
+/* One-rank statistics in two launches instead of three: csg_norm_stats's first stage, then ONE kernel that reduces the
+ * partial table (the same fixed order: bit-identical sums) and finalises as csg_norm_finalize does with mode 0 — mean,
+ * invstd = (var + eps)^-1/2 and the running statistics of up to two modules that see the same batch (norm_0 and norm_s of
+ * a SPADE residual block, architecture.py:37-47).  Not for N > 1 ranks: there the sums travel between the two steps. */
+int csg_norm_stats_finalize(const float* x, int64_t G, int64_t P, int64_t C, double* partial, int64_t nchunk, double count,
+                            float eps, float* mean, float* invstd, float* running_mean, float* running_var,
+                            float* running_mean2, float* running_var2, float momentum, void* stream);
 /* y = leaky((x-mean)*invstd*(1+gamma)+beta, slope); gb (G*P, 2C) = [gamma | beta] or NULL; slope 1 = no act.
  * (gb2, slope2, y2), nullable: a second modulation of the same normalised x written in the same pass.           */
 int csg_norm_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gb, float slope,

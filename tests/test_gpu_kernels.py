@@ -635,3 +635,40 @@ def test_object_crops_golden(ops):
 def test_cpu_tensor_is_refused(ops):
     with pytest.raises(RuntimeError):
         ops.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 3, 3), None, 1, 1)
+
+
+@pytest.mark.parametrize("G,P,C,nch", [(1, 4096, 64, 128), (1, 1000, 36, 31), (3, 640, 128, 20), (1, 64, 1024, 2), (5, 37, 20, 1)])
+def test_norm_stats_finalize_in_one_launch_matches_the_three_launch_path(ops, G, P, C, nch):
+    """csg_norm_stats_finalize (one rank: partial sums, then reduction + finalisation in one kernel) against csg_norm_stats +
+    csg_norm_finalize: the same mean / invstd / running statistics bit for bit (the columns are reduced in the same order),
+    for batch (G = 1, two modules' running buffers) and instance (G > 1) statistics, channel counts that do not fill the
+    16-channel blocks, one chunk."""
+    from canonicalsg2im_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(G * 1000 + C)
+    x = (torch.randn(G * P, C, generator=g) * 3.0 + 1.5).cuda()
+    count, eps, mom = float(P), 1e-5, 0.1
+    part = torch.empty(G * nch * 2 * C, device="cuda", dtype=torch.float64)
+    sums = torch.empty(G * 2 * C, device="cuda", dtype=torch.float64)
+    m0, i0 = torch.empty(G * C, device="cuda"), torch.empty(G * C, device="cuda")
+    m1, i1 = torch.empty(G * C, device="cuda"), torch.empty(G * C, device="cuda")
+    run = G == 1
+    rm = [torch.randn(C, generator=g).cuda() for _ in range(2)]
+    rv = [(torch.rand(C, generator=g) + 0.5).cuda() for _ in range(2)]
+    rm_a, rv_a = [t.clone() for t in rm], [t.clone() for t in rv]
+    rm_b, rv_b = [t.clone() for t in rm], [t.clone() for t in rv]
+    check(lib.csg_norm_stats(ptr(x), G, P, C, ptr(sums), ptr(part), nch, stream()), "stats")
+    for k in range(2 if run else 1):
+        check(lib.csg_norm_finalize(ptr(sums), G, C, count, eps, 0, ptr(m0), ptr(i0), ptr(rm_a[k]) if run else None,
+                                    ptr(rv_a[k]) if run else None, mom, stream()), "finalize")
+    part.fill_(float("nan"))
+    check(lib.csg_norm_stats_finalize(ptr(x), G, P, C, ptr(part), nch, count, eps, ptr(m1), ptr(i1), ptr(rm_b[0]) if run else None,
+                                      ptr(rv_b[0]) if run else None, ptr(rm_b[1]) if run else None, ptr(rv_b[1]) if run else None,
+                                      mom, stream()), "stats_finalize")
+    assert torch.equal(m0, m1) and torch.equal(i0, i1)
+    if run:
+        for k in range(2):
+            assert torch.equal(rm_a[k], rm_b[k]) and torch.equal(rv_a[k], rv_b[k])
+            assert not torch.equal(rm_a[k], rm[k])
+    xs = x.view(G, P, C).double()
+    assert_close(m1.view(G, C), xs.mean(1).float(), 1e-5, 1e-6, "mean")
+    assert_close(i1.view(G, C), (1.0 / torch.sqrt(xs.var(1, unbiased=False) + eps)).float(), 1e-5, 1e-6, "invstd")
