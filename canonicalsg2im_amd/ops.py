@@ -343,7 +343,8 @@ def prepack_weights(root):
             packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
             it = WinoPackItem()
             it.w, it.s_o, it.s_i, it.s_h, it.s_w = w.data_ptr(), st[0], st[1], st[2], st[3]
-            it.Cout, it.Cin, it.backward_data, it.variant, it.packed = Cout, Cin, 1 if backward_data else 0, variant, packed.data_ptr()
+            it.Cout, it.Cin, it.backward_data, it.variant = Cout, Cin, 1 if backward_data else 0, variant
+            it.packed = packed.data_ptr()
             items.append(it)
             key = (w.data_ptr(), backward_data, variant)
             keep.append((key, (packed,) + tag))

@@ -1,8 +1,6 @@
 """Multi-tensor Winograd weight packs (csg_wino_pack_weights_multi) and the pack-ahead registry of ops.prepack_weights on a
 real MI355X: bit-identical operands, bit-identical training steps with the registry on and off, operands actually served
 from the registry, nothing stale after an optimiser step or an in-place edit."""
-import ctypes
-
 import pytest
 import torch
 
