@@ -193,9 +193,22 @@ def _wino_desc(B, H, W, Cin, Cout, act=ACT_NONE, slope=0.0):
     return d
 
 
-def wino_variant(B, H, W, Cin, Cout):
-    """4: the layer runs Winograd F(4x4,3x3) (csrc/wino4.hip: maps >= 32 wide); 2: F(2x2,3x3) (csrc/wino.hip)."""
-    return 4 if lib.csg_wino4_supported(_wino_desc(B, H, W, Cin, Cout)) == 1 else 2
+WINO4_MIN_ITEMS = int(os.environ.get("CSG_WINO4_MIN_ITEMS", "160"))
+
+
+def wino_variant(B, H, W, Cin, Cout, plain=False):
+    """4: the layer runs Winograd F(4x4,3x3) (csrc/wino4.hip: maps >= 32 wide); 2: F(2x2,3x3) (csrc/wino.hip).
+    F(4x4,3x3) works on (32 x 16 pixel region, 64 output channels) items, one per CU at a time: a launch with fewer than
+    ~160 of them (small batches on the 32 x 32 / 64 x 64 maps: config C4's shard of 4 images) leaves half the chip idle and
+    F(2x2,3x3) — 1.78x the multiplications in 4x the blocks — is 1.2-1.9x faster (profiles/r05t_variant_ab.txt: 64-128 items;
+    at 192 the larger tile wins again).  `plain` (no bias / activation / residual / gate): such a launch is split over >= 256
+    input channels instead and stays on F(4x4,3x3)."""
+    if lib.csg_wino4_supported(_wino_desc(B, H, W, Cin, Cout)) != 1:
+        return 2
+    items = B * ((H + 15) // 16) * ((W + 31) // 32) * ((Cout + 63) // 64)
+    if items < WINO4_MIN_ITEMS and not (plain and Cin >= 256):
+        return 2
+    return 4
 
 
 WINO34_MODE = int(os.environ.get("CSG_WINO34_MODE", "2"))      # bit 0: forward passes, bit 1: backward-data passes (see below)
@@ -357,12 +370,13 @@ def prepack_weights(root):
         mine.append(key)
 
 
-def _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad):
+def _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad, gated):
     """At FORWARD time: (variant, parked backward-data operand or None) of a convolution whose backward-data pass will run
-    Winograd — kept in the Function's ctx, so that the backward uses the operand of the weights its forward saw."""
+    Winograd — kept in the Function's ctx, so that the backward uses the operand of the weights its forward saw.  `gated`:
+    that pass carries the producer's activation derivative as its epilogue (in_act)."""
     if not _PREPACKED or not wino_eligible(B, IH, IW, Cout, Cin, KH, KW, stride, pad):
         return None
-    var = wino_variant(B, IH, IW, Cout, Cin)
+    var = wino_variant(B, IH, IW, Cout, Cin, plain=not gated)
     return (var, take_prepacked(_f32(weight.detach()), True, var))
 
 
@@ -505,10 +519,10 @@ class _Conv2d(torch.autograd.Function):
         elif dx_range is None and wino_eligible(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
             OH, OW = IH, IW
             y = empty_nhwc(B, Cout, OH, OW, x.device)
-            var = wino_variant(B, IH, IW, Cin, Cout)
+            var = wino_variant(B, IH, IW, Cin, Cout, plain=bias is None and res is None and act == ACT_NONE)
             up = _frozen_pack(packs, False, var) if (packs is not None and len(packs) > 2) else wino_pack(weight, False, None, var)
             if packs is None and ctx.needs_input_grad[0]:
-                ctx.ut_pre = _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad)
+                ctx.ut_pre = _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad, in_act is not None)
             _wino_launch(x, up, bias.detach() if bias is not None else None, res, y, B, IH, IW, Cin, Cout, act, slope,
                          "wino_conv_fwd", variant=var)
         elif dx_range is None and packs is None and wino34_eligible(
@@ -593,7 +607,7 @@ class _Conv2d(torch.autograd.Function):
             _conv_launch_classes(descs, dpre, wt, ctypes_ptr_off(dx, lo), dy.device, "conv_bwd_data")
         elif ctx.needs_input_grad[0] and wino_eligible(B, IH, IW, Cout, Cin, KH, KW, stride, pad):
             # dX = conv3x3(dY, flipped W^T): the same Winograd kernel with the roles of the channel counts swapped
-            var = wino_variant(B, IH, IW, Cout, Cin)
+            var = wino_variant(B, IH, IW, Cout, Cin, plain=ctx.in_act is None)
             pre = getattr(ctx, "ut_pre", None)           # parked at forward time (prepack_weights)
             if ctx.packs is not None and len(ctx.packs) > 3:
                 ut = _frozen_pack(ctx.packs, True, var)
@@ -1151,7 +1165,8 @@ class _SpadeFused(torch.autograd.Function):
                 raise RuntimeError("spade_fused: weight %s / actv %s do not fit x %s" % (tuple(w.shape), tuple(actv.shape),
                                                                                          tuple(x.shape)))
             up = wino_pack(w, False, None, 4)
-            pres.append(_take_bwd_operand(w, B, H, W, nh, 2 * C, 3, 3, 1, 1) if ctx.needs_input_grad[4 + k * 7] else None)
+            pres.append(_take_bwd_operand(w, B, H, W, nh, 2 * C, 3, 3, 1, 1, in_slope is not None)
+                        if ctx.needs_input_grad[4 + k * 7] else None)
             bd = b.detach().contiguous()
             gbuf = empty_nhwc(B, C, H, W, dev)                # gamma only: beta is consumed in the epilogue that forms it
             d = _wino_desc(B, H, W, nh, C)

@@ -155,6 +155,17 @@ def test_wino4_split_over_input_channels(ops, shape):
     assert lib.csg_wino4_conv_workspace(d) == 0                  # with an epilogue the plan never splits
 
 
+def test_variant_follows_the_grid(ops):
+    """F(4x4,3x3) on launches that fill the chip, F(2x2,3x3) where fewer than ~160 (region, channel block) items would leave
+    it half idle — unless the launch is plain and long enough to be split over its input channels."""
+    assert ops.wino_variant(16, 64, 64, 512, 256) == 4            # 512 items
+    assert ops.wino_variant(4, 64, 64, 512, 256) == 2             # 128 items, epilogue: not splittable
+    assert ops.wino_variant(4, 64, 64, 512, 256, plain=True) == 4     # split over 512 input channels instead
+    assert ops.wino_variant(4, 32, 32, 128, 512, plain=True) == 2     # 64 items, too few channels to split
+    assert ops.wino_variant(6, 64, 64, 256, 256) == 4             # 192 items
+    assert ops.wino_variant(4, 16, 16, 512, 512) == 2             # below 32 pixels: never F(4x4,3x3)
+
+
 def _both_forms(fn):
     """fn() with the persistent form of k_wino4_conv_v switched on, then off (csg_wino4_persistent)."""
     from canonicalsg2im_amd._lib import lib
@@ -238,10 +249,11 @@ def test_wino4_persistent_form_epilogues(ops):
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 256, 32, 64), (1, 64, 64, 64, 32)])
-def test_wino4_backward_data_through_autograd(ops, shape):
+def test_wino4_backward_data_through_autograd(ops, shape, monkeypatch):
     """conv2d on a >= 32-wide map: forward and backward-data both run F(4x4,3x3) (the weight gradient stays on
     F(3x3,2x2)); gradients against the fp64 reference."""
     B, Cin, Cout, H, W = shape
+    monkeypatch.setattr(ops, "WINO4_MIN_ITEMS", 0)               # (the small test shapes would otherwise take F(2x2,3x3))
     assert ops.wino_variant(B, H, W, Cin, Cout) == 4 and ops.wino_variant(B, H, W, Cout, Cin) == 4
     x, w, b = _data(shape)
     gy = torch.randn(B, Cout, H, W, generator=torch.Generator().manual_seed(3))
