@@ -370,13 +370,14 @@ def prepack_weights(root):
         mine.append(key)
 
 
-def _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad, gated):
+def _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad):
     """At FORWARD time: (variant, parked backward-data operand or None) of a convolution whose backward-data pass will run
-    Winograd — kept in the Function's ctx, so that the backward uses the operand of the weights its forward saw.  `gated`:
-    that pass carries the producer's activation derivative as its epilogue (in_act)."""
+    Winograd — kept in the Function's ctx, so that the backward uses the operand of the weights its forward saw.  (That
+    pass counts as plain for `wino_variant`: its only epilogue is the producer's activation derivative, which a launch split
+    over the input channels leaves to a separate pass — _wino_launch.)"""
     if not _PREPACKED or not wino_eligible(B, IH, IW, Cout, Cin, KH, KW, stride, pad):
         return None
-    var = wino_variant(B, IH, IW, Cout, Cin, plain=not gated)
+    var = wino_variant(B, IH, IW, Cout, Cin, plain=True)
     return (var, take_prepacked(_f32(weight.detach()), True, var))
 
 
@@ -522,7 +523,7 @@ class _Conv2d(torch.autograd.Function):
             var = wino_variant(B, IH, IW, Cin, Cout, plain=bias is None and res is None and act == ACT_NONE)
             up = _frozen_pack(packs, False, var) if (packs is not None and len(packs) > 2) else wino_pack(weight, False, None, var)
             if packs is None and ctx.needs_input_grad[0]:
-                ctx.ut_pre = _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad, in_act is not None)
+                ctx.ut_pre = _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad)
             _wino_launch(x, up, bias.detach() if bias is not None else None, res, y, B, IH, IW, Cin, Cout, act, slope,
                          "wino_conv_fwd", variant=var)
         elif dx_range is None and packs is None and wino34_eligible(
@@ -607,7 +608,7 @@ class _Conv2d(torch.autograd.Function):
             _conv_launch_classes(descs, dpre, wt, ctypes_ptr_off(dx, lo), dy.device, "conv_bwd_data")
         elif ctx.needs_input_grad[0] and wino_eligible(B, IH, IW, Cout, Cin, KH, KW, stride, pad):
             # dX = conv3x3(dY, flipped W^T): the same Winograd kernel with the roles of the channel counts swapped
-            var = wino_variant(B, IH, IW, Cout, Cin, plain=ctx.in_act is None)
+            var = wino_variant(B, IH, IW, Cout, Cin, plain=True)
             pre = getattr(ctx, "ut_pre", None)           # parked at forward time (prepack_weights)
             if ctx.packs is not None and len(ctx.packs) > 3:
                 ut = _frozen_pack(ctx.packs, True, var)
@@ -1165,8 +1166,7 @@ class _SpadeFused(torch.autograd.Function):
                 raise RuntimeError("spade_fused: weight %s / actv %s do not fit x %s" % (tuple(w.shape), tuple(actv.shape),
                                                                                          tuple(x.shape)))
             up = wino_pack(w, False, None, 4)
-            pres.append(_take_bwd_operand(w, B, H, W, nh, 2 * C, 3, 3, 1, 1, in_slope is not None)
-                        if ctx.needs_input_grad[4 + k * 7] else None)
+            pres.append(_take_bwd_operand(w, B, H, W, nh, 2 * C, 3, 3, 1, 1) if ctx.needs_input_grad[4 + k * 7] else None)
             bd = b.detach().contiguous()
             gbuf = empty_nhwc(B, C, H, W, dev)                # gamma only: beta is consumed in the epilogue that forms it
             d = _wino_desc(B, H, W, nh, C)

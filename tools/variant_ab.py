@@ -14,7 +14,8 @@ from canonicalsg2im_amd import ops  # noqa: E402
 from canonicalsg2im_amd._lib import WinoDesc, check, lib, ptr, stream  # noqa: E402
 
 SHAPES = [(512, 256, 64), (256, 256, 64), (128, 512, 64), (128, 256, 64), (1024, 512, 32), (512, 512, 32), (128, 1024, 32),
-          (128, 512, 32), (256, 128, 128), (128, 128, 128), (128, 256, 128), (128, 64, 256), (64, 64, 256), (32, 128, 64), (32, 128, 32)]
+          (128, 512, 32), (256, 128, 128), (128, 128, 128), (128, 256, 128), (128, 64, 256), (64, 64, 256), (32, 128, 64), (32, 128, 32),
+          (2048, 128, 32), (1024, 128, 32), (1024, 128, 64), (512, 128, 64)]   # backward-data of the gamma || beta convolutions
 
 
 def bench(fn, n=10):
