@@ -126,6 +126,31 @@ def test_bench_contract_with_two_ranks():
     assert "parity_b16" not in d
 
 
+@pytest.mark.timeout(600)
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` with NO torchrun around it (bench.spawn_ranks): the file starts its own two ranks as a child
+    torch.distributed.run before touching the GPU, relays rank 0's line and exits with the children's status.  Both ranks on
+    cuda:0 over gloo (the test hooks), as above."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CSG_DIST_BACKEND="gloo", CSG_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--image_size", "64", "--ngf", "8", "--ndf", "8", "--no_vgg_variant"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=540)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
+    assert d["comm"]["world_size"] == 2 and d["comm"]["backend"] == "gloo" and d["losses_finite"]
+    # a failing child fails the parent: an unknown flag makes every rank exit 2
+    bad = subprocess.run(cmd + ["--no_such_flag"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
+
+
 # ------------------------------------------------------------------ SyncBN backward and the converse all-gather
 def _syncbn_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),

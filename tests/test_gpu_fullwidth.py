@@ -102,8 +102,10 @@ def _step_losses_image_only(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed,
         from oracle.fp64 import generated_image64
         img64 = generated_image64(ts_before, batch)            # the forward half of oracle.train_step, in fp64
         d32 = (img_o.detach().double() - img64).abs()
-        # the yardstick's own distance from fp64 is recorded, and bounded: a broken oracle must not pass as "fp32 noise"
-        assert float(d32.max()) <= 5e-4 and float(d32.norm() / img64.norm()) <= 2e-5, (float(d32.max()), float(d32.norm() / img64.norm()))
+        # the yardstick's own distance from fp64 is bounded by a SANITY limit only (bench.ORACLE_SANITY_*: fp32 noise of the
+        # oracle measures 0.7e-5 .. 2.7e-5 here, a broken oracle is off by orders of magnitude) — the verdict on the HIP step
+        # below does not depend on how close to it the oracle sits
+        assert float(d32.max()) <= 5e-4 and float(d32.norm() / img64.norm()) <= 1e-4, (float(d32.max()), float(d32.norm() / img64.norm()))
         img_o = img64.float()
     _check_losses_and_image(tr, G, D, Go, Do, img_o, tag)
     del tr
