@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <tuple>
 #include <utility>
 
@@ -138,3 +139,14 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
       return (code);                  \
     }                                 \
   } while (0)
+
+// Per-device "already done" flags for idempotent one-time host setup (hipFuncSetAttribute on a kernel): lock-free and
+// re-entrant — two threads racing on a device's first launch both do the setup (harmless), a device id beyond the table does
+// it on every launch (correct, a few microseconds slower).
+struct DeviceOnce {
+  std::atomic<bool> done[32];
+  bool pending(int dev) const { return dev < 0 || dev >= 32 || !done[dev].load(std::memory_order_acquire); }
+  void mark(int dev) {
+    if (dev >= 0 && dev < 32) done[dev].store(true, std::memory_order_release);
+  }
+};

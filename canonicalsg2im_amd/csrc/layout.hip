@@ -379,8 +379,14 @@ __global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict
       __syncthreads();
       if (px0 < npx) {
         for (int a = 0; a < nact; ++a) {
-          const float4 v = *(const float4*)&s_vec[a * S + q4];
           const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
+          // the cull above is per block (ROWS rows x the whole pixel chunk); a wave owns 64 / (S/4) groups of eight pixels
+          // — 16 pixels at S = 128 — and most objects active in the chunk miss them: an object whose x coverage is zero on
+          // every pixel of the wave would add exact zeros (w = wy * 0), so the wave skips it (same sums, same order)
+          const bool hit = (w0.x != 0.f) | (w0.y != 0.f) | (w0.z != 0.f) | (w0.w != 0.f) | (w1.x != 0.f) | (w1.y != 0.f) |
+                           (w1.z != 0.f) | (w1.w != 0.f);
+          if (!__any(hit)) continue;
+          const float4 v = *(const float4*)&s_vec[a * S + q4];
           const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
           for (int r = 0; r < ROWS; ++r) {
@@ -514,13 +520,18 @@ __global__ __launch_bounds__(256) void k_layout_bwd_tiles(const float* __restric
         if (px0 < npx) {
           const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
           const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          // (as in the forward: a wave none of whose pixels the object covers would sum exact zeros — it keeps acc = 0)
+          const bool hit = (w0.x != 0.f) | (w0.y != 0.f) | (w0.z != 0.f) | (w0.w != 0.f) | (w1.x != 0.f) | (w1.y != 0.f) |
+                           (w1.z != 0.f) | (w1.w != 0.f);
+          if (__any(hit)) {
 #pragma unroll
-          for (int r = 0; r < ROWS; ++r) {
-            const float wy = s_wy[(a0 + a) * ROWS + r];
+            for (int r = 0; r < ROWS; ++r) {
+              const float wy = s_wy[(a0 + a) * ROWS + r];
 #pragma unroll
-            for (int i = 0; i < LAY_EPT; ++i) {
-              const float w = wy * wv[i];
-              acc.x += d[r][i].x * w; acc.y += d[r][i].y * w; acc.z += d[r][i].z * w; acc.w += d[r][i].w * w;
+              for (int i = 0; i < LAY_EPT; ++i) {
+                const float w = wy * wv[i];
+                acc.x += d[r][i].x * w; acc.y += d[r][i].y * w; acc.z += d[r][i].z * w; acc.w += d[r][i].w * w;
+              }
             }
           }
         }

@@ -808,10 +808,10 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
   }
   CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 16) == 0, CSG_E_UNSUPPORTED,
               "csg_wino_conv: pointers must be 16-byte aligned");
-  static bool attr_set[16] = {};
+  static DeviceOnce attr_once;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+  if (attr_once.pending(dev)) {
     const void* fns[10] = {(const void*)k_wino_conv<32>, (const void*)k_wino_conv<16>, (const void*)k_wino_conv<8>,
                           (const void*)k_wino_conv<4>, (const void*)k_wino_conv2<16, 2>, (const void*)k_wino_conv2<8, 2>,
                           (const void*)k_wino_conv2<4, 2>, (const void*)k_wino_conv2<16, 1>, (const void*)k_wino_conv2<8, 1>,
@@ -820,7 +820,7 @@ int csg_wino_conv(const csg_wino_desc* d, const float* x, const float* packed, c
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }
-    attr_set[dev] = true;
+    attr_once.mark(dev);
   }
   CSG_REQUIRE(shm <= 96 * 1024, CSG_E_UNSUPPORTED, "csg_wino_conv: %zu bytes of LDS", shm);
   hipStream_t s = (hipStream_t)stream;
@@ -1179,7 +1179,7 @@ int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy,
   const int64_t need = (int64_t)p.nsplit * (wsize + d->Cout) * 4;
   CSG_REQUIRE(workspace != nullptr && workspace_bytes >= need, CSG_E_WORKSPACE, "csg_wino_bwd_weight: workspace %ld < %ld bytes",
               (long)workspace_bytes, (long)need);
-  static bool attr_set[16] = {};
+  static DeviceOnce attr_once;
   int dev = 0;
   (void)hipGetDevice(&dev);
   const int tsx = wn_wg_tsx(d->W), tsy = 16 / tsx;
@@ -1188,14 +1188,14 @@ int csg_wino_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy,
   const size_t stage_bytes = 2 * (x_f4 * 16 + (size_t)(2 * tsy) * (2 * tsx) * 64 * 4);
   const size_t ep_bytes = (size_t)4 * 3 * 32 * WG_EPS * 4;
   const size_t shm = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+  if (attr_once.pending(dev)) {
     const void* fns[6] = {(const void*)k_wino_wgrad<16, 2>, (const void*)k_wino_wgrad<8, 2>, (const void*)k_wino_wgrad<4, 2>,
                           (const void*)k_wino_wgrad<16, 1>, (const void*)k_wino_wgrad<8, 1>, (const void*)k_wino_wgrad<4, 1>};
     for (const void* fn : fns) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino_bwd_weight: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }
-    attr_set[dev] = true;
+    attr_once.mark(dev);
   }
   CSG_REQUIRE(shm <= 128 * 1024, CSG_E_UNSUPPORTED, "csg_wino_bwd_weight: %zu bytes of LDS", shm);
   hipStream_t s = (hipStream_t)stream;

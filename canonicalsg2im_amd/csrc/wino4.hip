@@ -770,25 +770,57 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 #ifndef W4_SPLIT
 #define W4_SPLIT 3
 #endif
-  auto stage = [&](int s, auto par_tag) {        // par = (s - s_begin) & 1
+  // Developer variants (tools/wino4_variants.py; none is on in the shipped build):
+  //   -DW4_PRIO       the matrix clusters run at raised wave priority (s_setprio), the transform at 0
+  //   -DW4_STAGGER=k  the three waves of a SIMD (wave12 >> 2) split their MFMAs around the transform at 3-k | 3 | 3+k
+  //   -DW4_HALF_PRODUCE  ablation (wrong results): the transform of every other stage only
+  auto stage_body = [&](int s, auto par_tag, auto split_tag) {        // par = (s - s_begin) & 1
     constexpr int par = decltype(par_tag)::value;
     typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, W4_SPLIT> IS;
+    typedef std::integral_constant<int, decltype(split_tag)::value> IS;
     typedef std::integral_constant<int, 6> I6;
 #ifndef W4_NO_MFMA
+#ifdef W4_PRIO
+    __builtin_amdgcn_s_setprio(W4_PRIO);
+#endif
     consume(I0(), IS(), par, s);
+#ifdef W4_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef W4_NO_PRODUCE
+#ifdef W4_HALF_PRODUCE
+    if (s + 1 < s_end && par == 0) produce(par ^ 1, par ^ 1);
+#else
     if (s + 1 < s_end) produce(par ^ 1, par ^ 1);   // V[k+1] from raw[k+1]
+#endif
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef W4_NO_MFMA
+#ifdef W4_PRIO
+    __builtin_amdgcn_s_setprio(W4_PRIO);
+#endif
     consume(IS(), I6(), par, s);
+#ifdef W4_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
     store_stage(smem + W4V_RAW0 + par * W4_BUFW);   // raw[k+2] takes the buffer raw[k] left
     __syncthreads();
     load_stage(s + 3);
+  };
+#ifdef W4_STAGGER
+  const int simd_slot = __builtin_amdgcn_readfirstlane(wave12 >> 2);
+#endif
+  auto stage = [&](int s, auto par_tag) {
+#ifdef W4_STAGGER
+    if (simd_slot == 0) stage_body(s, par_tag, std::integral_constant<int, W4_SPLIT - W4_STAGGER>());
+    else if (simd_slot == 1) stage_body(s, par_tag, std::integral_constant<int, W4_SPLIT>());
+    else stage_body(s, par_tag, std::integral_constant<int, W4_SPLIT + W4_STAGGER>());
+#else
+    stage_body(s, par_tag, std::integral_constant<int, W4_SPLIT>());
+#endif
   };
 
   y += (long long)split * p.slab;
@@ -934,36 +966,42 @@ static int w4_plan(const csg_wino_desc* d, int T, int pad, Wino4Params& p, size_
 // the launch shared by both tile sizes
 template <int T, bool P>
 static int w4_set_lds_limit(const char* who) {
-  static bool attr_set[16] = {};
+  static DeviceOnce attr_once;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+  if (attr_once.pending(dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)k_wino4_conv_v<T, P>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (P ? 160 : 128) * 1024);
     CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(e));
-    attr_set[dev] = true;
+    attr_once.mark(dev);
   }
   return CSG_OK;
 }
 
 // blocks of the persistent form: one per CU, a multiple of 8 (one share per XCD); 0 = the launch does not qualify.
 // CSG_WINO4_PERSIST=0 switches it off (A/B runs).
-static int w4_persist_on = -1;                     // -1: CSG_WINO4_PERSIST (default 1) decides at the first launch
+static std::atomic<int> w4_persist_on{-1};         // -1: CSG_WINO4_PERSIST (default 1) decides at the first launch
 static int w4_persistent_blocks(const Wino4Params& p, int64_t items) {
-  static int cus[16] = {};
-  if (w4_persist_on < 0) w4_persist_on = getenv("CSG_WINO4_PERSIST") ? atoi(getenv("CSG_WINO4_PERSIST")) : 1;
+  static std::atomic<int> cus[32];                 // CU count per device (0 = not asked yet, -1 = unusable)
+  int on = w4_persist_on.load(std::memory_order_relaxed);
+  if (on < 0) {
+    on = getenv("CSG_WINO4_PERSIST") ? atoi(getenv("CSG_WINO4_PERSIST")) : 1;
+    int expect = -1;
+    w4_persist_on.compare_exchange_strong(expect, on);          // (csg_wino4_persistent() may have decided meanwhile)
+    on = w4_persist_on.load(std::memory_order_relaxed);
+  }
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (!w4_persist_on || dev < 0 || dev >= 16) return 0;
-  if (cus[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = -1;
-    cus[dev] = n;
+  if (!on || dev < 0) return 0;
+  int ncu = dev < 32 ? cus[dev].load(std::memory_order_relaxed) : 0;
+  if (ncu == 0) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = -1;
+    if (dev < 32) cus[dev].store(ncu, std::memory_order_relaxed);
   }
-  const int g = cus[dev] > 0 ? (cus[dev] & ~7) : 0;
+  const int g = ncu > 0 ? (ncu & ~7) : 0;
   if (g == 0 || p.ksplit != 1 || (p.nstage & 1) || p.nstage < 4 || (p.Cout & 63) || items < 2 * (int64_t)g) return 0;
 #ifdef W4_TRACE
-  if (w4_persist_on == 2 && (items & 7) == 0) return (int)items;   // experiment: the persistent code, one item per block
+  if (on == 2 && (items & 7) == 0) return (int)items;   // experiment: the persistent code, one item per block
 #endif
   return g;
 }

@@ -515,17 +515,17 @@ int csg_wino4_bwd_weight(const csg_wino_desc* d, const float* x, const float* dy
   const int64_t need = (int64_t)nslab * (wsize + d->Cout) * 4;
   CSG_REQUIRE(workspace != nullptr && workspace_bytes >= need, CSG_E_WORKSPACE, "csg_wino4_bwd_weight: workspace %ld < %ld bytes",
               (long)workspace_bytes, (long)need);
-  static bool attr_set[16] = {};
+  static DeviceOnce attr_once;
   int dev = 0;
   (void)hipGetDevice(&dev);
   const size_t ep_bytes = (size_t)2 * 18 * 32 * WW_EXR * 4;
   const size_t shm = (size_t)WW_LDS_FLOATS * 4 > ep_bytes ? (size_t)WW_LDS_FLOATS * 4 : ep_bytes;
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+  if (attr_once.pending(dev)) {
     for (const void* fn : {(const void*)k_wino4_wgrad<true>, (const void*)k_wino4_wgrad<false>}) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_wino4_bwd_weight: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }
-    attr_set[dev] = true;
+    attr_once.mark(dev);
   }
   hipStream_t s = (hipStream_t)stream;
   float* dbslabs = db != nullptr ? workspace + (int64_t)nslab * wsize : nullptr;

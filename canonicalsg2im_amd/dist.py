@@ -23,6 +23,9 @@ def init_from_env(backend=None):
             backend = os.environ.get("CSG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # ProcessGroupNCCL's flight recorder on (it is what drain_watchdog() below reads; a ring of 2000 small records)
+        os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "2000")
+        os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -50,6 +53,44 @@ def capturable():
     """Whether the collectives may be issued inside a HIP-graph capture: RCCL's are (ProcessGroupNCCL records them on its
     own stream, joined to the capturing stream); gloo's go through the host."""
     return active() and dist.get_backend() == "nccl"
+
+
+def drain_watchdog(timeout_s=10.0):
+    """Wait until ProcessGroupNCCL's watchdog thread holds no pending work — the condition a HIP-graph capture needs (the
+    watchdog polls the end event of every work still on its list from its own thread; such a poll inside a capture aborts the
+    process, graphs._quiesce_before_capture).  The device is drained first by the caller; what remains is the watchdog
+    noticing, on its next 100 ms tick, that the works have completed and retiring them.  That is OBSERVABLE: the flight
+    recorder marks an entry retired when the watchdog drops the work, and `_dump_nccl_trace_json(onlyActive=True)` lists the
+    entries it has not.  Returns "drained" (no active entry left: nothing for the watchdog to poll), "no_recorder" (the
+    recorder holds no entry at all although collectives were issued — it is off, the caller falls back to a timed wait) or
+    "timeout"."""
+    import json
+    import time
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+        return "drained"
+    try:
+        from torch._C._distributed_c10d import _dump_nccl_trace_json as dump
+    except ImportError:
+        return "no_recorder"
+
+    def entries(only_active):
+        try:
+            return json.loads(dump(includeCollectives=True, onlyActive=only_active)).get("entries", [])
+        except (RuntimeError, ValueError):
+            return None
+
+    everything = entries(False)
+    if not everything:                   # (a trainer has broadcast its parameters by now: an empty recorder is a recorder that is off)
+        return "no_recorder"
+    t0 = time.monotonic()
+    while time.monotonic() - t0 < timeout_s:
+        act = entries(True)
+        if act is None:
+            return "no_recorder"
+        if not act:
+            return "drained"
+        time.sleep(0.005)
+    return "timeout"
 
 
 # ---- communication audit (bench.py's "comm" object, tests): what was exchanged since the last comm_reset()
@@ -155,6 +196,8 @@ class GradBuckets:
         self._pending, self._fired, self._works, self._next, self._streams = [], set(), [], 0, {}
         self.allocations = 0                                    # flat buffers ever allocated (tests: steady state adds none)
         self.rebuilds = 0
+        self.generation = 0                                     # bumped whenever the flats are (re)allocated: captured HIP graphs
+        #                                                         bake slot ADDRESSES in and go stale with it (graphs.py)
         self.late_dropped = 0                                   # late gradients dropped (one step each) before a rebuild
         self._launch_in_hooks = True
         self._flag = self._flag_host = self._flag_event = None  # the "late gradient seen" float riding in the last bucket
@@ -165,6 +208,7 @@ class GradBuckets:
     def _build(self):
         for h in self._hooks:
             h.remove()
+        self.generation += 1
         wanted = set(self.slot) | self._late_ids                # a rebuild keeps the members and adds the late arrivals
         self._late_ids = set()
         self._hooks, self.flats, self.members, self.slot = [], [], [], {}
@@ -259,6 +303,14 @@ class GradBuckets:
                           "step (it was dropped for that step on every rank); re-agreeing the set now (rebuild #%d)"
                           % (self.rebuilds + 1))
             self.rebuild()
+
+    def resolve(self):
+        """COLLECTIVE when it fires (see _resolve_flag): read the late-gradient flag of the previous exchange NOW.  Trainer.step
+        calls it for every bucket set at the top of an iteration, whichever path (eager or graph replay) the iteration then
+        takes: every rank rebuilds at the same point, and a replay can compare `generation` before it touches a graph."""
+        if active() and self.built:
+            self._resolve_flag()
+        return self.generation
 
     def _launch_ready(self, force=False):
         """Launch, in bucket order (identical on every rank), the all-reduces of the buckets that are complete."""

@@ -136,15 +136,30 @@ class _Capture:
                 gc.enable()
 
 
+QUIESCE = {"drained": 0, "no_recorder": 0, "timeout": 0}            # how the captures of this process found the watchdog
+
+
 def _quiesce_before_capture():
-    """Drain the device — and, with a process group up, let ProcessGroupNCCL's watchdog finish with the collectives issued so
-    far: it polls the end events of pending works every ~100 ms from its own thread, and a poll that lands inside a capture
-    killed the process half of the time (hipErrorCapturedEvent from WorkNCCL::isCompleted, ROCm 7.2 / torch 2.10,
-    tools/probe/nccl_graph_step_probe.py).  A capture happens once per shape key and encoder bucket."""
+    """Drain the device — and, with a process group up, wait until ProcessGroupNCCL's watchdog holds no pending work: it polls
+    the end events of the works on its list every ~100 ms from its own thread, and a poll that lands inside a capture killed
+    the process half of the time (hipErrorCapturedEvent from WorkNCCL::isCompleted, ROCm 7.2 / torch 2.10,
+    tools/probe/nccl_graph_step_probe.py).  The condition is explicit, not timed: every Work handle this package still holds
+    is waited for and dropped by its owner before a capture (GradBuckets.finish(), the SyncBN handles), the device is
+    synchronised, and dist.drain_watchdog() then reads the flight recorder until no entry is active — i.e. the watchdog has
+    retired everything and has nothing left to query.  Only if the recorder is off (TORCH_NCCL_TRACE_BUFFER_SIZE=0 set by the
+    integrator) does this fall back to a timed wait of three watchdog periods, and says so in QUIESCE.  A capture happens once
+    per shape key and encoder bucket."""
     torch.cuda.synchronize()
     if csg_dist.active():
-        import time
-        time.sleep(float(os.environ.get("CSG_GRAPH_DRAIN_S", "0.35")))
+        how = csg_dist.drain_watchdog()
+        QUIESCE[how] += 1
+        if how != "drained":
+            import time
+            import warnings
+            if QUIESCE[how] == 1:
+                warnings.warn("graphs: ProcessGroupNCCL's flight recorder could not confirm an idle watchdog (%s); falling back "
+                              "to a timed wait before HIP-graph captures" % how)
+            time.sleep(float(os.environ.get("CSG_GRAPH_DRAIN_S", "0.35")))
 
 
 def _pad_objects(n):
@@ -254,6 +269,7 @@ class _GraphSet:
         self.sg = {}                     # padded triplet count -> _SgGraph
         self.sg_seen = {}
         self.fired = {}                  # (N > 1) graph name -> ids of the bucket members its captured backward fills
+        self.bucket_generation = owner.tr.bucket_generation   # (N > 1) the flats whose slot addresses the captures bake in
 
     def load(self, imgs, objs, boxes):
         O = objs.shape[1]
@@ -300,6 +316,7 @@ class StepGraphs:
         self.active = None
         self.replays = self.eager_steps = self.captures = 0
         self.sg_replays = self.sg_captures = 0
+        self.stale_drops = 0             # (N > 1) graph sets dropped because the gradient buckets were rebuilt under them
         self.side = self.side2 = None    # streams of the overlapped pieces (OVERLAP)
         self.marks = _Marks() if TIMING else None
 
@@ -332,6 +349,13 @@ class StepGraphs:
     def step(self, batch):
         key = self.key_of(batch)
         gs = self.sets.get(key) if key is not None else None
+        if gs is not None and gs.bucket_generation != self.tr.bucket_generation:
+            # (N > 1) GradBuckets.rebuild() ran since the capture: the graphs write gradients into flats that are no longer
+            # the ones flush() exchanges and p.grad points at.  Every set is stale; this iteration runs eagerly and the keys
+            # are captured again on their next sightings.
+            self.invalidate()
+            self.stale_drops += 1
+            gs = None
         if gs is None:
             n = self.seen.get(key, 0)
             self.seen[key] = n + 1

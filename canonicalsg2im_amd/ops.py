@@ -261,7 +261,9 @@ _PACK_OWNER = {}         # data_ptr -> (weakref to module, attribute): who to no
 
 
 def _pack_tag(w):
-    return (tuple(w.shape), tuple(w.stride()), weight_epoch())
+    # `_version`: detach() shares the version counter with its source, so an in-place edit outside an optimiser (copy_,
+    # load_state_dict, an EMA swap that forgot invalidate_weight_caches) between prepack_weights and the take shows here
+    return (tuple(w.shape), tuple(w.stride()), weight_epoch(), int(w._version))
 
 
 def take_prepacked(w, backward_data, variant):
@@ -271,8 +273,8 @@ def take_prepacked(w, backward_data, variant):
     hit = _PREPACKED.pop((w.data_ptr(), bool(backward_data), int(variant)), None)
     if hit is None:
         return None
-    packed, shape, strides, epoch = hit
-    if (shape, strides, epoch) != _pack_tag(w) or packed.device != w.device:
+    packed, tag = hit[0], tuple(hit[1:])
+    if tag != _pack_tag(w) or packed.device != w.device:
         return None
     return packed
 
@@ -419,8 +421,10 @@ def invalidate_weight_caches():
     """Call after editing parameters in place OUTSIDE an optimiser step through `.data` (a broadcast, an EMA swap,
     weight clipping): such edits bump neither `_version` nor the optimiser hook, so tensors derived from the weights
     (Winograd operands, the PatchGAN's permuted first-layer weight) would otherwise stay stale until the next step.
-    `dist.broadcast_module` and `Trainer.load_checkpoint` call it."""
+    `dist.broadcast_module` and `Trainer.load_checkpoint` call it.  Parked Winograd operands are dropped as well (they
+    would be refused by their epoch tag anyway; dropping them frees their memory now)."""
     _bump_weight_epoch()
+    _PREPACKED.clear()
 
 
 # ---- gradient destinations (N > 1 ranks): `dist.GradBuckets` registers, for the backward that is about to run, where each
@@ -1523,6 +1527,9 @@ class _Embed(torch.autograd.Function):
         rows = idx2.shape[0]
         dims = [t.shape[1] for t in tables]
         D = sum(dims)
+        if any(ctx.needs_input_grad[1:]) and max(dims) > 256:
+            # the limit of csg_embed_bwd (include/csg_hip.h): refused HERE, before a step is half executed
+            raise RuntimeError("embedding lookup: the backward supports embedding_dim <= 256 (got %d)" % max(dims))
         out = torch.empty((rows, D), device=idx.device, dtype=torch.float32)
         off = 0
         for k, t in enumerate(tables):
@@ -1810,6 +1817,10 @@ class _CropObjects(torch.autograd.Function):
         boxes = _f32(boxes).contiguous()
         N = boxes.shape[0]
         Cp = (C + 3) // 4 * 4
+        if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and (C > 4 or HH > 64):
+            # the limits of csg_crop_bwd (include/csg_hip.h): refused HERE, before a step is half executed
+            raise RuntimeError("crop_objects: the backward supports at most 4 image channels and 64 x 64 crops "
+                               "(got C = %d, crop_size = %d)" % (C, HH))
         out = empty_nhwc(N, Cp, HH, HH, img.device)
         check(lib.csg_crop_fwd(ptr(img), B, H, W, C, C, ptr(boxes), ptr(img_idx), N, HH, HH, ptr(out), Cp, stream()),
               "crop_fwd")

@@ -64,6 +64,7 @@ class Trainer:
         self.g_params = [p for p in self.model.layout_to_image_model.parameters()] if self.model.has_image else []
         self._grads_dirty, self._eager_steps = False, 0
         self.graphs = csg_graphs.StepGraphs(self) if use_graphs else None
+        self.bucket_generation = ()            # (N > 1) generations of the gradient buckets, refreshed at the top of every step
         self.use_graphs = True                 # False: run eagerly without dropping the captured graphs (bench.py's event legs)
 
     def freeze_weights(self, module):
@@ -109,6 +110,11 @@ class Trainer:
     def step(self, batch):
         """One training iteration.  Shape keys that repeat are replayed from captured HIP graphs (graphs.py); anything
         else — a new shape, N > 1 ranks, masks, `--learned_converse` — runs the eager path below, in this process."""
+        if csg_dist.active():
+            # a late-gradient flag of the previous iteration re-agrees the bucket set HERE, on every rank and on either path
+            # (dist.GradBuckets.resolve): a rebuild re-allocates the flats that captured graphs address
+            self.bucket_generation = tuple(b.resolve() for b in (self.g_buckets, self.d_buckets, self.dobj_buckets,
+                                                                 self.dmask_buckets) if b is not None)
         if self.graphs is not None and self.use_graphs:
             out = self.graphs.step(batch)
             if out is not None:

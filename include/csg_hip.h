@@ -69,7 +69,10 @@ int csg_embed_fwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const fl
                   int64_t dim, float* out, int64_t out_stride, int64_t out_off, void* stream);
 /* dtable[idx[r], :] += dout[r, out_off..] — replaces the backward of nn.Embedding (attribute_embed.py:40-45): rows added in
  * row order (no atomics, bit-reproducible).  More than one chunk of 8192 / dim rows needs a workspace of csg_embed_bwd_workspace(...) bytes for
- * the per-chunk partial tables (0 = none needed).                                                */
+ * the per-chunk partial tables (0 = none needed).
+ * LIMITS: dim <= 256 and num_emb * dim < 2^30 (CSG_E_BADSHAPE otherwise; the reference's --embedding_dim is 128).  The
+ * workspace is chunks * num_emb * dim floats and the grid re-stages a chunk once per 256 table entries: sized for vocabularies of
+ * 10^2..10^3 rows (COCO 184, VG 179 + 46 predicates, CLEVR 4 x <= 9), not for 10^5-row tables.            */
 int64_t csg_embed_bwd_workspace(int64_t rows, int64_t num_emb, int64_t dim);
 int csg_embed_bwd(const int64_t* idx, int64_t rows, int64_t idx_stride, const float* dout, int64_t out_stride,
                   int64_t out_off, int64_t num_emb, int64_t dim, float* dtable, float* workspace, int64_t workspace_bytes,
@@ -446,8 +449,11 @@ int csg_avgpool3s2_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t
 /* ---- object crops for the object discriminator (sg2im/bilinear.py:44-94) ---------------------------
  * out[n, y, x, c] = bilinear sample (grid_sample, align_corners=False, zeros padding) of image
  * img_idx[n] over box n ([x0,y0,w,h] in [0,1]); img is NHWC with img_cs floats per pixel, C used;
- * out is (N,HH,WW,out_cs) with channels >= C written as 0.  Backward adds into dimg (zeroed by the
- * caller) with float atomics. */
+ * out is (N,HH,WW,out_cs) with channels >= C written as 0.  Backward: dimg is OVERWRITTEN — every image pixel gathers the
+ * contributions of the crops that sampled it, in crop order (no atomics, bit-reproducible).
+ * LIMITS of csg_crop_bwd: C <= 4 and HH, WW <= 64 (CSG_E_UNSUPPORTED otherwise; the reference crops 3-channel images at
+ * --crop_size 32).  The forward and csg_crop_bwd_boxes have no such limit; the Python wrapper refuses a differentiable
+ * crop outside them at FORWARD time. */
 int csg_crop_fwd(const float* img, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C, const float* boxes,
                  const int64_t* img_idx, int64_t N, int64_t HH, int64_t WW, float* out, int64_t out_cs, void* stream);
 int csg_crop_bwd(const float* dout, int64_t B, int64_t H, int64_t W, int64_t img_cs, int64_t C, const float* boxes,

@@ -146,8 +146,8 @@ def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
     assert d["comm"]["world_size"] == 2 and d["comm"]["backend"] == "gloo" and d["losses_finite"]
-    # a failing child fails the parent: an unknown flag makes every rank exit 2
-    bad = subprocess.run(cmd + ["--no_such_flag"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    # a failing child fails the parent: an unknown config raises in every rank
+    bad = subprocess.run(cmd + ["--config", "C9"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
 
 

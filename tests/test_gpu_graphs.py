@@ -213,7 +213,8 @@ def _one_rank_nccl_worker(rank, port, out):
     bucketed ReduceOp.AVG gradient all-reduces, the fp64 SyncBN statistics messages (N-replica formula), the late-gradient
     flag — and is the identity, so the replayed trainer must track the eager one exactly as it does without a group."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      CSG_DIST_FORCE="1", CSG_GRAPHS_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      CSG_DIST_FORCE="1", CSG_GRAPHS_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      TORCH_NCCL_TRACE_BUFFER_SIZE="2000", TORCH_FR_BUFFER_SIZE="2000")   # (dist.init_from_env sets these)
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1)
@@ -246,8 +247,33 @@ def _one_rank_nccl_worker(rank, port, out):
         res[use_img_disc] = {"rows": rows, "captures": graphed.graphs.captures, "replays": graphed.graphs.replays,
                              "comm": rep, "param_rel": float((pe - pg).norm() / pe.norm()),
                              "g_buckets": len(graphed.g_buckets.flats), "rebuilds": graphed.g_buckets.rebuilds,
+                             "quiesce": dict(__import__("canonicalsg2im_amd.graphs", fromlist=["QUIESCE"]).QUIESCE),
                              "grads_are_slots": all(p.grad is None or p.grad.data_ptr() == graphed.g_buckets.slot[id(p)][1].data_ptr()
                                                     for p in graphed.g_buckets.params if id(p) in graphed.g_buckets.slot)}
+        if use_img_disc == 0:
+            # a bucket REBUILD between two replays (what the late-gradient protocol does from begin() / resolve()): the flats are
+            # re-allocated, the captured graphs still address the old ones.  The next step must notice (generation counter),
+            # drop the sets, run eagerly, and capture again — and the gradients Adam reads must be the exchanged ones.
+            old_ptrs = [f.data_ptr() for f in graphed.g_buckets.flats]
+            keep = list(graphed.g_buckets.flats)             # (held: the allocator must not hand the same addresses back)
+            graphed.g_buckets.rebuild()
+            moved = all(f.data_ptr() not in old_ptrs for f in graphed.g_buckets.flats)
+            rows2 = []
+            for it in range(5, 10):
+                Ge, De = eager.step(bs[it % 2])
+                Gg, Dg = graphed.step(bs[it % 2])
+                rows2.append(({k: float(v) for k, v in Ge.items() if v.numel() == 1},
+                              {k: float(v) for k, v in Gg.items() if v.numel() == 1}))
+            torch.cuda.synchronize()
+            pe = torch.cat([p.detach().flatten() for p in eager.model.parameters()])
+            pg = torch.cat([p.detach().flatten() for p in graphed.model.parameters()])
+            gb = graphed.g_buckets
+            res["rebuild"] = {"moved": moved, "stale_drops": graphed.graphs.stale_drops, "captures": graphed.graphs.captures,
+                              "replays": graphed.graphs.replays, "rows": rows2, "param_rel": float((pe - pg).norm() / pe.norm()),
+                              "generation": gb.generation,
+                              "grads_are_slots": all(p.grad is None or p.grad.data_ptr() == gb.slot[id(p)][1].data_ptr()
+                                                     for p in gb.params if id(p) in gb.slot)}
+            del keep
     out.update(res)
     dist.barrier()
     dist.destroy_process_group()
@@ -271,6 +297,9 @@ def test_one_rank_nccl_group_replays_with_collectives_captured():
         r = out[use_img_disc]
         assert r["captures"] == 1 and r["replays"] == 4, (r["captures"], r["replays"])
         assert r["rebuilds"] == 0 and r["g_buckets"] >= 1 and r["grads_are_slots"]
+        # every capture found the watchdog idle by READING it (flight recorder), not by sleeping
+        q = r["quiesce"]
+        assert q["drained"] >= 4 and q["no_recorder"] == 0 and q["timeout"] == 0, q
         c = r["comm"]
         assert c["backend"] == "nccl" and c["grad_allreduce_calls_per_step"] >= 2 and c["syncbn_allreduce_calls_per_step"] > 10, c
         for it, (Ge, Gg, De, Dg) in enumerate(r["rows"]):
@@ -280,3 +309,12 @@ def test_one_rank_nccl_group_replays_with_collectives_captured():
             for k in De:
                 assert abs(De[k] - Dg[k]) <= tol * abs(De[k]) + 1e-5, (use_img_disc, it, k, De[k], Dg[k])
         assert r["param_rel"] < 5e-3, r["param_rel"]
+    # captured graphs must not outlive the flats they address
+    rb = out["rebuild"]
+    assert rb["moved"] and rb["generation"] == 2 and rb["stale_drops"] == 1, rb
+    assert rb["captures"] == 2 and rb["replays"] >= 4 + 2, (rb["captures"], rb["replays"])     # dropped, re-captured, replayed again
+    assert rb["grads_are_slots"]
+    for it, (Ge, Gg) in enumerate(rb["rows"]):
+        for k in Ge:
+            assert abs(Ge[k] - Gg[k]) <= 2e-2 * abs(Ge[k]) + 1e-5, ("after rebuild", it, k, Ge[k], Gg[k])
+    assert rb["param_rel"] < 5e-3, rb["param_rel"]

@@ -16,7 +16,8 @@ first_csv() {   # first file matching a pattern under a directory, or fail loudl
   echo "$f"
 }
 
-python3 bench.py > "$O/${TAG}_bench.json.tmp" 2> "$O/${TAG}_bench.err"
+# the driver's exact command (BENCH_r*.json "cmd"): the parity gate is validated at THESE flags
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$O/${TAG}_bench.json.tmp" 2> "$O/${TAG}_bench.err"
 mv "$O/${TAG}_bench.json.tmp" "$O/${TAG}_bench.json"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/p_stats" -- python3 bench.py --steps 10 --warmup 2 --no_c5_leg \
