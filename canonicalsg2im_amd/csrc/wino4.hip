@@ -770,23 +770,17 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 #ifndef W4_SPLIT
 #define W4_SPLIT 3
 #endif
-  // Developer variants (tools/wino4_variants.py; none is on in the shipped build):
-  //   -DW4_PRIO       the matrix clusters run at raised wave priority (s_setprio), the transform at 0
-  //   -DW4_STAGGER=k  the three waves of a SIMD (wave12 >> 2) split their MFMAs around the transform at 3-k | 3 | 3+k
-  //   -DW4_HALF_PRODUCE  ablation (wrong results): the transform of every other stage only
-  auto stage_body = [&](int s, auto par_tag, auto split_tag) {        // par = (s - s_begin) & 1
+  // (-DW4_HALF_PRODUCE: ablation for tools/wino4_variants.py — the transform of every other stage only, wrong results.
+  // Round 6 measured two more placements with that tool and dropped them: s_setprio 1 / 3 around the matrix clusters
+  // -3 % on every shape; different split points on the three waves of a SIMD needed the stage body as a callable the
+  // compiler no longer inlined — 1 KB of scratch, 30x slower.  profiles/r06b_wino4_variants.txt.)
+  auto stage = [&](int s, auto par_tag) {        // par = (s - s_begin) & 1
     constexpr int par = decltype(par_tag)::value;
     typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, decltype(split_tag)::value> IS;
+    typedef std::integral_constant<int, W4_SPLIT> IS;
     typedef std::integral_constant<int, 6> I6;
 #ifndef W4_NO_MFMA
-#ifdef W4_PRIO
-    __builtin_amdgcn_s_setprio(W4_PRIO);
-#endif
     consume(I0(), IS(), par, s);
-#ifdef W4_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef W4_NO_PRODUCE
@@ -798,29 +792,11 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef W4_NO_MFMA
-#ifdef W4_PRIO
-    __builtin_amdgcn_s_setprio(W4_PRIO);
-#endif
     consume(IS(), I6(), par, s);
-#ifdef W4_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
 #endif
     store_stage(smem + W4V_RAW0 + par * W4_BUFW);   // raw[k+2] takes the buffer raw[k] left
     __syncthreads();
     load_stage(s + 3);
-  };
-#ifdef W4_STAGGER
-  const int simd_slot = __builtin_amdgcn_readfirstlane(wave12 >> 2);
-#endif
-  auto stage = [&](int s, auto par_tag) {
-#ifdef W4_STAGGER
-    if (simd_slot == 0) stage_body(s, par_tag, std::integral_constant<int, W4_SPLIT - W4_STAGGER>());
-    else if (simd_slot == 1) stage_body(s, par_tag, std::integral_constant<int, W4_SPLIT>());
-    else stage_body(s, par_tag, std::integral_constant<int, W4_SPLIT + W4_STAGGER>());
-#else
-    stage_body(s, par_tag, std::integral_constant<int, W4_SPLIT>());
-#endif
   };
 
   y += (long long)split * p.slab;

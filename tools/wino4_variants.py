@@ -1,4 +1,4 @@
-"""Developer A/B of compile-time variants of k_wino4_conv_v (csrc/wino4.hip: -DW4_PRIO, -DW4_STAGGER, -DW4_SPLIT, the ablations).
+"""Developer A/B of compile-time variants of k_wino4_conv_v (csrc/wino4.hip: -DW4_SPLIT, the ablations).
 
     python tools/wino4_variants.py --build      HERE (no GPU): one libcsg_hip_<tag>.so per variant under csrc/build/variants/
                                                 (only wino4.o is recompiled; the .so files travel with gpurun)
@@ -17,10 +17,7 @@ VDIR = os.path.join(ROOT, "canonicalsg2im_amd", "csrc", "build", "variants")
 # tag -> extra flags for wino4.hip ("valid": results are right; the ablations compute garbage and only time the loop)
 VARIANTS = {
     "base": [],
-    "prio1": ["-DW4_PRIO=1"],
-    "prio3": ["-DW4_PRIO=3"],
-    "stag1": ["-DW4_STAGGER=1"],
-    "stag2": ["-DW4_STAGGER=2"],
+    "split2": ["-DW4_SPLIT=2"],
     "abl_half_produce": ["-DW4_HALF_PRODUCE"],
     "abl_no_produce": ["-DW4_NO_PRODUCE"],
 }
