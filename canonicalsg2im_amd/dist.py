@@ -59,11 +59,13 @@ def drain_watchdog(timeout_s=10.0):
     """Wait until ProcessGroupNCCL's watchdog thread holds no pending work — the condition a HIP-graph capture needs (the
     watchdog polls the end event of every work still on its list from its own thread; such a poll inside a capture aborts the
     process, graphs._quiesce_before_capture).  The device is drained first by the caller; what remains is the watchdog
-    noticing, on its next 100 ms tick, that the works have completed and retiring them.  That is OBSERVABLE: the flight
-    recorder marks an entry retired when the watchdog drops the work, and `_dump_nccl_trace_json(onlyActive=True)` lists the
-    entries it has not.  Returns "drained" (no active entry left: nothing for the watchdog to poll), "no_recorder" (the
-    recorder holds no entry at all although collectives were issued — it is off, the caller falls back to a timed wait) or
-    "timeout"."""
+    noticing, on its next 100 ms tick, that the works have completed and dropping them.  That is OBSERVABLE: the watchdog
+    marks a work's flight-recorder entry `retired` in the same breath as it erases the work from its list, and
+    `_dump_nccl_trace_json` lists every entry with that flag.  (NOT `onlyActive=True` / the entry's `state`: the dump itself
+    queries the events to fill those in, so they turn "completed" the moment the device is idle whether or not the watchdog
+    has looked — round 6 tried that first and the race stayed.)  Returns "drained" (every recorded collective is retired:
+    nothing is left for the watchdog to query), "no_recorder" (no entries, or entries without the flag: the caller falls back
+    to a timed wait) or "timeout"."""
     import json
     import time
     if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
@@ -72,25 +74,20 @@ def drain_watchdog(timeout_s=10.0):
         from torch._C._distributed_c10d import _dump_nccl_trace_json as dump
     except ImportError:
         return "no_recorder"
-
-    def entries(only_active):
-        try:
-            return json.loads(dump(includeCollectives=True, onlyActive=only_active)).get("entries", [])
-        except (RuntimeError, ValueError):
-            return None
-
-    everything = entries(False)
-    if not everything:                   # (a trainer has broadcast its parameters by now: an empty recorder is a recorder that is off)
-        return "no_recorder"
     t0 = time.monotonic()
-    while time.monotonic() - t0 < timeout_s:
-        act = entries(True)
-        if act is None:
+    while True:
+        try:
+            entries = json.loads(dump(includeCollectives=True, onlyActive=False)).get("entries", [])
+        except (RuntimeError, ValueError, TypeError):
             return "no_recorder"
-        if not act:
+        if not entries or any("retired" not in e for e in entries):
+            # (a trainer has broadcast its parameters by now: an empty recorder is a recorder that is off)
+            return "no_recorder"
+        if all(e["retired"] for e in entries):
             return "drained"
+        if time.monotonic() - t0 > timeout_s:
+            return "timeout"
         time.sleep(0.005)
-    return "timeout"
 
 
 # ---- communication audit (bench.py's "comm" object, tests): what was exchanged since the last comm_reset()
