@@ -136,6 +136,8 @@ SIGNATURES = {
     "csg_wino4_conv": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_i64, c_p]),
     "csg_wino4_conv_part": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_f32,
                                     c_p, c_p]),
+    "csg_wino4_conv_spade_supported": (c_i32, [ctypes.POINTER(WinoDesc)]),
+    "csg_wino4_conv_spade": (c_i32, [ctypes.POINTER(WinoDesc), c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_f32, c_p, c_p]),
     "csg_wino34_supported": (c_i32, [ctypes.POINTER(WinoDesc), c_i32]),
     "csg_wino34_pack_weights": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_p, c_p, c_p]),
     "csg_wino34_conv_workspace": (c_i64, [ctypes.POINTER(WinoDesc), c_i32]),

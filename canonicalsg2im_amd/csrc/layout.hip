@@ -315,11 +315,11 @@ __global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict
   float ty[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) ty[r] = lin01(min((int)(((int64_t)min(y0 + r, OH - 1) * H) / OH), H - 1), H);
-  float4 acc[ROWS][LAY_EPT];
+  csg_f32x2 acc[ROWS][LAY_EPT][2];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-    for (int i = 0; i < LAY_EPT; ++i) acc[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < LAY_EPT; ++i) acc[r][i][0] = acc[r][i][1] = csg_f32x2{0.f, 0.f};
   const float* bx = boxes + (int64_t)b * O * 4;
   const uint8_t* vb = valid + (int64_t)b * O;
   const float* vv = vecs + (int64_t)b * O * S;
@@ -379,26 +379,47 @@ __global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict
       }
       __syncthreads();
       if (px0 < npx) {
+        // The operands of object a + 1 (two coverage quads, one vector quad, ROWS row weights: LDS reads whose latency two
+        // waves per SIMD cannot hide) are fetched before the FMAs of object a; the FMAs are packed (two channels per
+        // instruction: v_pk_fma_f32 — the same fused multiply-add per lane).  The cull above is per block (ROWS rows x the
+        // whole pixel chunk); a wave owns 64 / (S/4) groups of eight pixels and skips the objects whose x coverage is zero
+        // on all of them (they would add exact zeros: same sums, same order).
+        float4 w0n = make_float4(0.f, 0.f, 0.f, 0.f), w1n = w0n, vn = w0n;
+        float wyn[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) wyn[r] = 0.f;
+        if (nact > 0) {
+          w0n = *(const float4*)&s_wx[px0];
+          w1n = *(const float4*)&s_wx[px0 + 4];
+          vn = *(const float4*)&s_vec[q4];
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) wyn[r] = s_wy[a0 * ROWS + r];
+        }
         for (int a = 0; a < nact; ++a) {
-          const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
-          // the cull above is per block (ROWS rows x the whole pixel chunk); a wave owns 64 / (S/4) groups of eight pixels
-          // — 16 pixels at S = 128 — and most objects active in the chunk miss them: an object whose x coverage is zero on
-          // every pixel of the wave would add exact zeros (w = wy * 0), so the wave skips it (same sums, same order)
+          const float4 w0 = w0n, w1 = w1n, v = vn;
+          float wyc[ROWS];
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) wyc[r] = wyn[r];
+          if (a + 1 < nact) {
+            w0n = *(const float4*)&s_wx[(a + 1) * pxc + px0];
+            w1n = *(const float4*)&s_wx[(a + 1) * pxc + px0 + 4];
+            vn = *(const float4*)&s_vec[(a + 1) * S + q4];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) wyn[r] = s_wy[(a0 + a + 1) * ROWS + r];
+          }
           const bool hit = (w0.x != 0.f) | (w0.y != 0.f) | (w0.z != 0.f) | (w0.w != 0.f) | (w1.x != 0.f) | (w1.y != 0.f) |
                            (w1.z != 0.f) | (w1.w != 0.f);
           if (!__any(hit)) continue;
-          const float4 v = *(const float4*)&s_vec[a * S + q4];
+          const csg_f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
           const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
           for (int r = 0; r < ROWS; ++r) {
-            const float wy = s_wy[(a0 + a) * ROWS + r];
 #pragma unroll
             for (int i = 0; i < LAY_EPT; ++i) {
-              const float w = wy * wv[i];
-              acc[r][i].x += v.x * w;
-              acc[r][i].y += v.y * w;
-              acc[r][i].z += v.z * w;
-              acc[r][i].w += v.w * w;
+              const float w = wyc[r] * wv[i];
+              const csg_f32x2 ww = {w, w};
+              acc[r][i][0] = __builtin_elementwise_fma(vlo, ww, acc[r][i][0]);
+              acc[r][i][1] = __builtin_elementwise_fma(vhi, ww, acc[r][i][1]);
             }
           }
         }
@@ -412,179 +433,10 @@ __global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict
 #pragma unroll
     for (int i = 0; i < LAY_EPT; ++i)
       if (px0 + i < npx) {
-        *(float4*)&orow[(int64_t)(px0 + i) * out_cs + q4] = acc[r][i];
+        *(float4*)&orow[(int64_t)(px0 + i) * out_cs + q4] =
+            make_float4(acc[r][i][0].x, acc[r][i][0].y, acc[r][i][1].x, acc[r][i][1].y);
         if (tail.img != nullptr && q4 == 0) lay_write_tail(tail, orow + (int64_t)(px0 + i) * out_cs, S, b, y0 + r, x0 + px0 + i);
       }
-  }
-}
-
-// ---- the same sum, a block walking a vertical STRIP (round 6) ------------------------------------------------------
-// k_layout_fwd_rows pays its whole latency chain per four rows: box loads -> cull -> barrier -> x coverage and object
-// vectors staged from global memory -> barrier -> FMAs -> stores, then the block retires; with 128 accumulator registers
-// two or three blocks share a CU, so the stores of one block overlap little else (C5, 256 x 256 x 128 channels: 60 us
-// where the HBM needs 25; skipping objects a wave's pixels miss changed nothing — the kernel was latency-, not FMA-bound).
-// Here a block keeps its pixel chunk and walks NG row groups of ROWS rows: the objects whose x support meets the chunk are
-// compacted ONCE (index order), their x coverage, vectors and (y0, h) staged ONCE; per row group only the row weights are
-// formed (from LDS) and the row-active sub-list compacted, again in index order, and the stores of group g drain under the
-// FMAs of group g + 1.  Per pixel the same objects are added in the same order with the same fused multiply-adds as in
-// k_layout_fwd / k_layout_fwd_rows (objects skipped anywhere would add exact zeros): bit-identical outputs.
-// More x-active objects than the LDS batch holds (LAY_SA), or more than 256 objects: every row group runs every cull pass
-// and re-stages batch after batch (slow, correct).
-#define LAY_SA_MAX 64 // x-active objects staged per batch: at most one wave's worth (wave 0 compacts the row-active list)
-static size_t layout_strip_lds(int SA, int pxc, int S, int ROWS) {
-  return ((size_t)SA * (pxc + S + 2 + 2 * ROWS + 2) + LAY_CULL + 4 + 4) * 4;
-}
-template <int ROWS>
-__global__ __launch_bounds__(256) void k_layout_fwd_strip(const float* __restrict__ vecs, const float* __restrict__ boxes,
-                                                           const uint8_t* __restrict__ valid, int O, int S, int H, int W,
-                                                           int OH, int OW, int pxc, int NG, int LAY_SA,
-                                                           float* __restrict__ out, int out_cs, int out_off, LayTail tail) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* s_wx = sm;                               // [LAY_SA][pxc]
-  float* s_vec = s_wx + LAY_SA * pxc;             // [LAY_SA][S]
-  float* s_yb = s_vec + LAY_SA * S;               // [LAY_SA][2]   (y0, h) of the staged objects
-  float* s_wy = s_yb + LAY_SA * 2;                // [2][LAY_SA][ROWS]   row weights of the row-active slots (double-buffered)
-  int* s_ra = (int*)(s_wy + 2 * LAY_SA * ROWS);   // [2][LAY_SA]         staged slot of each row-active entry
-  int* s_xact = s_ra + 2 * LAY_SA;                // [LAY_CULL] object index of each x-active entry of the current cull pass
-  int* s_cnt = s_xact + LAY_CULL;                 // [4] per-wave counts of the cull pass
-  int* s_rc = s_cnt + 4;                          // [2] row-active count (only wave 0 compacts: LAY_SA <= 64 staged objects)
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = blockIdx.z, x0 = blockIdx.x * pxc;
-  const int g0 = blockIdx.y * NG;                 // first row group of the strip
-  const int npx = min(pxc, OW - x0);
-  const int qpp = S >> 2;
-  const int px0 = (tid / qpp) * LAY_EPT, q4 = (tid % qpp) * 4;
-  const float* bx = boxes + (int64_t)b * O * 4;
-  const uint8_t* vb = valid + (int64_t)b * O;
-  const float* vv = vecs + (int64_t)b * O * S;
-  const int xs0 = min((int)(((int64_t)x0 * W) / OW), W - 1);
-  const int xs1 = min((int)(((int64_t)(x0 + npx - 1) * W) / OW), W - 1);
-  const float step = W > 1 ? 1.0f / (float)(W - 1) : 1.0f;
-  const float tx_lo = lin01(xs0, W) - step, tx_hi = lin01(xs1, W) + step;
-  const int ngroups = min(NG, (OH + ROWS - 1) / ROWS - g0);
-
-  csg_f32x2 acc[ROWS][LAY_EPT][2];
-  int rbuf = 0;
-  // `single`: one cull pass and one staged batch cover the strip (the common case) — staged at the first group, reused by
-  // the others.  Otherwise every group runs every cull pass and re-stages batch after batch (slow, correct).
-  bool single = false;
-  for (int g = 0; g < ngroups; ++g) {
-    const int y0 = (g0 + g) * ROWS;
-    float ty[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) ty[r] = lin01(min((int)(((int64_t)min(y0 + r, OH - 1) * H) / OH), H - 1), H);
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-      for (int i = 0; i < LAY_EPT; ++i) acc[r][i][0] = acc[r][i][1] = csg_f32x2{0.f, 0.f};
-    for (int ob = 0;; ob += LAY_CULL) {
-      if (!single) {
-        // ---- cull pass over up to 256 objects: valid and x support meets the chunk (the test of k_layout_fwd)
-        __syncthreads();
-        const int o = ob + tid;
-        bool act = false;
-        if (o < O && vb[o]) {
-          const float4 bq = *(const float4*)(bx + o * 4);
-          const float lo = fminf(bq.x - bq.z / 16.0f, bq.x + bq.z * (1.0f + 1.0f / 16.0f));
-          const float hi = fmaxf(bq.x - bq.z / 16.0f, bq.x + bq.z * (1.0f + 1.0f / 16.0f));
-          act = !(tx_hi < lo || tx_lo > hi);
-        }
-        const unsigned long long m = __ballot(act);
-        if (lane == 0) s_cnt[wv] = __popcll(m);
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wv; ++w) base += s_cnt[w];
-        if (act) s_xact[base + __popcll(m & ((1ull << lane) - 1ull))] = o;
-        __syncthreads();
-      }
-      const int nx = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-      const bool staged = single;                 // (true from the second group on)
-      if (g == 0 && ob == 0) single = O <= LAY_CULL && nx <= LAY_SA;
-      for (int a0 = 0; a0 < nx; a0 += LAY_SA) {
-        const int nact = min(LAY_SA, nx - a0);
-        if (!staged) {
-          __syncthreads();                        // the previous batch may still be read
-          for (int i = tid; i < nact * npx; i += 256) {
-            const int a = i / npx, xl = i - a * npx;
-            const int o = s_xact[a0 + a];
-            const int xsrc = min((int)(((int64_t)(x0 + xl) * W) / OW), W - 1);
-            s_wx[a * pxc + xl] = coverage(lin01(xsrc, W), bx[o * 4 + 0], bx[o * 4 + 2]);
-          }
-          for (int i = tid; i < nact * qpp; i += 256) {
-            const int a = i / qpp, d4 = i - a * qpp;
-            *(float4*)&s_vec[a * S + d4 * 4] = *(const float4*)&vv[(int64_t)s_xact[a0 + a] * S + d4 * 4];
-          }
-          if (tid < nact) {
-            const int o = s_xact[a0 + tid];
-            s_yb[tid * 2 + 0] = bx[o * 4 + 1];
-            s_yb[tid * 2 + 1] = bx[o * 4 + 3];
-          }
-          __syncthreads();
-        }
-        // ---- row weights of this group and the row-active sub-list (wave 0: at most 64 staged objects, index order)
-        if (wv == 0) {
-          float wy[ROWS];
-          bool act = false;
-#pragma unroll
-          for (int r = 0; r < ROWS; ++r) wy[r] = 0.f;
-          if (lane < nact) {
-            const float by = s_yb[lane * 2 + 0], bh = s_yb[lane * 2 + 1];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-              wy[r] = (y0 + r < OH) ? coverage(ty[r], by, bh) : 0.f;
-              act = act || (wy[r] != 0.0f);
-            }
-          }
-          const unsigned long long m = __ballot(act);
-          if (act) {
-            const int slot = __popcll(m & ((1ull << lane) - 1ull));
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) s_wy[(rbuf * LAY_SA + slot) * ROWS + r] = wy[r];
-            s_ra[rbuf * LAY_SA + slot] = lane;
-          }
-          if (lane == 0) s_rc[rbuf] = __popcll(m);
-        }
-        __syncthreads();
-        const int nra = s_rc[rbuf];
-        if (px0 < npx) {
-          for (int e = 0; e < nra; ++e) {
-            const int a = s_ra[rbuf * LAY_SA + e];
-            const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
-            const bool hit = (w0.x != 0.f) | (w0.y != 0.f) | (w0.z != 0.f) | (w0.w != 0.f) | (w1.x != 0.f) | (w1.y != 0.f) |
-                             (w1.z != 0.f) | (w1.w != 0.f);
-            if (!__any(hit)) continue;            // (exact zeros, see k_layout_fwd_rows)
-            const float4 v = *(const float4*)&s_vec[a * S + q4];
-            const csg_f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
-            const float wv8[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-              const float wy = s_wy[(rbuf * LAY_SA + e) * ROWS + r];
-#pragma unroll
-              for (int i = 0; i < LAY_EPT; ++i) {
-                const float w = wy * wv8[i];
-                const csg_f32x2 ww = {w, w};
-                acc[r][i][0] = __builtin_elementwise_fma(vlo, ww, acc[r][i][0]);   // acc += v * w, fused, two lanes
-                acc[r][i][1] = __builtin_elementwise_fma(vhi, ww, acc[r][i][1]);
-              }
-            }
-          }
-        }
-        rbuf ^= 1;
-      }
-      if (single || ob + LAY_CULL >= O) break;
-    }
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      if (y0 + r >= OH) break;
-      float* orow = out + ((int64_t)(b * OH + y0 + r) * OW + x0) * out_cs + out_off;
-#pragma unroll
-      for (int i = 0; i < LAY_EPT; ++i)
-        if (px0 + i < npx) {
-          *(float4*)&orow[(int64_t)(px0 + i) * out_cs + q4] =
-              make_float4(acc[r][i][0].x, acc[r][i][0].y, acc[r][i][1].x, acc[r][i][1].y);
-          if (tail.img != nullptr && q4 == 0) lay_write_tail(tail, orow + (int64_t)(px0 + i) * out_cs, S, b, y0 + r, x0 + px0 + i);
-        }
-    }
   }
 }
 
@@ -1137,36 +989,8 @@ static int layout_fwd_launch(const float* vecs, const float* boxes, const uint8_
   CSG_REQUIRE(pxc >= 1, CSG_E_UNSUPPORTED, "csg_layout_fwd: S too large for one chunk");
   size_t shm = (size_t)(LAY_OB * pxc + LAY_OB * S) * 4 + (size_t)4 * LAY_CULL * 4 + 16;
   ProfScope p(K_LAYOUT_FWD, (double)B * OH * OW * S * 4, s);  // algorithmic bytes: the output, once
-  static const int strip_ng = getenv("CSG_LAYOUT_NG") ? atoi(getenv("CSG_LAYOUT_NG")) : -1;   // 0: k_layout_fwd_rows (A/B)
-  if (masks == nullptr && (256 % qpp) == 0 && (pxc % LAY_EPT) == 0 && OH >= 32 && strip_ng != 0) {
-    // boxes_to_layout on maps from 32 rows up: a block walks a strip of NG groups of four rows over its pixel chunk with the
-    // x coverage and object vectors staged once (k_layout_fwd_strip).  NG: as many groups as still leave >= 384 blocks
-    // (1.5 per CU: with 128 accumulator registers two to three blocks share a CU, all of them resident at once).
-    constexpr int ROWS = 4;
-    const int64_t groups = cdiv(OH, ROWS), cols = cdiv(OW, pxc);
-    int NG = 8;
-    while (NG > 1 && cols * cdiv(groups, NG) * B < 384) NG >>= 1;
-    if (strip_ng > 0) NG = strip_ng;
-    int SA = (int)((O + 7) / 8 * 8);
-    if (SA > LAY_SA_MAX) SA = LAY_SA_MAX;
-    if (SA < 8) SA = 8;
-    const size_t shm_s = layout_strip_lds(SA, pxc, (int)S, ROWS);
-    static DeviceOnce lds_once;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (lds_once.pending(dev)) {
-      hipError_t e = hipFuncSetAttribute((const void*)k_layout_fwd_strip<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      CSG_REQUIRE(e == hipSuccess, CSG_E_LAUNCH, "csg_layout_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      lds_once.mark(dev);
-    }
-    CSG_REQUIRE(shm_s <= 96 * 1024, CSG_E_UNSUPPORTED, "csg_layout_fwd: %zu bytes of LDS", shm_s);
-    dim3 grid_s((unsigned)cols, (unsigned)cdiv(groups, NG), (unsigned)B);
-    CSG_LAUNCH(k_layout_fwd_strip<ROWS>, grid_s, dim3(256), shm_s, s, vecs, boxes, valid, (int)O, (int)S, (int)H, (int)W,
-               (int)OH, (int)OW, pxc, NG, SA, out, (int)out_cs, (int)out_off, tail);
-    return check_launch("csg_layout_fwd");
-  }
   if (masks == nullptr && (256 % qpp) == 0 && (pxc % LAY_EPT) == 0 && OH >= 32) {
-    // (CSG_LAYOUT_NG=0) four rows per block share the staged x coverage and object vectors
+    // boxes_to_layout on maps from 32 rows up: four rows per block share the staged x coverage and object vectors
     constexpr int ROWS = 4;
     const size_t shm4 = (size_t)(LAY_OB * pxc + LAY_OB * S) * 4 + (size_t)LAY_CULL * ROWS * 4 + (size_t)LAY_CULL * 4 + 16;
     dim3 grid4((unsigned)cdiv(OW, pxc), (unsigned)cdiv(OH, ROWS), (unsigned)B);

@@ -107,7 +107,8 @@ struct Wino4Params {
   float slope;
   float gate_slope;
   int nt_off;          // first 32-channel tile of the packed operand this launch computes (a slice of the outputs)
-  int mod, g_cs;       // SPADE modulation in the epilogue (below); pixel stride of the gamma tensor
+  int mod, g_cs;       // SPADE modulation in the epilogue (below: 1 = beta half, 2 = joint); pixel stride of the gamma tensor
+  int gb_off;          // joint gamma | beta launch: tiles of the packed operand between a gamma tile and its beta tile (C / 32)
   float mod_slope;
   const float* mod_mean;
   const float* mod_invstd;
@@ -336,6 +337,91 @@ __device__ __forceinline__ void w4_store_columns(const Wino4Params& p, const flo
   }
 }
 
+// MODE 3 (joint, round 6): ONE launch for a SPADE modulation.  A block's two channel groups hold the gamma tile and the beta
+// tile of the SAME 32 output channels (group g reads U tile nb + g * C/32 of the ordinary gamma || beta operand), so both
+// meet in the exchange buffers and  y = leaky(xhat (1 + gamma) + beta)  is formed without gamma making a round trip through
+// HBM and without a second launch staging the 128-channel input again: per pixel the launch pair moved 2 Cin + 4 C floats,
+// this one Cin + 3 C (gamma is still WRITTEN when `gout` is set — the backward needs it; inference passes nullptr).  A work
+// item is (tile, channel quad, output column, half of the four rows): 512 * NB items over all 768 threads, each reading both
+// groups' six rows.  Same expressions in the same order as MODE 0 (gamma) followed by MODE 2 (beta): bit-identical outputs.
+__device__ __forceinline__ csg_f32x2 w4_out_row(int a, const csg_f32x2 (&m)[6]) {
+  if (a == 0) return ((m[0] + m[1]) + (m[2] + m[3])) + m[4];
+  if (a == 1) return w4_pfma(-2.0f, m[4], w4_pfma(0.5f, m[3], m[1] - m[2]));
+  if (a == 2) return w4_pfma(4.0f, m[4], w4_pfma(0.25f, m[3], m[1] + m[2]));
+  return w4_pfma(-8.0f, m[4], w4_pfma(0.125f, m[3], m[1] - m[2])) + m[5];
+}
+template <int NB>
+__device__ __forceinline__ void w4_store_joint(const Wino4Params& p, const float* rbuf0, int tid, int round, int nb, int img,
+                                               int X0, int Y0, const float* __restrict__ bias, const float* __restrict__ xin,
+                                               float* __restrict__ gout, float* __restrict__ y) {
+  const float* rbuf1 = rbuf0 + W4_RBUF / 2 * NB;            // the beta group's exchange buffer
+  for (int item = tid; item < 512 * NB; item += W4_THREADS) {
+    const int cq = item & 7, tile = (item >> 3) & 31, half = (item >> 8) & 1, bb = item >> 9;
+    const int n = nb * 32 + cq * 4;
+    const int ttx = tile & (W4_TW - 1), tty = tile >> 3;
+    const int oy = Y0 + 4 * tty, ox = X0 + 4 * ttx + NB * round + bb;
+    if (oy < p.Ho && ox < p.Wo) {                            // Ho and Wo are multiples of 4; n < C by construction
+      // gamma first, then beta (one group's six rows live at a time: the one-item form still carries its accumulators here)
+      csg_f32x2 gl2[2], gh2[2], bl2[2], bh2[2];
+      {
+        csg_f32x2 lo[6], hi[6];
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi) {
+          const csg_f32x4 g = *(const csg_f32x4*)(rbuf0 + ((xi * NB + bb) * 32 + tile) * W4_RSE + cq * 4);
+          lo[xi] = __builtin_shufflevector(g, g, 0, 1);
+          hi[xi] = __builtin_shufflevector(g, g, 2, 3);
+        }
+        const csg_f32x4 bg = *(const csg_f32x4*)(bias + n);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          gl2[r] = w4_out_row(2 * half + r, lo) + csg_f32x2{bg.x, bg.y};
+          gh2[r] = w4_out_row(2 * half + r, hi) + csg_f32x2{bg.z, bg.w};
+        }
+      }
+      {
+        csg_f32x2 lo[6], hi[6];
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi) {
+          const csg_f32x4 b = *(const csg_f32x4*)(rbuf1 + ((xi * NB + bb) * 32 + tile) * W4_RSE + cq * 4);
+          lo[xi] = __builtin_shufflevector(b, b, 0, 1);
+          hi[xi] = __builtin_shufflevector(b, b, 2, 3);
+        }
+        const csg_f32x4 bbv = *(const csg_f32x4*)(bias + p.Cout + n);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          bl2[r] = w4_out_row(2 * half + r, lo) + csg_f32x2{bbv.x, bbv.y};
+          bh2[r] = w4_out_row(2 * half + r, hi) + csg_f32x2{bbv.z, bbv.w};
+        }
+      }
+      const float4 mm = *(const float4*)(p.mod_mean + n), mr = *(const float4*)(p.mod_invstd + n);
+      const int64_t rowstride = (int64_t)p.Wo * p.y_cs;
+      const int64_t pix0 = ((int64_t)img * p.Ho + oy + 2 * half) * p.Wo + ox;
+      const int64_t off = pix0 * p.y_cs + n;
+      float4 mx[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) mx[r] = *(const float4*)(xin + off + r * rowstride);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const csg_f32x2 gl = gl2[r], gh = gh2[r], bl = bl2[r], bh = bh2[r];
+        const float gs[4] = {gl.x, gl.y, gh.x, gh.y}, vv[4] = {bl.x, bl.y, bh.x, bh.y};
+        const float xs[4] = {mx[r].x, mx[r].y, mx[r].z, mx[r].w};
+        const float ms[4] = {mm.x, mm.y, mm.z, mm.w}, rs[4] = {mr.x, mr.y, mr.z, mr.w};
+        float out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xs[e] - ms[e]) * rs[e];
+          float o = xh * (1.f + gs[e]) + vv[e];
+          if (p.mod_slope != 1.0f) o = o > 0.f ? o : o * p.mod_slope;
+          out[e] = o;
+        }
+        if (gout != nullptr)
+          *(float4*)(gout + (pix0 + (int64_t)r * p.Wo) * p.g_cs + n) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+        *(float4*)(y + off + r * rowstride) = make_float4(out[0], out[1], out[2], out[3]);
+      }
+    }
+  }
+}
+
 template <int NB>
 __device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[6], const Wino4Params& p, float* rbase, int tid, int wave, int grp,
                                             int j, int h, int nt32, int img, int X0, int Y0, const float* __restrict__ bias,
@@ -397,7 +483,9 @@ __device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[6], const Wino4Params&
     }
     __syncthreads();
     if (NB == 2 && round == 0) { W4_T(4) }
-    if (p.mod)
+    if (NB == 1 && p.mod == 2)            // (the persistent form only: the one-item form carries its accumulators through the rounds)
+      w4_store_joint<NB>(p, rbase, tid, round, nt32 - grp * p.gb_off, img, X0, Y0, bias, res, const_cast<float*>(gate), y);
+    else if (p.mod)
       w4_store_columns<2, NB>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
     else if (plain)
       w4_store_columns<0, NB>(p, rbuf, tig, round, nt32, img, X0, Y0, bias, res, gate, y);
@@ -671,7 +759,8 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
   // producer: V words of (xi = wave, nu = 0, half h, tile j), channel pair slot grp;  consumer: the same row, float4
   float* pv = smem + W4V_V0 + (((wave * 6) * 2 + h) * 32 + j) * 4;
 
-  int nt32 = nb * 2 + grp;
+  // U tile of this wave's channel group: neighbours, or (joint gamma | beta launch) the gamma tile nb and its beta tile
+  int nt32 = p.gb_off ? nb + grp * p.gb_off : nb * 2 + grp;
   // U operand of (position (xi = wave, nu), k-oct q, this wave's 32-channel tile): wave-uniform base in a scalar
   // register, the lane's 16 bytes in a vector register (out of range when the tile lies beyond Cout)
   auto u_tile = [&]() { return ((wave * 6) * p.NT32 + nt32 + p.nt_off) * p.Q8 * 1024; };
@@ -838,11 +927,11 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       item_n = more ? v + v_step : v;
       if (more) decode(item_n);
       fill_plan(W4_TAB(tsel ^ 1), more);
-      nt32 = nb * 2 + grp;
+      nt32 = p.gb_off ? nb + grp * p.gb_off : nb * 2 + grp;
       ubase_nxt = u_tile();
       nb_n = nb; img_n = img; X0_n = X0; Y0_n = Y0;
       nb = nb_c; img = img_c; X0 = X0_c; Y0 = Y0_c;
-      nt32 = nb * 2 + grp;
+      nt32 = p.gb_off ? nb + grp * p.gb_off : nb * 2 + grp;
     }
     int s = s_begin;
     W4_TI(1)
@@ -865,7 +954,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       asm volatile("" : "+s"(ka));
       Wino4Params pe = p;
 #define W4_F(f) pe.f = ka->p.f;
-      W4_F(Cout) W4_F(y_cs) W4_F(Ho) W4_F(Wo) W4_F(act) W4_F(slope) W4_F(gate_slope) W4_F(mod) W4_F(g_cs) W4_F(mod_slope)
+      W4_F(Cout) W4_F(y_cs) W4_F(Ho) W4_F(Wo) W4_F(act) W4_F(slope) W4_F(gate_slope) W4_F(mod) W4_F(g_cs) W4_F(gb_off) W4_F(mod_slope)
       W4_F(mod_mean) W4_F(mod_invstd)
 #undef W4_F
       w4_epilogue<1>(acc, pe, smem + W4V_V0, tid_o, wave, grp, tid_o & 31, (tid_o >> 5) & 1, nt32, img, X0, Y0, ka->bias,
@@ -880,7 +969,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     // the next item: raw[0] and raw[1] are in place, its U ring is loaded and its stage 2 in flight (the last stage's loads)
     v = item_n;
     nb = nb_n; img = img_n; X0 = X0_n; Y0 = Y0_n;
-    nt32 = nb * 2 + grp;
+    nt32 = p.gb_off ? nb + grp * p.gb_off : nb * 2 + grp;
     ubase = ubase_nxt;
     tsel ^= 1;
     __syncthreads();                             // the exchange buffer sat in the V buffers
@@ -929,7 +1018,7 @@ static int w4_plan(const csg_wino_desc* d, int T, int pad, Wino4Params& p, size_
   p.NT32 = (d->Cout + 31) / 32;
   p.Q8 = (d->Cin + 7) / 8;
   p.act = d->act; p.slope = d->slope; p.gate_slope = 0.f;
-  p.nt_off = 0; p.mod = 0; p.g_cs = 0; p.mod_slope = 1.f; p.mod_mean = nullptr; p.mod_invstd = nullptr;
+  p.nt_off = 0; p.mod = 0; p.g_cs = 0; p.gb_off = 0; p.mod_slope = 1.f; p.mod_mean = nullptr; p.mod_invstd = nullptr;
   p.nstage = d->Cin / W4_PS;
   p.ksplit = 1;
   p.sps = p.nstage;
@@ -975,7 +1064,7 @@ static int w4_persistent_blocks(const Wino4Params& p, int64_t items) {
     if (dev < 32) cus[dev].store(ncu, std::memory_order_relaxed);
   }
   const int g = ncu > 0 ? (ncu & ~7) : 0;
-  if (g == 0 || p.ksplit != 1 || (p.nstage & 1) || p.nstage < 4 || (p.Cout & 63) || items < 2 * (int64_t)g) return 0;
+  if (g == 0 || p.ksplit != 1 || (p.nstage & 1) || p.nstage < 4 || (p.gb_off == 0 && (p.Cout & 63)) || items < 2 * (int64_t)g) return 0;
 #ifdef W4_TRACE
   if (on == 2 && (items & 7) == 0) return (int)items;   // experiment: the persistent code, one item per block
 #endif
@@ -1228,6 +1317,54 @@ int csg_wino4_conv_part(const csg_wino_desc* d, const float* x, const float* pac
               CSG_E_UNSUPPORTED, "csg_wino4_conv_part: pointers must be 16-byte aligned");
   return w4_launch<4>(p, shm, K_WINO4_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * p.Cout, x, packed, bias, mod_x, mod_gamma, y,
                       nullptr, y, (hipStream_t)stream, "csg_wino4_conv_part");
+}
+
+// the joint launch exists in the persistent form only (w4_persistent_blocks: >= 2 items per CU, an even number of >= 4 stages)
+static int w4_spade_plan(const csg_wino_desc* d, Wino4Params& p, size_t& shm, const char* who) {
+  CSG_REQUIRE(d != nullptr && d->Cout % 32 == 0, CSG_E_UNSUPPORTED, "%s: C must be a multiple of 32", who);
+  int rc = w4_plan(d, 4, 1, p, shm, who);
+  if (rc) return rc;
+  const int tiles = d->Cout / 32;
+  p.NT32 = 2 * tiles;                              // the packed operand: gamma tiles then beta tiles
+  p.nblocks = tiles;                               // a block = gamma tile nb + beta tile nb
+  p.gb_off = tiles;
+  p.mod = 2;
+  const int64_t items = (int64_t)p.B * p.tby * p.tbx * p.nblocks;
+  CSG_REQUIRE(items < (1ll << 31) && w4_persistent_blocks(p, items) > 0, CSG_E_UNSUPPORTED,
+              "%s: the launch does not qualify for the persistent form (%ld items, %d stages)", who, (long)items, p.nstage);
+  return CSG_OK;
+}
+
+int32_t csg_wino4_conv_spade_supported(const csg_wino_desc* d) {
+  if (!csg_wino4_supported(d)) return 0;
+  Wino4Params p;
+  size_t shm = 0;
+  const int rc = w4_spade_plan(d, p, shm, "csg_wino4_conv_spade_supported");
+  return rc == CSG_OK ? 1 : 0;
+}
+
+int csg_wino4_conv_spade(const csg_wino_desc* d, const float* x, const float* packed, const float* bias, const float* mod_x,
+                         float* gamma_out, int64_t gamma_cs, const float* mod_mean, const float* mod_invstd, float mod_slope,
+                         float* y, void* stream) {
+  Wino4Params p;
+  size_t shm = 0;
+  int rc = w4_spade_plan(d, p, shm, "csg_wino4_conv_spade");
+  if (rc) return rc;
+  CSG_REQUIRE(d->act == CSG_ACT_NONE, CSG_E_UNSUPPORTED, "csg_wino4_conv_spade: no activation (the modulation has its own)");
+  CSG_REQUIRE(bias != nullptr && mod_x != nullptr && mod_mean != nullptr && mod_invstd != nullptr,
+              CSG_E_BADSHAPE, "csg_wino4_conv_spade: needs the 2C biases, x, mean, invstd");
+  CSG_REQUIRE(gamma_out == nullptr || (gamma_cs >= d->Cout && gamma_cs % 4 == 0 && ((uintptr_t)gamma_out % 16) == 0),
+              CSG_E_BADSHAPE, "csg_wino4_conv_spade: bad gamma buffer");
+  const int tiles = d->Cout / 32;
+  CSG_REQUIRE((int64_t)36 * 2 * tiles * p.Q8 * 1024 < CSG_MAX_RECORDS, CSG_E_UNSUPPORTED,
+              "csg_wino4_conv_spade: packed weights too large for 32-bit byte offsets");
+  CSG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
+                  ((uintptr_t)mod_x % 16) == 0 && ((uintptr_t)mod_mean % 16) == 0 && ((uintptr_t)mod_invstd % 16) == 0,
+              CSG_E_UNSUPPORTED, "csg_wino4_conv_spade: pointers must be 16-byte aligned");
+  p.g_cs = (int)gamma_cs; p.mod_slope = mod_slope; p.mod_mean = mod_mean; p.mod_invstd = mod_invstd;
+  // algorithmic FLOPs of the direct gamma || beta convolution: 2C outputs
+  return w4_launch<4>(p, shm, K_WINO4_CONV, 2.0 * p.B * p.H * p.W * 9.0 * p.Cin * 2.0 * p.Cout, x, packed, bias, mod_x, gamma_out,
+                      y, nullptr, y, (hipStream_t)stream, "csg_wino4_conv_spade");
 }
 
 }  // extern "C"

@@ -1125,6 +1125,9 @@ def spade_fused_eligible(x, nhidden, C, ks, training):
     return lib.csg_wino4_supported(_wino_desc(B, H, W, nhidden, C)) == 1
 
 
+SPADE_JOINT = os.environ.get("CSG_SPADE_JOINT", "1") != "0"      # 0: the gamma / beta launch pair also on one rank (A/B)
+
+
 class _SpadeFused(torch.autograd.Function):
     """K = 1 or 2 SPADE modulations of ONE batch-normalised x (reference normalization.py:96-110; K = 2: norm_s and norm_0
     of a residual block, architecture.py:37-47), each `leaky(xhat (1 + gamma_k) + beta_k, slope_k)` with gamma_k || beta_k =
@@ -1162,6 +1165,10 @@ class _SpadeFused(torch.autograd.Function):
             # N > 1: the statistics travel while the gamma halves (which do not need them) are computed
             pending = csg_dist.all_reduce_stats_async(sums)
         saved, outs, cfg, launches, pres = [x, mean, invstd], [], [], [], []
+        # One rank, C a multiple of 32: ONE launch per modulation (csg_wino4_conv_spade: blocks own a gamma tile and its beta
+        # tile; gamma is written for the backward but never read back, the 128-channel input is staged once).  N > 1 ranks keep
+        # the launch pair: the gamma halves, which need no statistics, run while the SyncBN message travels.
+        joint = SPADE_JOINT and not multi and C % 32 == 0
         for k in range(K):
             actv, w, b, rm, rv, slope, in_slope = mods[k * 7:(k + 1) * 7]
             actv = nhwc(_f32(actv))
@@ -1175,6 +1182,14 @@ class _SpadeFused(torch.autograd.Function):
             gbuf = empty_nhwc(B, C, H, W, dev)                # gamma only: beta is consumed in the epilogue that forms it
             d = _wino_desc(B, H, W, nh, C)
             d.y_cs = C
+            if joint and lib.csg_wino4_conv_spade_supported(d):
+                y = torch.empty_like(x)
+                check(lib.csg_wino4_conv_spade(d, ptr(actv), ptr(up), ptr(bd), ptr(x), ptr(gbuf), C, ptr(mean), ptr(invstd),
+                                               slope, ptr(y), stream()), "wino4_conv_spade")
+                saved += [actv, w, gbuf, y]
+                outs.append(y)
+                cfg.append((slope, in_slope, nh))
+                continue
             check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), 0, 2 * C // 32, ptr(bd), None, None, 0, None, None, 1.0,
                                           ptr(gbuf), stream()), "wino4_conv_part(gamma)")
             launches.append((actv, w, up, bd, gbuf, nh, slope, in_slope))

@@ -308,6 +308,20 @@ int csg_wino4_conv_part(const csg_wino_desc* d, const float* x, const float* pac
                         const float* bias, const float* mod_x, const float* mod_gamma, int64_t gamma_cs,
                         const float* mod_mean, const float* mod_invstd, float mod_slope, float* y, void* stream);
 
+/* ONE launch for a SPADE modulation (normalization.py:89-110; round 6): the gamma || beta convolution (`packed`: the ordinary
+ * F(4x4,3x3) forward operand of the (2C, Cin, 3, 3) weight, gamma tiles then beta tiles; `bias`: its 2C biases) with
+ *     y = leaky(((mod_x - mean) * invstd) * (1 + gamma) + beta, mod_slope)
+ * as the epilogue of blocks that own a gamma tile and the beta tile of the same 32 channels.  d->Cout = C (the modulated map's
+ * channels, a multiple of 32), y and mod_x are (B,H,W,y_cs).  `gamma_out` (nullable; pixel stride gamma_cs): gamma = conv +
+ * bias is also written there — the backward reads it (csg_norm_apply_bwd_reduce / _dx); inference passes NULL.  beta never
+ * reaches memory.  Outputs are bit-identical to csg_wino4_conv_part(gamma) followed by csg_wino4_conv_part(beta).
+ * Served by the persistent form of the kernel only: csg_wino4_conv_spade_supported(d) = 1 when the launch has at least two
+ * (region, 32-channel gamma + beta block) items per CU and an even number (>= 4) of 8-channel stages; else the launch pair. */
+int32_t csg_wino4_conv_spade_supported(const csg_wino_desc* d);
+int csg_wino4_conv_spade(const csg_wino_desc* d, const float* x, const float* packed, const float* bias, const float* mod_x,
+                         float* gamma_out, int64_t gamma_cs, const float* mod_mean, const float* mod_invstd, float mod_slope,
+                         float* y, void* stream);
+
 /* ---- K8w34: 4x4 / stride 1 convolutions by Winograd F(3x3,4x4) (csrc/wino4.hip, the same kernel on 3x3 output tiles)
  * The PatchGAN's fourth layer (discriminator.py:184-189: 4x4, stride 1, padding 2, 256 -> 512 channels at 1/8
  * resolution) and its backward-data pass (the 4x4 correlation with the flipped, transposed weight and padding 1):

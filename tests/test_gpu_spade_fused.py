@@ -132,3 +132,73 @@ def test_joined_spade_is_the_plain_path_bit_for_bit(shape):
     assert torch.equal(ya, yb) and torch.equal(gxa, gxb) and torch.equal(gsa, gsb)
     assert set(ga) == set(gb) and all(torch.equal(ga[k], gb[k]) for k in gb), [k for k in gb if not torch.equal(ga[k], gb[k])]
     assert all(torch.equal(sa[k], sb[k]) for k in sb)
+
+
+# ------------------------------------------------------------------ round 6: ONE launch per modulation (csg_wino4_conv_spade)
+@pytest.mark.parametrize("shape", [(8, 128, 64, 128, 128, 0.2), (16, 128, 128, 64, 64, 1.0), (6, 32, 96, 128, 128, 0.2)])
+def test_joint_launch_is_bit_identical_to_the_launch_pair(shape):
+    """Raw C ABI.  csg_wino4_conv_spade (blocks own a gamma tile and the beta tile of the same 32 channels; gamma written once,
+    never read back) against csg_wino4_conv_part(gamma) + csg_wino4_conv_part(beta): y AND the gamma map, bit for bit; with
+    gamma_out = NULL (inference) y is unchanged; a launch too small for the persistent form is refused by the query."""
+    from canonicalsg2im_amd import ops
+    from canonicalsg2im_amd._lib import check, lib, ptr, stream
+    B, nh, C, H, W, slope = shape
+    g = torch.Generator().manual_seed(3)
+    actv = ops.nhwc(torch.randn(B, nh, H, W, generator=g).clamp_min(0).cuda())
+    x = ops.nhwc(torch.randn(B, C, H, W, generator=g).cuda())
+    w = (torch.randn(2 * C, nh, 3, 3, generator=g) / (3 * nh ** 0.5)).cuda()
+    b = (0.1 * torch.randn(2 * C, generator=g)).cuda()
+    mean = (0.1 * torch.randn(C, generator=g)).cuda()
+    invstd = (1.0 + 0.1 * torch.rand(C, generator=g)).cuda()
+    up = ops.wino_pack(w, False, None, 4)
+    d = ops._wino_desc(B, H, W, nh, C)
+    d.y_cs = C
+    assert lib.csg_wino4_conv_spade_supported(d) == 1
+    gam_a, y_a = ops.empty_nhwc(B, C, H, W, x.device), torch.empty_like(x)
+    check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), 0, 2 * C // 32, ptr(b), None, None, 0, None, None, 1.0, ptr(gam_a),
+                                  stream()), "gamma")
+    check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), C // 32, 2 * C // 32, ptr(b[C:]), ptr(x), ptr(gam_a), C, ptr(mean),
+                                  ptr(invstd), slope, ptr(y_a), stream()), "beta")
+    gam_b, y_b = torch.full_like(gam_a, float("nan")), torch.full_like(y_a, float("nan"))
+    check(lib.csg_wino4_conv_spade(d, ptr(actv), ptr(up), ptr(b), ptr(x), ptr(gam_b), C, ptr(mean), ptr(invstd), slope,
+                                   ptr(y_b), stream()), "joint")
+    torch.cuda.synchronize()
+    assert torch.equal(gam_a, gam_b), float((gam_a - gam_b).abs().max())
+    assert torch.equal(y_a, y_b), float((y_a - y_b).abs().max())
+    y_c = torch.full_like(y_a, float("nan"))
+    check(lib.csg_wino4_conv_spade(d, ptr(actv), ptr(up), ptr(b), ptr(x), None, 0, ptr(mean), ptr(invstd), slope, ptr(y_c),
+                                   stream()), "joint, no gamma")
+    torch.cuda.synchronize()
+    assert torch.equal(y_a, y_c)
+    # against fp64: the modulation of a direct convolution
+    gb = F.conv2d(actv.double(), w.double(), b.double(), padding=1)
+    xh = (x.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    ref = F.leaky_relu(xh * (1 + gb[:, :C]) + gb[:, C:], slope) if slope != 1.0 else xh * (1 + gb[:, :C]) + gb[:, C:]
+    assert float((y_b.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    small = ops._wino_desc(1, 32, 32, nh, C)
+    small.y_cs = C
+    assert lib.csg_wino4_conv_spade_supported(small) == 0
+
+
+def test_joint_and_pair_training_blocks_agree_bit_for_bit():
+    """A residual block at a size where the joint launch is taken (ops.SPADE_JOINT) against the same block on the launch pair:
+    outputs, every gradient and the running statistics are identical bits (the backward reads the same gamma map)."""
+    from canonicalsg2im_amd import ops
+    B, fin, fout, H, W, S = 8, 128, 64, 128, 128, 8
+    blk_a = _block(fin, fout, S)
+    blk_b = copy.deepcopy(blk_a)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, fin, H, W, generator=g)
+    seg = torch.randn(B, S, H, W, generator=g)
+    w = torch.randn(B, fout, H, W, generator=g)
+    saved = ops.SPADE_JOINT
+    try:
+        ops.SPADE_JOINT = True
+        ya, gxa, gsa, ga, sa = _run(blk_a, x, seg, w, True)
+        ops.SPADE_JOINT = False
+        yb, gxb, gsb, gb, sb = _run(blk_b, x, seg, w, True)
+    finally:
+        ops.SPADE_JOINT = saved
+    assert torch.equal(ya, yb) and torch.equal(gxa, gxb) and torch.equal(gsa, gsb)
+    assert set(ga) == set(gb) and all(torch.equal(ga[k], gb[k]) for k in gb)
+    assert all(torch.equal(sa[k], sb[k]) for k in sb)
