@@ -9,7 +9,6 @@
 // and the kernel writes each output byte exactly once (HBM-bound: S*H*W*4 bytes per image).
 // Output is NHWC; it may be a channel slice of a wider buffer (the discriminator's input), and it
 // may be a nearest-neighbour down-sampled view (the SPADE seg pyramid).
-#include "csg_buffer.h"
 #include "csg_common.h"
 
 using namespace csg;
@@ -315,11 +314,11 @@ __global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict
   float ty[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) ty[r] = lin01(min((int)(((int64_t)min(y0 + r, OH - 1) * H) / OH), H - 1), H);
-  csg_f32x2 acc[ROWS][LAY_EPT][2];
+  float4 acc[ROWS][LAY_EPT];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-    for (int i = 0; i < LAY_EPT; ++i) acc[r][i][0] = acc[r][i][1] = csg_f32x2{0.f, 0.f};
+    for (int i = 0; i < LAY_EPT; ++i) acc[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* bx = boxes + (int64_t)b * O * 4;
   const uint8_t* vb = valid + (int64_t)b * O;
   const float* vv = vecs + (int64_t)b * O * S;
@@ -379,47 +378,20 @@ __global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict
       }
       __syncthreads();
       if (px0 < npx) {
-        // The operands of object a + 1 (two coverage quads, one vector quad, ROWS row weights: LDS reads whose latency two
-        // waves per SIMD cannot hide) are fetched before the FMAs of object a; the FMAs are packed (two channels per
-        // instruction: v_pk_fma_f32 — the same fused multiply-add per lane).  The cull above is per block (ROWS rows x the
-        // whole pixel chunk); a wave owns 64 / (S/4) groups of eight pixels and skips the objects whose x coverage is zero
-        // on all of them (they would add exact zeros: same sums, same order).
-        float4 w0n = make_float4(0.f, 0.f, 0.f, 0.f), w1n = w0n, vn = w0n;
-        float wyn[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) wyn[r] = 0.f;
-        if (nact > 0) {
-          w0n = *(const float4*)&s_wx[px0];
-          w1n = *(const float4*)&s_wx[px0 + 4];
-          vn = *(const float4*)&s_vec[q4];
-#pragma unroll
-          for (int r = 0; r < ROWS; ++r) wyn[r] = s_wy[a0 * ROWS + r];
-        }
         for (int a = 0; a < nact; ++a) {
-          const float4 w0 = w0n, w1 = w1n, v = vn;
-          float wyc[ROWS];
-#pragma unroll
-          for (int r = 0; r < ROWS; ++r) wyc[r] = wyn[r];
-          if (a + 1 < nact) {
-            w0n = *(const float4*)&s_wx[(a + 1) * pxc + px0];
-            w1n = *(const float4*)&s_wx[(a + 1) * pxc + px0 + 4];
-            vn = *(const float4*)&s_vec[(a + 1) * S + q4];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) wyn[r] = s_wy[(a0 + a + 1) * ROWS + r];
-          }
-          const bool hit = (w0.x != 0.f) | (w0.y != 0.f) | (w0.z != 0.f) | (w0.w != 0.f) | (w1.x != 0.f) | (w1.y != 0.f) |
-                           (w1.z != 0.f) | (w1.w != 0.f);
-          if (!__any(hit)) continue;
-          const csg_f32x2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
+          const float4 v = *(const float4*)&s_vec[a * S + q4];
+          const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
           const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
           for (int r = 0; r < ROWS; ++r) {
+            const float wy = s_wy[(a0 + a) * ROWS + r];
 #pragma unroll
             for (int i = 0; i < LAY_EPT; ++i) {
-              const float w = wyc[r] * wv[i];
-              const csg_f32x2 ww = {w, w};
-              acc[r][i][0] = __builtin_elementwise_fma(vlo, ww, acc[r][i][0]);
-              acc[r][i][1] = __builtin_elementwise_fma(vhi, ww, acc[r][i][1]);
+              const float w = wy * wv[i];
+              acc[r][i].x += v.x * w;
+              acc[r][i].y += v.y * w;
+              acc[r][i].z += v.z * w;
+              acc[r][i].w += v.w * w;
             }
           }
         }
@@ -433,8 +405,7 @@ __global__ __launch_bounds__(256) void k_layout_fwd_rows(const float* __restrict
 #pragma unroll
     for (int i = 0; i < LAY_EPT; ++i)
       if (px0 + i < npx) {
-        *(float4*)&orow[(int64_t)(px0 + i) * out_cs + q4] =
-            make_float4(acc[r][i][0].x, acc[r][i][0].y, acc[r][i][1].x, acc[r][i][1].y);
+        *(float4*)&orow[(int64_t)(px0 + i) * out_cs + q4] = acc[r][i];
         if (tail.img != nullptr && q4 == 0) lay_write_tail(tail, orow + (int64_t)(px0 + i) * out_cs, S, b, y0 + r, x0 + px0 + i);
       }
   }
@@ -543,18 +514,13 @@ __global__ __launch_bounds__(256) void k_layout_bwd_tiles(const float* __restric
         if (px0 < npx) {
           const float4 w0 = *(const float4*)&s_wx[a * pxc + px0], w1 = *(const float4*)&s_wx[a * pxc + px0 + 4];
           const float wv[LAY_EPT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-          // (as in the forward: a wave none of whose pixels the object covers would sum exact zeros — it keeps acc = 0)
-          const bool hit = (w0.x != 0.f) | (w0.y != 0.f) | (w0.z != 0.f) | (w0.w != 0.f) | (w1.x != 0.f) | (w1.y != 0.f) |
-                           (w1.z != 0.f) | (w1.w != 0.f);
-          if (__any(hit)) {
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-              const float wy = s_wy[(a0 + a) * ROWS + r];
+          for (int r = 0; r < ROWS; ++r) {
+            const float wy = s_wy[(a0 + a) * ROWS + r];
 #pragma unroll
-              for (int i = 0; i < LAY_EPT; ++i) {
-                const float w = wy * wv[i];
-                acc.x += d[r][i].x * w; acc.y += d[r][i].y * w; acc.z += d[r][i].z * w; acc.w += d[r][i].w * w;
-              }
+            for (int i = 0; i < LAY_EPT; ++i) {
+              const float w = wy * wv[i];
+              acc.x += d[r][i].x * w; acc.y += d[r][i].y * w; acc.z += d[r][i].z * w; acc.w += d[r][i].w * w;
             }
           }
         }
