@@ -383,10 +383,23 @@ def _take_bwd_operand(weight, B, IH, IW, Cin, Cout, KH, KW, stride, pad):
     return (var, take_prepacked(_f32(weight.detach()), True, var))
 
 
+WINO4_AUDIT = None     # developer audit (tools/wino4_traffic_model.py): a dict collects the ALGORITHMIC HBM bytes of the
+#                        F(4x4,3x3) convolution launches (every operand once, the packed weights included) and their count
+
+
+def _wino4_audit(kind, pixels, floats_per_pixel, packed):
+    if WINO4_AUDIT is not None:
+        a = WINO4_AUDIT.setdefault(kind, [0, 0.0])
+        a[0] += 1
+        a[1] += 4.0 * pixels * floats_per_pixel + 4.0 * packed.numel()
+
+
 def _wino_launch(x, packed, bias, res, y, B, H, W, Cin, Cout, act, slope, what, gate=None, gate_slope=0.0, variant=2):
     """Returns True when `gate` was folded into the launch (a launch split over the input channels has no epilogue:
     the caller applies the gate in a separate pass then)."""
     d = _wino_desc(B, H, W, Cin, Cout, act, slope)
+    if variant == 4:
+        _wino4_audit(what, B * H * W, Cin + Cout + (Cout if res is not None else 0) + (Cout if gate is not None else 0), packed)
     ws_fn, conv_fn = (lib.csg_wino4_conv_workspace, lib.csg_wino4_conv) if variant == 4 else \
         (lib.csg_wino_conv_workspace, lib.csg_wino_conv)
     ws, nws = None, 0
@@ -1184,12 +1197,15 @@ class _SpadeFused(torch.autograd.Function):
             d.y_cs = C
             if joint and lib.csg_wino4_conv_spade_supported(d):
                 y = torch.empty_like(x)
+                _wino4_audit("spade_joint", B * H * W, nh + 3 * C, up)          # actv, x read; gamma, y written
                 check(lib.csg_wino4_conv_spade(d, ptr(actv), ptr(up), ptr(bd), ptr(x), ptr(gbuf), C, ptr(mean), ptr(invstd),
                                                slope, ptr(y), stream()), "wino4_conv_spade")
                 saved += [actv, w, gbuf, y]
                 outs.append(y)
                 cfg.append((slope, in_slope, nh))
                 continue
+            _wino4_audit("spade_gamma", B * H * W, nh + C, up)
+            _wino4_audit("spade_beta", B * H * W, nh + 3 * C, up)
             check(lib.csg_wino4_conv_part(d, ptr(actv), ptr(up), 0, 2 * C // 32, ptr(bd), None, None, 0, None, None, 1.0,
                                           ptr(gbuf), stream()), "wino4_conv_part(gamma)")
             launches.append((actv, w, up, bd, gbuf, nh, slope, in_slope))

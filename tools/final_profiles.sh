@@ -8,6 +8,10 @@ TAG="${1:?usage: final_profiles.sh <tag>}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 mkdir -p "$O"
+# the counter passes see C3 training steps ONLY (no CPU leg, no VGG variant, no generator-only passes, no C5 leg): their
+# per-launch averages cover exactly the launch mix of the timed region
+PMC_FLAGS="--steps 3 --warmup 1 --no_c5_leg --no_vgg_variant --no_cpu_baseline --no_gen_metric"
+export PMC_FLAGS_NOTE="bench.py $PMC_FLAGS"
 
 first_csv() {   # first file matching a pattern under a directory, or fail loudly
   local f
@@ -27,9 +31,9 @@ mv "$O/${TAG}_bench_under_rocprof.json.tmp" "$O/${TAG}_bench_under_rocprof.json"
 python3 tools/trace_gaps.py "$O/p_stats" 6 > "$O/${TAG}_trace_gaps.txt" || true
 rm -rf "$O/p_stats"
 
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 bench.py --steps 3 --warmup 1 --no_c5_leg \
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 bench.py $PMC_FLAGS \
   > /dev/null 2> "$O/p_err2.txt"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 bench.py --steps 3 --warmup 1 --no_c5_leg \
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 bench.py $PMC_FLAGS \
   > /dev/null 2> "$O/p_err3.txt"
 first_csv "$O/pmc_fetch" '*counter_collection.csv' > /dev/null
 first_csv "$O/pmc_write" '*counter_collection.csv' > /dev/null
@@ -38,7 +42,7 @@ mv "$O/${TAG}_pmc_traffic.json.tmp" "$O/${TAG}_pmc_traffic.json"
 rm -rf "$O/pmc_fetch" "$O/pmc_write"
 
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY \
-  SQ_WAVE_CYCLES --output-format csv -d "$O/pmc_mfma" -- python3 bench.py --steps 3 --warmup 1 --no_c5_leg > /dev/null 2> "$O/p_err4.txt"
+  SQ_WAVE_CYCLES --output-format csv -d "$O/pmc_mfma" -- python3 bench.py $PMC_FLAGS > /dev/null 2> "$O/p_err4.txt"
 first_csv "$O/pmc_mfma" '*counter_collection.csv' > /dev/null
 python3 tools/pmc_summarize.py "$O/pmc_mfma" > "$O/${TAG}_pmc_mfma.txt.tmp"
 mv "$O/${TAG}_pmc_mfma.txt.tmp" "$O/${TAG}_pmc_mfma.txt"

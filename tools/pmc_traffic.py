@@ -40,8 +40,8 @@ def main():
                   "hbm_bytes_per_launch": round(rd + wr)}
     tag = sys.argv[3] if len(sys.argv) > 3 else None
     print(json.dumps({"capture": ("profiles/%s_pmc_traffic.json" % tag) if tag else "untagged capture", "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per the gfx950 "
-                                "note of MI355X_MICROARCH.md; command: bench.py --steps 2 --warmup 1 --no_cpu_baseline "
-                                "--no_gen_metric --no_prof", "kernels": out}, indent=1))
+                                "note of MI355X_MICROARCH.md; command: " + os.environ.get("PMC_FLAGS_NOTE", "bench.py (flags not recorded)"),
+                      "kernels": out}, indent=1))
 
 
 if __name__ == "__main__":

@@ -29,19 +29,21 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
         tr.step(batch)
         torch.cuda.synchronize()
-    ka = prof.key_averages(group_by_input_shape=True, group_by_stack_n=6)
+    ka = prof.key_averages(group_by_input_shape=True, group_by_stack_n=12)
     rows = []
     for e in ka:
         t = getattr(e, "self_device_time_total", None)
         if t is None:
             t = getattr(e, "self_cuda_time_total", 0)
         if t > 0 and e.key.startswith("aten::"):
-            rows.append((t, e.count, e.key, str(e.input_shapes)[:110], [s for s in e.stack if "canonicalsg2im_amd" in s or "torch/nn/utils" in s or "optim" in s][:3]))
+            st = [s for s in e.stack if "canonicalsg2im_amd" in s or "torch/nn/utils" in s or "optim" in s or "autograd" in s]
+            rows.append((t, e.count, e.key, str(e.input_shapes)[:110], st[:4]))
     rows.sort(key=lambda r: -r[0])
     tot = sum(r[0] for r in rows)
     print("total self device time of ATen ops: %.2f ms" % (tot / 1e3))
-    for t, c, k, sh, st in rows[:70]:
-        print("%8.1f us x%-4d %-28s %s\n           %s" % (t, c, k[:28], sh, " <- ".join(s.split("/")[-1][:60] for s in st)))
+    print("launch-like ATen ops: %d" % sum(r[1] for r in rows))
+    for t, c, k, sh, st in rows[:110]:
+        print("%8.1f us x%-4d %-28s %s\n           %s" % (t, c, k[:28], sh, " <- ".join(s.split("/")[-1][:70] for s in st)))
 
 
 if __name__ == "__main__":
