@@ -792,10 +792,19 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       const int co = rbufsel * W4_BUFW + ((c % T) * W4_CQ + (c / T)) * W4_PS;
       const csg_f32x2 e0 = *(w4_lds_cv2)(p0 + co);
       const csg_f32x2 e1 = *(w4_lds_cv2)(p0 + co + W4_RS);
+#ifdef W4_HALF_READS   // ablation (wrong results): half the raw LDS reads of the transform at the same VALU count
+      const csg_f32x2 e2 = e0 * 1.5f;
+      const csg_f32x2 e3 = e1 * 0.75f;
+#else
       const csg_f32x2 e2 = *(w4_lds_cv2)(p0 + co + O2);
       const csg_f32x2 e3 = *(w4_lds_cv2)(p0 + co + O3);
+#endif
       if (XI == 0 || XI == 5) {
+#ifdef W4_HALF_READS
+        const csg_f32x2 e4 = e0 * 0.5f;
+#else
         const csg_f32x2 e4 = *(w4_lds_cv2)(p0 + co + 4 * W4_RS + 2);
+#endif
         t[c] = w4_pfma(1.5f, e3 - e1, w4_pfma(-2.0f, e2, e0 + e4));
       } else if (XI == 1) {
         t[c] = w4_pfma(2.5f, e2, w4_pfma(0.5f, e1, e3 - e0));
@@ -850,7 +859,9 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
       acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[slot].y, v.y, acc[nu], 0, 0, 0);
       acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[slot].z, v.z, acc[nu], 0, 0, 0);
       acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[slot].w, v.w, acc[nu], 0, 0, 0);
+#ifndef W4_NO_ULOAD
       if (nu < 3) load_ur(slot, nu + 3, s); else load_ur(slot, nu - 3, s + 1);
+#endif
     }
   };
   // One stage.  The transform of stage k+1 sits BETWEEN the MFMAs of stage k (W4_SPLIT positions in front of it): after
@@ -859,7 +870,8 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 #ifndef W4_SPLIT
 #define W4_SPLIT 3
 #endif
-  // (-DW4_HALF_PRODUCE: ablation for tools/wino4_variants.py — the transform of every other stage only, wrong results.
+  // (-DW4_HALF_PRODUCE, -DW4_HALF_READS, -DW4_NO_BARRIER, -DW4_NO_ULOAD, -DW4_NO_STAGING: ablations for
+  // tools/wino4_variants.py — wrong results, loop timing only.
   // Round 6 measured two more placements with that tool and dropped them: s_setprio 1 / 3 around the matrix clusters
   // -3 % on every shape; different split points on the three waves of a SIMD needed the stage body as a callable the
   // compiler no longer inlined — 1 KB of scratch, 30x slower.  profiles/r06b_wino4_variants.txt.)
@@ -883,9 +895,15 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 #ifndef W4_NO_MFMA
     consume(IS(), I6(), par, s);
 #endif
+#ifndef W4_NO_STAGING
     store_stage(smem + W4V_RAW0 + par * W4_BUFW);   // raw[k+2] takes the buffer raw[k] left
+#endif
+#ifndef W4_NO_BARRIER
     __syncthreads();
+#endif
+#ifndef W4_NO_STAGING
     load_stage(s + 3);
+#endif
   };
 
   y += (long long)split * p.slab;

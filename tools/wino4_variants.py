@@ -17,7 +17,12 @@ VDIR = os.path.join(ROOT, "canonicalsg2im_amd", "csrc", "build", "variants")
 # tag -> extra flags for wino4.hip ("valid": results are right; the ablations compute garbage and only time the loop)
 VARIANTS = {
     "base": [],
-    "split2": ["-DW4_SPLIT=2"],
+    "abl_half_reads": ["-DW4_HALF_READS"],
+    "abl_no_barrier": ["-DW4_NO_BARRIER"],
+    "abl_no_uload": ["-DW4_NO_ULOAD"],
+    "abl_no_staging": ["-DW4_NO_STAGING"],
+    "abl_no_produce_no_uload": ["-DW4_NO_PRODUCE", "-DW4_NO_ULOAD"],
+    "abl_mfma_only": ["-DW4_NO_PRODUCE", "-DW4_NO_ULOAD", "-DW4_NO_STAGING", "-DW4_NO_BARRIER"],
     "abl_half_produce": ["-DW4_HALF_PRODUCE"],
     "abl_no_produce": ["-DW4_NO_PRODUCE"],
 }
