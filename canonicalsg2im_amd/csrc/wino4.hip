@@ -895,13 +895,13 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 #ifndef W4_NO_MFMA
     consume(IS(), I6(), par, s);
 #endif
-#ifndef W4_NO_STAGING
+#if !defined(W4_NO_STAGING) && !defined(W4_NO_STAGING_STORE)
     store_stage(smem + W4V_RAW0 + par * W4_BUFW);   // raw[k+2] takes the buffer raw[k] left
 #endif
 #ifndef W4_NO_BARRIER
     __syncthreads();
 #endif
-#ifndef W4_NO_STAGING
+#if !defined(W4_NO_STAGING) && !defined(W4_NO_STAGING_LOAD)
     load_stage(s + 3);
 #endif
   };
