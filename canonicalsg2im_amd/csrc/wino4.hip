@@ -625,7 +625,7 @@ struct W4Geo {
   static constexpr int BUFW = R * RS + 8 + 16;         // + the skew of the last row group + a dump slot
   static constexpr int V0 = 2 * BUFW;
   static constexpr int OFFTAB = (2 * BUFW + 2 * W4_VBUF) > 2 * W4_RBUF ? (2 * BUFW + 2 * W4_VBUF) : 2 * W4_RBUF;
-  static_assert((T * RS) % 64 == 0 && R * C * 2 <= W4_NLD * W4_THREADS && (C + T - 1) / T <= W4_CQ, "staging geometry");
+  static_assert((T * RS) % 64 == 0 && R * C * 2 <= W4_NLD * W4_THREADS && (C + T - 1) / T <= W4_CQ && BUFW < 65536, "staging geometry");
 };
 #define W4V_RAW0 0
 // the kernel-argument segment of k_wino4_conv_v as the persistent form reads it back in its epilogue
@@ -711,12 +711,14 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
     for (int i = 0; i < W4_NLD; ++i) {
       const int e = tid_o + W4_THREADS * i;
       goff[i] = CSG_OOB_OFF;
-      int lo = (W4_BUFW - 16) / 4 + (tid_o & 3);
+      int lo = (W4_BUFW - 16) + (tid_o & 3) * 4;     // the dump slot
       if (e < Geo::R * Geo::C * 2) {
         const int pix = e >> 1, c4 = e & 1;
         const int row = pix / Geo::C, col = pix - row * Geo::C;
         const int iy = Y0 + row - p.pad, ix = X0 + col - p.pad;
-        lo = (row * W4_RS + ((col % T) * W4_CQ + (col / T)) * W4_PS + c4 * 4) / 4 + ((row / T) << 13);
+        // the float index of the piece inside a raw buffer, skew of its row group included (16 bits: BUFW < 65536) — the
+        // per-stage store decodes nothing (round 6: +1-2 % on every shape over a packed quad index + skew code)
+        lo = row * W4_RS + ((col % T) * W4_CQ + (col / T)) * W4_PS + c4 * 4 + (row / T) * 2;
         if (valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
           goff[i] = (unsigned)(((img * p.H + iy) * p.W + ix) * p.x_cs + c4 * 4) * 4u;
       }
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, c
 #pragma unroll
     for (int i = 0; i < W4_NLD; ++i) {
       const unsigned lo = (i & 1) ? (lp >> 16) : (lp & 0xffffu);
-      float* dst = base + (lo & 0x1fffu) * 4 + (lo >> 13) * 2;
+      float* dst = base + lo;
       *(float2*)dst = make_float2(st[i].x, st[i].y);
       *(float2*)(dst + 2) = make_float2(st[i].z, st[i].w);
     }

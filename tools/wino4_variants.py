@@ -17,9 +17,14 @@ VDIR = os.path.join(ROOT, "canonicalsg2im_amd", "csrc", "build", "variants")
 # tag -> extra flags for wino4.hip ("valid": results are right; the ablations compute garbage and only time the loop)
 VARIANTS = {
     "base": [],
+    "abl_half_reads": ["-DW4_HALF_READS"],
+    "abl_half_produce": ["-DW4_HALF_PRODUCE"],
+    "abl_no_produce": ["-DW4_NO_PRODUCE"],
+    "abl_no_barrier": ["-DW4_NO_BARRIER"],
+    "abl_no_uload": ["-DW4_NO_ULOAD"],
     "abl_no_staging": ["-DW4_NO_STAGING"],
     "abl_no_staging_load": ["-DW4_NO_STAGING_LOAD"],
-    "abl_no_staging_store": ["-DW4_NO_STAGING_STORE"],
+    "abl_mfma_only": ["-DW4_NO_PRODUCE", "-DW4_NO_ULOAD", "-DW4_NO_STAGING", "-DW4_NO_BARRIER"],
 }
 SHAPES = [(16, 128, 256, 256), (16, 128, 512, 128), (16, 128, 1024, 64), (16, 256, 128, 128), (16, 1024, 512, 32),
           (16, 32, 128, 256), (4, 128, 256, 256)]
