@@ -226,3 +226,10 @@ def test_two_rank_data_parallel_equals_single_process():
     ys = oracle.syncbn_multi_replica([r0["xs"], r1["xs"]], torch.zeros(C), torch.ones(C))
     mine0 = (r0["xs"] - mean.float().view(1, C, 1, 1)) * inv_std.float().view(1, C, 1, 1)
     assert torch.allclose(mine0, ys[0], rtol=1e-4, atol=1e-5)
+
+
+def test_drain_watchdog_without_an_nccl_group_is_a_no_op():
+    """dist.drain_watchdog() only has work to do under an nccl group (ProcessGroupNCCL's watchdog): with no group — or gloo —
+    it reports "drained" at once and never touches the flight recorder."""
+    from canonicalsg2im_amd import dist as D
+    assert D.drain_watchdog(timeout_s=0.01) == "drained"
