@@ -250,7 +250,7 @@ def cpu_baseline(snapshot, batch0, gpu_step0, image_size, snapshot_k=None, gpu_s
     small = min(phys, 32)
     t_phys, (Go, Do, img_o) = one(snapshot, phys)
     # `dense` (config C5: 128 layout channels, up to 128 overlapping objects per scene): the fp32 ORACLE is itself 1.7e-4 away
-    # from fp64 on a few pixels there (profiles/r04_c5_image_vs_fp64.txt; the HIP path 7e-5), so that configuration's image is
+    # from fp64 on a few pixels there (profiles/archive/r04_c5_image_vs_fp64.txt; the HIP path 7e-5), so that configuration's image is
     # judged against the oracle's fp64 evaluation — same rule, rtol 1e-4 + 1e-4 absolute, 2e-5 in relative L2
     parity0 = _parity(gpu_step0, Go, Do, img_o,
                       "step 0 of the GPU trainer (taken before warm-up) vs oracle.train_step on the same weights and batch: "

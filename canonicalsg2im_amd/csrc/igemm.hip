@@ -15,7 +15,7 @@
 // Loads go through buffer descriptors (SRDs): a lane whose tap falls outside the image, whose
 // row is past M/N or whose k is past K simply gets an out-of-range offset and the hardware returns
 // zeros — the loader is branch-free, so hipcc interleaves its ~50 VALU ops with the MFMAs
-// (the first version's exec-masked loads left 30 % of the matrix pipe idle: profiles/r01b).
+// (the first version's exec-masked loads left 30 % of the matrix pipe idle: profiles/archive/r01b).
 //
 // Small grids (few output tiles, long K — the low-resolution layers and their backward-data) are
 // split along K into slabs that a second ordered pass sums and finishes (bias/activation/residual);

@@ -22,7 +22,7 @@ __device__ __forceinline__ float lrelu_g(float pre, float s) { return pre > 0.f 
 // grid (nchunk, G); partial[(g*nchunk + chunk)*2C + {c | C + c}] = {sum x, sum x^2} over the chunk.
 // Sums are carried in fp64 from the first addition on: var = E[x^2] - E[x]^2 cancels mean^2 / var leading digits,
 // and the discriminator's InstanceNorm maps (mean^2 >> var on 16 641-pixel planes) lost 3-4 digits of inv_std
-// with fp32 partial sums (profiles/r02_band_*.txt: 1e-4 gradient error where the fp32 reference has 1e-6).
+// with fp32 partial sums (profiles/archive/r02_band_*.txt: 1e-4 gradient error where the fp32 reference has 1e-6).
 // x and x*x are exact in fp64, so the result is the correctly rounded statistic whatever the chunking.
 struct d4 {
   double x, y, z, w;

@@ -170,7 +170,7 @@ constexpr int wn_row_stride(int TW) {
 }
 
 // Every VALU instruction of the single wave per SIMD takes issue time away from the fp32 MFMAs (measured: 57 % matrix
-// pipe busy with 2 VALU per MFMA in the loop, profiles/r02_pmc_wino.md), so the loop body carries none that is not
+// pipe busy with 2 VALU per MFMA in the loop, profiles/archive/r02_pmc_wino.md), so the loop body carries none that is not
 // arithmetic of the transform: the tile geometry is a template parameter (LDS offsets become instruction immediates),
 // the per-stage advance of the global loads rides in the SCALAR offset of the buffer instructions, and the stage loop
 // is unrolled by two so that the LDS buffer is a compile-time constant.

@@ -34,7 +34,7 @@
 //   * Epilogue: each wave reduces its row over nu (M A), the six rows meet in LDS (A^T .) two output columns at a
 //     time, 16-byte stores.
 //
-// How it got here (MI355X, B = 16; profiles/r03_wino4_notes.md).  (1) Six-wave blocks, two per CU, V formed in
+// How it got here (MI355X, B = 16; profiles/archive/r03_wino4_notes.md).  (1) Six-wave blocks, two per CU, V formed in
 // registers by every wave: the dispatcher never co-scheduled two six-wave workgroups (a six-wave group lands 2+2+1+1 on
 // the four SIMDs and the next one needs the mirror image): half occupancy, 31 % matrix-pipe busy, 1.4x SLOWER than
 // F(2x2,3x3).  (2) Twelve-wave blocks (two channel groups): full occupancy, par with F(2x2,3x3).  Ablations of that
@@ -643,7 +643,7 @@ typedef const __attribute__((address_space(4))) W4KernArgs* w4_kernargs_ptr;
 // stages runs ACROSS items — the last two stages of an item store the first two stages of the next one (raw[0], raw[1]),
 // the third is in flight and the U ring already holds the next item's operands when the epilogue starts; the epilogue
 // exchanges one output column per round inside the V buffers.  What a one-item block pays outside its loop on a
-// Cin = 128 layer (profiles/r05p_conv_phase_trace.txt: 7.7k cycles until the first stage lands + 2.6k to prime, of
+// Cin = 128 layer (profiles/archive/r05p_conv_phase_trace.txt: 7.7k cycles until the first stage lands + 2.6k to prime, of
 // 121k) shrinks to the transform of the first stage.  Same arithmetic in the same order: bit-identical outputs.
 template <int T, bool P>
 __global__ __launch_bounds__(W4_THREADS, 3) void k_wino4_conv_v(Wino4Params p, const float* __restrict__ x,

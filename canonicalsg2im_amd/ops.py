@@ -200,7 +200,7 @@ def wino_variant(B, H, W, Cin, Cout, plain=False):
     """4: the layer runs Winograd F(4x4,3x3) (csrc/wino4.hip: maps >= 32 wide); 2: F(2x2,3x3) (csrc/wino.hip).
     F(4x4,3x3) works on (32 x 16 pixel region, 64 output channels) items, one per CU at a time: a launch with fewer than
     ~160 of them (small batches on the 32 x 32 / 64 x 64 maps: config C4's shard of 4 images) leaves half the chip idle and
-    F(2x2,3x3) — 1.78x the multiplications in 4x the blocks — is 1.2-1.9x faster (profiles/r05t_variant_ab.txt: 64-128 items;
+    F(2x2,3x3) — 1.78x the multiplications in 4x the blocks — is 1.2-1.9x faster (profiles/archive/r05t_variant_ab.txt: 64-128 items;
     at 192 the larger tile wins again).  `plain` (no bias / activation / residual / gate): such a launch is split over >= 256
     input channels instead and stays on F(4x4,3x3)."""
     if lib.csg_wino4_supported(_wino_desc(B, H, W, Cin, Cout)) != 1:

@@ -1,5 +1,5 @@
 """Why do the graph-encoder gradients of the C5 whole-step test (tests/test_gpu_fullwidth.py::
-test_c5_full_generator_step_vs_oracle, profiles/r03q_band_C5.txt) sit 5-28x further from fp64 than the fp32 oracle,
+test_c5_full_generator_step_vs_oracle, profiles/archive/r03q_band_C5.txt) sit 5-28x further from fp64 than the fp32 oracle,
 uniformly from gconvs.3 upwards, while gconvs.4.net2 / box_net are clean?
 
 The encoder's only objective is the box regression (the generator consumes the ground-truth boxes), so the scene of that

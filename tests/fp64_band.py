@@ -6,7 +6,7 @@ sign() of the L1 feature-matching term make them piecewise-constant in the activ
 rounding noise of ANY fp32 implementation flips a few hundred of the 10^7..10^8 gates and moves a gradient
 tensor by 1e-4..1e-2 of its norm (more the deeper the layer).  Measured on the oracle itself: the same step
 evaluated in fp32 and in fp64 on the CPU differs by up to 9e-3 in relative L2 norm at ngf=64, 256x256
-(profiles/r02_fp64_noise_band.txt) while the losses agree to 1e-7.
+(profiles/archive/r02_fp64_noise_band.txt) while the losses agree to 1e-7.
 
 The parity statement that CAN be tested is therefore: against the fp64 evaluation of the oracle, the HIP
 path's gradient error is within a small factor (3x) of the fp32 reference arithmetic's own error (plus the 1e-4
@@ -28,7 +28,7 @@ class Band:
     """Collects (name, hip-vs-fp64 error, fp32-reference-vs-fp64 error) rows and judges them."""
 
     def __init__(self, k_l2=3.0, max_cap=0.05, floor=1e-4):
-        """L2 criterion: hip_l2 <= k_l2 * ref_l2 + floor (k_l2 = 3: the round-2 tables, profiles/r02_band_C{3,4,5}.txt,
+        """L2 criterion: hip_l2 <= k_l2 * ref_l2 + floor (k_l2 = 3: the round-2 tables, profiles/archive/r02_band_C{3,4,5}.txt,
         hold 0 of 464 tensors beyond 3x and a worst ratio of 2.6 where the reference noise is measurable).  The max-norm is only capped (no single entry off by more
         than 5 % of the tensor's largest): one flipped gate in front of a large activation moves ONE entry of a
         weight gradient by percents of the maximum in either implementation (the fp32 oracle shows 1.4e-1 on
@@ -65,19 +65,19 @@ class Band:
         are grouped by the network they belong to (one PatchGAN scale, the object discriminator, the generator with the
         encoder behind it) — one flipped gate accounts for every outlier of its group, at most the group's five tensors in
         a discriminator scale.  At most `outliers` = TWO groups may hold outliers, with at most five tensors each (none was
-        outside the band in the round-2 runs of C3, C4 and C5; profiles/r05q_band_C3.txt is a run with one event on each
+        outside the band in the round-2 runs of C3, C4 and C5; profiles/archive/r05q_band_C3.txt is a run with one event on each
         side: the fp32 ORACLE at 8.4e-4 on D0.model0 — a flip behind model0 — and the HIP path at 1.4-1.8e-4 on D0.model1..3
         where the oracle drew none), as long as no tensor is off by more than 1e-2 (the fp32 reference itself reaches 9e-3
         against fp64), and the typical tensor must be as accurate as the reference's: median of hip_l2 / ref_l2 <= 1.5
         over the tensors whose reference noise is measurable (measured: 0.75 / 1.02 / 0.63).
 
         `outliers=None` (dense scenes, config C5: 65-129 objects per image, S = 128 layout channels, batch 2): events are
-        frequent there and ONE of them moves every tensor upstream of it — the r03 run (profiles/r03_band_C5.txt) has
+        frequent there and ONE of them moves every tensor upstream of it — the r03 run (profiles/archive/r03_band_C5.txt) has
         the fp32 reference itself at 2.4e-3 on D0.model0/1 where the HIP path is at 7.6e-4 and the HIP path at 3e-3 on all
         of D1 where the reference drew no flip.  Counting tensors says nothing in that regime; the verdict is the cap (no
         tensor beyond 1e-2) and the median ratio.  The graph encoder's rows of that scene (uniformly 2.2-3.3e-4 from fp64
         from gconvs.3 upwards, 5-28x the fp32 oracle's distance) are NOT judged here any more: tests/dev/debug_sg_c5.py
-        (profiles/r04_debug_sg_c5.txt) shows them to be ReLU decisions on pre-activations within rounding distance of
+        (profiles/archive/r04_debug_sg_c5.txt) shows them to be ReLU decisions on pre-activations within rounding distance of
         zero at the input of gconvs.4 — evaluated with the HIP path's gate decisions, the fp64 oracle agrees with every
         HIP gradient to 4e-7 — and `forced_gate_rows` below holds them to that much sharper statement.  (Round 3's
         docstring blamed an event in the generator's 8x8 head; the encoder receives no gradient from the generator,

@@ -83,7 +83,7 @@ def _step_losses_image_only(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed,
     >1 GB tensors next to the 32-bit offset guards — and every one of those decisions shows in the losses and in the image.
     `image_vs_fp64`: the image is held to the fp64 oracle instead (config C5: 128 layout channels and up to 128
     overlapping objects put the mean |pixel| at 0.2, and the fp32 ORACLE is then itself up to 1.7e-4 away from fp64 on a
-    few pixels — profiles/r04_c5_image_vs_fp64.txt: HIP 7.1e-5 / 4.4e-6 in relative L2, the fp32 oracle 1.7e-4 / 7.4e-6)."""
+    few pixels — profiles/archive/r04_c5_image_vs_fp64.txt: HIP 7.1e-5 / 4.4e-6 in relative L2, the fp32 oracle 1.7e-4 / 7.4e-6)."""
     import oracle
     from canonicalsg2im_amd import train as T
     from canonicalsg2im_amd.synth import make_batch, make_vocab
@@ -114,7 +114,7 @@ def _step_losses_image_only(cuda, vocab_kind, argv, batch_cfg, seed, batch_seed,
 
 def _check_gd_against_fp32(res, tag):
     """Generator / PatchGAN gradients against the fp32 oracle alone (no fp64 evaluation: minutes of CPU).  Gate flips are
-    drawn on BOTH sides (profiles/r04_band_C5.txt, taken with the fp64 leg on: HIP up to 3.9e-3 from fp64, the fp32 oracle
+    drawn on BOTH sides (profiles/archive/r04_band_C5.txt, taken with the fp64 leg on: HIP up to 3.9e-3 from fp64, the fp32 oracle
     up to 2.4e-3), so two fp32 evaluations may differ by their sum: cap 1.5e-2 per tensor, median 3e-3."""
     errs = []
     for group in ("G", "D"):
