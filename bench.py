@@ -472,7 +472,10 @@ def main():
 
     # BASELINE.json's second metric: the SPADE generator alone, forward + backward (no optimiser step)
     gen_ms = gen_exec_ratio = None
-    if H in (64, 128, 256) and args.ngf == 64 and not args.no_gen_metric:
+    # (the auxiliary legs below — generator-only passes, the VGG-on variant, the C5 leg — run on ONE rank only: the N > 1 line
+    # is the scaling measurement, and every extra trainer construction there is more collectives between the timed region
+    # and the JSON line it has to deliver)
+    if H in (64, 128, 256) and args.ngf == 64 and not args.no_gen_metric and world == 1:
         gen = trainer.model.layout_to_image_model
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 3
@@ -505,7 +508,7 @@ def main():
     # SURVEY.md 8(d)'s --no_vgg_loss configuration.  A short second measurement with the term on (random-feature
     # VGG19: the pretrained weights cannot be downloaded) makes that number visible to the driver as well.
     vgg_variant = None
-    if not args.vgg_loss and not args.no_vgg_variant:
+    if not args.vgg_loss and not args.no_vgg_variant and world == 1:
         os.environ.setdefault("CSG_VGG19_RANDOM", "1")
         argv_v = [a for a in opt_argv if a != "--no_vgg_loss"]
         opt_v = T.make_opt(vocab, argv_v + ["--batch_size", str(args.batch * world), "--gpu_ids",
