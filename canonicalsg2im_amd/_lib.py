@@ -159,6 +159,7 @@ SIGNATURES = {
     "csg_upsample2x_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_avgpool3s2_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_avgpool3s2_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "csg_avgpool3s2_bwd_add": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "csg_crop_fwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p]),
     "csg_crop_bwd": (c_i32, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "csg_crop_bwd_boxes": (c_i32, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p,

@@ -488,8 +488,11 @@ __device__ __forceinline__ int win_count(int o, int n) {  // in-bounds taps of a
   return hi - lo + 1;
 }
 
+// `add` (nullable, may alias dx): dx = add + pool_bwd(dy) — the input fans out to a consumer of its own AND to the pooled
+// copy (the PatchGAN's two scales), and its gradient is the sum of both; the pooled part is summed first, as autograd's
+// separate addition of the two tensors did (a two-term fp32 sum does not depend on the order of its terms).
 __global__ void k_avgpool3s2_bwd(const float* __restrict__ dy, int H, int W, int OH, int OW, int Q, int64_t n4,
-                                 float* __restrict__ dx) {
+                                 const float* add, float* dx) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
     int64_t pix = e / Q;
     int q = (int)(e - pix * Q);
@@ -508,6 +511,10 @@ __global__ void k_avgpool3s2_bwd(const float* __restrict__ dy, int H, int W, int
         float4 v = ld4(dy + (((b * OH + oy) * OW + ox) * (int64_t)Q + q) * 4);
         a.x += v.x * inv; a.y += v.y * inv; a.z += v.z * inv; a.w += v.w * inv;
       }
+    }
+    if (add != nullptr) {
+      const float4 o = ld4(add + e * 4);
+      a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
     }
     st4(dx + e * 4, a);
   }
@@ -696,15 +703,26 @@ int csg_avgpool3s2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t 
   return check_launch("csg_avgpool3s2_fwd");
 }
 
-int csg_avgpool3s2_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream) {
-  CSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "csg_avgpool3s2_bwd: bad shape");
+static int avgpool3s2_bwd_launch(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, const float* add, float* dx,
+                                 void* stream, const char* who) {
+  CSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, CSG_E_BADSHAPE, "%s: bad shape", who);
   hipStream_t s = (hipStream_t)stream;
   const int64_t OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const int64_t n4 = B * H * W * C / 4;
-  ProfScope p(K_AVGPOOL_BWD, (double)(B * H * W * C + B * OH * OW * C) * 4, s);
+  ProfScope p(K_AVGPOOL_BWD, (double)(B * H * W * C * (add != nullptr ? 2 : 1) + B * OH * OW * C) * 4, s);
   CSG_LAUNCH(k_avgpool3s2_bwd, dim3(ew_grid(n4)), dim3(256), 0, s, dy, (int)H, (int)W, (int)OH, (int)OW,
-                     (int)(C / 4), n4, dx);
-  return check_launch("csg_avgpool3s2_bwd");
+                     (int)(C / 4), n4, add, dx);
+  return check_launch(who);
+}
+
+int csg_avgpool3s2_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream) {
+  return avgpool3s2_bwd_launch(dy, B, H, W, C, nullptr, dx, stream, "csg_avgpool3s2_bwd");
+}
+
+int csg_avgpool3s2_bwd_add(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, const float* add, float* dx,
+                           void* stream) {
+  CSG_REQUIRE(add != nullptr && ((uintptr_t)add % 16) == 0, CSG_E_BADSHAPE, "csg_avgpool3s2_bwd_add: needs a 16-byte aligned addend");
+  return avgpool3s2_bwd_launch(dy, B, H, W, C, add, dx, stream, "csg_avgpool3s2_bwd_add");
 }
 
 }  // extern "C"

@@ -1461,6 +1461,50 @@ def avgpool3s2(x):
     return _AvgPool3s2.apply(x)
 
 
+class _PoolFanout(torch.autograd.Function):
+    """x -> (x, avgpool3s2(x)): a map that feeds one consumer at full resolution and another through its pooled copy (the two
+    scales of MultiscaleDiscriminator, reference discriminator.py:120-131).  The backward receives both gradients and forms
+    d x = g_full + avgpool_bwd(g_pooled) in ONE pass (csg_avgpool3s2_bwd_add) — where autograd would have run the pooling
+    backward into a map of its own and then added the two (600 MB of traffic at 256 x 256 x 36 channels where this pass moves
+    340, three times per step, and one launch less).  Out of place: an incoming gradient may be shared with another node.
+    Bit-identical: a two-term fp32 sum does not depend on the order of its terms."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xc = nhwc(_f32(x))
+        B, C, H, W = xc.shape
+        y = empty_nhwc(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, xc.device)
+        check(lib.csg_avgpool3s2_fwd(ptr(xc), B, H, W, C, ptr(y), stream()), "avgpool_fwd")
+        ctx.shape = (B, C, H, W)
+        ctx.set_materialize_grads(False)          # an unused output arrives as None, not as a map of zeros
+        return xc.view_as(xc), y
+
+    @staticmethod
+    def backward(ctx, g_full, g_pool):
+        B, C, H, W = ctx.shape
+        if g_pool is None:
+            return g_full
+        g_pool = nhwc(g_pool)
+        if g_full is None:
+            dx = empty_nhwc(B, C, H, W, g_pool.device)
+            check(lib.csg_avgpool3s2_bwd(ptr(g_pool), B, H, W, C, ptr(dx), stream()), "avgpool_bwd")
+            return dx
+        g_full = nhwc(g_full)
+        dx = empty_nhwc(B, C, H, W, g_pool.device)
+        check(lib.csg_avgpool3s2_bwd_add(ptr(g_pool), B, H, W, C, ptr(g_full), ptr(dx), stream()), "avgpool_bwd_add")
+        return dx
+
+
+POOL_FANOUT = os.environ.get("CSG_POOL_FANOUT", "1") != "0"       # 0: plain avgpool3s2 + autograd's own addition (A/B)
+
+
+def pool_fanout(x):
+    """(x, avgpool3s2(x)) with the two gradients of x summed inside the pooling backward (ops._PoolFanout)."""
+    if not POOL_FANOUT:
+        return x, avgpool3s2(x)
+    return _PoolFanout.apply(x)
+
+
 class _MaxPool2(torch.autograd.Function):
     """nn.MaxPool2d(2, 2) (torchvision vgg19().features, reference architecture.py:96-110)."""
 

@@ -120,10 +120,13 @@ class MultiscaleDiscriminator(BaseNetwork):
         if len(scales) > 1 and SCALE_STREAMS and x.is_cuda:
             return self._forward_concurrent(scales, x, S, grad_channels)
         result = []
-        for D in scales:
+        for i, D in enumerate(scales):
+            # the input of a scale feeds that scale AND, pooled, the next one: ops.pool_fanout sums its two gradients inside
+            # the pooling backward (the last scale's input has one consumer)
+            x, nxt = ops.pool_fanout(x) if (i + 1 < len(scales) and x.is_cuda) else (x, None)
             out = D(x, seg_first=S, grad_channels=grad_channels)
             result.append(out if not self.opt.no_ganFeat_loss else [out])
-            x = self.downsample(x)
+            x = nxt
         return result
 
     def _forward_concurrent(self, scales, x, S, grad_channels):
@@ -131,13 +134,16 @@ class MultiscaleDiscriminator(BaseNetwork):
         stream, joined by events at both ends; autograd replays each scale's backward on the stream of its forward."""
         main = torch.cuda.current_stream(x.device)
         side = _side_stream(x.device)
+        # the fan-out of the input (scale 0 | pooled copy for the lower scales) stays on the caller's stream: its backward
+        # (ops._PoolFanout: d x = g_scale0 + avgpool_bwd(g_lower) in one pass) then runs there too, on gradients of both streams
+        x, xs = ops.pool_fanout(x)
         side.wait_stream(main)
-        x.record_stream(side)
+        xs.record_stream(side)
         lower = []
         with torch.cuda.stream(side):
-            xs = x
-            for D in scales[1:]:
-                xs = self.downsample(xs)
+            for i, D in enumerate(scales[1:]):
+                if i > 0:
+                    xs = self.downsample(xs)
                 lower.append(D(xs, seg_first=S, grad_channels=grad_channels))
         first = scales[0](x, seg_first=S, grad_channels=grad_channels)
         main.wait_stream(side)

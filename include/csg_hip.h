@@ -459,6 +459,10 @@ int csg_upsample2x_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t
 /* F.avg_pool2d(3, stride 2, pad 1, count_include_pad=False) (discriminator.py:92-93) */
 int csg_avgpool3s2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
 int csg_avgpool3s2_bwd(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, float* dx, void* stream);
+/* dx = add + avgpool_bwd(dy): the gradient of a map that feeds a consumer of its own (gradient `add`, laid out like dx; may BE
+ * dx) and its pooled copy — MultiscaleDiscriminator's input (discriminator.py:120-131).  Replaces autograd's separate addition. */
+int csg_avgpool3s2_bwd_add(const float* dy, int64_t B, int64_t H, int64_t W, int64_t C, const float* add, float* dx,
+                           void* stream);
 
 /* ---- object crops for the object discriminator (sg2im/bilinear.py:44-94) ---------------------------
  * out[n, y, x, c] = bilinear sample (grid_sample, align_corners=False, zeros padding) of image

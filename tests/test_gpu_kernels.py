@@ -672,3 +672,37 @@ def test_norm_stats_finalize_in_one_launch_matches_the_three_launch_path(ops, G,
     xs = x.view(G, P, C).double()
     assert_close(m1.view(G, C), xs.mean(1).float(), 1e-5, 1e-6, "mean")
     assert_close(i1.view(G, C), (1.0 / torch.sqrt(xs.var(1, unbiased=False) + eps)).float(), 1e-5, 1e-6, "invstd")
+
+
+def test_pool_fanout_sums_both_gradients_in_the_pooling_backward():
+    """ops.pool_fanout(x) = (x, avgpool3s2(x)) whose backward forms g_full + avgpool_bwd(g_pooled) in one pass
+    (csg_avgpool3s2_bwd_add): outputs and d x bit-identical to the plain pooling + autograd's own addition; one consumer only
+    (either gradient missing) still works."""
+    from canonicalsg2im_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(3, 36, 33, 47, generator=g)
+    w_full, w_pool = torch.randn(3, 36, 33, 47, generator=g), torch.randn(3, 36, 17, 24, generator=g)
+
+    def run(fused, use_full=True, use_pool=True):
+        saved = ops.POOL_FANOUT
+        ops.POOL_FANOUT = fused
+        try:
+            x = ops.nhwc(x0.clone().cuda()).requires_grad_(True)
+            a, b = ops.pool_fanout(x)
+            loss = 0
+            if use_full:
+                loss = loss + (a * a * w_full.cuda()).sum()
+            if use_pool:
+                loss = loss + (b * w_pool.cuda()).sum()
+            loss.backward()
+            return a.detach(), b.detach(), x.grad.detach()
+        finally:
+            ops.POOL_FANOUT = saved
+
+    for use_full, use_pool in ((True, True), (True, False), (False, True)):
+        a1, b1, g1 = run(True, use_full, use_pool)
+        a0, b0, g0 = run(False, use_full, use_pool)
+        assert torch.equal(a1, a0) and torch.equal(b1, b0)
+        assert torch.equal(g1, g0), (use_full, use_pool, float((g1 - g0).abs().max()))
+    ref = torch.nn.functional.avg_pool2d(x0, 3, 2, 1, count_include_pad=False)
+    assert_close(b1.cpu(), ref, 1e-5, 1e-6, "pooled")
