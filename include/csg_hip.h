@@ -41,6 +41,8 @@ extern "C" {
 
 #define CSG_MAX_TAPS 16
 
+/* 100 + the number of additive revisions of this header: entry points are only ever added, never changed or removed
+ * (106: csg_wino4_conv_spade, csg_wino4_conv_spade_supported, csg_avgpool3s2_bwd_add) */
 int csg_version(void);
 const char* csg_last_error(void);
 
