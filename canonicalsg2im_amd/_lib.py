@@ -43,6 +43,11 @@ class WinoPackItem(ctypes.Structure):
                 ("backward_data", c_i32), ("variant", c_i32), ("packed", c_p)]
 
 
+class HingeItem(ctypes.Structure):
+    """Mirror of `csg_hinge_item` (include/csg_hip.h)."""
+    _fields_ = [("x", c_p), ("dx", c_p), ("sb", c_i64), ("sh", c_i64), ("sw", c_i64), ("B", c_i64), ("H", c_i64), ("W", c_i64)]
+
+
 class FewDesc(ctypes.Structure):
     """Mirror of `csg_few_desc` (include/csg_hip.h)."""
     _fields_ = [("B", c_i32), ("IH", c_i32), ("IW", c_i32), ("Cin", c_i32), ("x_cs", c_i32), ("KH", c_i32), ("KW", c_i32),
@@ -171,6 +176,8 @@ SIGNATURES = {
     "csg_l1_mean_workspace": (c_i64, [c_i64]),
     "csg_l1_mean_fwd": (c_i32, [c_p, c_p, c_i64, c_p, c_p, c_i64, c_p]),
     "csg_l1_mean_bwd": (c_i32, [c_p, c_p, c_p, c_i64, c_p, c_p]),
+    "csg_hinge_mean_fwd": (c_i32, [ctypes.POINTER(HingeItem), c_i32, c_i32, c_p, c_p]),
+    "csg_hinge_mean_bwd": (c_i32, [ctypes.POINTER(HingeItem), c_i32, c_i32, c_p, c_p]),
     "csg_spectral_norm_workspace": (c_i64, [c_i64, c_i64]),
     "csg_spectral_norm_fwd": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f32, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64,
                                       c_p]),

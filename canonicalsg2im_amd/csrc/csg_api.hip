@@ -131,7 +131,7 @@ static const char* kNames[K_COUNT] = {
 
 extern "C" {
 
-int csg_version(void) { return 106; }
+int csg_version(void) { return 108; }
 const char* csg_last_error(void) { return csg::g_err; }
 
 int csg_prof_enable(int on) {

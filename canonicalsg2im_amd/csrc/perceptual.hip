@@ -169,6 +169,61 @@ __global__ void k_avgpool2_bwd(const float* __restrict__ dy, int H, int W, int O
   }
 }
 
+// ---- hinge / Wasserstein-style GAN terms on the PatchGAN's prediction maps (reference spade/models/networks/loss.py:60-93) ----
+// kind 0: -mean(x) (generator), 1: -mean(min(x - 1, 0)) (discriminator, real), 2: -mean(min(-x - 1, 0)) (discriminator, fake),
+// averaged over up to four scales: ONE launch where torch ran sub / clamp / mean / neg per scale + the sum and the division
+// (and as many in the backward).  A map is (B, 1, h, w) with arbitrary element strides (the one real channel of a padded
+// NHWC buffer).  fp64 sums in a fixed order (one block, strided per thread, LDS tree): bit-reproducible.
+struct HingeItems {
+  const float* x[4];
+  float* dx[4];                 // backward: contiguous (B, h, w)
+  long long sb[4], sh[4], sw[4];
+  int B[4], H[4], W[4];
+  int n;
+};
+__device__ __forceinline__ float hinge_term(float x, int kind) {
+  if (kind == 0) return x;
+  const float m = kind == 1 ? x - 1.0f : -x - 1.0f;
+  return m < 0.f ? m : 0.f;
+}
+__global__ __launch_bounds__(1024) void k_hinge_mean(HingeItems it, int kind, float* __restrict__ out) {
+  __shared__ double red[1024];
+  double total = 0.0;
+  for (int i = 0; i < it.n; ++i) {
+    const int hw = it.H[i] * it.W[i];
+    const int N = it.B[i] * hw;
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < N; e += 1024) {
+      const int b = e / hw, r = e - b * hw, y = r / it.W[i], xx = r - y * it.W[i];
+      acc += (double)hinge_term(it.x[i][b * it.sb[i] + y * it.sh[i] + xx * it.sw[i]], kind);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+      __syncthreads();
+    }
+    total += -(red[0] / (double)N);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(total / (double)it.n);
+}
+// d x = g * (-1 / (N n)) * d term / d x
+__global__ void k_hinge_bwd(HingeItems it, int kind, const float* __restrict__ g) {
+  const int i = blockIdx.y;
+  const int hw = it.H[i] * it.W[i];
+  const int N = it.B[i] * hw;
+  const float s = -g[0] / ((float)N * (float)it.n);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N; e += gridDim.x * blockDim.x) {
+    const int b = e / hw, r = e - b * hw, y = r / it.W[i], xx = r - y * it.W[i];
+    const float x = it.x[i][b * it.sb[i] + y * it.sh[i] + xx * it.sw[i]];
+    float d = 1.0f;
+    if (kind == 1) d = (x - 1.0f) < 0.f ? 1.0f : 0.f;
+    if (kind == 2) d = (-x - 1.0f) < 0.f ? -1.0f : 0.f;
+    it.dx[i][e] = s * d;
+  }
+}
+
 extern "C" {
 
 int csg_maxpool2_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream) {
@@ -243,6 +298,45 @@ int csg_l1_mean_bwd(const float* a, const float* b, const float* gout, int64_t n
   ProfScope p(K_L1_BWD, (double)n * 3 * 4, s);
   CSG_LAUNCH(k_l1_bwd, dim3(ew_grid(n / 4)), dim3(256), 0, s, a, b, gout, (float)(1.0 / (double)n), n / 4, da);
   return check_launch("csg_l1_mean_bwd");
+}
+
+static int hinge_items(const csg_hinge_item* items, int32_t n, bool need_dx, HingeItems& it, const char* who) {
+  CSG_REQUIRE(items != nullptr && n >= 1 && n <= 4, CSG_E_BADSHAPE, "%s: 1..4 maps (got %d)", who, (int)n);
+  it.n = n;
+  for (int i = 0; i < 4; ++i) {
+    const csg_hinge_item& d = items[i < n ? i : 0];
+    CSG_REQUIRE(d.x != nullptr && d.B > 0 && d.H > 0 && d.W > 0 && d.B * d.H * d.W < (1ll << 30) && (!need_dx || d.dx != nullptr),
+                CSG_E_BADSHAPE, "%s: bad map %d", who, i);
+    it.x[i] = d.x; it.dx[i] = d.dx; it.sb[i] = d.sb; it.sh[i] = d.sh; it.sw[i] = d.sw;
+    it.B[i] = (int)d.B; it.H[i] = (int)d.H; it.W[i] = (int)d.W;
+  }
+  return CSG_OK;
+}
+
+int csg_hinge_mean_fwd(const csg_hinge_item* items, int32_t n, int32_t kind, float* out, void* stream) {
+  CSG_REQUIRE(kind >= 0 && kind <= 2 && out != nullptr, CSG_E_BADSHAPE, "csg_hinge_mean_fwd: kind 0..2, an output");
+  HingeItems it;
+  int rc = hinge_items(items, n, false, it, "csg_hinge_mean_fwd");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  double bytes = 0;
+  for (int i = 0; i < n; ++i) bytes += (double)it.B[i] * it.H[i] * it.W[i] * 4;
+  ProfScope p(K_L1_FWD, bytes, s);
+  CSG_LAUNCH(k_hinge_mean, dim3(1), dim3(1024), 0, s, it, (int)kind, out);
+  return check_launch("csg_hinge_mean_fwd");
+}
+
+int csg_hinge_mean_bwd(const csg_hinge_item* items, int32_t n, int32_t kind, const float* gout, void* stream) {
+  CSG_REQUIRE(kind >= 0 && kind <= 2 && gout != nullptr, CSG_E_BADSHAPE, "csg_hinge_mean_bwd: kind 0..2, a gradient");
+  HingeItems it;
+  int rc = hinge_items(items, n, true, it, "csg_hinge_mean_bwd");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t nmax = 0;
+  for (int i = 0; i < n; ++i) nmax = nmax > (int64_t)it.B[i] * it.H[i] * it.W[i] ? nmax : (int64_t)it.B[i] * it.H[i] * it.W[i];
+  ProfScope p(K_L1_BWD, (double)nmax * 8 * n, s);
+  CSG_LAUNCH(k_hinge_bwd, dim3(ew_grid(nmax), (unsigned)n), dim3(256), 0, s, it, (int)kind, gout);
+  return check_launch("csg_hinge_mean_bwd");
 }
 
 }  // extern "C"

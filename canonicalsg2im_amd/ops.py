@@ -15,7 +15,7 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _register
 
 from . import _lib
 from . import dist as csg_dist
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, GemmDesc, WinoDesc, WinoPackItem, check, lib, ptr, stream
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvDesc, FewDesc, GemmDesc, HingeItem, WinoDesc, WinoPackItem, check, lib, ptr, stream
 
 __all__ = [
     "nhwc", "empty_nhwc", "conv2d", "linear", "norm_act", "upsample2x", "nearest_resize", "avgpool3s2", "embed", "real_object_mask",
@@ -1503,6 +1503,52 @@ def pool_fanout(x):
     if not POOL_FANOUT:
         return x, avgpool3s2(x)
     return _PoolFanout.apply(x)
+
+
+HINGE_FUSED = os.environ.get("CSG_HINGE_FUSED", "1") != "0"       # 0: the GAN terms as torch's sub / clamp / mean / neg chain (A/B)
+
+
+class _HingeMean(torch.autograd.Function):
+    """(1/n) sum_i -mean(term(pred_i)) over the PatchGAN's scales in ONE launch (reference loss.py:60-93: hinge and `w` modes;
+    kind 0: -mean(x), 1: -mean(min(x - 1, 0)), 2: -mean(min(-x - 1, 0))) and one launch in the backward, where torch ran four
+    small kernels per scale and direction plus the sum over scales.  A prediction is (B, 1, h, w), any strides."""
+
+    @staticmethod
+    def _items(preds, dxs=None):
+        arr = (HingeItem * len(preds))()
+        for i, p in enumerate(preds):
+            B, _, H, W = p.shape
+            st = p.stride()
+            arr[i].x, arr[i].dx = p.data_ptr(), (dxs[i].data_ptr() if dxs is not None else None)
+            arr[i].sb, arr[i].sh, arr[i].sw = st[0], st[2], st[3]
+            arr[i].B, arr[i].H, arr[i].W = B, H, W
+        return arr
+
+    @staticmethod
+    def forward(ctx, kind, *preds):
+        preds = [_f32(p.detach()) for p in preds]
+        out = torch.empty(1, device=preds[0].device, dtype=torch.float32)
+        check(lib.csg_hinge_mean_fwd(_HingeMean._items(preds), len(preds), int(kind), ptr(out), stream()), "hinge_mean_fwd")
+        ctx.kind = int(kind)
+        ctx.save_for_backward(*preds)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        preds = ctx.saved_tensors
+        dxs = [torch.empty((p.shape[0], 1, p.shape[2], p.shape[3]), device=p.device, dtype=torch.float32) for p in preds]
+        g = _f32(g).contiguous()
+        check(lib.csg_hinge_mean_bwd(_HingeMean._items(preds, dxs), len(preds), ctx.kind, ptr(g), stream()), "hinge_mean_bwd")
+        return (None,) + tuple(dxs)
+
+
+def hinge_mean(preds, kind):
+    """None when the fused form does not apply (CPU tensors, more than four scales, maps with more than one channel)."""
+    if not HINGE_FUSED or not (1 <= len(preds) <= 4):
+        return None
+    if any((not p.is_cuda) or p.dim() != 4 or p.shape[1] != 1 or p.dtype != torch.float32 for p in preds):
+        return None
+    return _HingeMean.apply(kind, *preds)
 
 
 class _MaxPool2(torch.autograd.Function):

@@ -32,9 +32,23 @@ class GANLoss(nn.Module):
         label = torch.full_like(input, self.real_label if target_is_real else self.fake_label)
         return F.binary_cross_entropy_with_logits(input, label) if mode == 'original' else F.mse_loss(input, label)
 
+    def _kind(self, target_is_real, for_discriminator):
+        """ops.hinge_mean's term for this call, or None (modes / calls it does not serve)."""
+        if self.gan_mode == 'hinge':
+            if not for_discriminator:
+                return 0 if target_is_real else None
+            return 1 if target_is_real else 2
+        return None
+
     def __call__(self, input, target_is_real, for_discriminator=True):
         if not isinstance(input, list):
             return self.loss(input, target_is_real, for_discriminator)
+        kind = self._kind(target_is_real, for_discriminator)
+        if kind is not None:
+            from .... import ops
+            fused = ops.hinge_mean([p[-1] if isinstance(p, list) else p for p in input], kind)   # every scale in one launch
+            if fused is not None:
+                return fused
         per_scale = [self.loss(p[-1] if isinstance(p, list) else p, target_is_real, for_discriminator).reshape(1)
                      for p in input]
         total = 0

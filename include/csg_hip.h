@@ -42,7 +42,7 @@ extern "C" {
 #define CSG_MAX_TAPS 16
 
 /* 100 + the number of additive revisions of this header: entry points are only ever added, never changed or removed
- * (106: csg_wino4_conv_spade, csg_wino4_conv_spade_supported, csg_avgpool3s2_bwd_add) */
+ * (108: csg_wino4_conv_spade, csg_wino4_conv_spade_supported, csg_avgpool3s2_bwd_add, csg_hinge_mean_fwd / _bwd) */
 int csg_version(void);
 const char* csg_last_error(void);
 
@@ -499,6 +499,19 @@ int64_t csg_l1_mean_workspace(int64_t n);
 int csg_l1_mean_fwd(const float* a, const float* b, int64_t n, float* out, void* workspace, int64_t workspace_bytes,
                     void* stream);
 int csg_l1_mean_bwd(const float* a, const float* b, const float* gout, int64_t n, float* da, void* stream);
+
+/* ---- GAN terms on the PatchGAN's prediction maps (spade/models/networks/loss.py:60-93, gan_mode hinge / w) in one launch:
+ * out[0] = (1/n) sum_i -mean(term(x_i)) over up to four scales, term = x (kind 0: the generator's term), min(x - 1, 0)
+ * (kind 1: discriminator on real), min(-x - 1, 0) (kind 2: discriminator on fake).  A map is (B, 1, H, W) with element strides
+ * (sb, sh, sw); the backward writes d x_i into the contiguous (B, H, W) buffer dx.  fp64 sums in a fixed order. */
+typedef struct csg_hinge_item {
+  const float* x;
+  float* dx;                    /* backward only */
+  int64_t sb, sh, sw;
+  int64_t B, H, W;
+} csg_hinge_item;
+int csg_hinge_mean_fwd(const csg_hinge_item* items, int32_t n, int32_t kind, float* out, void* stream);
+int csg_hinge_mean_bwd(const csg_hinge_item* items, int32_t n, int32_t kind, const float* gout, void* stream);
 
 /* ---- canonical scene-graph construction of the packed datasets -----------------------------------
  * Replaces, per batch, the per-sample numpy/python pipeline of the data loader:

@@ -706,3 +706,37 @@ def test_pool_fanout_sums_both_gradients_in_the_pooling_backward():
         assert torch.equal(g1, g0), (use_full, use_pool, float((g1 - g0).abs().max()))
     ref = torch.nn.functional.avg_pool2d(x0, 3, 2, 1, count_include_pad=False)
     assert_close(b1.cpu(), ref, 1e-5, 1e-6, "pooled")
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_hinge_mean_over_scales_vs_torch(kind):
+    """ops.hinge_mean: the PatchGAN's GAN term over both scales in one launch (reference loss.py:60-93) against the torch chain
+    it replaces — value and d/d(prediction) — on predictions that are the one real channel of padded NHWC buffers."""
+    from canonicalsg2im_amd import ops
+    from canonicalsg2im_amd.spade.models.networks.loss import GANLoss
+    g = torch.Generator().manual_seed(20 + kind)
+    bufs = [torch.randn(16, 35, 35, 4, generator=g).cuda(), torch.randn(16, 19, 19, 4, generator=g).cuda() * 2.0]
+    crit = GANLoss('hinge')
+    real, for_d = {0: (True, False), 1: (True, True), 2: (False, True)}[kind]
+
+    def run(fused):
+        saved = ops.HINGE_FUSED
+        ops.HINGE_FUSED = fused
+        try:
+            leaves = [b.clone().requires_grad_(True) for b in bufs]
+            preds = [[l.permute(0, 3, 1, 2)[:, :1]] for l in leaves]      # (B,1,h,w) views, element stride 4
+            out = crit(preds, real, for_discriminator=for_d)
+            (out * 3.0).sum().backward()
+            return out.detach(), [l.grad.detach() for l in leaves]
+        finally:
+            ops.HINGE_FUSED = saved
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert o1.shape == o0.shape == (1,)
+    assert abs(float(o1) - float(o0)) <= 2e-6 * abs(float(o0)) + 1e-7, (float(o1), float(o0))
+    for a, b in zip(g1, g0):
+        assert torch.equal(a[..., 1:], torch.zeros_like(a[..., 1:]))       # the pad channels get no gradient
+        assert_close(a, b, 1e-6, 1e-9, "d prediction")
+    # non-hinge modes and single tensors keep the torch path
+    assert ops.hinge_mean([bufs[0].permute(0, 3, 1, 2)], 0) is None          # 4 channels: not a prediction map
